@@ -1,0 +1,140 @@
+/*
+ * nanosnp.h -- C ABI of libnanosnp_hip.so: the MI355X (gfx950) implementation of NanoSNP's
+ * candidate-site inference hot path.  Plain pointers and sizes only (no torch / HIP types in
+ * the signatures; `stream` is a hipStream_t passed as void*, NULL = the default stream).
+ *
+ * The reference (huangnengCSU/NanoSNP) has no FFI of its own; each entry point replaces the
+ * narrowest existing call site of the hot path (paths relative to the upstream repository):
+ *
+ *   nsnp_pileup_forward          LSTMNetwork.predict            PileupModel/model.py:114-119
+ *                                called from                    PileupModel/predict.py:49-51
+ *   nsnp_pileup_encode_columns   TensorMaker::make_tensor       dna_sv_tensor/src/make_candidate_snp_tensor/tensor_maker.cpp:61-249
+ *                                + candidate test               dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:194-201
+ *   nsnp_pileup_select_sites     window / pending-queue rule    dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:174-217
+ *   nsnp_pileup_gather_windows   33-column window emission      dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:233-244
+ *   nsnp_pileup_postprocess      argmax / max / depth           PileupModel/predict.py:52-65
+ *   nsnp_hap_features            get_frequency_feature + ref row HaplotypeModel/dataset_dev.py:55-87,337-349
+ *   nsnp_hap_forward             LSTMNetwork.predict            HaplotypeModel/model_dev.py:133-143
+ *                                called from                    HaplotypeModel/predict_dev.py:35-39
+ *
+ * Conventions: every pointer marked "device" is device memory owned by the caller; functions
+ * are asynchronous on `stream` unless stated, return 0 on success or a negative NSNP_E* code
+ * (never abort/throw; the reference's native stage abort()s, cpp_aux.cpp:10-21), and a
+ * context is bound to one device and must be used by one host thread at a time.  Use one
+ * context per stream when several batches are in flight.
+ */
+#ifndef NANOSNP_H
+#define NANOSNP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSNP_OK          0
+#define NSNP_EINVAL     (-1)   /* bad argument                              */
+#define NSNP_ENOMEM     (-2)   /* host or device allocation failed          */
+#define NSNP_EHIP       (-3)   /* a HIP runtime call failed (see nsnp_last_hip_error) */
+#define NSNP_ENOWEIGHTS (-4)   /* forward called before load_weights        */
+#define NSNP_EARCH      (-5)   /* device is not gfx950                      */
+#define NSNP_ESHAPE     (-6)   /* unsupported model dimensions              */
+
+#define NSNP_PILEUP_WINDOW   33   /* PileupModel/dataset.py:11-12, 2*flanking_base+1 */
+#define NSNP_PILEUP_CHANNELS 18   /* dna_sv_tensor/src/common/tensor.hpp:6-26        */
+#define NSNP_GT_CLASSES      21   /* PileupModel/config/ont_pileup.yaml:17           */
+#define NSNP_ZY_CLASSES       3
+#define NSNP_HAP_FEATURES   105   /* HaplotypeModel/config/ont_haplotype.yaml:8-9    */
+
+/* per-column flag bits written by nsnp_pileup_encode_columns */
+#define NSNP_FLAG_PASS_AF     1u  /* pass_af as make_tensor returns it (tensor_maker.cpp:248) */
+#define NSNP_FLAG_PASS_SNP    2u
+#define NSNP_FLAG_PASS_INDEL  4u
+#define NSNP_FLAG_CANDIDATE   8u  /* ref in ACGT && pass_af && depth >= min_coverage (main.cpp:195) */
+
+typedef struct nsnp_ctx nsnp_ctx;
+
+int         nsnp_version(void);
+const char* nsnp_strerror(int code);
+/* last hipError_t seen by this context (0 = hipSuccess) and its text */
+int         nsnp_last_hip_error(const nsnp_ctx* ctx, const char** text);
+
+/* Creates a context on `device` (must be gfx950).  Allocates no workspace yet. */
+int nsnp_ctx_create(int device, nsnp_ctx** ctx);
+int nsnp_ctx_destroy(nsnp_ctx* ctx);
+/* Workspace is sized for `max_sites` sites per internal chunk (default 32768); larger calls are
+ * processed in chunks.  Synchronous; call before the first forward to keep allocation out of
+ * the hot loop (and out of hipGraph capture). */
+int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
+
+/* ---- PileupModel ---------------------------------------------------------------------- */
+/* host_tensors: the 24 fp32 tensors LSTMNetwork.predict uses, HOST pointers, in the
+ * state-dict order of ont_pileup.chkpt (PileupModel/predict.py:212-214):
+ *   encoder.lstm: l0 {w_ih[256,18], w_hh[256,64], b_ih[256], b_hh[256]}, l0_reverse {..},
+ *                 l1 {w_ih[256,128], w_hh[256,64], b_ih, b_hh}, l1_reverse {..}      (16)
+ *   encoder.output_proj {weight[128,128], bias[128]}                                 (2)
+ *   forward_layer.dense {weight[256,128], bias[256]}                                 (2)
+ *   forward_layer.genotype_layer {weight[21,256], bias[21]}, zygosity_layer {[3,256],[3]} (4)
+ * Synchronous (packs and uploads the MFMA weight images). */
+int nsnp_pileup_load_weights(nsnp_ctx* ctx, const float* const* host_tensors, int n_tensors);
+
+/* x: device int32 [N,33,18] (the position_matrix of make_bin_predict_data.py:90-100; the
+ * int->float conversion of predict.py:49 happens inside).  Outputs: device fp32 softmax
+ * probabilities gt_prob [N,21], zy_prob [N,3] (model.py:117-118). */
+int nsnp_pileup_forward(nsnp_ctx* ctx, const int32_t* x, int64_t N,
+                        float* gt_prob, float* zy_prob, void* stream);
+
+/* Same forward reading the windows straight out of the per-column count matrix:
+ * site n uses counts[center_idx[n]-16 .. center_idx[n]+16][18] (no gathered copy). */
+int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,
+                                int64_t N, float* gt_prob, float* zy_prob, void* stream);
+
+/* predict.py:54-65: gt_arg/zy_arg = argmax, gt_max/zy_max = max probability,
+ * depth = -(sum of the negative entries of x[n,16,{0,1,2,3,9,10,11,12}]).  All device. */
+int nsnp_pileup_postprocess(nsnp_ctx* ctx, const float* gt_prob, const float* zy_prob,
+                            const int32_t* x, int64_t N, uint8_t* gt_arg, uint8_t* zy_arg,
+                            float* gt_max, float* zy_max, int32_t* depth, void* stream);
+
+/* ---- pileup encode -------------------------------------------------------------------- */
+/* bases: device bytes, the concatenated column-5 strings of M mpileup lines; col_off: device
+ * int64 [M+1]; ref: device uint8 [M], chr_seq[pos-1] as stored in the FASTA.  Outputs (device):
+ * counts int32 [M,18], depth int32 [M], flags uint8 [M] (NSNP_FLAG_*).  min_af is used for the
+ * SNP and the indel test (make_predict_data.sh:120-124 passes .12 for both). */
+int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, const int64_t* col_off,
+                               const uint8_t* ref, int64_t M, double min_af, int min_coverage,
+                               int32_t* counts, int32_t* depth, uint8_t* flags, void* stream);
+
+/* pos: device int64 [M], strictly increasing inside a contig (fold the contig index into the
+ * high bits when several contigs share a call).  center_idx: device int64 [cap] receives the
+ * column indices of emitted sites in ascending order; *n_sites (device int64) their number
+ * (may exceed cap: then only the first cap were written). */
+int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M,
+                             int64_t* center_idx, int64_t cap, int64_t* n_sites, void* stream);
+
+/* x[n][t][c] = counts[center_idx[n]-16+t][c]; x: device int32 [N,33,18]. */
+int nsnp_pileup_gather_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,
+                               int64_t N, int32_t* x, void* stream);
+
+/* ---- HaplotypeModel ------------------------------------------------------------------- */
+/* seq/bq/mq/hap: device int32 [N,D,L] planes as write_to_bins.py:44-61 stores them (padding
+ * rows are -2); ref_row: device int32 [N,L].  out: device fp32 [N,105,L] -- float64 math as
+ * numpy does, then the fp32 cast of predict_dev.py:35-36. */
+int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_t* bq, const int32_t* mq,
+                      const int32_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
+                      float* out, void* stream);
+
+/* host_tensors: the 58 fp32 tensors of model_dev.LSTMNetwork.state_dict() in order
+ * (pileup_encoder 26, haplotype_encoder 26, forward_layer 6), HOST pointers.
+ * hidden must be a multiple of 64; F = 105 input features; 3 layers as ont_haplotype.yaml. */
+int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* host_tensors, int n_tensors,
+                          int n_features, int hidden, int n_layers, int n_gt, int n_zy);
+
+/* xp: device fp32 [N,105,33], xh: device fp32 [N,105,11] -> gt [N,n_gt], zy [N,n_zy]. */
+int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N,
+                     float* gt_prob, float* zy_prob, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

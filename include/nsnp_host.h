@@ -1,0 +1,71 @@
+/*
+ * nsnp_host.h -- host-side (CPU, plain C) helpers of the NanoSNP MI355X hot path:
+ * synthetic workload generators and the text/binary readers that feed the device path.
+ * Built into nanosnp_amd/libnanosnp_host.so with gcc; no GPU, no torch types.
+ *
+ * These are the native counterparts of the reference's libdnasv readers
+ * (dna_sv_tensor/src/common/line_reader.cpp, ref_reader.cpp, cpp_aux.cpp:43-59) and of the
+ * text->tensor converters (dna_sv_tensor/src/make_bin_data/make_bin_predict_data.py:48-77),
+ * re-designed to hand flat arrays to the device instead of text/HDF5 files.
+ *
+ * All functions return >= 0 on success and a negative NSNP_HOST_E* code on failure; none
+ * aborts the process (the reference's readers abort(): cpp_aux.cpp:10-21).
+ */
+#ifndef NSNP_HOST_H
+#define NSNP_HOST_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSNP_HOST_EINVAL (-1)
+#define NSNP_HOST_ENOMEM (-2)
+#define NSNP_HOST_EIO    (-3)
+#define NSNP_HOST_EFORMAT (-4)
+#define NSNP_HOST_ERANGE (-5)
+
+/* ---- synthetic generators (G1/G2/G3) -------------------------------- */
+
+/* G1/G2: M pileup columns in mpileup column-5 grammar.  ref[M] receives the reference base of
+ * each column, col_off[M+1] the byte offsets into bases.  window = 0: plain G1 (a fraction
+ * het_rate of columns heterozygous).  window = 33: stand-alone windows, the centre column
+ * (c % 33 == 16) forced heterozygous w.p. 0.7, homozygous-alt 0.1, noise-only 0.2.
+ * Returns the number of bytes written, or -(needed + 16) when cap is too small / bases NULL. */
+int64_t nsnp_synth_columns(uint64_t seed, int64_t M, double coverage, int max_depth,
+                           double het_rate, int window, uint8_t* ref, uint8_t* bases,
+                           int64_t cap, int64_t* col_off);
+
+/* G3: haplotype read planes [N][D][L] int32 (base, baseq, mapq, hap) + ref_row [N][L]. */
+int nsnp_synth_hap_planes(uint64_t seed, int64_t N, double coverage, int D, int L,
+                          int32_t* seq, int32_t* bq, int32_t* mq, int32_t* hap, int32_t* ref_row);
+
+/* ---- mpileup text -> column arrays ---------------------------------------------------- */
+/* Parses samtools-mpileup text (columns 0,1,4 are used, as
+ * make_candidate_snp_tensor/main.cpp:162-172 does; tokens are maximal runs of non-tab bytes,
+ * cpp_aux.cpp:43-59).  Two-call protocol: with bases == NULL returns the sizes through
+ * n_cols / n_bytes; otherwise fills pos[M], col_off[M+1], bases[n_bytes].  All lines must
+ * belong to one contig (the per-chromosome files DNA_ExtractChrPileupData writes). */
+int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int64_t* n_bytes,
+                       int64_t* pos, int64_t* col_off, uint8_t* bases);
+
+/* ---- FASTA (+.fai) -------------------------------------------------------------------- */
+/* Loads one contig of a FASTA file into seq (capacity cap).  Uses the .fai when present
+ * (ref_reader.cpp:9-33) and a linear scan otherwise.  Returns the contig length, or a
+ * negative code; with seq == NULL only the length is returned. */
+int64_t nsnp_fasta_load_contig(const char* fasta_path, const char* contig, uint8_t* seq, int64_t cap);
+
+/* ---- .pd text (make_predict_data/main.cpp:120-123) ------------------------------------ */
+/* Parses n_sites lines "594 ints \t ctg:pos:REF33 \t alt_info" into x[N][33][18] int32,
+ * pos[N], ref_base[N] (byte 16 of REF33, PileupModel/dataset.py:128-131) and contig ids
+ * (index into a caller-visible table is left to Python; here ctg_off[N+1] are byte ranges of
+ * the contig names inside text).  With x == NULL returns the number of sites. */
+int64_t nsnp_pd_parse(const char* text, int64_t text_len, int32_t* x, int64_t* pos,
+                      uint8_t* ref_base, int64_t* ctg_begin, int64_t* ctg_end, int64_t cap_sites);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,235 @@
+"""ctypes loader of ``libnanosnp_hip.so`` -- the C ABI declared in include/nanosnp.h.
+
+There is no CPU fallback: importing works everywhere (so the symbol table can be checked on a
+machine without a GPU), but creating a :class:`Context` requires the built library and a
+gfx950 device and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnanosnp_hip.so")
+
+
+class NanoSNPError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "nsnp_version": (C.c_int, []),
+    "nsnp_strerror": (C.c_char_p, [C.c_int]),
+    "nsnp_last_hip_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
+    "nsnp_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nsnp_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "nsnp_ctx_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "nsnp_pileup_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
+    "nsnp_pileup_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsnp_pileup_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsnp_pileup_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "nsnp_pileup_encode_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "nsnp_pileup_select_sites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p]),
+    "nsnp_pileup_gather_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p]),
+    "nsnp_hap_features": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nsnp_hap_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int] + [C.c_int] * 5),
+    "nsnp_hap_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed for this) and binds every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NanoSNPError(
+            f"{LIB_PATH} not found. The HIP extension is required (there is no CPU fallback): "
+            "build it with `make -C nanosnp_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None, what=""):
+    if rc == 0:
+        return
+    lib = load()
+    msg = lib.nsnp_strerror(rc).decode()
+    if rc == -3 and ctx is not None:
+        txt = C.c_char_p()
+        code = lib.nsnp_last_hip_error(ctx, C.byref(txt))
+        msg += f" (hipError {code}: {txt.value.decode() if txt.value else '?'})"
+    raise NanoSNPError(f"{what or 'nanosnp'} failed: {msg}")
+
+
+def _stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Context:
+    """One nsnp_ctx bound to one device (one per stream when batches overlap)."""
+
+    def __init__(self, device=0, chunk_sites=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise NanoSNPError("no GPU visible: nanosnp_amd has no CPU fallback (the CPU restatement "
+                               "under oracle/ is test infrastructure only)")
+        self.lib = load()
+        self.device = int(device)
+        h = C.c_void_p()
+        check(self.lib.nsnp_ctx_create(self.device, C.byref(h)), None, "nsnp_ctx_create")
+        self.handle = h
+        if chunk_sites:
+            self.reserve(chunk_sites)
+
+    def reserve(self, max_sites):
+        check(self.lib.nsnp_ctx_reserve(self.handle, int(max_sites)), self.handle, "nsnp_ctx_reserve")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nsnp_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- PileupModel -------------------------------------------------------------------------
+    def pileup_load_weights(self, tensors):
+        """tensors: 24 contiguous fp32 CPU arrays/tensors in state-dict order."""
+        import numpy as np
+        arrs = [np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+                for t in tensors]
+        if len(arrs) < 24:
+            raise NanoSNPError(f"expected 24 weight tensors, got {len(arrs)}")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        check(self.lib.nsnp_pileup_load_weights(self.handle, ptrs, len(arrs)), self.handle,
+              "nsnp_pileup_load_weights")
+
+    def pileup_forward(self, x, gt=None, zy=None, stream=None):
+        import torch
+        assert x.is_cuda and x.dtype == torch.int32 and x.is_contiguous() and tuple(x.shape[1:]) == (33, 18)
+        n = x.shape[0]
+        gt = gt if gt is not None else torch.empty((n, 21), dtype=torch.float32, device=x.device)
+        zy = zy if zy is not None else torch.empty((n, 3), dtype=torch.float32, device=x.device)
+        check(self.lib.nsnp_pileup_forward(self.handle, _dptr(x), n, _dptr(gt), _dptr(zy), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_forward")
+        return gt, zy
+
+    def pileup_forward_windows(self, counts, center_idx, gt=None, zy=None, stream=None):
+        import torch
+        assert counts.is_cuda and counts.dtype == torch.int32 and counts.is_contiguous()
+        assert center_idx.is_cuda and center_idx.dtype == torch.int64 and center_idx.is_contiguous()
+        n = center_idx.shape[0]
+        gt = gt if gt is not None else torch.empty((n, 21), dtype=torch.float32, device=counts.device)
+        zy = zy if zy is not None else torch.empty((n, 3), dtype=torch.float32, device=counts.device)
+        check(self.lib.nsnp_pileup_forward_windows(self.handle, _dptr(counts), _dptr(center_idx), n, _dptr(gt),
+                                                   _dptr(zy), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_forward_windows")
+        return gt, zy
+
+    def pileup_postprocess(self, gt, zy, x=None, stream=None):
+        import torch
+        n = gt.shape[0]
+        dev = gt.device
+        gt_arg = torch.empty(n, dtype=torch.uint8, device=dev)
+        zy_arg = torch.empty(n, dtype=torch.uint8, device=dev)
+        gt_max = torch.empty(n, dtype=torch.float32, device=dev)
+        zy_max = torch.empty(n, dtype=torch.float32, device=dev)
+        depth = torch.empty(n, dtype=torch.int32, device=dev) if x is not None else None
+        check(self.lib.nsnp_pileup_postprocess(self.handle, _dptr(gt), _dptr(zy), _dptr(x), n, _dptr(gt_arg),
+                                               _dptr(zy_arg), _dptr(gt_max), _dptr(zy_max), _dptr(depth),
+                                               _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_postprocess")
+        return gt_arg, zy_arg, gt_max, zy_max, depth
+
+    # ---- pileup encode -----------------------------------------------------------------------
+    def pileup_encode_columns(self, bases, col_off, ref, min_af=0.12, min_coverage=6, stream=None):
+        import torch
+        assert bases.is_cuda and bases.dtype == torch.uint8 and col_off.dtype == torch.int64 and ref.dtype == torch.uint8
+        m = ref.shape[0]
+        dev = ref.device
+        counts = torch.empty((m, 18), dtype=torch.int32, device=dev)
+        depth = torch.empty(m, dtype=torch.int32, device=dev)
+        flags = torch.empty(m, dtype=torch.uint8, device=dev)
+        check(self.lib.nsnp_pileup_encode_columns(self.handle, _dptr(bases), _dptr(col_off), _dptr(ref), m,
+                                                  float(min_af), int(min_coverage), _dptr(counts), _dptr(depth),
+                                                  _dptr(flags), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_encode_columns")
+        return counts, depth, flags
+
+    def pileup_select_sites(self, pos, flags, cap=None, stream=None):
+        import torch
+        m = pos.shape[0]
+        cap = int(cap if cap is not None else m)
+        center = torch.empty(max(cap, 1), dtype=torch.int64, device=pos.device)
+        n_sites = torch.zeros(1, dtype=torch.int64, device=pos.device)
+        check(self.lib.nsnp_pileup_select_sites(self.handle, _dptr(pos), _dptr(flags), m, _dptr(center), cap,
+                                                _dptr(n_sites), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_select_sites")
+        n = int(n_sites.item())
+        return center[:min(n, cap)], n
+
+    def pileup_gather_windows(self, counts, center_idx, stream=None):
+        import torch
+        n = center_idx.shape[0]
+        x = torch.empty((n, 33, 18), dtype=torch.int32, device=counts.device)
+        check(self.lib.nsnp_pileup_gather_windows(self.handle, _dptr(counts), _dptr(center_idx), n, _dptr(x),
+                                                  _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_gather_windows")
+        return x
+
+    # ---- HaplotypeModel ----------------------------------------------------------------------
+    def hap_features(self, seq, bq, mq, hap, ref_row, stream=None):
+        import torch
+        n, d, l = seq.shape
+        out = torch.empty((n, 105, l), dtype=torch.float32, device=seq.device)
+        check(self.lib.nsnp_hap_features(self.handle, _dptr(seq), _dptr(bq), _dptr(mq), _dptr(hap), _dptr(ref_row),
+                                         n, d, l, _dptr(out), _stream_ptr(stream)),
+              self.handle, "nsnp_hap_features")
+        return out
+
+    def hap_load_weights(self, tensors, n_features=105, hidden=256, n_layers=3, n_gt=10, n_zy=3):
+        import numpy as np
+        arrs = [np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+                for t in tensors]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        check(self.lib.nsnp_hap_load_weights(self.handle, ptrs, len(arrs), n_features, hidden, n_layers, n_gt, n_zy),
+              self.handle, "nsnp_hap_load_weights")
+        self._hap_dims = (n_gt, n_zy)
+
+    def hap_forward(self, xp, xh, stream=None):
+        import torch
+        n = xp.shape[0]
+        n_gt, n_zy = self._hap_dims
+        gt = torch.empty((n, n_gt), dtype=torch.float32, device=xp.device)
+        zy = torch.empty((n, n_zy), dtype=torch.float32, device=xp.device)
+        check(self.lib.nsnp_hap_forward(self.handle, _dptr(xp), _dptr(xh), n, _dptr(gt), _dptr(zy),
+                                        _stream_ptr(stream)),
+              self.handle, "nsnp_hap_forward")
+        return gt, zy

@@ -1,0 +1,82 @@
+// nsnp_common.hpp -- shared definitions of the HIP side (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "nanosnp.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int   i32x4 __attribute__((ext_vector_type(4)));
+
+#define NSNP_CDIV(a, b) (((a) + (b) - 1) / (b))
+
+// ---- model constants of the PileupModel (PileupModel/config/ont_pileup.yaml:6-20) -----------
+constexpr int PW = NSNP_PILEUP_WINDOW;     // 33 positions
+constexpr int PC = NSNP_PILEUP_CHANNELS;   // 18 channels
+constexpr int PH = 64;                     // LSTM hidden size
+constexpr int PG = 4 * PH;                 // 256 gate rows
+constexpr int PCENTER = 16;                // ForwardLayer slices position 16 (model.py:68)
+constexpr int PSTEPS1 = PCENTER + 1;       // layer-1 steps each direction actually needs
+
+// ---- packed-weight image layout ---------------------------------------------------------------
+// One "A image" serves v_mfma_f32_16x16x4_f32 with the weight matrix as the A operand:
+//   img[tile][j4][lane][e]  (f32)   = Wp(row = 16*tile + (lane & 15), k = 4*(4*j4 + e) + (lane >> 4))
+// so one 16-byte read per lane feeds 4 consecutive K-steps of one 16-row tile.
+// Gate rows are permuted so that a lane's 4 accumulator registers of tile i are the (i,f,g,o)
+// pre-activations of hidden unit 4*i + (lane >> 4); see pack.cpp for the row/column maps.
+
+struct PileupWeightsDev {
+    // per direction d (0 fwd, 1 reverse)
+    float* l0_whh[2];   // [16][4][64][4]  64 KB   recurrent, K = 64
+    float* l0_wih[2];   // [16][1][64][4]  16 KB   input channels 0..15
+    float* l0_wlast[2]; // [16][64]         4 KB   K-step 4: channels 16,17, bias, zero (register operand)
+    float* l1_wih[2];   // [16][8][64][4] 128 KB   K = 128 in H0 storage order
+    float* l1_bias[2];  // [16][64][4]      4 KB   b_ih + b_hh in accumulator layout
+    float* l1_whh[2];   // [16][4][64][4]  64 KB
+    float* proj_w;      // [8][8][64][4]   64 KB   K = 128 in H1c storage order
+    float* proj_b;      // [8][64][4]
+    float* dense_w;     // [16][8][64][4] 128 KB   K = 128 in proj accumulator order
+    float* dense_b;     // [16][64][4]
+    float* head_w;      // [2][16][64][4]  32 KB   rows 0..20 genotype, 21..23 zygosity, rest 0
+    float* head_b;      // [2][64][4]
+    float* arena;       // one allocation holding all of the above
+    size_t arena_bytes;
+    bool   loaded;
+};
+
+struct HapWeightsDev;   // hap_forward.hip
+
+struct nsnp_ctx {
+    int device;
+    int n_cu;
+    hipError_t last_err;
+    bool attr_set;
+    // workspace (sized by nsnp_ctx_reserve)
+    int64_t chunk_sites;
+    float*  ws_h0;      // [chunk][33][128]
+    float*  ws_xp1;     // [2][chunk*17][256]
+    float*  ws_h1c;     // [chunk][128]
+    PileupWeightsDev pw;
+    HapWeightsDev* hw;
+    void*  hap_ws; size_t hap_ws_bytes;
+    int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
+};
+
+#define NSNP_HIP(ctx, call)                                                        \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) { (ctx)->last_err = e_; return NSNP_EHIP; }          \
+    } while (0)
+
+// host-side packers (pack.cpp compiled as part of the .hip translation unit set)
+typedef float (*nsnp_wfun)(const void* user, int row, int k);
+void nsnp_pack_image(float* img, int n_tiles, int n_j4, nsnp_wfun f, const void* user);
+
+// kernels' launchers (pileup_forward.hip)
+int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
+                             int64_t N, float* gt, float* zy, hipStream_t s);
+int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w);

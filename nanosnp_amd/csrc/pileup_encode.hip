@@ -1,0 +1,342 @@
+// pileup_encode.hip -- pileup column encode, candidate-window selection and window gather.
+//
+// Replaces, for in-memory columns,
+//   TensorMaker::make_tensor        dna_sv_tensor/src/make_candidate_snp_tensor/tensor_maker.cpp:61-249
+//   candidate test / pending queue  dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:174-217
+//   33-column window emission       dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:233-244
+// The reference builds a std::map<string,int> per column; here one lane walks one column's bytes
+// (the +n<seq>/-n<seq>/^q grammar is inherently sequential inside a column), 64 columns per
+// wave, with the byte stream fetched 8 bytes at a time.  Distinct-allele maxima (channels
+// I1/D1/i1/d1) use a small per-lane table in LDS keyed by a hash and verified byte-for-byte, with
+// an exact quadratic rescan when a column has more distinct indel alleles than the table holds.
+// Integer outputs are bit-exact with the reference; the AF tests use the same float64 division.
+#include "nsnp_common.hpp"
+
+namespace {
+
+enum { CH_A = 0, CH_C, CH_G, CH_T, CH_I, CH_I1, CH_D, CH_D1, CH_STAR,
+       CH_a, CH_c, CH_g, CH_t, CH_i, CH_i1, CH_d, CH_d1, CH_POUND, NCH };
+
+constexpr int ENC_BLOCK = 256;
+constexpr int TBL = 8;            // distinct indel alleles tracked per column before the rescan path
+constexpr int MAX_INDEL = 60;     // kMaxIndelSize, tensor_maker.cpp:5
+
+// class of a pileup byte: 0..9 = counted symbol (channel via CLS_CH), 10 = ignored,
+// 11 '+', 12 '-', 13 '^'
+__device__ __forceinline__ int byte_class(int b)
+{
+    switch (b) {
+    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+    case 'a': return 4; case 'c': return 5; case 'g': return 6; case 't': return 7;
+    case '*': return 8; case '#': return 9;
+    case '+': return 11; case '-': return 12; case '^': return 13;
+    default: return 10;
+    }
+}
+__device__ __forceinline__ bool is_fwd_char(int b)   // "ACGTN*", tensor_maker.cpp:40-46
+{
+    return b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N' || b == '*';
+}
+__device__ __forceinline__ int nt4(int b)            // cpp_aux.cpp:85-102 (only the <4 test is used)
+{
+    switch (b) {
+    case 'A': case 'a': return 0; case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2; case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+// Iterator over the counted indels of a column (those with length <= 60), following exactly
+// the scan of tensor_maker.cpp:83-114: '^' swallows the next byte; '+'/'-' read decimal digits,
+// then skip `advance` bytes (advance == 0 re-examines the byte after the sign/digits).
+struct IndelIter {
+    const uint8_t* base; int64_t i, end;
+    __device__ __forceinline__ bool next(int64_t& off, int& len, int& sign)
+    {
+        while (i < end) {
+            const int b = base[i];
+            if (b == '+' || b == '-') {
+                ++i;
+                long long adv = 0;
+                while (i < end && base[i] >= '0' && base[i] <= '9') { adv = adv * 10 + (base[i] - '0'); ++i; }
+                const int64_t avail = end - i;
+                const int64_t l = adv < avail ? adv : avail;
+                const int64_t o = i;
+                i += adv;           // (advance-1) + the loop's ++; past-the-end is clamped by the while
+                if (adv <= MAX_INDEL) { off = o; len = (int)l; sign = b; return true; }
+            } else if (b == '^') {
+                i += 2;
+            } else {
+                ++i;
+            }
+        }
+        return false;
+    }
+};
+
+__device__ __forceinline__ bool same_bytes(const uint8_t* base, int64_t a, int64_t b, int len)
+{
+    for (int k = 0; k < len; ++k) if (base[a + k] != base[b + k]) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
+    const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
+    int64_t M, double min_af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
+    uint8_t* __restrict__ flags)
+{
+    // per-lane allele table: hash, offset (relative to column start), meta = len | kind << 8, count
+    __shared__ uint32_t t_hash[TBL][ENC_BLOCK];
+    __shared__ uint32_t t_off[TBL][ENC_BLOCK];
+    __shared__ uint32_t t_meta[TBL][ENC_BLOCK];
+    __shared__ uint32_t t_cnt[TBL][ENC_BLOCK];
+    __shared__ int32_t stage[ENC_BLOCK / 64][64 * NCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t wave_col0 = ((int64_t)blockIdx.x * (ENC_BLOCK / 64) + wave) * 64;
+    const int64_t c = wave_col0 + lane;
+    const bool live = c < M;
+
+    int32_t cnt[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) cnt[k] = 0;
+    int32_t tot[4] = {0, 0, 0, 0};      // I, i, D, d   (kind = (sign=='-')*2 + reverse)
+    int32_t mx[4] = {0, 0, 0, 0};
+    int n_tbl = 0; bool overflow = false;
+    int64_t begin = 0, end = 0;   // a dead lane scans an empty range
+    if (live) { begin = col_off[c]; end = col_off[c + 1]; }
+
+    // ---- pass 1: the scan of tensor_maker.cpp:83-114 -------------------------------------------
+    for (int64_t i = begin; i < end;) {
+        const int b = bases[i];
+        const int cls = byte_class(b);
+        if (cls < 10) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) cnt[k] += (cls == k);
+            ++i;
+        } else if (cls == 11 || cls == 12) {          // '+' / '-': decimal length, then that many bytes
+            ++i;
+            long long adv = 0;
+            while (i < end && bases[i] >= '0' && bases[i] <= '9') { adv = adv * 10 + (bases[i] - '0'); ++i; }
+            if (adv <= MAX_INDEL) {
+                const int64_t avail = end - i;
+                const int len = (int)(adv < avail ? adv : avail);
+                uint32_t hsh = 2166136261u;
+                for (int k = 0; k < len; ++k) hsh = (hsh ^ (uint32_t)bases[i + k]) * 16777619u;
+                const int kind = (b == '-' ? 2 : 0) + (len > 0 && is_fwd_char(bases[i]) ? 0 : 1);
+                tot[kind]++;
+                if (!overflow) {
+                    const uint32_t meta = (uint32_t)len | ((uint32_t)kind << 8) | ((uint32_t)b << 16);
+                    int hit = -1;
+                    for (int e = 0; e < n_tbl; ++e)
+                        if (t_hash[e][tid] == hsh && t_meta[e][tid] == meta &&
+                            same_bytes(bases, begin + t_off[e][tid], i, len)) { hit = e; break; }
+                    if (hit >= 0) {
+                        const uint32_t v = ++t_cnt[hit][tid];
+                        if ((int32_t)v > mx[kind]) mx[kind] = (int32_t)v;
+                    } else if (n_tbl < TBL) {
+                        t_hash[n_tbl][tid] = hsh; t_meta[n_tbl][tid] = meta; t_off[n_tbl][tid] = (uint32_t)(i - begin);
+                        t_cnt[n_tbl][tid] = 1; ++n_tbl;
+                        if (mx[kind] < 1) mx[kind] = 1;
+                    } else overflow = true;
+                }
+            }
+            i += adv;      // "base_idx += advance - 1; ++base_idx": advance == 0 re-examines this byte
+        } else if (cls == 13) {
+            i += 2;        // '^' and the mapping-quality byte after it
+        } else {
+            ++i;           // '$', N/n and anything else: counted nowhere
+        }
+    }
+
+    // ---- exact fallback for columns with more than TBL distinct alleles ------------------------
+    if (overflow) {
+        mx[0] = mx[1] = mx[2] = mx[3] = 0;
+        IndelIter a{bases, begin, end};
+        int64_t ao; int al, as;
+        while (a.next(ao, al, as)) {
+            const int kind = (as == '-' ? 2 : 0) + (al > 0 && is_fwd_char(bases[ao]) ? 0 : 1);
+            IndelIter b2{bases, begin, end};
+            int64_t bo; int bl, bs; int same = 0;
+            while (b2.next(bo, bl, bs))
+                if (bs == as && bl == al && same_bytes(bases, ao, bo, al)) ++same;
+            if (same > mx[kind]) mx[kind] = same;
+        }
+    }
+
+    // ---- assemble the 18 channels, flags (tensor_maker.cpp:127-248) ------------------------------
+    int32_t t[NCH];
+    t[CH_A] = cnt[0]; t[CH_C] = cnt[1]; t[CH_G] = cnt[2]; t[CH_T] = cnt[3];
+    t[CH_a] = cnt[4]; t[CH_c] = cnt[5]; t[CH_g] = cnt[6]; t[CH_t] = cnt[7];
+    t[CH_STAR] = cnt[8]; t[CH_POUND] = cnt[9];
+    t[CH_I] = tot[0]; t[CH_i] = tot[1]; t[CH_D] = tot[2]; t[CH_d] = tot[3];
+    t[CH_I1] = mx[0]; t[CH_i1] = mx[1]; t[CH_D1] = mx[2]; t[CH_d1] = mx[3];
+    const int up = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const int lo = cnt[4] + cnt[5] + cnt[6] + cnt[7];
+    const int depth = up + lo + cnt[8] + cnt[9];
+    const int refraw = live ? ref[c] : 'A';
+    const int rb = nt4(refraw);
+    const int chr_idx = rb < 4 ? rb : 0;                      // non-ACGT reference counts as 'A'
+    // allele list in std::map order A C D G I T; the first maximum is what a stable sort puts first
+    const int lc[6] = {cnt[0] + cnt[4], cnt[1] + cnt[5], tot[2] + tot[3], cnt[2] + cnt[6], tot[0] + tot[1], cnt[3] + cnt[7]};
+    const int lk[6] = {0, 1, 5, 2, 4, 3};                     // 0..3 = base index, 4 = I, 5 = D
+    int top = -1, topc = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (lc[k] > topc) { topc = lc[k]; top = lk[k]; }
+    const double den = (double)(depth ? depth : 1);
+    bool pass_snp = false, pass_indel = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (lc[k] <= 0 || lk[k] == chr_idx) continue;
+        const bool ok = ((double)lc[k] / den) >= min_af;
+        if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
+    }
+    const bool pass_af = (top >= 0 && top != chr_idx) || pass_snp || pass_indel;
+    const int up_ch[4] = {CH_A, CH_C, CH_G, CH_T}, lo_ch[4] = {CH_a, CH_c, CH_g, CH_t};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k == chr_idx) { t[up_ch[k]] = -up; t[lo_ch[k]] = -lo; }
+
+    // ---- coalesced write-out through LDS -------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) stage[wave][lane * NCH + k] = t[k];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t n_valid = (M - wave_col0 < 64 ? (M - wave_col0 > 0 ? M - wave_col0 : 0) : 64) * NCH;
+    int32_t* __restrict__ dst = counts + wave_col0 * NCH;
+    for (int k = lane; k < n_valid; k += 64) dst[k] = stage[wave][k];
+    if (live) {
+        depth_out[c] = depth;
+        uint8_t f = 0;
+        if (pass_af) f |= NSNP_FLAG_PASS_AF;
+        if (pass_snp) f |= NSNP_FLAG_PASS_SNP;
+        if (pass_indel) f |= NSNP_FLAG_PASS_INDEL;
+        if (rb < 4 && pass_af && depth >= min_cov) f |= NSNP_FLAG_CANDIDATE;
+        flags[c] = f;
+    }
+}
+
+// ---- site selection: candidate && 33 consecutive positions around it -------------------------------
+__device__ __forceinline__ bool site_ok(const int64_t* pos, const uint8_t* flags, int64_t M, int64_t c)
+{
+    if (!(flags[c] & NSNP_FLAG_CANDIDATE)) return false;
+    if (c < PCENTER || c + PCENTER >= M) return false;
+    return pos[c + PCENTER] - pos[c] == PCENTER && pos[c] - pos[c - PCENTER] == PCENTER;
+}
+
+constexpr int SEL_BLOCK = 256, SEL_PER_THREAD = 8, SEL_TILE = SEL_BLOCK * SEL_PER_THREAD;
+
+__global__ __launch_bounds__(SEL_BLOCK) void k_select_count(const int64_t* pos, const uint8_t* flags, int64_t M,
+                                                             int64_t* block_cnt)
+{
+    __shared__ int wsum[SEL_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SEL_TILE + threadIdx.x * SEL_PER_THREAD;
+    int n = 0;
+    for (int k = 0; k < SEL_PER_THREAD; ++k) { const int64_t c = base + k; if (c < M && site_ok(pos, flags, M, c)) ++n; }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < SEL_BLOCK / 64; ++w) s += wsum[w]; block_cnt[blockIdx.x] = s; }
+}
+
+// exclusive scan of the block counts by one block; also writes the total
+__global__ __launch_bounds__(1024) void k_select_scan(int64_t* block_cnt, int64_t n_blocks, int64_t* total)
+{
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = NSNP_CDIV(n_blocks, 1024);
+    const int64_t b0 = tid * per, b1 = (b0 + per < n_blocks) ? b0 + per : n_blocks;
+    int64_t s = 0;
+    for (int64_t b = b0; b < b1; ++b) s += block_cnt[b];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {     // Hillis-Steele inclusive scan
+        int64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = tid ? part[tid - 1] : 0;
+    for (int64_t b = b0; b < b1; ++b) { const int64_t v = block_cnt[b]; block_cnt[b] = run; run += v; }
+    if (tid == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(SEL_BLOCK) void k_select_scatter(const int64_t* pos, const uint8_t* flags, int64_t M,
+                                                               const int64_t* block_off, int64_t* center_idx, int64_t cap)
+{
+    __shared__ int wsum[SEL_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SEL_TILE + tid * SEL_PER_THREAD;
+    bool ok[SEL_PER_THREAD]; int n = 0;
+#pragma unroll
+    for (int k = 0; k < SEL_PER_THREAD; ++k) { const int64_t c = base + k; ok[k] = c < M && site_ok(pos, flags, M, c); n += ok[k]; }
+    int incl = n;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int64_t o = block_off[blockIdx.x] + woff + incl - n;
+#pragma unroll
+    for (int k = 0; k < SEL_PER_THREAD; ++k) if (ok[k]) { if (o < cap) center_idx[o] = base + k; ++o; }
+}
+
+__global__ void k_gather_windows(const int32_t* __restrict__ counts, const int64_t* __restrict__ center_idx, int64_t N,
+                                 int32_t* __restrict__ x)
+{
+    constexpr int W = PW * PC;   // 594 ints per site
+    const int64_t total = N * W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = e / W; const int r = (int)(e - n * W);
+        x[e] = counts[(center_idx[n] - PCENTER) * PC + r];
+    }
+}
+
+}  // namespace
+
+extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, const int64_t* col_off,
+                                          const uint8_t* ref, int64_t M, double min_af, int min_coverage,
+                                          int32_t* counts, int32_t* depth, uint8_t* flags, void* stream)
+{
+    if (!ctx || M < 0 || (M > 0 && (!bases || !col_off || !ref || !counts || !depth || !flags))) return NSNP_EINVAL;
+    if (M == 0) return NSNP_OK;
+    const unsigned grid = (unsigned)NSNP_CDIV(M, ENC_BLOCK);
+    hipLaunchKernelGGL(k_encode_columns, dim3(grid), dim3(ENC_BLOCK), 0, (hipStream_t)stream,
+                       bases, col_off, ref, M, min_af, min_coverage, counts, depth, flags);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M,
+                                        int64_t* center_idx, int64_t cap, int64_t* n_sites, void* stream)
+{
+    if (!ctx || M < 0 || cap < 0 || !n_sites || (M > 0 && (!pos || !flags)) || (cap > 0 && !center_idx)) return NSNP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) { NSNP_HIP(ctx, hipMemsetAsync(n_sites, 0, sizeof(int64_t), s)); return NSNP_OK; }
+    const int64_t n_blocks = NSNP_CDIV(M, SEL_TILE);
+    const size_t need = (size_t)n_blocks * sizeof(int64_t);
+    if (ctx->sel_tmp_bytes < need) {
+        // grows only when a larger M than ever before arrives (synchronous; size it with a warm-up call)
+        NSNP_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
+        ctx->sel_tmp = nullptr; ctx->sel_tmp_bytes = 0;
+        NSNP_HIP(ctx, hipMalloc((void**)&ctx->sel_tmp, need));
+        ctx->sel_tmp_bytes = need;
+    }
+    hipLaunchKernelGGL(k_select_count, dim3((unsigned)n_blocks), dim3(SEL_BLOCK), 0, s, pos, flags, M, ctx->sel_tmp);
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, s, ctx->sel_tmp, n_blocks, n_sites);
+    hipLaunchKernelGGL(k_select_scatter, dim3((unsigned)n_blocks), dim3(SEL_BLOCK), 0, s, pos, flags, M,
+                       (const int64_t*)ctx->sel_tmp, center_idx, cap);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_pileup_gather_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,
+                                          int64_t N, int32_t* x, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!counts || !center_idx || !x))) return NSNP_EINVAL;
+    if (N == 0) return NSNP_OK;
+    int64_t blocks = NSNP_CDIV(N * PW * PC, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_gather_windows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, counts, center_idx, N, x);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}

@@ -1,0 +1,595 @@
+// pileup_forward.hip -- PileupModel forward (2-layer BiLSTM H=64 over 33 positions + heads) as
+// fp32 MFMA kernels for gfx950.
+//
+// Replaces LSTMNetwork.predict (PileupModel/model.py:114-119): BaseEncoder.forward
+// (model.py:31-39), ForwardLayer.forward (model.py:66-73) and the two softmaxes, called from
+// PileupModel/predict.py:49-51.  Not a translation: the reference runs nn.LSTM (cuDNN) on all 33
+// steps of both layers and the dense layers on all 33 positions; here
+//
+//   K1 k_pileup_l0    layer-0 recurrence, one workgroup per (128-site tile, direction).  W_hh and
+//                     the first 16 input channels live in LDS as MFMA A-operand images (80 KB, so
+//                     two workgroups share a CU); each wave owns 16 sites and ALL 256 gate rows,
+//                     so h_t never leaves registers: the accumulator layout of
+//                     v_mfma_f32_16x16x4_f32 (lane = site + 16*q, regs = gates i,f,g,o of hidden
+//                     unit 4*tile+q) is exactly the B-operand layout of the next step.
+//   K2 k_pileup_proj1 layer-1 input projection W_ih1 . [h0_fwd(t); h0_bwd(t)] + b for the 17
+//                     steps per direction that reach position 16 (only position 16 is consumed,
+//                     model.py:68), a [N*17 x 128] x [128 x 256] GEMM with W_ih1 (128 KB) in LDS.
+//   K3 k_pileup_l1    layer-1 recurrence, 17 steps, accumulators initialised from K2's output.
+//   K4 k_pileup_head  output_proj(128->128) at t=16, tanh(dense 128->256), genotype(21) and
+//                     zygosity(3) heads, softmax; weights streamed from L2.
+//
+// All dot products are exact-fp32 MFMA (v_mfma_f32_16x16x4_f32 == a k-ordered fmaf chain);
+// sigmoid/tanh use v_exp_f32 / v_rcp_f32 (1 ulp).  Reduced schedule: 6.29 MFLOP/site executed
+// vs 12.55 MFLOP/site in the reference schedule, results identical to fp32 rounding.
+#include "nsnp_common.hpp"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sigmoid_f(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x));
+}
+__device__ __forceinline__ float tanh_f(float x)
+{
+    // 1 - 2/(1+e^{2x}); saturates cleanly to +-1 through exp2 -> inf / 0
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x));
+}
+
+// acc[NT] += W(image rows, K-steps [4*J4B, 4*(J4B+J4N))) . b, with the weight image read 16 B per
+// lane per 4 K-steps.  w points at image element [tile 0][j4 0][lane 0]; NJ4 is the image's j4
+// extent and TB the first of the NT tiles to compute (acc is indexed from 0).
+// Tiles are walked in groups of 4 so that dependent MFMAs on one accumulator are
+// 4 issue slots apart (dependent latency 40 > issue 32 cycles).
+template <int NT, int NJ4, int J4B, int J4N, int TB = 0, typename WP>
+__device__ __forceinline__ void wave_gemm(WP w, int lane, const float* b, f32x4* acc)
+{
+#pragma unroll
+    for (int j = 0; j < J4N; ++j) {
+#pragma unroll
+        for (int ig = 0; ig < NT; ig += 4) {
+            f32x4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = w[((TB + ig + u) * NJ4 + (J4B + j)) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[ig + u] = mfma4(a[u][e], b[4 * j + e], acc[ig + u]);
+            // keep hipcc from hoisting every later weight read above these MFMAs (it spills
+            // hundreds of VGPRs otherwise); latency is covered by the other waves on the SIMD
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// two-tile variant (the heads' 32 padded rows): the generic path walks tiles in groups of 4
+__device__ __forceinline__ void wave_gemm2x16(const f32x4* w, int lane, const float* b, f32x4* acc)
+{
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const f32x4 a0 = w[(0 * 16 + j) * 64 + lane], a1 = w[(1 * 16 + j) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = mfma4(a0[e], b[4 * j + e], acc[0]);
+            acc[1] = mfma4(a1[e], b[4 * j + e], acc[1]);
+        }
+    }
+}
+
+// LSTM cell update for 8 of the 16 hidden units a lane owns (one per tile)
+__device__ __forceinline__ void lstm_pointwise8(const f32x4* acc, float* c, float* h)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float ig = sigmoid_f(acc[i][0]);
+        const float fg = sigmoid_f(acc[i][1]);
+        const float gg = tanh_f(acc[i][2]);
+        const float og = sigmoid_f(acc[i][3]);
+        c[i] = fg * c[i] + ig * gg;
+        h[i] = og * tanh_f(c[i]);
+    }
+}
+
+__device__ __forceinline__ void copy_to_lds(f32x4* dst, const float* __restrict__ src, int n_f32x4,
+                                            int tid, int nthreads)
+{
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    for (int i = tid; i < n_f32x4; i += nthreads) dst[i] = s4[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: layer 0.  grid = (ceil(N/128), 2 directions), block = 512 (8 waves x 16 sites).
+// LDS: [W_hh image 64 KB][W_ih image (channels 0..15) 16 KB] = 80 KB -> 2 workgroups per CU.
+// H0 layout: [site][t][dir][q][16] fp32 = what K2 reads back with 16-byte loads.
+// ---------------------------------------------------------------------------------------------
+constexpr int L0_WHH_F4 = 16 * 4 * 64;   // f32x4 elements
+constexpr int L0_WIH_F4 = 16 * 1 * 64;
+constexpr int L0_LDS_BYTES = (L0_WHH_F4 + L0_WIH_F4) * 16;
+
+__global__ __launch_bounds__(512, 4) void k_pileup_l0(
+    const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
+    const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ wih0, const float* __restrict__ wih1,
+    const float* __restrict__ wlast0, const float* __restrict__ wlast1,
+    float* __restrict__ H0)
+{
+    extern __shared__ f32x4 lds[];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds(lds, dir ? whh1 : whh0, L0_WHH_F4, tid, 512);
+    copy_to_lds(lds + L0_WHH_F4, dir ? wih1 : wih0, L0_WIH_F4, tid, 512);
+    const float* __restrict__ wlast = dir ? wlast1 : wlast0;
+    __syncthreads();
+
+    const int64_t site = (int64_t)blockIdx.x * 128 + wave * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    // window base: gathered [N,33,18] or straight out of the per-column count matrix
+    const int32_t* __restrict__ xs = center_idx ? x + (center_idx[sc] - PCENTER) * PC
+                                                : x + sc * (PW * PC);
+    const int klast = q < 2 ? 16 + q : 16;   // lanes q=2,3 feed the bias / a zero instead
+    float* __restrict__ hout = H0 + (sc * PW * 2 + dir) * 64 + q * 16;
+
+    float c[16], h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c[i] = 0.f; h[i] = 0.f; }
+
+    int xi[5];
+    {
+        const int t0 = dir ? PW - 1 : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xi[kk] = xs[t0 * PC + 4 * kk + q];
+        xi[4] = xs[t0 * PC + klast];
+    }
+    for (int s = 0; s < PW; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        float xb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xb[kk] = (float)xi[kk];   // predict.py:49 int -> float
+        const float xl = q == 2 ? 1.0f : (q == 3 ? 0.0f : (float)xi[4]);
+        if (s + 1 < PW) {   // prefetch the next position
+            const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xi[kk] = xs[tn * PC + 4 * kk + q];
+            xi[4] = xs[tn * PC + klast];
+        }
+        // two half-passes of 8 gate tiles each keep the live accumulators at 32 registers and let
+        // the second half's MFMAs overlap the first half's sigmoid/tanh work
+        float hn[16];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hf == 0) wave_gemm<8, 1, 0, 1, 0>(lds + L0_WHH_F4, lane, xb, acc);
+            else         wave_gemm<8, 1, 0, 1, 8>(lds + L0_WHH_F4, lane, xb, acc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = mfma4(wlast[(hf * 8 + i) * 64 + lane], xl, acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s > 0) {
+                if (hf == 0) wave_gemm<8, 4, 0, 4, 0>(lds, lane, h, acc);
+                else         wave_gemm<8, 4, 0, 4, 8>(lds, lane, h, acc);
+            }
+            lstm_pointwise8(acc, c + hf * 8, hn + hf * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = hn[i];
+        if (live) {
+            f32x4* o = reinterpret_cast<f32x4*>(hout + (int64_t)t * 128);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[v] = f32x4{h[4 * v], h[4 * v + 1], h[4 * v + 2], h[4 * v + 3]};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: layer-1 input projection.  grid = (G, 2 directions) persistent, block = 1024 (16 waves).
+// LDS: [W_ih1 image 128 KB][bias image 4 KB].  Rows m = site*17 + u, u = step index of
+// direction d (t = u for fwd, 32-u for reverse).  Output Xp1[d][m][tile][q][4] is the
+// accumulator image K3 starts each step from.
+// ---------------------------------------------------------------------------------------------
+constexpr int P1_W_F4 = 16 * 8 * 64;
+constexpr int P1_B_F4 = 16 * 64;
+constexpr int P1_LDS_BYTES = (P1_W_F4 + P1_B_F4) * 16;
+
+__global__ __launch_bounds__(1024, 4) void k_pileup_proj1(
+    const float* __restrict__ H0, int64_t N,
+    const float* __restrict__ w0, const float* __restrict__ w1,
+    const float* __restrict__ b0, const float* __restrict__ b1,
+    float* __restrict__ Xp1)
+{
+    extern __shared__ f32x4 lds[];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds(lds, dir ? w1 : w0, P1_W_F4, tid, 1024);
+    copy_to_lds(lds + P1_W_F4, dir ? b1 : b0, P1_B_F4, tid, 1024);
+    __syncthreads();
+    const int64_t M = N * PSTEPS1;
+    const int64_t n_rt = NSNP_CDIV(M, 16);
+    float* __restrict__ out = Xp1 + (int64_t)dir * M * 256;
+    for (int64_t rt = (int64_t)blockIdx.x * 16 + wave; rt < n_rt; rt += (int64_t)gridDim.x * 16) {
+        const int64_t m = rt * 16 + (lane & 15);
+        const bool live = m < M;
+        const int64_t mc = live ? m : M - 1;
+        const int64_t site = mc / PSTEPS1;
+        const int u = (int)(mc - site * PSTEPS1);
+        const int t = dir ? PW - 1 - u : u;
+        const f32x4* __restrict__ hin = reinterpret_cast<const f32x4*>(H0 + (site * PW + t) * 128 + q * 16);
+        float b[32];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const f32x4 a = hin[v], bb = hin[16 + v];   // fwd half, reverse half (+64 floats)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { b[4 * v + e] = a[e]; b[16 + 4 * v + e] = bb[e]; }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(out + mc * 256 + q * 4);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = lds[P1_W_F4 + (hf * 8 + i) * 64 + lane];
+            if (hf == 0) wave_gemm<8, 8, 0, 8, 0>(lds, lane, b, acc);
+            else         wave_gemm<8, 8, 0, 8, 8>(lds, lane, b, acc);
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[(hf * 8 + i) * 4] = acc[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: layer-1 recurrence, 17 steps.  grid = (ceil(N/128), 2), block = 512.  LDS: W_hh1 image 64 KB.
+// Writes h1 at position 16 to H1c[site][dir][q][16].
+// ---------------------------------------------------------------------------------------------
+constexpr int L1_LDS_BYTES = L0_WHH_F4 * 16;
+
+__global__ __launch_bounds__(512, 4) void k_pileup_l1(
+    const float* __restrict__ Xp1, int64_t N,
+    const float* __restrict__ whh0, const float* __restrict__ whh1,
+    float* __restrict__ H1c)
+{
+    extern __shared__ f32x4 lds[];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds(lds, dir ? whh1 : whh0, L0_WHH_F4, tid, 512);
+    __syncthreads();
+    const int64_t site = (int64_t)blockIdx.x * 128 + wave * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    const int64_t M = N * PSTEPS1;
+    const f32x4* __restrict__ xin =
+        reinterpret_cast<const f32x4*>(Xp1 + ((int64_t)dir * M + sc * PSTEPS1) * 256 + q * 4);
+    float c[16], h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c[i] = 0.f; h[i] = 0.f; }
+    for (int u = 0; u < PSTEPS1; ++u) {
+        float hn[16];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = xin[(int64_t)u * 64 + (hf * 8 + i) * 4];
+            if (u > 0) {
+                if (hf == 0) wave_gemm<8, 4, 0, 4, 0>(lds, lane, h, acc);
+                else         wave_gemm<8, 4, 0, 4, 8>(lds, lane, h, acc);
+            }
+            lstm_pointwise8(acc, c + hf * 8, hn + hf * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = hn[i];
+    }
+    if (live) {
+        f32x4* o = reinterpret_cast<f32x4*>(H1c + site * 128 + dir * 64 + q * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v] = f32x4{h[4 * v], h[4 * v + 1], h[4 * v + 2], h[4 * v + 3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: heads.  block = 256 (4 waves x 16 sites), weights streamed from L2 (216 KB of images).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pileup_head(
+    const float* __restrict__ H1c, int64_t N,
+    const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+    const float* __restrict__ dense_w, const float* __restrict__ dense_b,
+    const float* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ gt_prob, float* __restrict__ zy_prob)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    const int64_t site = ((int64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    const f32x4* __restrict__ hin = reinterpret_cast<const f32x4*>(H1c + sc * 128 + q * 16);
+    float b[32];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const f32x4 a = hin[v], bb = hin[16 + v];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[4 * v + e] = a[e]; b[16 + 4 * v + e] = bb[e]; }
+    }
+    // output_proj 128 -> 128 (model.py:37)
+    f32x4 ap[8];
+    {
+        const f32x4* pb = reinterpret_cast<const f32x4*>(proj_b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ap[i] = pb[i * 64 + lane];
+        wave_gemm<8, 8, 0, 8>(reinterpret_cast<const f32x4*>(proj_w), lane, b, ap);
+    }
+    // dense 128 -> 256 + tanh (model.py:67)
+    float b2[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b2[4 * i + g] = ap[i][g];
+    f32x4 ad[16];
+    {
+        const f32x4* db = reinterpret_cast<const f32x4*>(dense_b);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ad[i] = db[i * 64 + lane];
+        wave_gemm<16, 8, 0, 8>(reinterpret_cast<const f32x4*>(dense_w), lane, b2, ad);
+    }
+    float b3[64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b3[4 * i + g] = tanh_f(ad[i][g]);
+    // genotype (rows 0..20) and zygosity (rows 21..23) heads (model.py:69-70)
+    f32x4 ah[2];
+    {
+        const f32x4* hb = reinterpret_cast<const f32x4*>(head_b);
+        ah[0] = hb[lane]; ah[1] = hb[64 + lane];
+        wave_gemm2x16(reinterpret_cast<const f32x4*>(head_w), lane, b3, ah);
+    }
+    // lane (site, q) holds rows 4q..4q+3 of tile 0 and rows 16+4q.. of tile 1.
+    // genotype rows: tile0 all 16; tile1 rows 16..19 (q=0, g=0..3) and row 20 (q=1, g=0)
+    // zygosity rows 21..23: tile1, q=1, g=1..3
+    const float NEG = -3.0e38f;
+    float g0[4], g1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        g0[g] = ah[0][g];
+        const bool is_gt = (q == 0) || (q == 1 && g == 0);
+        g1[g] = is_gt ? ah[1][g] : NEG;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3])), fmaxf(fmaxf(g1[0], g1[1]), fmaxf(g1[2], g1[3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float e0[4], e1[4], sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        e0[g] = __expf(g0[g] - mx);
+        e1[g] = g1[g] > -1.0e38f ? __expf(g1[g] - mx) : 0.f;
+        sum += e0[g] + e1[g];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    // zygosity softmax is local to lane q == 1
+    const float z1 = ah[1][1], z2 = ah[1][2], z3 = ah[1][3];
+    const float zm = fmaxf(z1, fmaxf(z2, z3));
+    const float ez1 = __expf(z1 - zm), ez2 = __expf(z2 - zm), ez3 = __expf(z3 - zm);
+    const float zs = ez1 + ez2 + ez3;
+    if (live) {
+        float* gp = gt_prob + site * NSNP_GT_CLASSES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gp[4 * q + g] = e0[g] / sum;
+        if (q == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gp[16 + g] = e1[g] / sum;
+        }
+        if (q == 1) {
+            gp[20] = e1[0] / sum;
+            float* zp = zy_prob + site * NSNP_ZY_CLASSES;
+            zp[0] = ez1 / zs; zp[1] = ez2 / zs; zp[2] = ez3 / zs;
+        }
+    }
+}
+
+// ---- postprocess: predict.py:54-65 --------------------------------------------------------------
+__global__ void k_pileup_post(const float* __restrict__ gt, const float* __restrict__ zy,
+                              const int32_t* __restrict__ x, int64_t N, uint8_t* gt_arg, uint8_t* zy_arg,
+                              float* gt_max, float* zy_max, int32_t* depth)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* g = gt + n * NSNP_GT_CLASSES;
+    int bi = 0; float bv = g[0];
+    for (int i = 1; i < NSNP_GT_CLASSES; ++i) if (g[i] > bv) { bv = g[i]; bi = i; }   // first max, as np.argmax
+    gt_arg[n] = (uint8_t)bi; gt_max[n] = bv;
+    const float* z = zy + n * NSNP_ZY_CLASSES;
+    bi = 0; bv = z[0];
+    for (int i = 1; i < NSNP_ZY_CLASSES; ++i) if (z[i] > bv) { bv = z[i]; bi = i; }
+    zy_arg[n] = (uint8_t)bi; zy_max[n] = bv;
+    if (depth) {
+        const int32_t* c = x + n * (PW * PC) + PCENTER * PC;
+        const int idx[8] = {0, 1, 2, 3, 9, 10, 11, 12};
+        int d = 0;
+        for (int k = 0; k < 8; ++k) { const int v = c[idx[k]]; if (v < 0) d -= v; }
+        depth[n] = d;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side: weight packing
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+inline int gate_row(int row)   // accumulator row -> torch gate-major row (H = 64)
+{
+    const int i = row >> 4, r = row & 15, qp = r >> 2, g = r & 3;
+    return g * PH + 4 * i + qp;
+}
+struct MatRef { const float* w; int ld; const float* b0; const float* b1; };
+
+float f_whh(const void* u, int row, int k) { const MatRef* m = (const MatRef*)u; return m->w[gate_row(row) * m->ld + k]; }
+float f_wih0(const void* u, int row, int k) { const MatRef* m = (const MatRef*)u; return m->w[gate_row(row) * m->ld + k]; }
+// K index in H0 / H1c storage order: k = 4*j + q, j = dir*16 + i  ->  feature dir*64 + 4*i + q
+inline int h_store_col(int k) { const int j = k >> 2, q = k & 3; return (j >> 4) * 64 + 4 * (j & 15) + q; }
+float f_wih1(const void* u, int row, int k) { const MatRef* m = (const MatRef*)u; return m->w[gate_row(row) * m->ld + h_store_col(k)]; }
+float f_proj(const void* u, int row, int k) { const MatRef* m = (const MatRef*)u; return m->w[row * m->ld + h_store_col(k)]; }
+// K index in accumulator order of the previous layer: k = 4*j + q, j = 4*i + g -> feature 16*i + 4*q + g
+inline int acc_col(int k) { const int j = k >> 2, q = k & 3; return 16 * (j >> 2) + 4 * q + (j & 3); }
+float f_dense(const void* u, int row, int k) { const MatRef* m = (const MatRef*)u; return m->w[row * m->ld + acc_col(k)]; }
+struct HeadRef { const float* gt; const float* zy; };
+float f_head(const void* u, int row, int k)
+{
+    const HeadRef* m = (const HeadRef*)u;
+    if (row < 21) return m->gt[row * 256 + acc_col(k)];
+    if (row < 24) return m->zy[(row - 21) * 256 + acc_col(k)];
+    return 0.f;
+}
+
+}  // namespace
+
+void nsnp_pack_image(float* img, int n_tiles, int n_j4, nsnp_wfun f, const void* user)
+{
+    for (int tile = 0; tile < n_tiles; ++tile)
+        for (int j4 = 0; j4 < n_j4; ++j4)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * tile + (lane & 15);
+                    const int k = 4 * (4 * j4 + e) + (lane >> 4);
+                    img[(((size_t)tile * n_j4 + j4) * 64 + lane) * 4 + e] = f(user, row, k);
+                }
+}
+
+int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w)
+{
+    PileupWeightsDev& pw = ctx->pw;
+    // arena layout (floats)
+    const size_t n_whh = 16 * 4 * 256, n_wih0 = 16 * 1 * 256, n_wlast = 16 * 64, n_wih1 = 16 * 8 * 256,
+                 n_b1 = 16 * 256, n_proj = 8 * 8 * 256, n_pb = 8 * 256, n_dense = 16 * 8 * 256, n_db = 16 * 256,
+                 n_head = 2 * 16 * 256, n_hb = 2 * 256;
+    const size_t total = 2 * (n_whh + n_wih0 + n_wlast + n_wih1 + n_b1 + n_whh) + n_proj + n_pb + n_dense + n_db + n_head + n_hb;
+    std::vector<float> host(total);
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = host.data() + off; off += n; return p; };
+    float* h_l0_whh[2]; float* h_l0_wih[2]; float* h_l0_wlast[2]; float* h_l1_wih[2]; float* h_l1_b[2]; float* h_l1_whh[2];
+    for (int d = 0; d < 2; ++d) {
+        h_l0_whh[d] = take(n_whh); h_l0_wih[d] = take(n_wih0); h_l0_wlast[d] = take(n_wlast);
+        h_l1_wih[d] = take(n_wih1); h_l1_b[d] = take(n_b1); h_l1_whh[d] = take(n_whh);
+    }
+    float* h_proj = take(n_proj); float* h_pb = take(n_pb); float* h_dense = take(n_dense); float* h_db = take(n_db);
+    float* h_head = take(n_head); float* h_hb = take(n_hb);
+
+    for (int d = 0; d < 2; ++d) {
+        const float* const* l0 = w + d * 4;        // w_ih, w_hh, b_ih, b_hh
+        const float* const* l1 = w + 8 + d * 4;
+        MatRef m;
+        m = MatRef{l0[1], PH, nullptr, nullptr};  nsnp_pack_image(h_l0_whh[d], 16, 4, f_whh, &m);
+        m = MatRef{l0[0], PC, nullptr, nullptr};  nsnp_pack_image(h_l0_wih[d], 16, 1, f_wih0, &m);
+        for (int tile = 0; tile < 16; ++tile)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int tr = gate_row(16 * tile + (lane & 15)), kq = lane >> 4;
+                float v = 0.f;
+                if (kq < 2) v = l0[0][tr * PC + 16 + kq];
+                else if (kq == 2) v = l0[2][tr] + l0[3][tr];   // b_ih + b_hh rides on a constant-1 input
+                h_l0_wlast[d][tile * 64 + lane] = v;
+            }
+        m = MatRef{l1[0], 2 * PH, nullptr, nullptr};  nsnp_pack_image(h_l1_wih[d], 16, 8, f_wih1, &m);
+        for (int tile = 0; tile < 16; ++tile)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int g = 0; g < 4; ++g) {
+                    const int tr = gate_row(16 * tile + 4 * (lane >> 4) + g);
+                    h_l1_b[d][(tile * 64 + lane) * 4 + g] = l1[2][tr] + l1[3][tr];
+                }
+        m = MatRef{l1[1], PH, nullptr, nullptr};  nsnp_pack_image(h_l1_whh[d], 16, 4, f_whh, &m);
+    }
+    {
+        MatRef m{w[16], 128, nullptr, nullptr};  nsnp_pack_image(h_proj, 8, 8, f_proj, &m);
+        for (int tile = 0; tile < 8; ++tile) for (int lane = 0; lane < 64; ++lane) for (int g = 0; g < 4; ++g)
+            h_pb[(tile * 64 + lane) * 4 + g] = w[17][16 * tile + 4 * (lane >> 4) + g];
+        MatRef md{w[18], 128, nullptr, nullptr}; nsnp_pack_image(h_dense, 16, 8, f_dense, &md);
+        for (int tile = 0; tile < 16; ++tile) for (int lane = 0; lane < 64; ++lane) for (int g = 0; g < 4; ++g)
+            h_db[(tile * 64 + lane) * 4 + g] = w[19][16 * tile + 4 * (lane >> 4) + g];
+        HeadRef hr{w[20], w[22]};  nsnp_pack_image(h_head, 2, 16, f_head, &hr);
+        for (int tile = 0; tile < 2; ++tile) for (int lane = 0; lane < 64; ++lane) for (int g = 0; g < 4; ++g) {
+            const int row = 16 * tile + 4 * (lane >> 4) + g;
+            h_hb[(tile * 64 + lane) * 4 + g] = row < 21 ? w[21][row] : (row < 24 ? w[23][row - 21] : 0.f);
+        }
+    }
+    if (pw.arena && pw.arena_bytes != total * sizeof(float)) { (void)hipFree(pw.arena); pw.arena = nullptr; }
+    if (!pw.arena) {
+        NSNP_HIP(ctx, hipMalloc((void**)&pw.arena, total * sizeof(float)));
+        pw.arena_bytes = total * sizeof(float);
+    }
+    NSNP_HIP(ctx, hipMemcpy(pw.arena, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    auto dev = [&](const float* hp) { return pw.arena + (hp - host.data()); };
+    for (int d = 0; d < 2; ++d) {
+        pw.l0_whh[d] = dev(h_l0_whh[d]); pw.l0_wih[d] = dev(h_l0_wih[d]); pw.l0_wlast[d] = dev(h_l0_wlast[d]);
+        pw.l1_wih[d] = dev(h_l1_wih[d]); pw.l1_bias[d] = dev(h_l1_b[d]); pw.l1_whh[d] = dev(h_l1_whh[d]);
+    }
+    pw.proj_w = dev(h_proj); pw.proj_b = dev(h_pb); pw.dense_w = dev(h_dense); pw.dense_b = dev(h_db);
+    pw.head_w = dev(h_head); pw.head_b = dev(h_hb);
+    pw.loaded = true;
+    return NSNP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------
+static int set_lds_attr_once(nsnp_ctx* ctx)
+{
+    if (ctx->attr_set) return NSNP_OK;
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l0, hipFuncAttributeMaxDynamicSharedMemorySize, L0_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_proj1, hipFuncAttributeMaxDynamicSharedMemorySize, P1_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+    ctx->attr_set = true;
+    return NSNP_OK;
+}
+
+int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
+                             int64_t N, float* gt, float* zy, hipStream_t s)
+{
+    if (!ctx->pw.loaded) return NSNP_ENOWEIGHTS;
+    if (N == 0) return NSNP_OK;
+    int rc = set_lds_attr_once(ctx);
+    if (rc) return rc;
+    if (!ctx->ws_h0) { rc = nsnp_ctx_reserve(ctx, ctx->chunk_sites); if (rc) return rc; }
+    const PileupWeightsDev& pw = ctx->pw;
+    for (int64_t base = 0; base < N; base += ctx->chunk_sites) {
+        const int64_t n = (N - base < ctx->chunk_sites) ? N - base : ctx->chunk_sites;
+        const int32_t* xc = center_idx ? x : x + base * (PW * PC);
+        const int64_t* cc = center_idx ? center_idx + base : nullptr;
+        const dim3 g_rec((unsigned)NSNP_CDIV(n, 128), 2);
+        hipLaunchKernelGGL(k_pileup_l0, g_rec, dim3(512), L0_LDS_BYTES, s, xc, cc, n,
+                           pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1],
+                           ctx->ws_h0);
+        const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
+        int64_t gp = NSNP_CDIV(n_rt, 16);
+        if (gp > ctx->n_cu) gp = ctx->n_cu;
+        hipLaunchKernelGGL(k_pileup_proj1, dim3((unsigned)gp, 2), dim3(1024), P1_LDS_BYTES, s, ctx->ws_h0, n,
+                           pw.l1_wih[0], pw.l1_wih[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_xp1);
+        hipLaunchKernelGGL(k_pileup_l1, g_rec, dim3(512), L1_LDS_BYTES, s, ctx->ws_xp1, n,
+                           pw.l1_whh[0], pw.l1_whh[1], ctx->ws_h1c);
+        hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,
+                           pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,
+                           gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);
+    }
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_pileup_postprocess(nsnp_ctx* ctx, const float* gt_prob, const float* zy_prob,
+                                       const int32_t* x, int64_t N, uint8_t* gt_arg, uint8_t* zy_arg,
+                                       float* gt_max, float* zy_max, int32_t* depth, void* stream)
+{
+    if (!ctx || N < 0 || !gt_prob || !zy_prob || !gt_arg || !zy_arg || !gt_max || !zy_max || (depth && !x)) return NSNP_EINVAL;
+    if (N == 0) return NSNP_OK;
+    hipLaunchKernelGGL(k_pileup_post, dim3((unsigned)NSNP_CDIV(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gt_prob, zy_prob, x, N, gt_arg, zy_arg, gt_max, zy_max, depth);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}

@@ -1,0 +1,153 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py import this
+module (see oracle/oracle.h).  The product package ``nanosnp_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+NCH = 18
+
+
+def build(force=False):
+    """(Re)build liboracle.so (and oracle/_ref when the reference tree is mounted)."""
+    if force or not os.path.exists(_LIB):
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+
+
+def _load():
+    build()
+    lib = C.CDLL(_LIB)
+    p = C.c_void_p
+    lib.orc_encode_columns.restype = None
+    lib.orc_encode_columns.argtypes = [p, p, p, C.c_int64, C.c_double, C.c_int, p, p, p]
+    lib.orc_select_sites.restype = C.c_int64
+    lib.orc_select_sites.argtypes = [p, p, C.c_int64, C.c_int, p, C.c_int64]
+    lib.orc_gather_windows.restype = None
+    lib.orc_gather_windows.argtypes = [p, p, C.c_int64, C.c_int, p]
+    lib.orc_mpileup_to_pd.restype = C.c_int64
+    lib.orc_mpileup_to_pd.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_double, C.c_int,
+                                      C.c_int, C.c_char_p]
+    lib.orc_pileup_forward.restype = None
+    lib.orc_pileup_forward.argtypes = [p, p, C.c_int64, p, p, C.c_int]
+    lib.orc_hap_features_batch.restype = None
+    lib.orc_hap_features_batch.argtypes = [p, p, p, p, p, C.c_int64, C.c_int, C.c_int, p, C.c_int]
+    lib.orc_hap_features.restype = None
+    lib.orc_hap_features.argtypes = [p, p, p, p, p, C.c_int, C.c_int, p]
+    lib.orc_hap_forward.restype = None
+    lib.orc_hap_forward.argtypes = [p, p, p, C.c_int64] + [C.c_int] * 7 + [p, p, C.c_int]
+    lib.orc_calculate_score.restype = C.c_double
+    lib.orc_calculate_score.argtypes = [C.c_double]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def encode_columns(bases, col_off, ref, min_af=0.12, min_coverage=6):
+    bases = _c(bases, np.uint8); col_off = _c(col_off, np.int64); ref = _c(ref, np.uint8)
+    M = ref.shape[0]
+    counts = np.empty((M, NCH), np.int32); depth = np.empty(M, np.int32); flags = np.empty(M, np.uint8)
+    if bases.size == 0:
+        bases = np.zeros(1, np.uint8)
+    lib().orc_encode_columns(_p(bases), _p(col_off), _p(ref), M, min_af, min_coverage,
+                             _p(counts), _p(depth), _p(flags))
+    return counts, depth, flags
+
+
+def select_sites(pos, flags, flank=16):
+    pos = _c(pos, np.int64); flags = _c(flags, np.uint8)
+    M = pos.shape[0]
+    out = np.empty(max(M, 1), np.int64)
+    n = lib().orc_select_sites(_p(pos), _p(flags), M, flank, _p(out), M)
+    return out[:n].copy()
+
+
+def gather_windows(counts, center_idx, flank=16):
+    counts = _c(counts, np.int32); center_idx = _c(center_idx, np.int64)
+    N = center_idx.shape[0]
+    x = np.empty((N, 2 * flank + 1, NCH), np.int32)
+    if N:
+        lib().orc_gather_windows(_p(counts), _p(center_idx), N, flank, _p(x))
+    return x
+
+
+def mpileup_to_pd(mpileup_path, chr_seq: bytes, pd_path, min_af=0.12, min_coverage=6, flank=16):
+    n = lib().orc_mpileup_to_pd(os.fsencode(mpileup_path), chr_seq, len(chr_seq), min_af,
+                                min_coverage, flank, os.fsencode(pd_path))
+    if n < 0:
+        raise RuntimeError(f"orc_mpileup_to_pd failed: {n}")
+    return n
+
+
+def _wptrs(weights):
+    ws = [_c(w, np.float32) for w in weights]
+    arr = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    return ws, arr
+
+
+def pileup_forward(weights, x, nthreads=1):
+    """weights: the 24 fp32 arrays of ont_pileup.chkpt in state-dict order."""
+    ws, arr = _wptrs(weights)
+    x = _c(x, np.int32)
+    N = x.shape[0]
+    gt = np.empty((N, 21), np.float32); zy = np.empty((N, 3), np.float32)
+    lib().orc_pileup_forward(arr, _p(x), N, _p(gt), _p(zy), nthreads)
+    return gt, zy
+
+
+def hap_features(seq, bq, mq, hap, ref_row):
+    """One site, float64 [105, L] -- the exact counterpart of get_frequency_feature + ref row."""
+    seq = _c(seq, np.int32); bq = _c(bq, np.int32); mq = _c(mq, np.int32); hap = _c(hap, np.int32)
+    ref_row = _c(ref_row, np.int32)
+    D, L = seq.shape
+    out = np.empty((105, L), np.float64)
+    lib().orc_hap_features(_p(seq), _p(bq), _p(mq), _p(hap), _p(ref_row), D, L, _p(out))
+    return out
+
+
+def hap_features_batch(seq, bq, mq, hap, ref_row, nthreads=1):
+    seq = _c(seq, np.int32); bq = _c(bq, np.int32); mq = _c(mq, np.int32); hap = _c(hap, np.int32)
+    ref_row = _c(ref_row, np.int32)
+    N, D, L = seq.shape
+    out = np.empty((N, 105, L), np.float32)
+    lib().orc_hap_features_batch(_p(seq), _p(bq), _p(mq), _p(hap), _p(ref_row), N, D, L, _p(out),
+                                 nthreads)
+    return out
+
+
+def hap_forward(weights, xp, xh, H=256, n_layers=3, n_gt=10, n_zy=3, nthreads=1):
+    ws, arr = _wptrs(weights)
+    xp = _c(xp, np.float32); xh = _c(xh, np.float32)
+    N, F, Lp = xp.shape
+    Lh = xh.shape[2]
+    gt = np.empty((N, n_gt), np.float32); zy = np.empty((N, n_zy), np.float32)
+    lib().orc_hap_forward(arr, _p(xp), _p(xh), N, F, H, n_layers, Lp, Lh, n_gt, n_zy,
+                          _p(gt), _p(zy), nthreads)
+    return gt, zy
+
+
+def calculate_score(p):
+    return lib().orc_calculate_score(float(p))

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE ITSELF.
+
+Runs only in the development container, where the upstream tree is mounted read-only at
+/root/reference; the fixtures it writes are data (inputs + expected outputs) and are what the
+tests on the GPU box compare against -- the reference does not travel.
+
+    python tools/make_golden.py            # all fixtures
+    python tools/make_golden.py pileup     # one group: encode | pileup | hapfeat | hapfwd
+
+Groups (each runs in its own interpreter: the reference's two model packages both define
+top-level modules named model/optim/utils/options):
+  encode   oracle/_ref (the reference's dna_sv_tensor programs compiled from the reference
+           tree) on synthetic + adversarial mpileup text  -> encode_*.{mpileup,fa,pd}.gz
+  pileup   PileupModel/model.py LSTMNetwork.predict with the shipped ont_pileup.chkpt
+           (CPU torch)                                    -> ont_pileup_weights.npz, pileup_fwd.npz
+  hapfeat  HaplotypeModel/dataset_dev.get_frequency_feature -> hap_features.npz
+  hapfwd   HaplotypeModel/model_dev.LSTMNetwork.predict with seeded weights
+           (trained weights are absent upstream)          -> hap_fwd_h32.npz, hap_fwd_h256.npz
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("NANOSNP_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _stub_modules():
+    for name, attrs in (("ranger", {"Ranger": object}), ("ranger21", {"Ranger21": object}),
+                        ("tables", {"Filters": lambda **k: None}), ("pysam", {})):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+
+# ------------------------------------------------------------------------------------------
+def run_ref_encode(workdir, contig, fasta, mpileup_bytes):
+    """DNA_CreateCanSnpTensor + DNA_CreatePredictData with the flags of
+    make_predict_data.sh:184-194,210-215; returns the .pd bytes."""
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    pile = os.path.join(workdir, "pile"); os.makedirs(pile, exist_ok=True)
+    with open(os.path.join(pile, contig + ".mpileup"), "wb") as f:
+        f.write(mpileup_bytes)
+    subprocess.run([os.path.join(refdir, "DNA_CreateCanSnpTensor"), "-reference", fasta,
+                    "-chr_pileup_dir", pile, "-output_dir", os.path.join(workdir, "tensor"),
+                    "-min_af", "0.12", "-snp_min_af", "0.12", "-indel_min_af", "0.12",
+                    "-min_coverage", "6", "-flanking_base", "16", "-num_threads", "1", contig],
+                   check=True, capture_output=True)
+    subprocess.run([os.path.join(refdir, "DNA_CreatePredictData"), "-chr_tensor_dir",
+                    os.path.join(workdir, "tensor"), "-reference", fasta, "-output_dir",
+                    os.path.join(workdir, "pd"), "-num_threads", "1", contig],
+                   check=True, capture_output=True)
+    with open(os.path.join(workdir, "pd", contig + ".pd"), "rb") as f:
+        return f.read()
+
+
+def adversarial_columns(rng, n_cols, ref_seq):
+    """Columns that exercise every branch of tensor_maker.cpp:83-114,127-188: long indels
+    (> 60 are skipped but not counted), multi-digit lengths, '^' swallowing a base-like
+    quality char, '$', N/n reads, '*'/'#', mixed-case duplicates of one allele, very deep
+    and very shallow columns, digits-free '+'."""
+    cols = []
+    up, lo = "ACGT", "acgt"
+    for c in range(n_cols):
+        kind = rng.integers(0, 10)
+        depth = int(rng.choice([1, 2, 5, 6, 7, 30, 60, 144, 200]))
+        r = chr(ref_seq[c]).upper()
+        ri = up.find(r) if r in up else 0
+        parts = []
+        for _ in range(depth):
+            rev = rng.random() < 0.5
+            tab = lo if rev else up
+            s = ""
+            if rng.random() < 0.05:
+                s += "^" + rng.choice(list("ACGT+-*#I!~0"))   # the char after ^ is a quality
+            u = rng.random()
+            if kind == 0 and u < 0.5:
+                s += tab[(ri + 1) % 4]
+            elif kind == 1 and u < 0.9:
+                s += tab[(ri + 2) % 4]
+            elif u < 0.06:
+                s += "#" if rev else "*"
+            elif u < 0.10:
+                s += "n" if rev else "N"
+            elif u < 0.16:
+                s += tab[int(rng.integers(0, 4))]
+            else:
+                s += tab[ri]
+            v = rng.random()
+            p_indel = 0.5 if kind in (2, 3) else 0.05
+            if v < p_indel:
+                sign = "+" if (kind == 2 or (kind != 3 and rng.random() < 0.5)) else "-"
+                L = int(rng.choice([1, 1, 1, 2, 2, 3, 9, 10, 11, 59, 60, 61, 75]))
+                if kind in (2, 3) and rng.random() < 0.7:
+                    seq = ("AC" * 40)[:L] if rng.random() < 0.6 else ("AG" * 40)[:L]
+                else:
+                    seq = "".join(rng.choice(list(up + "N"), L))
+                seq = seq.lower() if rev else seq
+                if rng.random() < 0.1:   # mixed-case duplicate of the same allele
+                    seq = seq.swapcase() if len(seq) > 1 else seq
+                s += f"{sign}{L}{seq}"
+            if rng.random() < 0.05:
+                s += "$"
+            parts.append(s)
+        cols.append("".join(parts))
+    return cols
+
+
+def group_encode():
+    from nanosnp_amd import host
+    os.makedirs(GOLD, exist_ok=True)
+    # (a) G1 synthetic contig with lower-case / N reference bases and position gaps
+    M = 6000
+    cols = host.synth_columns(20260000, M, coverage=30)
+    rng = np.random.default_rng(7)
+    seq = np.concatenate([cols.ref, np.frombuffer(b"ACGT" * 25, np.uint8)]).copy()
+    low = rng.random(seq.size) < 0.05
+    seq[low] |= 0x20
+    seq[rng.random(seq.size) < 0.003] = ord("N")
+    seq[rng.random(seq.size) < 0.001] = ord("n")
+    keep = np.ones(M, bool)
+    for g in rng.integers(100, M - 100, 8):
+        keep[g:g + int(rng.integers(1, 4))] = False
+    lines = cols.mpileup_text("chrS").split(b"\n")[:-1]
+    text_a = b"\n".join(l for i, l in enumerate(lines) if keep[i]) + b"\n"
+    # (b) adversarial contig
+    M2 = 1500
+    seq2 = rng.choice(list(b"ACGTacgtN"), M2 + 100,
+                      p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
+    acols = adversarial_columns(rng, M2, seq2)
+    text_b = b"".join(b"chrT\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c.encode(), b"I")
+                      for i, c in enumerate(acols) if c)
+    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b)):
+        with tempfile.TemporaryDirectory() as d:
+            fa = os.path.join(d, "ref.fa")
+            host.write_fasta(fa, contig, sq)
+            pd = run_ref_encode(d, contig, fa, text)
+            fa_bytes = open(fa, "rb").read()
+        for name, data in ((f"encode_{tag}.mpileup.gz", text), (f"encode_{tag}.fa.gz", fa_bytes),
+                           (f"encode_{tag}.pd.gz", pd)):
+            with gzip.GzipFile(os.path.join(GOLD, name), "wb", mtime=0) as f:
+                f.write(data)
+        print(f"encode_{tag}: {text.count(10)} columns -> {pd.count(10)} sites")
+
+
+# ------------------------------------------------------------------------------------------
+def group_pileup():
+    import torch
+    import yaml
+    from oracle import oracle
+    from nanosnp_amd import host
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "PileupModel"))
+    from model import LSTMNetwork          # noqa: E402  (reference module)
+    from utils import AttrDict             # noqa: E402
+    cfg = AttrDict(yaml.load(open(os.path.join(REF, "PileupModel/config/ont_pileup.yaml")),
+                             Loader=yaml.FullLoader))
+    m = LSTMNetwork(cfg.model)
+    ck = torch.load(os.path.join(REF, "PileupModel/models/ont_pileup.chkpt"), map_location="cpu",
+                    weights_only=False)
+    m.encoder.load_state_dict(ck["encoder"])
+    m.forward_layer.load_state_dict(ck["forward_layer"])
+    m.eval()
+    w = {}
+    for k, v in ck["encoder"].items():
+        w["encoder." + k] = v.numpy().astype(np.float32)
+    for k, v in ck["forward_layer"].items():
+        w["forward_layer." + k] = v.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "ont_pileup_weights.npz"), **w)
+
+    # inputs: G2 windows (seed 20260001) encoded by the oracle + hand-made edge windows
+    N = 224
+    cols = host.synth_columns(20260001, N * 33, coverage=30, window=33)
+    counts, depth, flags = oracle.encode_columns(cols.bases, cols.col_off, cols.ref)
+    x = counts.reshape(N, 33, 18)
+    rng = np.random.default_rng(3)
+    edge = np.zeros((32, 33, 18), np.int32)
+    edge[1] = 144
+    edge[2] = -144
+    edge[3, 16, :] = rng.integers(-144, 145, 18)
+    edge[4:16] = rng.integers(-60, 61, (12, 33, 18))
+    edge[16:32] = rng.integers(0, 8, (16, 33, 18)) * (rng.random((16, 33, 18)) < 0.2)
+    x = np.concatenate([x, edge]).astype(np.int32)
+    with torch.no_grad():
+        gt, zy = m.predict(torch.from_numpy(x).type(torch.FloatTensor))   # predict.py:49-51
+    np.savez_compressed(os.path.join(GOLD, "pileup_fwd.npz"), x=x.astype(np.int16),
+                        gt=gt.numpy(), zy=zy.numpy())
+    print("pileup_fwd:", x.shape, "gt argmax histogram", np.bincount(gt.numpy().argmax(1), minlength=21))
+
+
+# ------------------------------------------------------------------------------------------
+def group_hapfeat():
+    from nanosnp_amd import host
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    import dataset_dev                       # noqa: E402  (reference module)
+    out = {}
+    for tag, L in (("p", 33), ("h", 11)):
+        seq, bq, mq, hap, ref_row = host.synth_hap_planes(20260002 + L, 12, coverage=30, depth=90, length=L)
+        # edge sites: empty site, HP1 missing, single read, padded rows only at the end, all deletions
+        seq[0], bq[0], mq[0], hap[0] = -2, -2, -2, -2
+        hap[1][hap[1] == 1] = 3
+        seq[2, 1:], bq[2, 1:], mq[2, 1:], hap[2, 1:] = -2, -2, -2, -2
+        seq[3][seq[3] > 0] = -1; bq[3][seq[3] == -1] = 0
+        feats = np.stack([dataset_dev.get_frequency_feature(seq[i], bq[i], mq[i], hap[i])
+                          for i in range(seq.shape[0])])
+        assert feats.shape == (12, 104, L) and feats.dtype == np.float64
+        out.update({f"{tag}_seq": seq.astype(np.int8), f"{tag}_bq": bq.astype(np.int8),
+                    f"{tag}_mq": mq.astype(np.int8), f"{tag}_hap": hap.astype(np.int8),
+                    f"{tag}_ref": ref_row.astype(np.int8), f"{tag}_feat": feats})
+    np.savez_compressed(os.path.join(GOLD, "hap_features.npz"), **out)
+    print("hap_features: ok")
+
+
+def group_hapfwd():
+    import torch
+    from nanosnp_amd import host
+    from oracle import oracle
+    from tests.helpers import hap_weight_names, seeded_hap_weights
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    from model_dev import LSTMNetwork       # noqa: E402  (reference module)
+    from utils import AttrDict              # noqa: E402
+    for H, N, seed in ((32, 24, 11), (256, 8, 12)):
+        cfg = AttrDict({"model": {"pileup_dim": 105, "haplotype_dim": 105, "pileup_length": 33,
+                                  "haplotype_length": 11, "hidden_size": H, "lstm_layers": 3,
+                                  "gt_num_class": 10, "zy_num_class": 3, "dropout": 0.1}})
+        m = LSTMNetwork(cfg)
+        ws = seeded_hap_weights(seed, H=H)
+        sd = {k: torch.from_numpy(w) for k, w in zip(hap_weight_names(), ws)}
+        missing = m.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all("crit" in k for k in missing.missing_keys), missing
+        m.eval()
+        planes_p = host.synth_hap_planes(100 + seed, N, 30, 90, 33)
+        planes_h = host.synth_hap_planes(200 + seed, N, 30, 90, 11)
+        xp = oracle.hap_features_batch(*planes_p)     # oracle features are pinned by hapfeat
+        xh = oracle.hap_features_batch(*planes_h)
+        with torch.no_grad():
+            gt, zy = m.predict(torch.from_numpy(xp), torch.from_numpy(xh))   # predict_dev.py:35-39
+        np.savez_compressed(os.path.join(GOLD, f"hap_fwd_h{H}.npz"), xp=xp, xh=xh,
+                            gt=gt.numpy(), zy=zy.numpy(), seed=seed)
+        print(f"hap_fwd_h{H}: gt argmax", gt.numpy().argmax(1))
+
+
+GROUPS = {"encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
+          "hapfwd": group_hapfwd}
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit(f"{REF} is not mounted: goldens can only be generated in the development container")
+    which = sys.argv[1:] or list(GROUPS)
+    if len(which) == 1:
+        GROUPS[which[0]]()
+    else:
+        for g in which:
+            subprocess.run([sys.executable, os.path.abspath(__file__), g], check=True)
