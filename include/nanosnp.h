@@ -57,7 +57,8 @@ typedef struct nsnp_ctx nsnp_ctx;
 
 int         nsnp_version(void);
 const char* nsnp_strerror(int code);
-/* last hipError_t seen by this context (0 = hipSuccess) and its text */
+/* last hipError_t seen by this context (0 = hipSuccess) and its text; ctx == NULL reports the
+ * error of the last failed nsnp_ctx_create */
 int         nsnp_last_hip_error(const nsnp_ctx* ctx, const char** text);
 
 /* Creates a context on `device` (must be gfx950).  Allocates no workspace yet. */
@@ -67,6 +68,14 @@ int nsnp_ctx_destroy(nsnp_ctx* ctx);
  * processed in chunks.  Synchronous; call before the first forward to keep allocation out of
  * the hot loop (and out of hipGraph capture). */
 int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
+
+/* Optional per-kernel timing: when enabled every launch of the kernels below is bracketed by a
+ * HIP event pair recorded on the launch stream (up to 8192 launches per kernel between reads).
+ * nsnp_ctx_read_timing waits for the recorded events, returns their summed duration and count
+ * for kernel id (0 layer-0 recurrence, 1 layer-1 projection, 2 layer-1 recurrence, 3 heads,
+ * 4 column encode, 5 haplotype features) and resets the counter.  Synchronous. */
+int nsnp_ctx_enable_timing(nsnp_ctx* ctx, int enable);
+int nsnp_ctx_read_timing(nsnp_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
 
 /* ---- PileupModel ---------------------------------------------------------------------- */
 /* host_tensors: the 24 fp32 tensors LSTMNetwork.predict uses, HOST pointers, in the

@@ -1,0 +1,16 @@
+"""nanosnp_amd -- MI355X (gfx950) implementation of NanoSNP's candidate-site inference hot path.
+
+The compute path is the HIP library behind include/nanosnp.h (``nanosnp_amd/_lib.py`` binds it);
+this package holds only the host-side mirror of the reference's interface for that path:
+
+    pileup_model.LSTMNetwork     PileupModel/model.py LSTMNetwork (predict only)
+    haplotype_model.LSTMNetwork  HaplotypeModel/model_dev.py LSTMNetwork (predict only)
+    encode                       dna_sv_tensor make_candidate_snp_tensor + make_predict_data
+    predict                      PileupModel/predict.py / HaplotypeModel/predict_dev.py loops
+    dist                         static site sharding over the GPUs of a node + result gather
+    host                         native readers / synthetic generators (libnanosnp_host.so)
+
+There is no CPU fallback: without the built extension and a gfx950 device every compute entry
+point raises.  The CPU restatement under ``oracle/`` is test infrastructure only.
+"""
+__version__ = "0.1.0"

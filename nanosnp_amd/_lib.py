@@ -25,6 +25,8 @@ _SIGNATURES = {
     "nsnp_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "nsnp_ctx_destroy": (C.c_int, [C.c_void_p]),
     "nsnp_ctx_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "nsnp_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "nsnp_ctx_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nsnp_pileup_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "nsnp_pileup_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -59,6 +61,11 @@ def load():
         raise NanoSNPError(
             f"{LIB_PATH} not found. The HIP extension is required (there is no CPU fallback): "
             "build it with `make -C nanosnp_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7).  It has to be the
+    # HIP runtime of this process, so it is loaded first; libnanosnp_hip.so's NEEDED entry then
+    # resolves to it by soname.  Loading /opt/rocm's copy first would leave two HIP runtimes in one
+    # process and every call from the second one fails.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch
@@ -72,7 +79,7 @@ def check(rc, ctx=None, what=""):
         return
     lib = load()
     msg = lib.nsnp_strerror(rc).decode()
-    if rc == -3 and ctx is not None:
+    if rc == -3:
         txt = C.c_char_p()
         code = lib.nsnp_last_hip_error(ctx, C.byref(txt))
         msg += f" (hipError {code}: {txt.value.decode() if txt.value else '?'})"
@@ -107,6 +114,21 @@ class Context:
 
     def reserve(self, max_sites):
         check(self.lib.nsnp_ctx_reserve(self.handle, int(max_sites)), self.handle, "nsnp_ctx_reserve")
+
+    KERNELS = ("pileup_l0", "pileup_proj1", "pileup_l1", "pileup_head", "encode_columns", "hap_features")
+
+    def enable_timing(self, enable=True):
+        check(self.lib.nsnp_ctx_enable_timing(self.handle, int(bool(enable))), self.handle, "nsnp_ctx_enable_timing")
+
+    def read_timing(self):
+        """{kernel name: (total_ms, launches)} of the launches recorded since the last read."""
+        out = {}
+        for k, name in enumerate(self.KERNELS):
+            ms, n = C.c_double(0), C.c_int64(0)
+            check(self.lib.nsnp_ctx_read_timing(self.handle, k, C.byref(ms), C.byref(n)), self.handle,
+                  "nsnp_ctx_read_timing")
+            out[name] = (ms.value, n.value)
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

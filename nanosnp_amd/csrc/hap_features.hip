@@ -110,6 +110,7 @@ extern "C" int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_
     if (N == 0) return NSNP_OK;
     const size_t lds = (size_t)4 * NSTAT * L * 8 + (size_t)D * 4;
     if (lds > 64 * 1024) return NSNP_ESHAPE;
+    ScopedKernelTimer tm(ctx, NSNP_K_HAPFEAT, (hipStream_t)stream);
     hipLaunchKernelGGL(k_hap_features, dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream,
                        seq, bq, mq, hap, ref_row, D, L, out);
     NSNP_HIP(ctx, hipGetLastError());

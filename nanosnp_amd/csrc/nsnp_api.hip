@@ -19,11 +19,13 @@ extern "C" const char* nsnp_strerror(int code)
     }
 }
 
+static hipError_t g_create_err = hipSuccess;   // error of the last failed nsnp_ctx_create (no ctx yet)
+
 extern "C" int nsnp_last_hip_error(const nsnp_ctx* ctx, const char** text)
 {
-    if (!ctx) return -1;
-    if (text) *text = hipGetErrorString(ctx->last_err);
-    return (int)ctx->last_err;
+    const hipError_t e = ctx ? ctx->last_err : g_create_err;
+    if (text) *text = hipGetErrorString(e);
+    return (int)e;
 }
 
 extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
@@ -39,7 +41,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) { delete ctx; return NSNP_EHIP; }
+    if (e != hipSuccess) { g_create_err = e; delete ctx; return NSNP_EHIP; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return NSNP_EARCH; }
     ctx->n_cu = prop.multiProcessorCount;
     *out = ctx;
@@ -47,6 +49,55 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
 }
 
 void nsnp_hap_free(nsnp_ctx* ctx);   // hap_forward.hip
+
+// ---- per-kernel timing ----------------------------------------------------------------------------
+constexpr size_t TIMER_MAX_PAIRS = 8192;
+
+ScopedKernelTimer::ScopedKernelTimer(nsnp_ctx* c, int kernel, hipStream_t stream)
+    : ctx(c), k(kernel), s(stream), stop_ev(nullptr), on(false)
+{
+    KernelTimer* t = c->timer;
+    if (!t || !t->enabled || t->used[k] >= TIMER_MAX_PAIRS) return;
+    if (t->used[k] == t->start[k].size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        t->start[k].push_back(a); t->stop[k].push_back(b);
+    }
+    const size_t i = t->used[k]++;
+    (void)hipEventRecord(t->start[k][i], s);
+    stop_ev = t->stop[k][i];
+    on = true;
+}
+ScopedKernelTimer::~ScopedKernelTimer() { if (on) (void)hipEventRecord(stop_ev, s); }
+
+extern "C" int nsnp_ctx_enable_timing(nsnp_ctx* ctx, int enable)
+{
+    if (!ctx) return NSNP_EINVAL;
+    if (!ctx->timer) {
+        ctx->timer = new (std::nothrow) KernelTimer();
+        if (!ctx->timer) return NSNP_ENOMEM;
+        for (int k = 0; k < NSNP_K_COUNT; ++k) ctx->timer->used[k] = 0;
+    }
+    ctx->timer->enabled = enable != 0;
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_ctx_read_timing(nsnp_ctx* ctx, int kernel, double* total_ms, int64_t* launches)
+{
+    if (!ctx || kernel < 0 || kernel >= NSNP_K_COUNT || !total_ms || !launches) return NSNP_EINVAL;
+    *total_ms = 0.0; *launches = 0;
+    KernelTimer* t = ctx->timer;
+    if (!t) return NSNP_OK;
+    for (size_t i = 0; i < t->used[kernel]; ++i) {
+        NSNP_HIP(ctx, hipEventSynchronize(t->stop[kernel][i]));
+        float ms = 0.f;
+        NSNP_HIP(ctx, hipEventElapsedTime(&ms, t->start[kernel][i], t->stop[kernel][i]));
+        *total_ms += ms; ++*launches;
+    }
+    t->used[kernel] = 0;   // events are kept for reuse
+    return NSNP_OK;
+}
 
 static void free_ws(nsnp_ctx* ctx)
 {
@@ -65,6 +116,13 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     if (ctx->pw.arena) (void)hipFree(ctx->pw.arena);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
     nsnp_hap_free(ctx);
+    if (ctx->timer) {
+        for (int k = 0; k < NSNP_K_COUNT; ++k) {
+            for (hipEvent_t e : ctx->timer->start[k]) (void)hipEventDestroy(e);
+            for (hipEvent_t e : ctx->timer->stop[k]) (void)hipEventDestroy(e);
+        }
+        delete ctx->timer;
+    }
     delete ctx;
     return NSNP_OK;
 }

@@ -50,6 +50,14 @@ struct PileupWeightsDev {
 
 struct HapWeightsDev;   // hap_forward.hip
 
+// optional per-kernel timing with HIP events on the launch stream (nsnp_ctx_enable_timing)
+enum { NSNP_K_L0 = 0, NSNP_K_PROJ1, NSNP_K_L1, NSNP_K_HEAD, NSNP_K_ENCODE, NSNP_K_HAPFEAT, NSNP_K_COUNT };
+struct KernelTimer {
+    std::vector<hipEvent_t> start[NSNP_K_COUNT], stop[NSNP_K_COUNT];
+    size_t used[NSNP_K_COUNT];
+    bool enabled;
+};
+
 struct nsnp_ctx {
     int device;
     int n_cu;
@@ -64,6 +72,14 @@ struct nsnp_ctx {
     HapWeightsDev* hw;
     void*  hap_ws; size_t hap_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
+    KernelTimer* timer;
+};
+
+// records an event pair around one kernel launch when timing is enabled
+struct ScopedKernelTimer {
+    nsnp_ctx* ctx; int k; hipStream_t s; hipEvent_t stop_ev; bool on;
+    ScopedKernelTimer(nsnp_ctx* c, int kernel, hipStream_t stream);
+    ~ScopedKernelTimer();
 };
 
 #define NSNP_HIP(ctx, call)                                                        \

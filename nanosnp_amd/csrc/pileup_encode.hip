@@ -299,6 +299,7 @@ extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, c
     if (!ctx || M < 0 || (M > 0 && (!bases || !col_off || !ref || !counts || !depth || !flags))) return NSNP_EINVAL;
     if (M == 0) return NSNP_OK;
     const unsigned grid = (unsigned)NSNP_CDIV(M, ENC_BLOCK);
+    ScopedKernelTimer tm(ctx, NSNP_K_ENCODE, (hipStream_t)stream);
     hipLaunchKernelGGL(k_encode_columns, dim3(grid), dim3(ENC_BLOCK), 0, (hipStream_t)stream,
                        bases, col_off, ref, M, min_af, min_coverage, counts, depth, flags);
     NSNP_HIP(ctx, hipGetLastError());

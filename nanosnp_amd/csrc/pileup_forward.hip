@@ -564,16 +564,20 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         const int32_t* xc = center_idx ? x : x + base * (PW * PC);
         const int64_t* cc = center_idx ? center_idx + base : nullptr;
         const dim3 g_rec((unsigned)NSNP_CDIV(n, 128), 2);
+        { ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
         hipLaunchKernelGGL(k_pileup_l0, g_rec, dim3(512), L0_LDS_BYTES, s, xc, cc, n,
                            pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1],
-                           ctx->ws_h0);
+                           ctx->ws_h0); }
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
         int64_t gp = NSNP_CDIV(n_rt, 16);
         if (gp > ctx->n_cu) gp = ctx->n_cu;
+        { ScopedKernelTimer tm(ctx, NSNP_K_PROJ1, s);
         hipLaunchKernelGGL(k_pileup_proj1, dim3((unsigned)gp, 2), dim3(1024), P1_LDS_BYTES, s, ctx->ws_h0, n,
-                           pw.l1_wih[0], pw.l1_wih[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_xp1);
+                           pw.l1_wih[0], pw.l1_wih[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_xp1); }
+        { ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
         hipLaunchKernelGGL(k_pileup_l1, g_rec, dim3(512), L1_LDS_BYTES, s, ctx->ws_xp1, n,
-                           pw.l1_whh[0], pw.l1_whh[1], ctx->ws_h1c);
+                           pw.l1_whh[0], pw.l1_whh[1], ctx->ws_h1c); }
+        ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
         hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,
                            pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,
                            gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);

@@ -1,0 +1,55 @@
+"""Static sharding of candidate sites over the GPUs of one node and the final result gather.
+
+The reference is single-device (PileupModel/predict.py:208); every site is independent in
+encode, feature reduction and forward, so rank r of R owns the contiguous range
+[r*N/R, (r+1)*N/R) of the position-sorted site list, weights are replicated, and the only
+exchange is one rooted gather of the per-site results (RCCL over xGMI when the backend is
+"nccl", gloo in the CPU tests).  Result order = rank order = position order, so the merge is a
+concatenation.
+"""
+from __future__ import annotations
+
+import os
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), \
+        int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced, order-preserving: [lo, hi) of rank; sizes differ by at most one."""
+    if world <= 0 or not (0 <= rank < world) or n_items < 0:
+        raise ValueError("bad shard arguments")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_columns(n_cols, rank, world, halo=16):
+    """Column ranges for the encode stage: the owned range plus a halo of `halo` columns each side
+    (re-computed, not exchanged) so that every window centred in the owned range is complete."""
+    lo, hi = shard_range(n_cols, rank, world)
+    return max(0, lo - halo), min(n_cols, hi + halo), lo, hi
+
+
+def gather_results(local, n_total, root=0, group=None):
+    """Gathers per-site result rows (a 2-D tensor [n_local, k]) to `root` in rank order.
+    Returns the [n_total, k] tensor on root, None elsewhere.  One collective, no ring all-reduce."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    counts = [hi - lo for lo, hi in sizes]
+    assert local.shape[0] == counts[rank], (local.shape, counts[rank])
+    maxn = max(counts)
+    # equal-size all_gather of padded shards (a single grouped send/recv per peer pair on RCCL)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+    dist.gather(pad, bufs, dst=root, group=group)
+    if rank != root:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

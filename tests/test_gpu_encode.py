@@ -1,0 +1,128 @@
+"""Pileup encode / site selection / window gather on the GPU: bit-exact vs the reference goldens
+and the oracle."""
+import gzip
+
+import numpy as np
+import pytest
+
+from nanosnp_amd import host
+from tests.helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(ctx, bases, col_off, ref, **kw):
+    import torch
+    b = torch.from_numpy(np.ascontiguousarray(bases if bases.size else np.zeros(1, np.uint8))).cuda()
+    c, d, f = ctx.pileup_encode_columns(b, torch.from_numpy(np.ascontiguousarray(col_off)).cuda(),
+                                        torch.from_numpy(np.ascontiguousarray(ref)).cuda(), **kw)
+    torch.cuda.synchronize()
+    return c, d, f
+
+
+@pytest.mark.parametrize("tag", ["g1", "adv"])
+def test_reference_fixture_end_to_end(gpu_ctx, tag):
+    """mpileup text -> encode -> select -> gather == the tensors the reference programs wrote"""
+    import torch
+    text = gzip.open(golden(f"encode_{tag}.mpileup.gz")).read()
+    fa = gzip.open(golden(f"encode_{tag}.fa.gz")).read()
+    pd = gzip.open(golden(f"encode_{tag}.pd.gz")).read()
+    seq = np.frombuffer(b"".join(fa.split(b"\n")[1:]), np.uint8)
+    pos, col_off, bases = host.mpileup_parse(text)
+    ref = seq[pos - 1]
+    c, d, f = _enc(gpu_ctx, bases, col_off, ref)
+    centers, n = gpu_ctx.pileup_select_sites(torch.from_numpy(pos).cuda(), f)
+    x = gpu_ctx.pileup_gather_windows(c, centers)
+    gx, names, gpos, gref = host.pd_parse(pd)
+    assert n == gx.shape[0]
+    assert np.array_equal(x.cpu().numpy(), gx)
+    assert np.array_equal(pos[centers.cpu().numpy()], gpos)
+    pd_depth = np.array([int(l.split(b"\t")[2].split(b"-")[0]) for l in pd.splitlines()])
+    assert np.array_equal(d.cpu().numpy()[centers.cpu().numpy()], pd_depth)
+
+
+@pytest.mark.parametrize("seed,cov", [(1, 30), (2, 60), (3, 5)])
+def test_random_columns_vs_oracle(gpu_ctx, seed, cov):
+    from oracle import oracle
+    cols = host.synth_columns(seed, 200_000, coverage=cov)
+    ref = cols.ref.copy()
+    rng = np.random.default_rng(seed)
+    ref[rng.random(ref.size) < 0.05] |= 0x20
+    ref[rng.random(ref.size) < 0.01] = ord("N")
+    c, d, f = _enc(gpu_ctx, cols.bases, cols.col_off, ref)
+    oc, od, of = oracle.encode_columns(cols.bases, cols.col_off, ref)
+    assert np.array_equal(c.cpu().numpy(), oc)
+    assert np.array_equal(d.cpu().numpy(), od)
+    assert np.array_equal(f.cpu().numpy(), of)
+
+
+def test_thresholds_are_parameters(gpu_ctx):
+    from oracle import oracle
+    cols = host.synth_columns(9, 20_000, coverage=12)
+    for af, mc in ((0.12, 6), (0.2, 10), (0.0, 0), (1.0, 1)):
+        c, d, f = _enc(gpu_ctx, cols.bases, cols.col_off, cols.ref, min_af=af, min_coverage=mc)
+        oc, od, of = oracle.encode_columns(cols.bases, cols.col_off, cols.ref, af, mc)
+        assert np.array_equal(f.cpu().numpy(), of), (af, mc)
+
+
+def test_handwritten_edge_columns(gpu_ctx):
+    """empty column, '*' only, >60-base indel skipped, '^' swallowing '+', digit-free '+', truncated
+    indel at the end of the string, 12 distinct alleles (table overflow path), same allele 9x"""
+    from oracle import oracle
+    cols = [b"", b"*", b"A+61" + b"C" * 61 + b"A", b"^+A^-a$", b"A+CA", b"AAA+5AC", b"a-2",
+            b"".join(b"A+%d%s" % (k + 1, b"ACGTACGTACGT"[:k + 1]) for k in range(12)) + b"A+2AC" * 3,
+            b"g-3acg" * 9 + b"G-3ACG" * 2, b"NNNnnn", b"#*#*", b"T" * 1000 + b"+2GG" * 500]
+    bases = np.frombuffer(b"".join(cols), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    ref = np.frombuffer(b"ACGTNacgtnAC", np.uint8)[:len(cols)]
+    c, d, f = _enc(gpu_ctx, bases, off, ref)
+    oc, od, of = oracle.encode_columns(bases, off, ref)
+    assert np.array_equal(c.cpu().numpy(), oc), (c.cpu().numpy(), oc)
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
+
+
+def test_empty_call(gpu_ctx):
+    import torch
+    e8 = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    c, d, f = gpu_ctx.pileup_encode_columns(e8, torch.zeros(1, dtype=torch.int64, device="cuda"), e8[:0])
+    assert c.shape == (0, 18)
+    centers, n = gpu_ctx.pileup_select_sites(torch.zeros(0, dtype=torch.int64, device="cuda"), e8[:0])
+    assert n == 0
+
+
+@pytest.mark.parametrize("m", [1, 32, 33, 34, 1000, 100_003])
+def test_select_sites_vs_oracle(gpu_ctx, m):
+    """position gaps, candidates at run edges, runs shorter than a window"""
+    import torch
+    from oracle import oracle
+    rng = np.random.default_rng(m)
+    step = np.where(rng.random(m) < 0.02, rng.integers(2, 5, m), 1)
+    pos = np.cumsum(step).astype(np.int64)
+    flags = np.where(rng.random(m) < 0.3, 8, 0).astype(np.uint8) | rng.integers(0, 8, m).astype(np.uint8)
+    want = oracle.select_sites(pos, flags)
+    got, n = gpu_ctx.pileup_select_sites(torch.from_numpy(pos).cuda(), torch.from_numpy(flags).cuda())
+    assert n == len(want)
+    assert np.array_equal(got.cpu().numpy(), want)
+    if len(want) > 3:       # capacity smaller than the result: count still exact, prefix written
+        got2, n2 = gpu_ctx.pileup_select_sites(torch.from_numpy(pos).cuda(), torch.from_numpy(flags).cuda(), cap=3)
+        assert n2 == len(want) and np.array_equal(got2.cpu().numpy(), want[:3])
+
+
+def test_full_size_invariants_1m_columns(gpu_ctx):
+    """Size-independent checks at benchmark scale (33 x 32768 columns): the depth identity
+    depth = -(ref_upper + ref_lower) + '*' + '#', non-negative non-reference channels, I1 <= I, and
+    a random sample of columns against the oracle."""
+    from oracle import oracle
+    n = 32768
+    cols = host.synth_columns(20260000, n * 33, coverage=30, window=33)
+    c, d, f = _enc(gpu_ctx, cols.bases, cols.col_off, cols.ref)
+    c, d = c.cpu().numpy(), d.cpu().numpy()
+    ridx = np.searchsorted(np.frombuffer(b"ACGT", np.uint8), cols.ref)
+    rows = np.arange(c.shape[0])
+    assert np.array_equal(d, -(c[rows, ridx] + c[rows, 9 + ridx]) + c[:, 8] + c[:, 17])
+    assert (c[:, 5] <= c[:, 4]).all() and (c[:, 7] <= c[:, 6]).all() and (c[:, 14] <= c[:, 13]).all()
+    sample = np.random.default_rng(0).choice(c.shape[0], 20000, replace=False)
+    sb = np.concatenate([cols.bases[cols.col_off[i]:cols.col_off[i + 1]] for i in sample])
+    so = np.concatenate([[0], np.cumsum(cols.col_off[sample + 1] - cols.col_off[sample])]).astype(np.int64)
+    oc, od, _ = oracle.encode_columns(sb, so, cols.ref[sample])
+    assert np.array_equal(c[sample], oc) and np.array_equal(d[sample], od)

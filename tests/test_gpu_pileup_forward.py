@@ -1,0 +1,141 @@
+"""PileupModel forward on the GPU (through the C ABI) vs the reference goldens and the oracle.
+Tolerance: 1e-4 absolute on probabilities (BASELINE.json north_star); measured ~5e-7."""
+import numpy as np
+import pytest
+
+from tests.helpers import PROB_ATOL, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(gpu_ctx, pileup_weights):
+    gpu_ctx.pileup_load_weights(pileup_weights)
+    return gpu_ctx
+
+
+def _fwd(ctx, x_np):
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(x_np, dtype=np.int32)).cuda()
+    gt, zy = ctx.pileup_forward(x)
+    torch.cuda.synchronize()
+    return gt.cpu().numpy(), zy.cpu().numpy()
+
+
+def test_golden_outputs_of_the_reference_model(model):
+    z = np.load(golden("pileup_fwd.npz"))
+    gt, zy = _fwd(model, z["x"])
+    assert np.abs(gt - z["gt"]).max() < PROB_ATOL
+    assert np.abs(zy - z["zy"]).max() < PROB_ATOL
+    assert np.array_equal(gt.argmax(1), z["gt"].argmax(1))
+    assert np.array_equal(zy.argmax(1), z["zy"].argmax(1))
+    assert np.allclose(gt.sum(1), 1, atol=1e-5) and np.allclose(zy.sum(1), 1, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 127, 128, 129, 1000])
+def test_ragged_batch_sizes_vs_oracle(model, pileup_weights, n):
+    from oracle import oracle
+    rng = np.random.default_rng(n)
+    x = (rng.integers(0, 40, (n, 33, 18)) * (rng.random((n, 33, 18)) < 0.4)).astype(np.int32)
+    x[:, :, 0] = -rng.integers(0, 60, (n, 33))
+    gt, zy = _fwd(model, x)
+    assert gt.shape == (n, 21) and zy.shape == (n, 3)
+    if n:
+        ogt, ozy = oracle.pileup_forward(pileup_weights, x, nthreads=4)
+        assert np.abs(gt - ogt).max() < PROB_ATOL and np.abs(zy - ozy).max() < PROB_ATOL
+
+
+def test_extreme_counts(model, pileup_weights):
+    """depth-144 saturation, all-zero windows, large negatives: gates saturate, nothing overflows"""
+    from oracle import oracle
+    x = np.zeros((6, 33, 18), np.int32)
+    x[1] = 144; x[2] = -144; x[3, :, ::2] = 10000; x[4, 16] = -100000; x[5, ::3] = 2**20
+    gt, zy = _fwd(model, x)
+    assert np.isfinite(gt).all() and np.isfinite(zy).all()
+    ogt, ozy = oracle.pileup_forward(pileup_weights, x)
+    assert np.abs(gt - ogt).max() < PROB_ATOL and np.abs(zy - ozy).max() < PROB_ATOL
+
+
+def test_sites_are_independent_and_chunking_is_invisible(model, pileup_weights):
+    """Size-independent properties used at full batch sizes: a site's result does not depend on its
+    batch neighbours or on the internal chunk size; repeated runs are bit-identical."""
+    import torch
+    from nanosnp_amd import _lib
+    rng = np.random.default_rng(0)
+    n = 4096 + 77
+    x = torch.from_numpy((rng.integers(0, 50, (n, 33, 18)) - 10).astype(np.int32)).cuda()
+    gt, zy = model.pileup_forward(x)
+    gt2, zy2 = model.pileup_forward(x)
+    assert torch.equal(gt, gt2) and torch.equal(zy, zy2)
+    perm = torch.randperm(n, device="cuda")
+    gtp, zyp = model.pileup_forward(x[perm].contiguous())
+    assert torch.equal(gtp, gt[perm]) and torch.equal(zyp, zy[perm])
+    small = _lib.Context(0, chunk_sites=1000)        # forces 5 internal chunks
+    small.pileup_load_weights(pileup_weights)
+    gts, zys = small.pileup_forward(x)
+    assert torch.equal(gts, gt) and torch.equal(zys, zy)
+    sub, _ = model.pileup_forward(x[100:133].contiguous())
+    assert torch.equal(sub, gt[100:133])
+    small.close()
+
+
+def test_full_batch_4096_checksum_vs_oracle_sample(model, pileup_weights):
+    """BASELINE config 2 batch size: every 16th site of a 4096 batch against the oracle."""
+    import torch
+    from nanosnp_amd import host
+    from oracle import oracle
+    n = 4096
+    cols = host.synth_columns(20260001, n * 33, coverage=30, window=33)
+    counts, _, _ = oracle.encode_columns(cols.bases, cols.col_off, cols.ref)
+    x = counts.reshape(n, 33, 18)
+    gt, zy = _fwd(model, x)
+    idx = np.arange(0, n, 16)
+    ogt, ozy = oracle.pileup_forward(pileup_weights, x[idx], nthreads=8)
+    assert np.abs(gt[idx] - ogt).max() < PROB_ATOL and np.abs(zy[idx] - ozy).max() < PROB_ATOL
+    assert np.allclose(gt.sum(1), 1, atol=1e-5)
+
+
+def test_forward_windows_reads_the_count_matrix_in_place(model):
+    import torch
+    rng = np.random.default_rng(3)
+    m = 5000
+    counts = torch.from_numpy(rng.integers(-30, 40, (m, 18)).astype(np.int32)).cuda()
+    centers = torch.from_numpy(np.sort(rng.choice(np.arange(16, m - 16), 300, replace=False)).astype(np.int64)).cuda()
+    x = model.pileup_gather_windows(counts, centers)
+    ref = torch.stack([counts[c - 16:c + 17] for c in centers.tolist()])
+    assert torch.equal(x, ref)
+    g1, z1 = model.pileup_forward(x)
+    g2, z2 = model.pileup_forward_windows(counts, centers)
+    assert torch.equal(g1, g2) and torch.equal(z1, z2)
+
+
+def test_postprocess_matches_predict_py(model):
+    """argmax / max / depth of PileupModel/predict.py:54-65"""
+    import torch
+    z = np.load(golden("pileup_fwd.npz"))
+    x = torch.from_numpy(z["x"].astype(np.int32)).cuda()
+    gt, zy = model.pileup_forward(x)
+    ga, za, gm, zm, depth = model.pileup_postprocess(gt, zy, x)
+    gtn, zyn = gt.cpu().numpy(), zy.cpu().numpy()
+    assert np.array_equal(ga.cpu().numpy(), np.argmax(gtn, 1)) and np.array_equal(za.cpu().numpy(), np.argmax(zyn, 1))
+    assert np.array_equal(gm.cpu().numpy(), np.max(gtn, 1)) and np.array_equal(zm.cpu().numpy(), np.max(zyn, 1))
+    cov = z["x"].astype(np.int64)[:, 16][:, [0, 1, 2, 3, 9, 10, 11, 12]]
+    want = np.array([-1 * c[np.where(c < 0)].sum() for c in cov])
+    assert np.array_equal(depth.cpu().numpy(), want)
+
+
+def test_reference_style_interface(pileup_weights):
+    """nanosnp_amd.pileup_model.LSTMNetwork mirrors PileupModel/model.py + predict.py:208-214"""
+    import torch
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    m = LSTMNetwork.from_npz(golden("ont_pileup_weights.npz")).to("cuda").eval()
+    z = np.load(golden("pileup_fwd.npz"))
+    feature_tensor = torch.from_numpy(z["x"].astype(np.int32)).type(torch.FloatTensor).to("cuda")   # predict.py:49
+    gt, zy = m.predict(feature_tensor)
+    assert np.abs(gt.cpu().numpy() - z["gt"]).max() < PROB_ATOL
+    with pytest.raises(Exception):
+        LSTMNetwork({"feature_dim": 18, "gt_num_class": 21, "zy_num_class": 3,
+                     "enc": {"type": "lstm", "hidden_size": 128, "output_size": 128, "n_layers": 2, "bidirectional": True},
+                     "joint": {"inner_size": 256}})
+    with pytest.raises(Exception):
+        LSTMNetwork().predict(feature_tensor)      # weights not loaded

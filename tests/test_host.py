@@ -1,0 +1,79 @@
+"""Host-side readers and generators (libnanosnp_host.so)."""
+import numpy as np
+import pytest
+
+from nanosnp_amd import host
+
+
+def test_synth_is_deterministic_and_thread_independent(monkeypatch):
+    a = host.synth_columns(42, 5000, coverage=30)
+    b = host.synth_columns(42, 5000, coverage=30)
+    assert np.array_equal(a.bases, b.bases) and np.array_equal(a.col_off, b.col_off) and np.array_equal(a.ref, b.ref)
+    c = host.synth_columns(43, 5000, coverage=30)
+    assert not np.array_equal(a.ref, c.ref)
+    # ~Poisson(30) symbols per column, grammar characters only
+    per_col = np.diff(a.col_off)
+    assert 30 < per_col.mean() < 40
+    assert set(np.unique(a.bases)) <= set(b"ACGTacgt*#+-123^I$")
+
+
+def test_synth_windows_layout():
+    w = host.synth_columns(7, 33 * 10, window=33)
+    assert w.pos[32] + 1 != w.pos[33]            # a gap separates consecutive windows
+    assert np.all(np.diff(w.pos[:33]) == 1)
+
+
+def test_mpileup_roundtrip():
+    cols = host.synth_columns(3, 300)
+    text = cols.mpileup_text("chr1")
+    pos, col_off, bases = host.mpileup_parse(text)
+    assert np.array_equal(pos, cols.pos) and np.array_equal(col_off, cols.col_off) and np.array_equal(bases, cols.bases)
+    # \r\n line ends, consecutive tabs and a missing final newline (cpp_aux.cpp:43-59, line_reader.cpp:95-127)
+    t2 = text.replace(b"\n", b"\r\n").replace(b"\tN\t", b"\t\tN\t")[:-2]
+    pos2, col_off2, bases2 = host.mpileup_parse(t2)
+    assert np.array_equal(pos2, cols.pos) and np.array_equal(bases2, cols.bases)
+    with pytest.raises(host.HostError):
+        host.mpileup_parse(b"chr1\t5\tN\n")
+
+
+def test_empty_inputs():
+    pos, col_off, bases = host.mpileup_parse(b"")
+    assert pos.size == 0 and col_off.tolist() == [0]
+    x, names, p, r = host.pd_parse(b"")
+    assert x.shape == (0, 33, 18) and names == []
+
+
+def test_fasta_with_and_without_fai(tmp_path):
+    rng = np.random.default_rng(0)
+    s1 = rng.choice(list(b"ACGTN"), 1234).astype(np.uint8)
+    fa = tmp_path / "a.fa"
+    host.write_fasta(str(fa), "ctgA", s1, line=50)
+    assert np.array_equal(host.fasta_load_contig(str(fa), "ctgA"), s1)
+    # second contig, no index
+    with open(fa, "ab") as f:
+        f.write(b">ctgB some description\nACGTAC\nGG\n")
+    (tmp_path / "a.fa.fai").unlink()
+    assert bytes(host.fasta_load_contig(str(fa), "ctgB")) == b"ACGTACGG"
+    assert np.array_equal(host.fasta_load_contig(str(fa), "ctgA"), s1)
+    with pytest.raises(host.HostError):
+        host.fasta_load_contig(str(fa), "nope")
+
+
+def test_pd_parse_fields():
+    row = " ".join(str(i - 300) for i in range(594)) + " "
+    text = (row + "\tchr7:12345:" + "A" * 16 + "G" + "C" * 16 + "\t30-XT 5\n").encode()
+    x, names, pos, refb = host.pd_parse(text * 3)
+    assert x.shape == (3, 33, 18) and x[1].ravel().tolist() == [i - 300 for i in range(594)]
+    assert names == ["chr7"] * 3 and pos.tolist() == [12345] * 3 and refb.tolist() == [ord("G")] * 3
+
+
+def test_hap_planes_shape_and_padding():
+    seq, bq, mq, hap, ref = host.synth_hap_planes(1, 8, coverage=30, depth=90, length=33)
+    assert seq.shape == (8, 90, 33) and ref.shape == (8, 33)
+    assert set(np.unique(seq)) <= {-2, -1, 0, 1, 2, 3, 4}
+    pad = (seq == -2)
+    assert np.array_equal(pad, hap == -2) and np.array_equal(pad, bq == -2)
+    # rows are ordered by HP at the centre column (create_pileup_haplotype.py:158-165)
+    for n in range(8):
+        hp = hap[n, :, 16]; hp = hp[hp > 0]
+        assert np.all(np.diff(hp) >= 0)

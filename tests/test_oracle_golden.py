@@ -1,0 +1,124 @@
+"""The CPU oracle against the golden vectors generated from the reference itself
+(tools/make_golden.py), and against the reference's own compiled programs when oracle/_ref is
+present.  Integer results bit-exact; probabilities within 1e-4 (measured ~1e-6)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from nanosnp_amd import host
+from oracle import oracle
+from tests.helpers import GOLDEN, PROB_ATOL, ROOT, golden, load_pileup_weights, seeded_hap_weights
+
+
+def _load_encode_fixture(tag):
+    text = gzip.open(golden(f"encode_{tag}.mpileup.gz")).read()
+    fa = gzip.open(golden(f"encode_{tag}.fa.gz")).read()
+    pd = gzip.open(golden(f"encode_{tag}.pd.gz")).read()
+    seq = b"".join(fa.split(b"\n")[1:])
+    return text, seq, pd
+
+
+@pytest.mark.parametrize("tag", ["g1", "adv"])
+def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
+    text, seq, pd = _load_encode_fixture(tag)
+    mp = tmp_path / "x.mpileup"
+    mp.write_bytes(text)
+    n = oracle.mpileup_to_pd(str(mp), seq, str(tmp_path / "o.pd"))
+    assert n == pd.count(b"\n")
+    assert (tmp_path / "o.pd").read_bytes() == pd
+
+
+@pytest.mark.parametrize("tag", ["g1", "adv"])
+def test_array_path_matches_the_reference_tensors(tag):
+    """encode_columns -> select_sites -> gather_windows == the [N,33,18] matrices in the .pd"""
+    text, seq, pd = _load_encode_fixture(tag)
+    pos, col_off, bases = host.mpileup_parse(text)
+    ref = np.frombuffer(seq, np.uint8)[pos - 1]
+    counts, depth, flags = oracle.encode_columns(bases, col_off, ref)
+    centers = oracle.select_sites(pos, flags)
+    x = oracle.gather_windows(counts, centers)
+    gx, names, gpos, gref = host.pd_parse(pd)
+    assert np.array_equal(x, gx)
+    assert np.array_equal(pos[centers], gpos)
+    assert np.array_equal(ref[centers] & 0xDF, gref)
+    # the depth the .pd carries in its alt_info column ("depth-ALT cnt ...")
+    pd_depth = np.array([int(l.split(b"\t")[2].split(b"-")[0]) for l in pd.splitlines()])
+    assert np.array_equal(depth[centers], pd_depth)
+
+
+def test_pileup_forward_matches_reference_model_outputs():
+    w = load_pileup_weights()
+    z = np.load(golden("pileup_fwd.npz"))
+    gt, zy = oracle.pileup_forward(w, z["x"].astype(np.int32), nthreads=4)
+    assert np.abs(gt - z["gt"]).max() < PROB_ATOL
+    assert np.abs(zy - z["zy"]).max() < PROB_ATOL
+    assert np.array_equal(gt.argmax(1), z["gt"].argmax(1))
+    assert np.abs(gt - z["gt"]).max() < 5e-6     # what a plain fp32 restatement achieves
+
+
+@pytest.mark.parametrize("tag", ["p", "h"])
+def test_hap_features_bit_exact_float64(tag):
+    z = np.load(golden("hap_features.npz"))
+    seq, bq, mq, hap, ref = [z[f"{tag}_{k}"].astype(np.int32) for k in ("seq", "bq", "mq", "hap", "ref")]
+    for i in range(seq.shape[0]):
+        f = oracle.hap_features(seq[i], bq[i], mq[i], hap[i], ref[i])
+        assert np.array_equal(f[:104], z[f"{tag}_feat"][i]), i
+        assert np.array_equal(f[104], ref[i])
+
+
+@pytest.mark.parametrize("H", [32, 256])
+def test_hap_forward_matches_reference_module_with_seeded_weights(H):
+    z = np.load(golden(f"hap_fwd_h{H}.npz"))
+    ws = seeded_hap_weights(int(z["seed"]), H=H)
+    gt, zy = oracle.hap_forward(ws, z["xp"], z["xh"], H=H, nthreads=4)
+    assert np.abs(gt - z["gt"]).max() < PROB_ATOL and np.abs(zy - z["zy"]).max() < PROB_ATOL
+    assert np.abs(gt - z["gt"]).max() < 5e-6
+
+
+def test_calculate_score_matches_python_formula():
+    from math import e, log
+    def ref(p):   # PileupModel/predict.py:31-34 verbatim formula
+        tmp = max((-10 * log(e, 10)) * log(((1.0 - p) + 1e-300) / (p + 1e-300)) + 10, 0)
+        return float(round(tmp, 2))
+    rng = np.random.default_rng(1)
+    ps = np.concatenate([rng.random(2000), [0.0, 1.0, 0.5, 1e-9, 1 - 1e-9, 0.0909090909, 0.999]])
+    ps = np.concatenate([ps, ps.astype(np.float32).astype(np.float64)])
+    for p in ps:
+        assert oracle.calculate_score(p) == ref(p), p
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "DNA_CreateCanSnpTensor")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref not built (no reference tree)")
+def test_oracle_vs_reference_binaries_on_a_fresh_contig(tmp_path):
+    """Re-pins the oracle against the compiled reference on data that is NOT in the fixtures."""
+    M = 40000
+    cols = host.synth_columns(977, M, coverage=30)
+    rng = np.random.default_rng(5)
+    seq = np.concatenate([cols.ref, np.frombuffer(b"ACGT" * 25, np.uint8)]).copy()
+    seq[rng.random(seq.size) < 0.04] |= 0x20
+    seq[rng.random(seq.size) < 0.002] = ord("N")
+    fa = str(tmp_path / "ref.fa")
+    host.write_fasta(fa, "chrQ", seq)
+    pile = tmp_path / "pile"; pile.mkdir()
+    keep = np.ones(M, bool)
+    for g in rng.integers(100, M - 100, 20):
+        keep[g:g + int(rng.integers(1, 4))] = False
+    lines = cols.mpileup_text("chrQ").split(b"\n")[:-1]
+    (pile / "chrQ.mpileup").write_bytes(b"\n".join(l for i, l in enumerate(lines) if keep[i]) + b"\n")
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    subprocess.run([os.path.join(refdir, "DNA_CreateCanSnpTensor"), "-reference", fa, "-chr_pileup_dir", str(pile),
+                    "-output_dir", str(tmp_path / "tensor"), "-min_af", "0.12", "-snp_min_af", "0.12",
+                    "-indel_min_af", "0.12", "-min_coverage", "6", "-flanking_base", "16", "-num_threads", "1", "chrQ"],
+                   check=True, capture_output=True)
+    subprocess.run([os.path.join(refdir, "DNA_CreatePredictData"), "-chr_tensor_dir", str(tmp_path / "tensor"),
+                    "-reference", fa, "-output_dir", str(tmp_path / "pd"), "-num_threads", "1", "chrQ"],
+                   check=True, capture_output=True)
+    want = (tmp_path / "pd" / "chrQ.pd").read_bytes()
+    n = oracle.mpileup_to_pd(str(pile / "chrQ.mpileup"), bytes(seq), str(tmp_path / "o.pd"))
+    assert n == want.count(b"\n") and n > 500
+    assert (tmp_path / "o.pd").read_bytes() == want
