@@ -1,16 +1,482 @@
-// hap_forward.hip -- HaplotypeModel forward (model_dev.LSTMNetwork.predict,
-// HaplotypeModel/model_dev.py:133-143).  Kernels land in the next commit; until then the entry
-// points report NSNP_ENOWEIGHTS so that no caller can mistake a stub for a result.
+// hap_forward.hip -- HaplotypeModel forward: two 3-layer BiLSTM encoders (F=105 -> H=256) over the
+// 33-wide pileup window and the 11-wide haplotype window, Linear(512->256) at the centre step of
+// each, tanh(Linear(512->256)), genotype / zygosity heads, softmax.
+//
+// Replaces model_dev.LSTMNetwork.predict (HaplotypeModel/model_dev.py:133-143; BaseEncoder :59-84,
+// ForwardLayer :86-105) as called from HaplotypeModel/predict_dev.py:35-39.
+//
+// Design (not a translation of nn.LSTM/cuDNN): with H=256 one direction's weights are 1.5-3 MB, far
+// beyond LDS, so the recurrence is run as ONE fused GEMM+cell kernel launch per time step over all
+// sites of a chunk:  gates[1024 x N] = Wcat[1024 x (I+256)] . [x_t ; h_{t-1}]  on
+// v_mfma_f32_32x32x2_f32 (exact fp32), 128 gate-rows x 128 sites per workgroup, K streamed through
+// LDS in 16-wide chunks with register double-buffering; the epilogue applies the LSTM cell to the
+// accumulators in place (a lane owns the 4 gates of a hidden unit) and writes h_t straight into the
+// tile-image layout that the next step / next layer loads back with linear 8 KB copies.  Both
+// directions (and both encoders while the short one is still running) share a launch through
+// gridDim.z.  Only what position L/2 needs is computed in the last layer (17 of 33 / 6 of 11 steps).
 #include "nsnp_common.hpp"
 
-void nsnp_hap_free(nsnp_ctx*) {}
+#include <new>
 
-extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const*, int, int, int, int, int, int)
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)); }
+
+constexpr int TS = 128;        // sites per workgroup tile
+constexpr int TR = 128;        // weight rows per workgroup tile
+constexpr int BK = 16;         // K chunk
+constexpr int LDK = BK + 4;    // padded LDS row (80 B: conflict-free 16-byte reads across 16 lanes)
+constexpr int TILE_F = TS * BK;   // floats in one [128][16] tile image (8 KB)
+
+// position p inside a 16-unit chunk of the LSTM storage order <-> hidden unit within the chunk
+// (p = h*8 + 4*rt + r4  <->  unit = 8*rt + 2*r4 + h : what a lane half h owns after the MFMAs)
+__host__ __device__ inline int unit_of_pos(int p) { return 8 * ((p >> 2) & 1) + 2 * (p & 3) + (p >> 3); }
+
+struct StepArgs {
+    // per z-slice (direction / encoder) description of one fused step
+    const float* w;        // weight images  [row_tiles][n_chunks][128][16]
+    const float* bias;     // [rows] in image row order
+    const float* in0;      // input tile images for this step: [site_tiles][nk0][128][16] (may be NULL when nk0 == 0)
+    const float* in1;      // second input block (h_{t-1} in LSTM mode): [site_tiles][nk1][128][16]
+    float* out;            // LSTM: h_t images, 16 chunks per site tile; linear: rows/16 chunks per site tile
+    float* cstate;         // LSTM: c images, 16 chunks per site tile
+    int nk0, nk1;          // chunks taken from in0 / in1 (nk1 == 0 on the first step: h = 0)
+    int nk_img;            // chunks per row tile in the weight image (>= nk0 + nk1)
+    int in0_tile_stride;   // floats between consecutive site tiles of in0
+    int in1_tile_stride;
+    int out_tile_stride;   // floats between consecutive site tiles of out
+    int c_tile_stride;     // ... of cstate
+    int first;             // LSTM: 1 on the first step (c = 0)
+};
+struct StepLaunch { StepArgs z[4]; };
+
+enum { MODE_LSTM = 0, MODE_LINEAR = 1, MODE_LINEAR_TANH = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
 {
-    return ctx ? NSNP_ESHAPE : NSNP_EINVAL;
+    __shared__ float As[2][TR][LDK];
+    __shared__ float Bs[2][TS][LDK];
+    const StepArgs& a = L.z[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int bx = blockIdx.x;          // site tile
+    const int by = blockIdx.y;          // row tile
+    const int nk = a.nk0 + a.nk1;
+
+    const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_F;
+    const float* __restrict__ b0 = a.in0 ? a.in0 + (size_t)bx * a.in0_tile_stride : nullptr;
+    const float* __restrict__ b1 = a.in1 ? a.in1 + (size_t)bx * a.in1_tile_stride : nullptr;
+
+    // each thread moves two 16-byte pieces of each 8 KB tile image: row = tid/2, quarter = (tid&1)*2 + {0,1}
+    const int crow = tid >> 1, cq = (tid & 1) * 2;
+    auto gload = [&](int kc, f32x4& a0, f32x4& a1, f32x4& bb0, f32x4& bb1) {
+        const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_F) + crow * 4 + cq;
+        a0 = pa[0]; a1 = pa[1];
+        const float* src = kc < a.nk0 ? b0 + (size_t)kc * TILE_F : b1 + (size_t)(kc - a.nk0) * TILE_F;
+        const f32x4* pb = reinterpret_cast<const f32x4*>(src) + crow * 4 + cq;
+        bb0 = pb[0]; bb1 = pb[1];
+    };
+    auto lstore = [&](int buf, const f32x4& a0, const f32x4& a1, const f32x4& bb0, const f32x4& bb1) {
+        *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4]) = a0;
+        *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4 + 4]) = a1;
+        *reinterpret_cast<f32x4*>(&Bs[buf][crow][cq * 4]) = bb0;
+        *reinterpret_cast<f32x4*>(&Bs[buf][crow][cq * 4 + 4]) = bb1;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ga0, ga1, gb0, gb1;
+    gload(0, ga0, ga1, gb0, gb1);
+    lstore(0, ga0, ga1, gb0, gb1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) gload(kc + 1, ga0, ga1, gb0, gb1);
+        // fragments: lane (li, lh) takes floats [lh*8, lh*8+8) of its row = 8 k-steps of 32x32x2
+        f32x4 af[2][2], bf[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const float* p = &As[cur][64 * wr + 32 * rt + li][lh * 8];
+            af[rt][0] = *reinterpret_cast<const f32x4*>(p);
+            af[rt][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* p = &Bs[cur][64 * wc + 32 * ct + li][lh * 8];
+            bf[ct][0] = *reinterpret_cast<const f32x4*>(p);
+            bf[ct][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3],
+                                                                        acc[rt][ct], 0, 0, 0);
+        if (kc + 1 < nk) lstore(cur ^ 1, ga0, ga1, gb0, gb1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    // accumulator register r = 4*r4 + g of tile (rt, ct), lane (li, lh):
+    //   row within the 32-row tile = g + 8*r4 + 4*lh,  site = 64*wc + 32*ct + li
+    if (MODE == MODE_LSTM) {
+        // rows are [unit][gate]: unit8 = 2*r4 + lh, gate = g.  The wave's 16 units form chunk
+        // kc = 2*by + wr of the output image; a lane writes positions p = lh*8 + 4*rt + r4.
+        const size_t img = (size_t)(2 * by + wr) * TILE_F;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int site = 64 * wc + 32 * ct + li;
+            float* cptr = a.cstate + (size_t)bx * a.c_tile_stride + img + site * BK + lh * 8;
+            float* hptr = a.out + (size_t)bx * a.out_tile_stride + img + site * BK + lh * 8;
+            f32x4 cv[2];
+            if (a.first) { cv[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cv[1] = cv[0]; }
+            else { cv[0] = *reinterpret_cast<const f32x4*>(cptr); cv[1] = *reinterpret_cast<const f32x4*>(cptr + 4); }
+            f32x4 hv[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;   // image row of gate 0
+                    const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + row);
+                    const float ig = sigmoid_f(acc[rt][ct][4 * r4 + 0] + bz[0]);
+                    const float fg = sigmoid_f(acc[rt][ct][4 * r4 + 1] + bz[1]);
+                    const float gg = tanh_f(acc[rt][ct][4 * r4 + 2] + bz[2]);
+                    const float og = sigmoid_f(acc[rt][ct][4 * r4 + 3] + bz[3]);
+                    const float cn = fg * cv[rt][r4] + ig * gg;
+                    cv[rt][r4] = cn;
+                    hv[rt][r4] = og * tanh_f(cn);
+                }
+            *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
+            *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
+        }
+    } else {
+        // plain rows: feature f = 128*by + 64*wr + 32*rt + (g + 8*r4 + 4*lh); natural order in chunks of 16
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int site = 64 * wc + 32 * ct + li;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int f = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;
+                    const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + f);
+                    f32x4 v;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float t = acc[rt][ct][4 * r4 + g] + bz[g];
+                        v[g] = MODE == MODE_LINEAR_TANH ? tanh_f(t) : t;
+                    }
+                    float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK + (f & 15);
+                    *reinterpret_cast<f32x4*>(o) = v;
+                }
+        }
+    }
 }
 
-extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float*, const float*, int64_t, float*, float*, void*)
+// x [N][F][L] (predict_dev.py hands [N,105,L]; model_dev.py:136-137 permutes to [N,L,F]) ->
+// per-step tile images xT[t][site_tile][chunk][128][16], features in natural order, zero padded
+__global__ void k_hap_pack_input(const float* __restrict__ x, int64_t N, int F, int L, int n_tiles, int nkc,
+                                 float* __restrict__ xT)
 {
-    return ctx ? NSNP_ENOWEIGHTS : NSNP_EINVAL;
+    const int64_t total = (int64_t)L * n_tiles * nkc * TILE_F;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e & 15);
+        const int site = (int)((e >> 4) & 127);
+        int64_t r = e >> 11;
+        const int kc = (int)(r % nkc); r /= nkc;
+        const int tile = (int)(r % n_tiles);
+        const int t = (int)(r / n_tiles);
+        const int64_t n = (int64_t)tile * TS + site;
+        const int f = kc * 16 + p;
+        xT[e] = (n < N && f < F) ? x[(n * F + f) * L + t] : 0.f;
+    }
+}
+
+// heads: logits = W[rows x 256] . inner + b over the dense output image (natural order), softmax
+__global__ __launch_bounds__(256) void k_hap_heads(const float* __restrict__ inner, int64_t N,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    int n_gt, int n_zy, float* __restrict__ gt, float* __restrict__ zy)
+{
+    // one wave per site; lane k handles features k, k+64, ...
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int64_t tile = n / TS; const int site = (int)(n % TS);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = lane + 64 * j;
+        v[j] = inner[(tile * 16 + (f >> 4)) * TILE_F + site * BK + (f & 15)];
+    }
+    const int rows = n_gt + n_zy;
+    float logit[16];
+    for (int r = 0; r < rows; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += w[r * 256 + lane + 64 * j] * v[j];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        logit[r] = s + b[r];
+    }
+    if (lane == 0) {
+        float m = logit[0];
+        for (int r = 1; r < n_gt; ++r) m = fmaxf(m, logit[r]);
+        float sum = 0.f;
+        for (int r = 0; r < n_gt; ++r) { logit[r] = __expf(logit[r] - m); sum += logit[r]; }
+        for (int r = 0; r < n_gt; ++r) gt[n * n_gt + r] = logit[r] / sum;
+        m = logit[n_gt];
+        for (int r = 1; r < n_zy; ++r) m = fmaxf(m, logit[n_gt + r]);
+        sum = 0.f;
+        for (int r = 0; r < n_zy; ++r) { logit[n_gt + r] = __expf(logit[n_gt + r] - m); sum += logit[n_gt + r]; }
+        for (int r = 0; r < n_zy; ++r) zy[n * n_zy + r] = logit[n_gt + r] / sum;
+    }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+struct HapWeightsDev {
+    int F, H, n_layers, n_gt, n_zy, nk_in0;           // nk_in0 = ceil(F/16)
+    // [encoder][layer][dir]: weight images + bias
+    float* w[2][3][2]; float* b[2][3][2];
+    float* proj_w[2]; float* proj_b[2];                // Linear(2H -> H) per encoder, inputs in LSTM storage order
+    float* dense_w; float* dense_b;                    // Linear(2H -> H), inputs natural order (two proj outputs)
+    float* head_w; float* head_b;                      // [(n_gt+n_zy) x H] natural order
+    float* arena; size_t arena_floats;
+};
+
+void nsnp_hap_free(nsnp_ctx* ctx)
+{
+    if (ctx->hw) { if (ctx->hw->arena) (void)hipFree(ctx->hw->arena); delete ctx->hw; ctx->hw = nullptr; }
+    if (ctx->hap_ws) { (void)hipFree(ctx->hap_ws); ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0; }
+}
+
+namespace {
+
+// image element [row_tile][chunk][row 0..127][p 0..15]
+template <typename RowFn, typename ColFn>
+void pack_rows(float* img, int n_row_tiles, int n_chunks, const float* W, int ld, RowFn rowf, ColFn colf)
+{
+    for (int by = 0; by < n_row_tiles; ++by)
+        for (int kc = 0; kc < n_chunks; ++kc)
+            for (int row = 0; row < TR; ++row)
+                for (int p = 0; p < BK; ++p) {
+                    const int tr = rowf(by * TR + row);
+                    const int tc = colf(kc, p);
+                    img[(((size_t)by * n_chunks + kc) * TR + row) * BK + p] = (tr >= 0 && tc >= 0) ? W[(size_t)tr * ld + tc] : 0.f;
+                }
+}
+
+}  // namespace
+
+extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n_tensors,
+                                     int n_features, int hidden, int n_layers, int n_gt, int n_zy)
+{
+    if (!ctx || !t) return NSNP_EINVAL;
+    if (hidden != 256 || n_layers != 3 || n_features <= 0 || n_features > 128 || n_gt <= 0 || n_zy <= 0 || n_gt + n_zy > 16)
+        return NSNP_ESHAPE;                            // kernels are built for ont_haplotype.yaml:7-16
+    const int per_enc = n_layers * 2 * 4 + 2;
+    if (n_tensors < 2 * per_enc + 6) return NSNP_EINVAL;
+    for (int i = 0; i < 2 * per_enc + 6; ++i) if (!t[i]) return NSNP_EINVAL;
+    NSNP_HIP(ctx, hipSetDevice(ctx->device));
+    const int H = hidden, F = n_features, G = 4 * H;
+    const int nk0 = NSNP_CDIV(F, BK);
+    const int n_rt = G / TR;                           // 8 row tiles of gates
+    // LSTM image rows: image row R -> unit = R/4, gate = R%4 -> torch row gate*H + unit
+    auto lstm_row = [H](int R) { return (R & 3) * H + (R >> 2); };
+    auto nat_row = [](int R) { return R; };
+    size_t total = 0;
+    size_t off_w[2][3][2], off_b[2][3][2], off_pw[2], off_pb[2];
+    for (int e = 0; e < 2; ++e)
+        for (int l = 0; l < 3; ++l)
+            for (int d = 0; d < 2; ++d) {
+                const int nk = (l == 0 ? nk0 : 2 * H / BK) + H / BK;
+                off_w[e][l][d] = total; total += (size_t)n_rt * nk * TILE_F;
+                off_b[e][l][d] = total; total += G;
+            }
+    for (int e = 0; e < 2; ++e) { off_pw[e] = total; total += (size_t)(H / TR) * (2 * H / BK) * TILE_F; off_pb[e] = total; total += H; }
+    const size_t off_dw = total; total += (size_t)(H / TR) * (2 * H / BK) * TILE_F;
+    const size_t off_db = total; total += H;
+    const size_t off_hw = total; total += (size_t)(n_gt + n_zy) * H;
+    const size_t off_hb = total; total += 16;
+    std::vector<float> host(total, 0.f);
+    for (int e = 0; e < 2; ++e) {
+        for (int l = 0; l < 3; ++l)
+            for (int d = 0; d < 2; ++d) {
+                const float* const* q = t + e * per_enc + (l * 2 + d) * 4;
+                const int I = l == 0 ? F : 2 * H;
+                const int nki = l == 0 ? nk0 : 2 * H / BK, nkh = H / BK, nk = nki + nkh;
+                // one image with both column blocks: build [W_ih | W_hh] chunk maps
+                float* img = host.data() + off_w[e][l][d];
+                for (int by = 0; by < n_rt; ++by)
+                    for (int kc = 0; kc < nk; ++kc)
+                        for (int row = 0; row < TR; ++row)
+                            for (int p = 0; p < BK; ++p) {
+                                const int tr = lstm_row(by * TR + row);
+                                float v = 0.f;
+                                if (kc < nki) {
+                                    int col;
+                                    if (l == 0) col = kc * BK + p;                                          // natural features
+                                    else col = (kc / (H / BK)) * H + (kc % (H / BK)) * BK + unit_of_pos(p); // prev layer h, storage order
+                                    if (col < I) v = q[0][(size_t)tr * I + col];
+                                } else {
+                                    const int col = (kc - nki) * BK + unit_of_pos(p);
+                                    v = q[1][(size_t)tr * H + col];
+                                }
+                                img[(((size_t)by * nk + kc) * TR + row) * BK + p] = v;
+                            }
+                float* bz = host.data() + off_b[e][l][d];
+                for (int R = 0; R < G; ++R) bz[R] = q[2][lstm_row(R)] + q[3][lstm_row(R)];
+            }
+        // output_proj: Linear(2H -> H) on [h_fwd ; h_bwd] of the last layer at the centre step
+        const float* pw = t[e * per_enc + per_enc - 2]; const float* pb = t[e * per_enc + per_enc - 1];
+        pack_rows(host.data() + off_pw[e], H / TR, 2 * H / BK, pw, 2 * H, nat_row,
+                  [H](int kc, int p) { return (kc / (H / BK)) * H + (kc % (H / BK)) * BK + unit_of_pos(p); });
+        memcpy(host.data() + off_pb[e], pb, sizeof(float) * H);
+    }
+    const float* const* fw = t + 2 * per_enc;
+    pack_rows(host.data() + off_dw, H / TR, 2 * H / BK, fw[0], 2 * H, nat_row, [](int kc, int p) { return kc * BK + p; });
+    memcpy(host.data() + off_db, fw[1], sizeof(float) * H);
+    memcpy(host.data() + off_hw, fw[2], sizeof(float) * (size_t)n_gt * H);
+    memcpy(host.data() + off_hw + (size_t)n_gt * H, fw[4], sizeof(float) * (size_t)n_zy * H);
+    memcpy(host.data() + off_hb, fw[3], sizeof(float) * n_gt);
+    memcpy(host.data() + off_hb + n_gt, fw[5], sizeof(float) * n_zy);
+
+    if (!ctx->hw) { ctx->hw = new (std::nothrow) HapWeightsDev(); if (!ctx->hw) return NSNP_ENOMEM; memset((void*)ctx->hw, 0, sizeof(HapWeightsDev)); }
+    HapWeightsDev& hw = *ctx->hw;
+    if (hw.arena && hw.arena_floats != total) { (void)hipFree(hw.arena); hw.arena = nullptr; }
+    if (!hw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&hw.arena, total * sizeof(float))); hw.arena_floats = total; }
+    NSNP_HIP(ctx, hipMemcpy(hw.arena, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    hw.F = F; hw.H = H; hw.n_layers = n_layers; hw.n_gt = n_gt; hw.n_zy = n_zy; hw.nk_in0 = nk0;
+    for (int e = 0; e < 2; ++e) {
+        for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) { hw.w[e][l][d] = hw.arena + off_w[e][l][d]; hw.b[e][l][d] = hw.arena + off_b[e][l][d]; }
+        hw.proj_w[e] = hw.arena + off_pw[e]; hw.proj_b[e] = hw.arena + off_pb[e];
+    }
+    hw.dense_w = hw.arena + off_dw; hw.dense_b = hw.arena + off_db; hw.head_w = hw.arena + off_hw; hw.head_b = hw.arena + off_hb;
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N,
+                                float* gt_prob, float* zy_prob, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!xp || !xh || !gt_prob || !zy_prob))) return NSNP_EINVAL;
+    if (!ctx->hw) return NSNP_ENOWEIGHTS;
+    if (N == 0) return NSNP_OK;
+    const HapWeightsDev& hw = *ctx->hw;
+    hipStream_t s = (hipStream_t)stream;
+    const int H = hw.H, F = hw.F;
+    const int Lp = 33, Lh = 11;                       // ont_haplotype.yaml:10-11
+    const int64_t chunk = 4096;                        // sites per pass (workspace ~0.8 GB)
+    const int max_tiles = (int)(chunk / TS);
+    // workspace layout (floats)
+    const size_t xT_f = (size_t)Lp * max_tiles * hw.nk_in0 * TILE_F;       // packed input of the longer encoder
+    const size_t hbuf_f = (size_t)Lp * max_tiles * 2 * 16 * TILE_F;        // h of all steps, both directions, one layer
+    const size_t c_f = (size_t)4 * max_tiles * 16 * TILE_F;                // c for up to 4 z-slices
+    const size_t cat_f = (size_t)max_tiles * 32 * TILE_F;                  // [proj_p ; proj_h] (2 x 256 features)
+    const size_t inner_f = (size_t)max_tiles * 16 * TILE_F;
+    const size_t need = (2 * xT_f + 4 * hbuf_f + c_f + cat_f + inner_f) * sizeof(float);
+    if (ctx->hap_ws_bytes < need) {
+        NSNP_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->hap_ws) (void)hipFree(ctx->hap_ws);
+        ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0;
+        NSNP_HIP(ctx, hipMalloc(&ctx->hap_ws, need));
+        ctx->hap_ws_bytes = need;
+    }
+    float* base = (float*)ctx->hap_ws;
+    float* xT[2] = {base, base + xT_f};
+    float* hb[2][2] = {{base + 2 * xT_f, base + 2 * xT_f + hbuf_f}, {base + 2 * xT_f + 2 * hbuf_f, base + 2 * xT_f + 3 * hbuf_f}};
+    float* cst = base + 2 * xT_f + 4 * hbuf_f;
+    float* cat = cst + c_f;
+    float* inner = cat + cat_f;
+
+    for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+        const int64_t n = N - n0 < chunk ? N - n0 : chunk;
+        const int n_tiles = (int)NSNP_CDIV(n, TS);
+        const int Ls[2] = {Lp, Lh};
+        const float* xin[2] = {xp + n0 * F * Lp, xh + n0 * F * Lh};
+        for (int e = 0; e < 2; ++e) {
+            const int64_t tot = (int64_t)Ls[e] * n_tiles * hw.nk_in0 * TILE_F;
+            int blocks = (int)NSNP_CDIV(tot, 256); if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(k_hap_pack_input, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
+        }
+        // h of one layer: [t][site tile][dir][16 chunks][128][16] -> the 32 chunks [h_fwd ; h_bwd] of a site
+        // tile at time t are contiguous (what the next layer and output_proj consume)
+        const size_t tile_h = (size_t)16 * TILE_F;                 // one direction of one site tile at one step
+        const size_t step_h = (size_t)n_tiles * 2 * tile_h;
+        for (int l = 0; l < 3; ++l) {
+            // encoder e reads its layer input from (l == 0 ? xT[e] : hb[e][(l-1)&1]) and writes hb[e][l&1]
+            const int steps[2] = {l == 2 ? Lp / 2 + 1 : Lp, l == 2 ? Lh / 2 + 1 : Lh};
+            const int max_steps = steps[0] > steps[1] ? steps[0] : steps[1];
+            for (int st = 0; st < max_steps; ++st) {
+                StepLaunch L; int nz = 0;
+                for (int e = 0; e < 2; ++e) {
+                    if (st >= steps[e]) continue;
+                    for (int d = 0; d < 2; ++d) {
+                        const int t = d ? Ls[e] - 1 - st : st;
+                        const int tprev = d ? t + 1 : t - 1;
+                        StepArgs& a = L.z[nz];
+                        a.w = hw.w[e][l][d]; a.bias = hw.b[e][l][d];
+                        if (l == 0) {
+                            a.in0 = xT[e] + (size_t)t * n_tiles * hw.nk_in0 * TILE_F;
+                            a.nk0 = hw.nk_in0; a.in0_tile_stride = hw.nk_in0 * TILE_F;
+                        } else {
+                            a.in0 = hb[e][(l - 1) & 1] + (size_t)t * step_h;
+                            a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(2 * tile_h);
+                        }
+                        a.in1 = st ? hb[e][l & 1] + (size_t)tprev * step_h + (size_t)d * tile_h : nullptr;
+                        a.nk1 = st ? H / BK : 0; a.in1_tile_stride = (int)(2 * tile_h);
+                        a.nk_img = a.nk0 + H / BK;
+                        a.out = hb[e][l & 1] + (size_t)t * step_h + (size_t)d * tile_h;
+                        a.out_tile_stride = (int)(2 * tile_h);
+                        a.cstate = cst + (size_t)(e * 2 + d) * n_tiles * tile_h;
+                        a.c_tile_stride = (int)tile_h;
+                        a.first = st == 0;
+                        ++nz;
+                    }
+                }
+                hipLaunchKernelGGL(k_hap_gemm<MODE_LSTM>, dim3(n_tiles, 4 * H / TR, nz), dim3(256), 0, s, L);
+            }
+        }
+        // output_proj at the centre step of the last layer (which wrote hb[e][0]), both encoders in one
+        // launch -> cat image: 32 chunks per site tile = [proj_pileup(256) ; proj_haplotype(256)]
+        {
+            StepLaunch L;
+            for (int e = 0; e < 2; ++e) {
+                StepArgs& a = L.z[e];
+                a.w = hw.proj_w[e]; a.bias = hw.proj_b[e];
+                a.in0 = hb[e][0] + (size_t)(Ls[e] / 2) * step_h;
+                a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(2 * tile_h);
+                a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0;
+                a.out = cat + (size_t)e * 16 * TILE_F; a.out_tile_stride = 32 * TILE_F;
+                a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
+            }
+            hipLaunchKernelGGL(k_hap_gemm<MODE_LINEAR>, dim3(n_tiles, H / TR, 2), dim3(256), 0, s, L);
+        }
+        {
+            StepLaunch L; StepArgs& a = L.z[0];
+            a.w = hw.dense_w; a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
+            a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0; a.out = inner; a.out_tile_stride = 16 * TILE_F;
+            a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
+            hipLaunchKernelGGL(k_hap_gemm<MODE_LINEAR_TANH>, dim3(n_tiles, H / TR, 1), dim3(256), 0, s, L);
+        }
+        hipLaunchKernelGGL(k_hap_heads, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
+                           hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
+    }
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
 }

@@ -64,7 +64,10 @@ static double rng_normal(rng_t* r)
 static const char UP[4] = { 'A', 'C', 'G', 'T' };
 static const char LO[4] = { 'a', 'c', 'g', 't' };
 
-/* kind: 0 noise-only, 1 heterozygous (each read carries alt w.p. 0.5), 2 homozygous alt */
+/* kind: 0 noise-only, 1 heterozygous (each read carries alt w.p. 0.5), 2 homozygous alt.
+ * One 64-bit draw per read, sliced into independent fields (probabilities are k/1024):
+ *   strand 0.5 | "^I" prefix 10/1024 | symbol: random base 31/1024, '*'/'#' 20/1024, else ref (or
+ *   alt) | indel 31/1024 with length 1..3, sign and up to 3 bases | "$" suffix 10/1024 */
 static int64_t gen_column(rng_t* r, int ref_idx, int kind, double coverage, int max_depth,
                           uint8_t* out /* may be NULL: size only */)
 {
@@ -75,23 +78,24 @@ static int64_t gen_column(rng_t* r, int ref_idx, int kind, double coverage, int 
     int64_t n = 0;
 #define PUT(ch) do { const uint8_t ch_ = (uint8_t)(ch); if (out) out[n] = ch_; ++n; } while (0)
     for (int i = 0; i < d; ++i) {
-        const int rev = rng_u(r) < 0.5;
+        const uint64_t x = rng_next(r);
+        const int rev = (int)(x & 1);
         const char* tab = rev ? LO : UP;
-        if (rng_u(r) < 0.01) { PUT('^'); PUT('I'); }
-        double u = rng_u(r);
+        if (((x >> 1) & 1023) < 10) { PUT('^'); PUT('I'); }
+        const unsigned u = (unsigned)((x >> 11) & 1023);
         int sym;
-        if (kind == 2 || (kind == 1 && rng_u(r) < 0.5)) sym = tab[alt_idx];
-        else if (u < 0.03) sym = tab[rng_int(r, 4)];
-        else if (u < 0.05) sym = rev ? '#' : '*';
+        if (kind == 2 || (kind == 1 && ((x >> 21) & 1))) sym = tab[alt_idx];
+        else if (u < 31) sym = tab[(x >> 51) & 3];
+        else if (u < 51) sym = rev ? '#' : '*';
         else sym = tab[ref_idx];
         PUT(sym);
-        if (rng_u(r) < 0.03) {
-            const int len = 1 + rng_int(r, 3);
-            PUT(rng_u(r) < 0.5 ? '+' : '-');
+        if (((x >> 22) & 1023) < 31) {
+            const int len = 1 + (int)(((x >> 32) & 0xff) % 3);
+            PUT(((x >> 40) & 1) ? '+' : '-');
             PUT('0' + len);
-            for (int k = 0; k < len; ++k) PUT(tab[rng_int(r, 4)]);
+            for (int k = 0; k < len; ++k) PUT(tab[(x >> (41 + 2 * k)) & 3]);
         }
-        if (rng_u(r) < 0.01) PUT('$');
+        if (((x >> 53) & 1023) < 10) PUT('$');
     }
 #undef PUT
     return n;

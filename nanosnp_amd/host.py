@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libnanosnp_host.so")
 
+NSNP_EINVAL = -1
 _ERR = {-1: "invalid argument", -2: "out of memory", -3: "I/O error", -4: "malformed input",
         -5: "buffer too small"}
 
@@ -97,18 +98,17 @@ def synth_columns(seed, n_cols, coverage=30.0, max_depth=144, het_rate=0.02, win
     M = int(n_cols)
     ref = np.empty(M, np.uint8)
     col_off = np.empty(M + 1, np.int64)
-    cap = int(M * (coverage * 1.3 + 64)) + 1024
-    while True:
-        bases = np.empty(cap, np.uint8)
-        rc = lib().nsnp_synth_columns(int(seed), M, float(coverage), int(max_depth),
-                                      float(het_rate), int(window), _ptr(ref), _ptr(bases),
-                                      cap, _ptr(col_off))
-        if rc >= 0:
-            bases = bases[:rc].copy() if rc < cap // 2 else bases[:rc]
-            break
-        if rc > -16:
-            _check(rc, "nsnp_synth_columns")
-        cap = -int(rc) - 16 + 64
+    # size query (bases = NULL returns -(needed + 16)), then one exact allocation
+    rc = lib().nsnp_synth_columns(int(seed), M, float(coverage), int(max_depth), float(het_rate),
+                                  int(window), _ptr(ref), None, 0, _ptr(col_off))
+    if rc > -16:
+        _check(rc if rc < 0 else NSNP_EINVAL, "nsnp_synth_columns")
+    cap = -int(rc) - 16
+    bases = np.empty(max(cap, 1), np.uint8)
+    rc = _check(lib().nsnp_synth_columns(int(seed), M, float(coverage), int(max_depth),
+                                         float(het_rate), int(window), _ptr(ref), _ptr(bases),
+                                         cap, _ptr(col_off)), "nsnp_synth_columns")
+    bases = bases[:rc]
     if window:
         # stand-alone windows: leave a gap after each so that no window continues another
         idx = np.arange(M, dtype=np.int64)

@@ -48,3 +48,83 @@ def test_mixed_hp_rows_and_large_values(gpu_ctx):
     got = _feat(gpu_ctx, (seq, bq, mq, hap, ref))
     want = oracle.hap_features_batch(seq, bq, mq, hap, ref)
     assert np.array_equal(got, want)
+
+
+# ---- HaplotypeModel forward -------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hap_model(gpu_ctx):
+    from tests.helpers import seeded_hap_weights
+    ws = seeded_hap_weights(12, H=256)
+    gpu_ctx.hap_load_weights(ws)
+    return gpu_ctx, ws
+
+
+def _hfwd(ctx, xp, xh):
+    import torch
+    gt, zy = ctx.hap_forward(torch.from_numpy(np.ascontiguousarray(xp)).cuda(), torch.from_numpy(np.ascontiguousarray(xh)).cuda())
+    torch.cuda.synchronize()
+    return gt.cpu().numpy(), zy.cpu().numpy()
+
+
+def test_hap_forward_golden_of_the_reference_module(hap_model):
+    """model_dev.LSTMNetwork.predict with the seeded weights (trained weights are absent upstream)"""
+    from tests.helpers import PROB_ATOL
+    ctx, _ = hap_model
+    z = np.load(golden("hap_fwd_h256.npz"))
+    assert int(z["seed"]) == 12
+    gt, zy = _hfwd(ctx, z["xp"], z["xh"])
+    assert np.abs(gt - z["gt"]).max() < PROB_ATOL and np.abs(zy - z["zy"]).max() < PROB_ATOL
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 300])
+def test_hap_forward_vs_oracle_ragged(hap_model, n):
+    from oracle import oracle
+    from tests.helpers import PROB_ATOL
+    ctx, ws = hap_model
+    pp = host.synth_hap_planes(900 + n, n, 30, 90, 33)
+    ph = host.synth_hap_planes(950 + n, n, 30, 90, 11)
+    xp = oracle.hap_features_batch(*pp, nthreads=4)
+    xh = oracle.hap_features_batch(*ph, nthreads=4)
+    gt, zy = _hfwd(ctx, xp, xh)
+    ogt, ozy = oracle.hap_forward(ws, xp, xh, nthreads=8)
+    assert np.abs(gt - ogt).max() < PROB_ATOL and np.abs(zy - ozy).max() < PROB_ATOL
+    assert np.allclose(gt.sum(1), 1, atol=1e-5)
+
+
+def test_hap_forward_sensitive_inputs(hap_model):
+    """random O(1) features make the network input-sensitive (synthetic count features saturate the
+    seeded-weight gates), so layer/step/direction mix-ups show up as O(0.1) errors"""
+    from oracle import oracle
+    from tests.helpers import PROB_ATOL
+    ctx, ws = hap_model
+    rng = np.random.default_rng(4)
+    n = 96
+    xp = (rng.standard_normal((n, 105, 33)) * 300).astype(np.float32)
+    xh = (rng.standard_normal((n, 105, 11)) * 300).astype(np.float32)
+    gt, zy = _hfwd(ctx, xp, xh)
+    ogt, ozy = oracle.hap_forward(ws, xp, xh, nthreads=8)
+    assert ogt.std(0).max() > 1e-3          # outputs really differ between sites
+    assert np.abs(gt - ogt).max() < PROB_ATOL and np.abs(zy - ozy).max() < PROB_ATOL
+
+
+def test_hap_features_into_forward_pipeline(hap_model):
+    """predict_dev.py:34-39 end to end on the device: planes -> features -> forward"""
+    import torch
+    from oracle import oracle
+    from tests.helpers import PROB_ATOL
+    ctx, ws = hap_model
+    n = 64
+    pp = host.synth_hap_planes(1, n, 30, 90, 33)
+    ph = host.synth_hap_planes(2, n, 30, 90, 11)
+    fp = ctx.hap_features(*[torch.from_numpy(a).cuda() for a in pp])
+    fh = ctx.hap_features(*[torch.from_numpy(a).cuda() for a in ph])
+    gt, zy = ctx.hap_forward(fp, fh)
+    ogt, ozy = oracle.hap_forward(ws, oracle.hap_features_batch(*pp), oracle.hap_features_batch(*ph), nthreads=8)
+    assert np.abs(gt.cpu().numpy() - ogt).max() < PROB_ATOL
+
+
+def test_hap_unsupported_shape_is_an_error(gpu_ctx):
+    from nanosnp_amd import _lib
+    from tests.helpers import seeded_hap_weights
+    with pytest.raises(_lib.NanoSNPError):
+        gpu_ctx.hap_load_weights(seeded_hap_weights(11, H=32), hidden=32)

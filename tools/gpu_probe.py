@@ -87,3 +87,13 @@ planes = host.synth_hap_planes(5, 4096, 30, 90, 33)
 pt = [torch.from_numpy(a).to(dev) for a in planes]
 t = bench(lambda: ctx.hap_features(*pt))
 print("hap features N=4096 D=90 L=33: %.3f ms  %.2f M sites/s  %.1f GB/s" % (t * 1e3, 4096 / t / 1e6, 4096 * (4 * 90 * 33 * 4 + 105 * 33 * 4) / t / 1e9))
+
+# ---- hap forward timing
+from tests.helpers import seeded_hap_weights
+ws = seeded_hap_weights(12, H=256)
+ctx.hap_load_weights(ws)
+for N in (512, 4096):
+    xp = torch.randn((N, 105, 33), device=dev) * 100
+    xh = torch.randn((N, 105, 11), device=dev) * 100
+    t = bench(lambda: ctx.hap_forward(xp, xh), iters=3)
+    print("hap forward N=%d: %.2f ms  %.1f k sites/s  %.1f TFLOP/s (353.7 MFLOP/site alg)" % (N, t * 1e3, N / t / 1e3, 353.7e6 * N / t / 1e12))
