@@ -1,0 +1,119 @@
+"""Site sharding + result gather (nanosnp_amd/dist.py) with world_size 2 on CPU (gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from nanosnp_amd.dist import shard_columns, shard_range
+
+
+def test_shard_range_is_a_contiguous_order_preserving_partition():
+    for n in (0, 1, 7, 8, 9, 4096, 1_500_001):
+        for world in (1, 2, 3, 4, 8):
+            edges = [shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_shard_columns_halo_keeps_every_owned_window_complete():
+    m, world = 1000, 4
+    for r in range(world):
+        lo_h, hi_h, lo, hi = shard_columns(m, r, world)
+        assert lo_h == max(0, lo - 16) and hi_h == min(m, hi + 16)
+        for c in (lo, hi - 1):                 # a window centred on an owned column
+            if c - 16 >= 0 and c + 16 < m:
+                assert lo_h <= c - 16 and c + 16 < hi_h
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_total, q):
+    import torch
+    import torch.distributed as dist
+    from nanosnp_amd.dist import gather_results, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank "computes" its own site range: payload = f(site index), so order is checkable
+        lo, hi = shard_range(n_total, rank, world)
+        idx = torch.arange(lo, hi, dtype=torch.float32)
+        local = torch.stack([idx, idx * 2 + 1, torch.full_like(idx, rank)], dim=1)
+        merged = gather_results(local, n_total, root=0)
+        if rank == 0:
+            q.put(merged.numpy())
+        else:
+            assert merged is None
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [0, 1, 5, 4097])
+def test_gather_results_world2_gloo(n_total):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    merged = next(o for o in outs if o is not None)
+    assert merged.shape == (n_total, 3)
+    want = np.arange(n_total, dtype=np.float32)
+    assert np.array_equal(merged[:, 0], want) and np.array_equal(merged[:, 1], want * 2 + 1)
+    lo1, _ = shard_range(n_total, 1, 2)
+    assert np.array_equal(merged[:, 2], (np.arange(n_total) >= lo1).astype(np.float32))
+
+
+def _pipeline_worker(rank, world, port, q):
+    """Sharded oracle pipeline == single-process pipeline (the N>1 path, with the CPU checker
+    standing in for the device kernels)."""
+    import torch
+    import torch.distributed as dist
+    from nanosnp_amd import host
+    from nanosnp_amd.dist import gather_results, shard_range
+    from oracle import oracle
+    from tests.helpers import load_pileup_weights
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 37
+        cols = host.synth_columns(5, n * 33, window=33)
+        counts, _, _ = oracle.encode_columns(cols.bases, cols.col_off, cols.ref)
+        x = counts.reshape(n, 33, 18)
+        lo, hi = shard_range(n, rank, world)
+        gt, zy = oracle.pileup_forward(load_pileup_weights(), x[lo:hi])
+        merged = gather_results(torch.from_numpy(np.concatenate([gt, zy], 1)), n)
+        if rank == 0:
+            full_gt, full_zy = oracle.pileup_forward(load_pileup_weights(), x)
+            q.put(bool(np.array_equal(merged.numpy(), np.concatenate([full_gt, full_zy], 1))))
+        else:
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pipeline_equals_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert any(o is True for o in outs)
