@@ -8,7 +8,7 @@ reading the windows in place (-> softmax probabilities) + argmax/max/depth post-
 Batches are independent, so steps are issued round-robin over `--streams` HIP streams (one
 nsnp_ctx each) to keep all 256 CUs busy at this batch size.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096] [--streams 8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096] [--streams 16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: one process per GPU, every rank owns its own pool (weak scaling, no data-path
@@ -49,9 +49,13 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--streams", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--windows", type=int, default=1 << 20, help="windows resident per GPU")
     ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave)")
+    ap.add_argument("--rec-waves", type=int, default=0, help="force waves per recurrence workgroup (0 = auto)")
+    ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (extra values are informational)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     return ap.parse_args()
@@ -88,6 +92,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if args.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)      # must be set before HIP initialises
     import torch
     import torch.distributed as dist
     from nanosnp_amd import _lib, host
@@ -118,7 +124,9 @@ def main():
     for s in range(S):
         ctx = _lib.Context(local_rank, chunk_sites=batch)
         ctx.pileup_load_weights(weights)
-        ctx.enable_timing(True)
+        ctx.enable_timing(not args.no_kernel_timing)
+        if args.rec_waves:
+            ctx.set_option("recurrence_waves", args.rec_waves)
         ctxs.append(ctx)
         streams.append(torch.cuda.Stream(device=dev))
         bufs.append(dict(
@@ -171,19 +179,28 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def merge_results(n_done):
+        """final merge: compact per-site calls of this rank -> rank 0 (RCCL gather over xGMI)"""
+        compact = torch.stack([res["ga"][:n_done].float(), res["za"][:n_done].float(),
+                               res["gm"][:n_done], res["zm"][:n_done]], dim=1)
+        return gather_results(compact, n_done * world) if world > 1 else compact
+
+    n_done = min(K, n_batches) * batch
     run_steps(0, W)
     sync_all()
+    merge_results(n_done)               # warm the merge path (first-use module loads) outside the clock
+    sync_all()
+    extra = []
+    for rep in range(max(0, args.repeat - 1)):      # informational repeats BEFORE the reported region
+        sync_all(); t0 = time.perf_counter(); run_steps(W, K); sync_all()
+        extra.append(world * K * batch / (time.perf_counter() - t0))
     for ctx in ctxs:
         ctx.read_timing()               # drop warm-up launches
     barrier(); sync_all()
     t0 = time.perf_counter()
     run_steps(W, K)
     sync_all()
-    # final merge: compact per-site calls of this rank's K batches -> rank 0 (RCCL gather over xGMI)
-    n_done = min(K, n_batches) * batch
-    compact = torch.stack([res["ga"][:n_done].float(), res["za"][:n_done].float(),
-                           res["gm"][:n_done], res["zm"][:n_done]], dim=1)
-    merged = gather_results(compact, n_done * world) if world > 1 else compact
+    merged = merge_results(n_done)
     sync_all(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -198,6 +215,11 @@ def main():
             a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
     if rank == 0:
         avg_ms = {k: (v[0] / v[1]) for k, v in tot.items() if v[1]}
+        if not avg_ms:
+            print(json.dumps({"metric": METRIC, "value": world * K * batch / dt, "unit": "sites/s", "n_gpus": world,
+                              "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "note": "kernel timing disabled",
+                              "repeats_before": [round(v) for v in extra]}))
+            return
         dom = max(avg_ms, key=lambda k: tot[k][0])
         if dom in ALG_FLOP_PER_SITE:
             achieved = ALG_FLOP_PER_SITE[dom] * batch / (avg_ms[dom] * 1e-3) / 1e12
@@ -234,6 +256,8 @@ def main():
             "kernel_avg_ms": {k: round(v, 5) for k, v in sorted(avg_ms.items())},
             "forward_alg_tflops": (2 * 6_274_560 * batch / (fwd_ms * 1e-3) / 1e12) if fwd_ms else None,
         }
+        if extra:
+            out["repeats_before"] = [round(v) for v in extra]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cols, batch, weights, args.cpu_seconds)
         else:

@@ -69,6 +69,10 @@ int nsnp_ctx_destroy(nsnp_ctx* ctx);
  * the hot loop (and out of hipGraph capture). */
 int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
 
+/* Tuning knobs (tests / experiments).  "recurrence_waves": 0 = automatic (default), or 1/2/4/8 waves
+ * per workgroup of the PileupModel recurrence kernels.  Results do not depend on any option. */
+int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
+
 /* Optional per-kernel timing: when enabled every launch of the kernels below is bracketed by a
  * HIP event pair recorded on the launch stream (up to 8192 launches per kernel between reads).
  * nsnp_ctx_read_timing waits for the recorded events, returns their summed duration and count

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "nsnp_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "nsnp_ctx_destroy": (C.c_int, [C.c_void_p]),
     "nsnp_ctx_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "nsnp_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "nsnp_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "nsnp_ctx_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nsnp_pileup_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
@@ -114,6 +115,9 @@ class Context:
 
     def reserve(self, max_sites):
         check(self.lib.nsnp_ctx_reserve(self.handle, int(max_sites)), self.handle, "nsnp_ctx_reserve")
+
+    def set_option(self, name, value):
+        check(self.lib.nsnp_ctx_set_option(self.handle, name.encode(), int(value)), self.handle, f"nsnp_ctx_set_option({name})")
 
     KERNELS = ("pileup_l0", "pileup_proj1", "pileup_l1", "pileup_head", "encode_columns", "hap_features")
 

@@ -24,7 +24,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
-__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)); }
+__device__ __forceinline__ float tanh_f(float x) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f); }
 
 constexpr int TS = 128;        // sites per workgroup tile
 constexpr int TR = 128;        // weight rows per workgroup tile
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                     const float fg = sigmoid_f(acc[rt][ct][4 * r4 + 1] + bz[1]);
                     const float gg = tanh_f(acc[rt][ct][4 * r4 + 2] + bz[2]);
                     const float og = sigmoid_f(acc[rt][ct][4 * r4 + 3] + bz[3]);
-                    const float cn = fg * cv[rt][r4] + ig * gg;
+                    const float cn = __builtin_fmaf(fg, cv[rt][r4], ig * gg);
                     cv[rt][r4] = cn;
                     hv[rt][r4] = og * tanh_f(cn);
                 }

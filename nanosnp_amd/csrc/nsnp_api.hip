@@ -71,6 +71,17 @@ ScopedKernelTimer::ScopedKernelTimer(nsnp_ctx* c, int kernel, hipStream_t stream
 }
 ScopedKernelTimer::~ScopedKernelTimer() { if (on) (void)hipEventRecord(stop_ev, s); }
 
+extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return NSNP_EINVAL;
+    if (strcmp(name, "recurrence_waves") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NSNP_EINVAL;
+        ctx->force_wpb = (int)value;
+        return NSNP_OK;
+    }
+    return NSNP_EINVAL;
+}
+
 extern "C" int nsnp_ctx_enable_timing(nsnp_ctx* ctx, int enable)
 {
     if (!ctx) return NSNP_EINVAL;

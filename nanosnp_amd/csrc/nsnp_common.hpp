@@ -63,6 +63,7 @@ struct nsnp_ctx {
     int n_cu;
     hipError_t last_err;
     bool attr_set;
+    int force_wpb;      // 0 = automatic; else waves per recurrence workgroup (tuning / tests)
     // workspace (sized by nsnp_ctx_reserve)
     int64_t chunk_sites;
     float*  ws_h0;      // [chunk][33][128]

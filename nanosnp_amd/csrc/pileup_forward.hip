@@ -39,7 +39,7 @@ __device__ __forceinline__ float sigmoid_f(float x)
 __device__ __forceinline__ float tanh_f(float x)
 {
     // 1 - 2/(1+e^{2x}); saturates cleanly to +-1 through exp2 -> inf / 0
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x));
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f);
 }
 
 // acc[NT] += W(image rows, K-steps [4*J4B, 4*(J4B+J4N))) . b, with the weight image read 16 B per
@@ -91,7 +91,7 @@ __device__ __forceinline__ void lstm_pointwise8(const f32x4* acc, float* c, floa
         const float fg = sigmoid_f(acc[i][1]);
         const float gg = tanh_f(acc[i][2]);
         const float og = sigmoid_f(acc[i][3]);
-        c[i] = fg * c[i] + ig * gg;
+        c[i] = __builtin_fmaf(fg, c[i], ig * gg);
         h[i] = og * tanh_f(c[i]);
     }
 }
@@ -112,7 +112,10 @@ constexpr int L0_WHH_F4 = 16 * 4 * 64;   // f32x4 elements
 constexpr int L0_WIH_F4 = 16 * 1 * 64;
 constexpr int L0_LDS_BYTES = (L0_WHH_F4 + L0_WIH_F4) * 16;
 
-__global__ __launch_bounds__(512, 4) void k_pileup_l0(
+// WAVES (8, 4, 2 or 1) is picked by the launcher so that small batches still spread over all CUs:
+// LDS admits two workgroups per CU whatever their size.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))) void k_pileup_l0(
     const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
     const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ wih0, const float* __restrict__ wih1,
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(512, 4) void k_pileup_l0(
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4;
-    copy_to_lds(lds, dir ? whh1 : whh0, L0_WHH_F4, tid, 512);
-    copy_to_lds(lds + L0_WHH_F4, dir ? wih1 : wih0, L0_WIH_F4, tid, 512);
+    copy_to_lds(lds, dir ? whh1 : whh0, L0_WHH_F4, tid, 64 * WAVES);
+    copy_to_lds(lds + L0_WHH_F4, dir ? wih1 : wih0, L0_WIH_F4, tid, 64 * WAVES);
     const float* __restrict__ wlast = dir ? wlast1 : wlast0;
     __syncthreads();
 
-    const int64_t site = (int64_t)blockIdx.x * 128 + wave * 16 + (lane & 15);
+    const int64_t site = (int64_t)blockIdx.x * (16 * WAVES) + wave * 16 + (lane & 15);
     const bool live = site < N;
     const int64_t sc = live ? site : N - 1;
     // window base: gathered [N,33,18] or straight out of the per-column count matrix
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(1024, 4) void k_pileup_proj1(
 // ---------------------------------------------------------------------------------------------
 constexpr int L1_LDS_BYTES = L0_WHH_F4 * 16;
 
-__global__ __launch_bounds__(512, 4) void k_pileup_l1(
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))) void k_pileup_l1(
     const float* __restrict__ Xp1, int64_t N,
     const float* __restrict__ whh0, const float* __restrict__ whh1,
     float* __restrict__ H1c)
@@ -261,9 +265,9 @@ __global__ __launch_bounds__(512, 4) void k_pileup_l1(
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4;
-    copy_to_lds(lds, dir ? whh1 : whh0, L0_WHH_F4, tid, 512);
+    copy_to_lds(lds, dir ? whh1 : whh0, L0_WHH_F4, tid, 64 * WAVES);
     __syncthreads();
-    const int64_t site = (int64_t)blockIdx.x * 128 + wave * 16 + (lane & 15);
+    const int64_t site = (int64_t)blockIdx.x * (16 * WAVES) + wave * 16 + (lane & 15);
     const bool live = site < N;
     const int64_t sc = live ? site : N - 1;
     const int64_t M = N * PSTEPS1;
@@ -543,9 +547,15 @@ int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w)
 static int set_lds_attr_once(nsnp_ctx* ctx)
 {
     if (ctx->attr_set) return NSNP_OK;
-    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l0, hipFuncAttributeMaxDynamicSharedMemorySize, L0_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l0<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L0_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l0<4>, hipFuncAttributeMaxDynamicSharedMemorySize, L0_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l0<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L0_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l0<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L0_LDS_BYTES));
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_proj1, hipFuncAttributeMaxDynamicSharedMemorySize, P1_LDS_BYTES));
-    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
     ctx->attr_set = true;
     return NSNP_OK;
 }
@@ -563,11 +573,21 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         const int64_t n = (N - base < ctx->chunk_sites) ? N - base : ctx->chunk_sites;
         const int32_t* xc = center_idx ? x : x + base * (PW * PC);
         const int64_t* cc = center_idx ? center_idx + base : nullptr;
-        const dim3 g_rec((unsigned)NSNP_CDIV(n, 128), 2);
+        // waves per recurrence workgroup: the largest of 8/4/2/1 that still yields a workgroup for every
+        // second CU (LDS admits two workgroups per CU whatever their size): a 4096-site batch runs as
+        // 128 four-wave workgroups, which measured best when several batches are in flight on
+        // different streams (single-stream latency would prefer 1-wave workgroups: see DESIGN.md)
+        const int64_t waves_total = NSNP_CDIV(n, 16) * 2;
+        int wpb = 8;
+        while (wpb > 1 && waves_total / wpb < (int64_t)ctx->n_cu / 2) wpb >>= 1;
+        if (ctx->force_wpb) wpb = ctx->force_wpb;
+        const dim3 g_rec((unsigned)NSNP_CDIV(n, 16 * wpb), 2);
         { ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
-        hipLaunchKernelGGL(k_pileup_l0, g_rec, dim3(512), L0_LDS_BYTES, s, xc, cc, n,
-                           pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1],
-                           ctx->ws_h0); }
+#define LAUNCH_L0(W) hipLaunchKernelGGL(k_pileup_l0<W>, g_rec, dim3(64 * W), L0_LDS_BYTES, s, xc, cc, n, \
+                           pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1], ctx->ws_h0)
+        if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
+#undef LAUNCH_L0
+        }
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
         int64_t gp = NSNP_CDIV(n_rt, 16);
         if (gp > ctx->n_cu) gp = ctx->n_cu;
@@ -575,8 +595,11 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         hipLaunchKernelGGL(k_pileup_proj1, dim3((unsigned)gp, 2), dim3(1024), P1_LDS_BYTES, s, ctx->ws_h0, n,
                            pw.l1_wih[0], pw.l1_wih[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_xp1); }
         { ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
-        hipLaunchKernelGGL(k_pileup_l1, g_rec, dim3(512), L1_LDS_BYTES, s, ctx->ws_xp1, n,
-                           pw.l1_whh[0], pw.l1_whh[1], ctx->ws_h1c); }
+#define LAUNCH_L1(W) hipLaunchKernelGGL(k_pileup_l1<W>, g_rec, dim3(64 * W), L1_LDS_BYTES, s, ctx->ws_xp1, n, \
+                           pw.l1_whh[0], pw.l1_whh[1], ctx->ws_h1c)
+        if (wpb == 8) LAUNCH_L1(8); else if (wpb == 4) LAUNCH_L1(4); else if (wpb == 2) LAUNCH_L1(2); else LAUNCH_L1(1);
+#undef LAUNCH_L1
+        }
         ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
         hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,
                            pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,

@@ -139,3 +139,22 @@ def test_reference_style_interface(pileup_weights):
                      "joint": {"inner_size": 256}})
     with pytest.raises(Exception):
         LSTMNetwork().predict(feature_tensor)      # weights not loaded
+
+
+def test_workgroup_shape_does_not_change_results(model, pileup_weights):
+    """the launcher picks 1/2/4/8 waves per recurrence workgroup from the batch size; all give
+    bit-identical probabilities"""
+    import torch
+    from nanosnp_amd import _lib
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy((rng.integers(0, 50, (777, 33, 18)) - 10).astype(np.int32)).cuda()
+    ref_gt, ref_zy = model.pileup_forward(x)
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    for w in (1, 2, 4, 8):
+        c.set_option("recurrence_waves", w)
+        gt, zy = c.pileup_forward(x)
+        assert torch.equal(gt, ref_gt) and torch.equal(zy, ref_zy), w
+    with pytest.raises(_lib.NanoSNPError):
+        c.set_option("recurrence_waves", 3)
+    c.close()
