@@ -65,6 +65,27 @@ int64_t nsnp_fasta_load_contig(const char* fasta_path, const char* contig, uint8
 int64_t nsnp_pd_parse(const char* text, int64_t text_len, int32_t* x, int64_t* pos,
                       uint8_t* ref_base, int64_t* ctg_begin, int64_t* ctg_end, int64_t cap_sites);
 
+/* ---- text writers of the predict loops -------------------------------------------------- */
+/* One batch of the pileup predict loop -> pileup.vcf rows exactly as PileupModel/predict.py:66-194
+ * writes them (the batch boundary matters: see nsnp_vcf.c).  names_blob/name_off: contig name
+ * table; contig_id[B]; pos[B]; ref_base[B] (ASCII); gt_arg/zy_arg/gt_prob/zy_prob: argmax and max
+ * of the two softmaxes; cov[B*8]: float32 x[:,16,[0,1,2,3,9,10,11,12]].  score_mode 0 = float32
+ * arithmetic (NumPy >= 2), 1 = float64 (NumPy 1.x).  Returns bytes written, or -(needed+16)
+ * when cap is too small; *n_rows receives the number of rows. */
+int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* name_off,
+                              const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                              const uint8_t* gt_arg, const uint8_t* zy_arg,
+                              const float* gt_prob, const float* zy_prob, const float* cov,
+                              int score_mode, char* out, int64_t cap, int64_t* n_rows);
+
+/* haplotype.csv rows (HaplotypeModel/predict_dev.py:40-47) */
+int64_t nsnp_hap_csv_format(int64_t N, const char* names_blob, const int64_t* name_off,
+                            const int32_t* contig_id, const int64_t* pos, const uint8_t* gt_arg,
+                            const float* gt_prob, int score_mode, char* out, int64_t cap);
+
+/* calculate_score (predict.py:31-34); *ok = 0 where the Python code raises */
+double nsnp_calculate_score(float p, int score_mode, int* ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,97 @@ def write_fasta(path, contig, seq: np.ndarray, line=60):
             f.write(s[i:i + line] + b"\n")
     with open(path + ".fai", "w") as f:
         f.write(f"{contig}\t{len(s)}\t{len(header)}\t{line}\t{line + 1}\n")
+
+
+# ---- text writers of the predict loops (nsnp_vcf.c) -------------------------------------------------
+def _bind_vcf():
+    l = lib()
+    if getattr(l, "_vcf_bound", False):
+        return l
+    p = C.c_void_p
+    l.nsnp_vcf_format_batch.restype = C.c_int64
+    l.nsnp_vcf_format_batch.argtypes = [C.c_int64, C.c_char_p, p, p, p, p, p, p, p, p, p, C.c_int, p, C.c_int64,
+                                        C.POINTER(C.c_int64)]
+    l.nsnp_hap_csv_format.restype = C.c_int64
+    l.nsnp_hap_csv_format.argtypes = [C.c_int64, C.c_char_p, p, p, p, p, p, C.c_int, p, C.c_int64]
+    l.nsnp_calculate_score.restype = C.c_double
+    l.nsnp_calculate_score.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_int)]
+    l._vcf_bound = True
+    return l
+
+
+SCORE_FLOAT32, SCORE_FLOAT64 = 0, 1
+
+
+class ContigTable:
+    """contig names -> ids, as a blob + offsets for the C writers"""
+
+    def __init__(self, names):
+        uniq = list(dict.fromkeys(names))
+        self.index = {n: i for i, n in enumerate(uniq)}
+        self.blob = "".join(uniq).encode()
+        self.off = np.concatenate([[0], np.cumsum([len(n.encode()) for n in uniq])]).astype(np.int64)
+        self.ids = np.array([self.index[n] for n in names], np.int32)
+
+
+def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, score_mode=SCORE_FLOAT32):
+    """One batch of PileupModel/predict.py:66-194 -> (bytes, n_rows)."""
+    l = _bind_vcf()
+    B = len(pos)
+    args = [np.ascontiguousarray(contig_id, np.int32), np.ascontiguousarray(pos, np.int64),
+            np.ascontiguousarray(ref_base, np.uint8), np.ascontiguousarray(gt_arg, np.uint8),
+            np.ascontiguousarray(zy_arg, np.uint8), np.ascontiguousarray(gt_prob, np.float32),
+            np.ascontiguousarray(zy_prob, np.float32), np.ascontiguousarray(cov, np.float32)]
+    cap = 160 * B + 256
+    rows = C.c_int64(0)
+    while True:
+        buf = np.empty(cap, np.uint8)
+        n = l.nsnp_vcf_format_batch(B, table.blob, _ptr(table.off), *[_ptr(a) for a in args], int(score_mode),
+                                    _ptr(buf), cap, C.byref(rows))
+        if n >= 0:
+            return buf[:n].tobytes(), rows.value
+        if n > -16:
+            _check(n, "nsnp_vcf_format_batch")
+        cap = -int(n)
+
+
+def hap_csv_format(table, contig_id, pos, gt_arg, gt_prob, score_mode=SCORE_FLOAT32):
+    l = _bind_vcf()
+    N = len(pos)
+    args = [np.ascontiguousarray(contig_id, np.int32), np.ascontiguousarray(pos, np.int64),
+            np.ascontiguousarray(gt_arg, np.uint8), np.ascontiguousarray(gt_prob, np.float32)]
+    cap = 96 * N + 256
+    while True:
+        buf = np.empty(cap, np.uint8)
+        n = l.nsnp_hap_csv_format(N, table.blob, _ptr(table.off), *[_ptr(a) for a in args], int(score_mode),
+                                  _ptr(buf), cap)
+        if n >= 0:
+            return buf[:n].tobytes()
+        if n > -16:
+            _check(n, "nsnp_hap_csv_format")
+        cap = -int(n)
+
+
+def calculate_score(p, score_mode=SCORE_FLOAT32):
+    """(score, ok): ok is False where the reference's calculate_score raises"""
+    ok = C.c_int(0)
+    v = _bind_vcf().nsnp_calculate_score(float(np.float32(p)), int(score_mode), C.byref(ok))
+    return v, bool(ok.value)
+
+
+VCF_HEADER = ('##fileformat=VCFv4.3\n'
+              '##FILTER=<ID=PASS,Description="All filters passed">\n'
+              '##FILTER=<ID=RefCall,Description="Reference call">\n'
+              '{contigs}'
+              '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+              '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="Genotype Quality">\n'
+              '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read Depth">\n'
+              '##FORMAT=<ID=AF,Number=A,Type=Float,Description="Allele Frequency">\n'
+              '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSample\n')
+
+
+def vcf_header(fai_text: str):
+    """write_head of PileupModel/predict.py:13-27 from the text of a .fai"""
+    contigs = "".join('##contig=<ID={},length={}>\n'.format(*line.strip().split()[:2])
+                      for line in fai_text.splitlines() if line.strip())
+    return VCF_HEADER.format(contigs=contigs)

@@ -1,0 +1,69 @@
+"""The two predict loops of the reference on the MI355X path.
+
+    predict_pileup     PileupModel/predict.py:37-195     position_matrix -> pileup.vcf
+    predict_haplotype  HaplotypeModel/predict_dev.py:27-48  read planes -> haplotype.csv
+
+The loops keep the reference's batch structure (its VCF rows depend on the batch boundary, see
+nanosnp_amd/csrc/nsnp_vcf.c) but every per-site Python statement is gone: forward, argmax/max and
+the coverage slice run on the device, the text rows are produced by the native writer.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import host
+
+COV_CHANNELS = [0, 1, 2, 3, 9, 10, 11, 12]        # predict.py:63
+
+
+def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text, output_file,
+                   batch_size=1000, score_mode=host.SCORE_FLOAT32):
+    """model: nanosnp_amd.pileup_model.LSTMNetwork; x: int32 [N,33,18] (numpy or cuda tensor);
+    contig_names/positions/reference_bases: what PredictDataset yields (dataset.py:141-146).
+    Returns the number of VCF rows written."""
+    import torch
+    ctx = model.ctx
+    table = host.ContigTable(list(contig_names))
+    xt = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32))
+    xt = xt.to("cuda", torch.int32).contiguous()
+    pos = np.asarray(positions, np.int64)
+    refb = np.asarray(reference_bases, np.uint8)
+    n = xt.shape[0]
+    rows = 0
+    cov_idx = torch.tensor(COV_CHANNELS, device=xt.device)
+    with open(output_file, "wb") as f:
+        f.write(host.vcf_header(fai_text).encode())
+        for b0 in range(0, n, batch_size):
+            xb = xt[b0:b0 + batch_size]
+            gt, zy = model.predict(xb)
+            ga, za, gm, zm, _ = ctx.pileup_postprocess(gt, zy)
+            cov = xb[:, 16, :].index_select(1, cov_idx).to(torch.float32)        # predict.py:63 on a FloatTensor
+            text, r = host.vcf_format_batch(table, table.ids[b0:b0 + batch_size], pos[b0:b0 + batch_size],
+                                            refb[b0:b0 + batch_size], ga.cpu().numpy(), za.cpu().numpy(),
+                                            gm.cpu().numpy(), zm.cpu().numpy(), cov.cpu().numpy(), score_mode)
+            f.write(text)
+            rows += r
+    return rows
+
+
+def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions, output_file,
+                      batch_size=1000, score_mode=host.SCORE_FLOAT32):
+    """ctx: a Context with hap weights loaded; planes_*: (seq, baseq, mapq, hap, ref_row) int32
+    arrays [N,D,33] / [N,D,11]; candidate_positions: "ctg:pos" strings (dataset_dev.py:331-333)."""
+    import torch
+    n = len(candidate_positions)
+    ctgs, poss = zip(*[p.split(":") for p in candidate_positions]) if n else ((), ())
+    table = host.ContigTable(list(ctgs))
+    pos = np.array([int(p) for p in poss], np.int64)
+    with open(output_file, "wb") as f:
+        for b0 in range(0, n, batch_size):
+            sl = slice(b0, b0 + batch_size)
+            dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=np.int32)).cuda() for a in planes_pileup]
+            dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=np.int32)).cuda() for a in planes_haplotype]
+            xp = ctx.hap_features(*dp)
+            xh = ctx.hap_features(*dh)
+            gt, _ = ctx.hap_forward(xp, xh)
+            gm, ga = gt.max(dim=1)
+            f.write(host.hap_csv_format(table, table.ids[sl], pos[sl], ga.to(torch.uint8).cpu().numpy(),
+                                        gm.cpu().numpy(), score_mode))
+    return n

@@ -1,0 +1,62 @@
+"""End-to-end predict loops on the GPU vs what the reference's predict() wrote."""
+import re
+
+import numpy as np
+import pytest
+
+from nanosnp_amd import host
+from tests.helpers import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pileup_vcf_end_to_end(tmp_path, pileup_weights):
+    """position_matrix -> pileup.vcf.  Probabilities differ from CPU torch by ~1e-7, which can move a
+    QUAL by one unit in its second decimal; everything else must be identical."""
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.predict import predict_pileup
+    z = np.load(golden("pileup_vcf.npz"))
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    out = tmp_path / "pileup.vcf"
+    rows = predict_pileup(m, z["x"].astype(np.int32), list(z["names"]), z["pos"], z["refb"],
+                          bytes(z["fai"]).decode(), str(out), batch_size=1000)
+    got = out.read_bytes().decode().splitlines()
+    want = bytes(z["vcf_bs1000"]).decode().splitlines()
+    assert len(got) == len(want) and rows == sum(1 for l in want if not l.startswith("#"))
+    n_qual_diff = 0
+    for g, w in zip(got, want):
+        if g == w:
+            continue
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[:5] == wf[:5] and gf[6:9] == wf[6:9], (g, w)
+        assert abs(float(gf[5]) - float(wf[5])) <= 0.0101, (g, w)
+        gs, ws = gf[9].split(":"), wf[9].split(":")
+        assert gs[0] == ws[0] and gs[2:] == ws[2:] and abs(int(gs[1]) - int(ws[1])) <= 1
+        n_qual_diff += 1
+    assert n_qual_diff <= len(want) // 20
+
+
+def test_haplotype_csv_end_to_end(tmp_path, gpu_ctx):
+    from nanosnp_amd.predict import predict_haplotype
+    from oracle import oracle
+    from tests.helpers import seeded_hap_weights
+    ws = seeded_hap_weights(12, H=256)
+    gpu_ctx.hap_load_weights(ws)
+    n = 70
+    pp = host.synth_hap_planes(31, n, 30, 90, 33)
+    ph = host.synth_hap_planes(32, n, 30, 90, 11)
+    cands = [f"chr{1 + i % 2}:{1000 + 7 * i}" for i in range(n)]
+    out = tmp_path / "haplotype.csv"
+    predict_haplotype(gpu_ctx, pp, ph, cands, str(out), batch_size=32)
+    rows = out.read_text().splitlines()
+    assert len(rows) == n
+    ogt, _ = oracle.hap_forward(ws, oracle.hap_features_batch(*pp), oracle.hap_features_batch(*ph), nthreads=8)
+    labels = ["AA", "AC", "AG", "AT", "CC", "CG", "CT", "GG", "GT", "TT"]
+    for j, r in enumerate(rows):
+        ctg, pos, gt, q = r.split("\t")
+        assert f"{ctg}:{pos}" == cands[j] and re.fullmatch(r"\d+\.\d+", q)
+        top2 = np.sort(ogt[j])[-2:]
+        if top2[1] - top2[0] > 1e-3:                      # unambiguous argmax
+            assert gt == labels[int(ogt[j].argmax())]
+        want_q, ok = host.calculate_score(ogt[j].max())
+        assert ok and abs(float(q) - want_q) <= 0.0101

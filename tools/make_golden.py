@@ -253,7 +253,62 @@ def group_hapfwd():
         print(f"hap_fwd_h{H}: gt argmax", gt.numpy().argmax(1))
 
 
-GROUPS = {"encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
+def group_vcf():
+    """pileup.vcf exactly as PileupModel/predict.py:37-195 writes it: the reference's own predict()
+    is run on CPU with the shipped weights; only PredictDataset (PyTables reader) is replaced by an
+    in-memory stand-in with the same four fields (dataset.py:118-149).  Also haplotype.csv rows
+    as HaplotypeModel/predict_dev.py:40-47 formats them."""
+    import gzip as _gz
+    import torch
+    import yaml
+    from torch.utils.data import Dataset
+    from nanosnp_amd import host
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "PileupModel"))
+    import predict as ref_predict          # noqa: E402  (reference module)
+    from model import LSTMNetwork          # noqa: E402
+    from utils import AttrDict             # noqa: E402
+    cfg = AttrDict(yaml.load(open(os.path.join(REF, "PileupModel/config/ont_pileup.yaml")), Loader=yaml.FullLoader))
+    m = LSTMNetwork(cfg.model)
+    ck = torch.load(os.path.join(REF, "PileupModel/models/ont_pileup.chkpt"), map_location="cpu", weights_only=False)
+    m.encoder.load_state_dict(ck["encoder"]); m.forward_layer.load_state_dict(ck["forward_layer"]); m.eval()
+
+    # sites: the two encode fixtures' .pd files (real window tensors with positions / ref bases)
+    xs, names, poss, refs = [], [], [], []
+    for tag in ("g1", "adv"):
+        pd = _gz.open(os.path.join(GOLD, f"encode_{tag}.pd.gz")).read()
+        x, nm, pos, refb = host.pd_parse(pd)
+        xs.append(x); names += nm; poss.append(pos); refs.append(refb)
+    x = np.concatenate(xs); pos = np.concatenate(poss); refb = np.concatenate(refs)
+
+    class FakeDataset(Dataset):             # stands in for PredictDataset(datapath) (dataset.py:118-149)
+        def __init__(self, datapath):
+            pass
+        def __getitem__(self, i):
+            return names[i], pos[i], refb[i], x[i]
+        def __len__(self):
+            return len(x)
+
+    ref_predict.PredictDataset = FakeDataset
+    real_loader = ref_predict.DataLoader
+    ref_predict.DataLoader = lambda ds, batch_size, shuffle, num_workers: real_loader(ds, batch_size=batch_size, shuffle=False, num_workers=0)
+    with tempfile.TemporaryDirectory() as d:
+        fai = os.path.join(d, "ref.fa.fai")
+        open(fai, "w").write("chrS\t6100\t6\t60\t61\nchrT\t1600\t6\t60\t61\n")
+        out = {}
+        for bs in (1000, 64, 7):
+            vcf = os.path.join(d, f"p{bs}.vcf")
+            ref_predict.predict(m, ["x.bin"], fai, bs, vcf, torch.device("cpu"))
+            out[f"vcf_bs{bs}"] = np.frombuffer(open(vcf, "rb").read(), np.uint8)
+    with torch.no_grad():
+        gt, zy = m.predict(torch.from_numpy(x).type(torch.FloatTensor))
+    np.savez_compressed(os.path.join(GOLD, "pileup_vcf.npz"), x=x.astype(np.int16), pos=pos, refb=refb,
+                        names=np.array(names), gt=gt.numpy(), zy=zy.numpy(), fai=np.frombuffer(open(fai, "rb").read() if False else b"chrS\t6100\t6\t60\t61\nchrT\t1600\t6\t60\t61\n", np.uint8), **out)
+    for k, v in out.items():
+        print(k, len(bytes(v).splitlines()), "lines")
+
+
+GROUPS = {"vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
           "hapfwd": group_hapfwd}
 
 if __name__ == "__main__":
