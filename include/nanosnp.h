@@ -137,6 +137,15 @@ int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_t* bq, cons
                       const int32_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
                       float* out, void* stream);
 
+/* Read arrangement of the stage-4 generator (create_pileup_haplotype.py:140-207, write_to_bins.py:15-61):
+ * per site keep the reads whose base at the centre column is non-zero, order them by the HP tag at
+ * the centre column (ties keep input order), pad with -2 to D_out rows, cut at D_out.  Inputs are
+ * device int32 [N,R,L] read matrices (n_reads[N] valid rows each, NULL = all R); outputs device int32
+ * [N,D_out,L] planes in the layout nsnp_hap_features consumes; depth[N] (optional) = rows kept. */
+int nsnp_hap_arrange_reads(nsnp_ctx* ctx, const int32_t* seq, const int32_t* bq, const int32_t* mq,
+                           const int32_t* hap, const int32_t* n_reads, int64_t N, int R, int L, int D_out,
+                           int32_t* oseq, int32_t* obq, int32_t* omq, int32_t* ohap, int32_t* depth, void* stream);
+
 /* host_tensors: the 58 fp32 tensors of model_dev.LSTMNetwork.state_dict() in order
  * (pileup_encoder 26, haplotype_encoder 26, forward_layer 6), HOST pointers.
  * hidden must be a multiple of 64; F = 105 input features; 3 layers as ont_haplotype.yaml. */

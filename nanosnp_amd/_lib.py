@@ -43,6 +43,7 @@ _SIGNATURES = {
     "nsnp_pileup_gather_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p]),
     "nsnp_hap_features": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nsnp_hap_arrange_reads": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "nsnp_hap_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int] + [C.c_int] * 5),
     "nsnp_hap_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
@@ -239,6 +240,17 @@ class Context:
                                          n, d, l, _dptr(out), _stream_ptr(stream)),
               self.handle, "nsnp_hap_features")
         return out
+
+    def hap_arrange_reads(self, seq, bq, mq, hap, d_out, n_reads=None, stream=None):
+        import torch
+        n, r, l = seq.shape
+        outs = [torch.empty((n, d_out, l), dtype=torch.int32, device=seq.device) for _ in range(4)]
+        depth = torch.empty(n, dtype=torch.int32, device=seq.device)
+        check(self.lib.nsnp_hap_arrange_reads(self.handle, _dptr(seq), _dptr(bq), _dptr(mq), _dptr(hap), _dptr(n_reads),
+                                              n, r, l, int(d_out), *[_dptr(o) for o in outs], _dptr(depth),
+                                              _stream_ptr(stream)),
+              self.handle, "nsnp_hap_arrange_reads")
+        return outs[0], outs[1], outs[2], outs[3], depth
 
     def hap_load_weights(self, tensors, n_features=105, hidden=256, n_layers=3, n_gt=10, n_zy=3):
         import numpy as np

@@ -77,3 +77,28 @@ void orc_hap_features_batch(const int32_t* seq, const int32_t* bq, const int32_t
         free(tmp);
     }
 }
+
+/* H1/H2: read arrangement (create_pileup_haplotype.py:140-207, write_to_bins.py:15-61), ties stable */
+void orc_hap_arrange(const int32_t* seq, const int32_t* bq, const int32_t* mq, const int32_t* hap,
+                     int rows, int R, int L, int D_out,
+                     int32_t* oseq, int32_t* obq, int32_t* omq, int32_t* ohap, int32_t* depth)
+{
+    (void)R;
+    const int mid = L / 2;
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(rows > 0 ? rows : 1));
+    int n = 0;
+    for (int r = 0; r < rows; ++r) if (seq[r * L + mid] != 0) idx[n++] = r;      /* :145-149 */
+    for (int a = 1; a < n; ++a) {                                                  /* stable insertion sort by HP at centre */
+        int v = idx[a], b = a - 1;
+        while (b >= 0 && hap[idx[b] * L + mid] > hap[v * L + mid]) { idx[b + 1] = idx[b]; --b; }
+        idx[b + 1] = v;
+    }
+    for (int d = 0; d < D_out; ++d)
+        for (int l = 0; l < L; ++l) {
+            int32_t a = -2, b = -2, c = -2, h = -2;
+            if (d < n) { const int i = idx[d] * L + l; a = seq[i]; b = bq[i]; c = mq[i]; h = hap[i]; }
+            oseq[d * L + l] = a; obq[d * L + l] = b; omq[d * L + l] = c; ohap[d * L + l] = h;
+        }
+    if (depth) *depth = n < D_out ? n : D_out;
+    free(idx);
+}

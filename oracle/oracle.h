@@ -118,6 +118,12 @@ void orc_hap_features_batch(const int32_t* seq, const int32_t* bq, const int32_t
                             const int32_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
                             float* out /*[N,105,L] cast as predict_dev.py:35 does*/, int nthreads);
 
+/* H1/H2: keep reads covering the centre column, order by HP at the centre (stable), pad -2, cut at
+ * D_out (create_pileup_haplotype.py:140-207, write_to_bins.py:15-61).  One site: inputs [rows][L]. */
+void orc_hap_arrange(const int32_t* seq, const int32_t* bq, const int32_t* mq, const int32_t* hap,
+                     int rows, int R, int L, int D_out,
+                     int32_t* oseq, int32_t* obq, int32_t* omq, int32_t* ohap, int32_t* depth);
+
 /* ---- HaplotypeModel forward (H6): HaplotypeModel/model_dev.py:59-143 ------------------ */
 /* weights: state-dict order of model_dev.LSTMNetwork:
  *  pileup_encoder: 3 layers x 2 dirs x (w_ih,w_hh,b_ih,b_hh) = 24, output_proj w,b = 26

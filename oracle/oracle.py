@@ -41,6 +41,8 @@ def _load():
     lib.orc_hap_features_batch.argtypes = [p, p, p, p, p, C.c_int64, C.c_int, C.c_int, p, C.c_int]
     lib.orc_hap_features.restype = None
     lib.orc_hap_features.argtypes = [p, p, p, p, p, C.c_int, C.c_int, p]
+    lib.orc_hap_arrange.restype = None
+    lib.orc_hap_arrange.argtypes = [p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_int, p, p, p, p, p]
     lib.orc_hap_forward.restype = None
     lib.orc_hap_forward.argtypes = [p, p, p, C.c_int64] + [C.c_int] * 7 + [p, p, C.c_int]
     lib.orc_calculate_score.restype = C.c_double
@@ -151,3 +153,14 @@ def hap_forward(weights, xp, xh, H=256, n_layers=3, n_gt=10, n_zy=3, nthreads=1)
 
 def calculate_score(p):
     return lib().orc_calculate_score(float(p))
+
+
+def hap_arrange(seq, bq, mq, hap, d_out, rows=None):
+    """One site: read matrices [R, L] -> padded / cut planes [d_out, L] and the kept depth."""
+    seq = _c(seq, np.int32); bq = _c(bq, np.int32); mq = _c(mq, np.int32); hap = _c(hap, np.int32)
+    R, L = seq.shape
+    outs = [np.empty((d_out, L), np.int32) for _ in range(4)]
+    depth = np.zeros(1, np.int32)
+    lib().orc_hap_arrange(_p(seq), _p(bq), _p(mq), _p(hap), R if rows is None else int(rows), R, L, int(d_out),
+                          *[_p(o) for o in outs], _p(depth))
+    return outs[0], outs[1], outs[2], outs[3], int(depth[0])

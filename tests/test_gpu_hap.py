@@ -128,3 +128,24 @@ def test_hap_unsupported_shape_is_an_error(gpu_ctx):
     from tests.helpers import seeded_hap_weights
     with pytest.raises(_lib.NanoSNPError):
         gpu_ctx.hap_load_weights(seeded_hap_weights(11, H=32), hidden=32)
+
+
+def test_hap_arrange_reads_vs_oracle(gpu_ctx):
+    import torch
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    N, R, L = 50, 150, 33
+    for D_out in (90, 40, 200):
+        seq = rng.integers(-1, 5, (N, R, L)).astype(np.int32)
+        seq[rng.random((N, R)) < 0.25, L // 2] = 0
+        hap = np.where(seq != 0, rng.integers(1, 4, (N, R, 1)), 0).astype(np.int32)
+        bq = rng.integers(0, 60, (N, R, L)).astype(np.int32); mq = rng.integers(0, 61, (N, R, L)).astype(np.int32)
+        n_reads = rng.integers(0, R + 1, N).astype(np.int32)
+        outs = gpu_ctx.hap_arrange_reads(*[torch.from_numpy(a).cuda() for a in (seq, bq, mq, hap)], D_out,
+                                         n_reads=torch.from_numpy(n_reads).cuda())
+        torch.cuda.synchronize()
+        for n in range(N):
+            want = oracle.hap_arrange(seq[n], bq[n], mq[n], hap[n], D_out, rows=n_reads[n])
+            for k in range(4):
+                assert np.array_equal(outs[k][n].cpu().numpy(), want[k]), (n, k)
+            assert int(outs[4][n]) == want[4]

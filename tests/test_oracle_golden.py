@@ -122,3 +122,32 @@ def test_oracle_vs_reference_binaries_on_a_fresh_contig(tmp_path):
     n = oracle.mpileup_to_pd(str(pile / "chrQ.mpileup"), bytes(seq), str(tmp_path / "o.pd"))
     assert n == want.count(b"\n") and n > 500
     assert (tmp_path / "o.pd").read_bytes() == want
+
+
+def test_hap_arrange_matches_pandas_semantics():
+    """create_pileup_haplotype.py:140-165 with pandas itself: rows filtered on the centre base, sorted
+    by the centre HP.  pandas' quicksort leaves ties in an unspecified order, so the comparison is on
+    what is specified: the sorted HP column and the multiset of rows inside each HP group."""
+    import pandas as pd
+    rng = np.random.default_rng(8)
+    for R, L in ((40, 11), (120, 33), (5, 33)):
+        seq = rng.integers(-1, 5, (R, L)).astype(np.int32)
+        seq[rng.random(R) < 0.2, L // 2] = 0
+        hap = np.where(seq != 0, rng.integers(1, 4, (R, 1)), 0).astype(np.int32)
+        bq = rng.integers(0, 60, (R, L)).astype(np.int32); mq = rng.integers(0, 60, (R, L)).astype(np.int32)
+        gpos = list(range(100, 100 + L))
+        df = pd.DataFrame(seq, columns=gpos); hap_df = pd.DataFrame(hap, columns=gpos)
+        keep = [i for i in range(R) if df.iloc[i][gpos[L // 2]] != 0]                       # :145-149
+        sort_idx = hap_df[gpos].iloc[keep].sort_values(by=gpos[L // 2]).index              # :158-160
+        want_seq = df[gpos].iloc[keep].loc[sort_idx].values; want_hap = hap_df[gpos].iloc[keep].loc[sort_idx].values
+        D = len(keep) + 3
+        oseq, obq, omq, ohap, depth = oracle.hap_arrange(seq, bq, mq, hap, D)
+        assert depth == len(keep)
+        assert np.array_equal(ohap[:depth, L // 2], want_hap[:, L // 2])
+        assert (oseq[depth:] == -2).all() and (ohap[depth:] == -2).all() and (obq[depth:] == -2).all()
+        for g in (1, 2, 3):
+            a = oseq[:depth][ohap[:depth, L // 2] == g]; b = want_seq[want_hap[:, L // 2] == g]
+            assert sorted(map(bytes, a)) == sorted(map(bytes, b))
+        # truncation keeps a prefix of the sorted rows (write_to_bins.py:54-61)
+        cseq, _, _, chap, cdepth = oracle.hap_arrange(seq, bq, mq, hap, max(1, depth // 2))
+        assert cdepth == max(1, depth // 2) and np.array_equal(cseq, oseq[:cdepth])
