@@ -38,6 +38,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->device = device;
     ctx->last_err = hipSuccess;
     ctx->chunk_sites = 32768;
+    ctx->precision = 0;
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -74,6 +75,11 @@ ScopedKernelTimer::~ScopedKernelTimer() { if (on) (void)hipEventRecord(stop_ev, 
 extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NSNP_EINVAL;
+    if (strcmp(name, "pileup_precision") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->precision = (int)value;
+        return NSNP_OK;
+    }
     if (strcmp(name, "recurrence_waves") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NSNP_EINVAL;
         ctx->force_wpb = (int)value;
@@ -125,6 +131,7 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     (void)hipDeviceSynchronize();
     free_ws(ctx);
     if (ctx->pw.arena) (void)hipFree(ctx->pw.arena);
+    if (ctx->pw16.arena) (void)hipFree(ctx->pw16.arena);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
     nsnp_hap_free(ctx);
     if (ctx->timer) {
@@ -158,13 +165,15 @@ extern "C" int nsnp_pileup_load_weights(nsnp_ctx* ctx, const float* const* host_
     if (!ctx || !host_tensors || n_tensors < 24) return NSNP_EINVAL;
     for (int i = 0; i < 24; ++i) if (!host_tensors[i]) return NSNP_EINVAL;
     NSNP_HIP(ctx, hipSetDevice(ctx->device));
-    return nsnp_pileup_pack_weights(ctx, host_tensors);
+    const int rc = nsnp_pileup_pack_weights(ctx, host_tensors);
+    return rc ? rc : nsnp_pileup_pack_weights_f16(ctx, host_tensors);
 }
 
 extern "C" int nsnp_pileup_forward(nsnp_ctx* ctx, const int32_t* x, int64_t N,
                                    float* gt_prob, float* zy_prob, void* stream)
 {
     if (!ctx || N < 0 || (N > 0 && (!x || !gt_prob || !zy_prob))) return NSNP_EINVAL;
+    if (ctx->precision == 1) return nsnp_pileup_forward_f16x3(ctx, x, nullptr, N, gt_prob, zy_prob, (hipStream_t)stream);
     return nsnp_pileup_forward_impl(ctx, x, nullptr, N, gt_prob, zy_prob, (hipStream_t)stream);
 }
 
@@ -172,5 +181,6 @@ extern "C" int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts,
                                            int64_t N, float* gt_prob, float* zy_prob, void* stream)
 {
     if (!ctx || N < 0 || (N > 0 && (!counts || !center_idx || !gt_prob || !zy_prob))) return NSNP_EINVAL;
+    if (ctx->precision == 1) return nsnp_pileup_forward_f16x3(ctx, counts, center_idx, N, gt_prob, zy_prob, (hipStream_t)stream);
     return nsnp_pileup_forward_impl(ctx, counts, center_idx, N, gt_prob, zy_prob, (hipStream_t)stream);
 }

@@ -48,6 +48,13 @@ struct PileupWeightsDev {
     bool   loaded;
 };
 
+// fp16 hi/lo images of the same weights for the f16x3 path (pileup_forward_f16x3.hip)
+struct PileupWeightsF16 {
+    void* l0_whh[2]; void* l0_wih_hi[2]; void* l0_wih_lo[2]; void* l1_wih[2]; void* l1_whh[2];
+    void* proj_w; void* dense_w; void* head_w;
+    void* arena; size_t arena_bytes; bool loaded;
+};
+
 struct HapWeightsDev;   // hap_forward.hip
 
 // optional per-kernel timing with HIP events on the launch stream (nsnp_ctx_enable_timing)
@@ -63,6 +70,8 @@ struct nsnp_ctx {
     int n_cu;
     hipError_t last_err;
     bool attr_set;
+    bool attr_set_f16;
+    int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
     int force_wpb;      // 0 = automatic; else waves per recurrence workgroup (tuning / tests)
     // workspace (sized by nsnp_ctx_reserve)
     int64_t chunk_sites;
@@ -70,6 +79,7 @@ struct nsnp_ctx {
     float*  ws_xp1;     // [2][chunk*17][256]
     float*  ws_h1c;     // [chunk][128]
     PileupWeightsDev pw;
+    PileupWeightsF16 pw16;
     HapWeightsDev* hw;
     void*  hap_ws; size_t hap_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
@@ -97,3 +107,6 @@ void nsnp_pack_image(float* img, int n_tiles, int n_j4, nsnp_wfun f, const void*
 int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
                              int64_t N, float* gt, float* zy, hipStream_t s);
 int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w);
+int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
+                              int64_t N, float* gt, float* zy, hipStream_t s);
+int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w);

@@ -18,7 +18,6 @@ enum { CH_A = 0, CH_C, CH_G, CH_T, CH_I, CH_I1, CH_D, CH_D1, CH_STAR,
        CH_a, CH_c, CH_g, CH_t, CH_i, CH_i1, CH_d, CH_d1, CH_POUND, NCH };
 
 constexpr int ENC_BLOCK = 256;
-constexpr int TBL = 8;            // distinct indel alleles tracked per column before the rescan path
 constexpr int MAX_INDEL = 60;     // kMaxIndelSize, tensor_maker.cpp:5
 
 // class of a pileup byte: 0..9 = counted symbol (channel via CLS_CH), 10 = ignored,
@@ -80,88 +79,173 @@ __device__ __forceinline__ bool same_bytes(const uint8_t* base, int64_t a, int64
     return true;
 }
 
-__global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
-    const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
-    int64_t M, double min_af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
-    uint8_t* __restrict__ flags)
+// ---- slow exact path for one column straight from global memory (no size limits) ---------------------
+// Used for columns whose wave does not fit the LDS stage or that carry more indels than the per-lane
+// list holds.  O(k^2) in the number of indel reads k of the column.
+__device__ __noinline__ void scan_column_global(const uint8_t* __restrict__ bases, int64_t begin, int64_t end,
+                                                int32_t* cnt, int32_t* tot, int32_t* mx)
 {
-    // per-lane allele table: hash, offset (relative to column start), meta = len | kind << 8, count
-    __shared__ uint32_t t_hash[TBL][ENC_BLOCK];
-    __shared__ uint32_t t_off[TBL][ENC_BLOCK];
-    __shared__ uint32_t t_meta[TBL][ENC_BLOCK];
-    __shared__ uint32_t t_cnt[TBL][ENC_BLOCK];
-    __shared__ int32_t stage[ENC_BLOCK / 64][64 * NCH];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t wave_col0 = ((int64_t)blockIdx.x * (ENC_BLOCK / 64) + wave) * 64;
-    const int64_t c = wave_col0 + lane;
-    const bool live = c < M;
-
-    int32_t cnt[10];
-#pragma unroll
     for (int k = 0; k < 10; ++k) cnt[k] = 0;
-    int32_t tot[4] = {0, 0, 0, 0};      // I, i, D, d   (kind = (sign=='-')*2 + reverse)
-    int32_t mx[4] = {0, 0, 0, 0};
-    int n_tbl = 0; bool overflow = false;
-    int64_t begin = 0, end = 0;   // a dead lane scans an empty range
-    if (live) { begin = col_off[c]; end = col_off[c + 1]; }
-
-    // ---- pass 1: the scan of tensor_maker.cpp:83-114 -------------------------------------------
+    for (int k = 0; k < 4; ++k) { tot[k] = 0; mx[k] = 0; }
     for (int64_t i = begin; i < end;) {
         const int b = bases[i];
         const int cls = byte_class(b);
-        if (cls < 10) {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) cnt[k] += (cls == k);
-            ++i;
-        } else if (cls == 11 || cls == 12) {          // '+' / '-': decimal length, then that many bytes
+        if (cls < 10) { cnt[cls]++; ++i; }
+        else if (cls == 11 || cls == 12) {
             ++i;
             long long adv = 0;
             while (i < end && bases[i] >= '0' && bases[i] <= '9') { adv = adv * 10 + (bases[i] - '0'); ++i; }
             if (adv <= MAX_INDEL) {
                 const int64_t avail = end - i;
                 const int len = (int)(adv < avail ? adv : avail);
-                uint32_t hsh = 2166136261u;
-                for (int k = 0; k < len; ++k) hsh = (hsh ^ (uint32_t)bases[i + k]) * 16777619u;
-                const int kind = (b == '-' ? 2 : 0) + (len > 0 && is_fwd_char(bases[i]) ? 0 : 1);
-                tot[kind]++;
-                if (!overflow) {
-                    const uint32_t meta = (uint32_t)len | ((uint32_t)kind << 8) | ((uint32_t)b << 16);
-                    int hit = -1;
-                    for (int e = 0; e < n_tbl; ++e)
-                        if (t_hash[e][tid] == hsh && t_meta[e][tid] == meta &&
-                            same_bytes(bases, begin + t_off[e][tid], i, len)) { hit = e; break; }
-                    if (hit >= 0) {
-                        const uint32_t v = ++t_cnt[hit][tid];
-                        if ((int32_t)v > mx[kind]) mx[kind] = (int32_t)v;
-                    } else if (n_tbl < TBL) {
-                        t_hash[n_tbl][tid] = hsh; t_meta[n_tbl][tid] = meta; t_off[n_tbl][tid] = (uint32_t)(i - begin);
-                        t_cnt[n_tbl][tid] = 1; ++n_tbl;
-                        if (mx[kind] < 1) mx[kind] = 1;
-                    } else overflow = true;
-                }
+                tot[(b == '-' ? 2 : 0) + (len > 0 && is_fwd_char(bases[i]) ? 0 : 1)]++;
             }
-            i += adv;      // "base_idx += advance - 1; ++base_idx": advance == 0 re-examines this byte
-        } else if (cls == 13) {
-            i += 2;        // '^' and the mapping-quality byte after it
-        } else {
-            ++i;           // '$', N/n and anything else: counted nowhere
+            i += adv;
+        } else if (cls == 13) i += 2;
+        else ++i;
+    }
+    IndelIter a{bases, begin, end};
+    int64_t ao; int al, as;
+    while (a.next(ao, al, as)) {
+        const int kind = (as == '-' ? 2 : 0) + (al > 0 && is_fwd_char(bases[ao]) ? 0 : 1);
+        IndelIter b2{bases, begin, end};
+        int64_t bo; int bl, bs; int same = 0;
+        while (b2.next(bo, bl, bs))
+            if (bs == as && bl == al && same_bytes(bases, ao, bo, al)) ++same;
+        if (same > mx[kind]) mx[kind] = same;
+    }
+}
+
+// ---- main kernel ----------------------------------------------------------------------------------------
+// A wave stages the bytes of its 64 columns (one contiguous range) into LDS with 16-byte loads, every lane
+// then walks its own column out of LDS four bytes per read.  Indels met on the way are only RECORDED
+// (offset, length, sign) in a per-lane list; the distinct-allele maxima are worked out afterwards from that
+// list, byte-exact, so the main scan stays short and the lanes of a wave diverge as little as the grammar
+// allows.
+constexpr int ENC_WAVES = ENC_BLOCK / 64;
+constexpr int STAGE_BYTES = 7168;          // per wave; 64 columns at 60x average ~4.4 KB
+constexpr int KLIST = 12;                  // recorded indels per column before the slow path takes over
+
+__global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
+    const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
+    int64_t M, double min_af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
+    uint8_t* __restrict__ flags)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
+    __shared__ uint32_t ilist[ENC_WAVES][KLIST][64];      // off (16) | len (8) | sign (8)
+    __shared__ uint8_t lut[256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    lut[tid] = (uint8_t)byte_class(tid);
+    __syncthreads();
+    const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
+    if (wave_col0 >= M) return;                                   // whole wave idle (no later block barrier)
+    const int64_t c = wave_col0 + lane;
+    const bool live = c < M;
+    int64_t begin = 0, end = 0;
+    if (live) { begin = col_off[c]; end = col_off[c + 1]; }
+    const int n_live = (int)(M - wave_col0 < 64 ? M - wave_col0 : 64);
+    const int64_t b0 = __shfl(begin, 0);
+    const int64_t b1 = __shfl(end, n_live - 1);
+    const int64_t total = col_off[M];
+
+    // ---- stage [b0, b1) ------------------------------------------------------------------------------
+    uint8_t* st = stage_b[wave];
+    const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
+    const uintptr_t a_first = (uintptr_t)(bases + b0) & ~(uintptr_t)15;      // 16-byte aligned global address
+    const int mis = (int)((uintptr_t)(bases + b0) - a_first);
+    const bool staged = (b1 - b0) + mis + 16 <= STAGE_BYTES;                  // wave-uniform
+    if (staged) {
+        const uintptr_t a_end = (uintptr_t)(bases + b1);
+        const uintptr_t a_total = (uintptr_t)(bases + total);
+        for (uintptr_t a = a_first + (uintptr_t)lane * 16; a < a_end; a += 64 * 16) {
+            uint4 v;
+            if (a + 16 <= a_total && a >= (uintptr_t)bases) v = *reinterpret_cast<const uint4*>(a);
+            else {                                                               // buffer edge: byte loads
+                uint8_t tmp[16];
+                for (int k = 0; k < 16; ++k) { const uintptr_t p = a + k; tmp[k] = (p >= (uintptr_t)bases && p < a_total) ? *reinterpret_cast<const uint8_t*>(p) : 0; }
+                v = *reinterpret_cast<uint4*>(tmp);
+            }
+            *reinterpret_cast<uint4*>(st + (a - a_first)) = v;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- exact fallback for columns with more than TBL distinct alleles ------------------------
-    if (overflow) {
-        mx[0] = mx[1] = mx[2] = mx[3] = 0;
-        IndelIter a{bases, begin, end};
-        int64_t ao; int al, as;
-        while (a.next(ao, al, as)) {
-            const int kind = (as == '-' ? 2 : 0) + (al > 0 && is_fwd_char(bases[ao]) ? 0 : 1);
-            IndelIter b2{bases, begin, end};
-            int64_t bo; int bl, bs; int same = 0;
-            while (b2.next(bo, bl, bs))
-                if (bs == as && bl == al && same_bytes(bases, ao, bo, al)) ++same;
-            if (same > mx[kind]) mx[kind] = same;
+    int32_t cnt[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) cnt[k] = 0;
+    int32_t tot[4] = {0, 0, 0, 0};      // I, i, D, d   (kind = (sign=='-')*2 + reverse)
+    int32_t mx[4] = {0, 0, 0, 0};
+    bool slow = live && !staged;
+
+    if (live && staged) {
+        // LDS byte index of global offset g: (g - b0) + mis
+        const int lbeg = (int)(begin - b0) + mis, lend = (int)(end - b0) + mis;
+        int cur_wi = -1; uint32_t cur_w = 0;
+        auto rd = [&](int li) -> int {
+            const int wi = li >> 2;
+            if (wi != cur_wi) { cur_w = st32[wi]; cur_wi = wi; }
+            return (int)((cur_w >> ((li & 3) * 8)) & 0xffu);
+        };
+        int n_list = 0;
+        for (int i = lbeg; i < lend;) {
+            const int b = rd(i);
+            const int cls = lut[b];
+            if (cls < 10) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) cnt[k] += (cls == k);
+                ++i;
+            } else if (cls == 11 || cls == 12) {
+                ++i;
+                int adv = 0; bool huge = false;
+                while (i < lend) {
+                    const int d = rd(i);
+                    if (d < '0' || d > '9') break;
+                    if (adv > 100000) huge = true; else adv = adv * 10 + (d - '0');
+                    ++i;
+                }
+                if (huge) { i = lend; }
+                else {
+                    if (adv <= MAX_INDEL) {
+                        const int avail = lend - i;
+                        const int len = adv < avail ? adv : avail;
+                        if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)i | ((uint32_t)len << 16) | ((uint32_t)b << 24);
+                        ++n_list;
+                    }
+                    i += adv;
+                }
+            } else if (cls == 13) i += 2;
+            else ++i;
         }
+        if (n_list > KLIST) slow = true;
+        else {
+            // distinct-allele maxima from the recorded list: m(e) = #{f <= e equal to e}
+            for (int e = 0; e < n_list; ++e) {
+                const uint32_t ve = ilist[wave][e][lane];
+                const int oe = ve & 0xffff, le = (ve >> 16) & 0xff, se = ve >> 24;
+                const int kind = (se == '-' ? 2 : 0) + (le > 0 && is_fwd_char(st[oe]) ? 0 : 1);
+                tot[kind]++;
+                int same = 1;
+                for (int f = 0; f < e; ++f) {
+                    const uint32_t vf = ilist[wave][f][lane];
+                    if ((vf >> 16) != (ve >> 16)) continue;               // length and sign
+                    const int of = vf & 0xffff;
+                    bool eq = true;
+                    for (int k = 0; k < le; ++k) if (st[oe + k] != st[of + k]) { eq = false; break; }
+                    same += eq;
+                }
+                if (same > mx[kind]) mx[kind] = same;
+            }
+        }
+    }
+    if (slow) {          // private arrays: passing cnt/tot/mx by address would pin them in scratch for every lane
+        int32_t c2[10], t2[4], m2[4];
+        scan_column_global(bases, begin, end, c2, t2, m2);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) cnt[k] = c2[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tot[k] = t2[k]; mx[k] = m2[k]; }
     }
 
     // ---- assemble the 18 channels, flags (tensor_maker.cpp:127-248) ------------------------------
@@ -196,13 +280,16 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (k == chr_idx) { t[up_ch[k]] = -up; t[lo_ch[k]] = -lo; }
 
-    // ---- coalesced write-out through LDS -------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) stage[wave][lane * NCH + k] = t[k];
+    // ---- coalesced write-out through the (now free) stage buffer ---------------------------------
     __builtin_amdgcn_wave_barrier();
-    const int64_t n_valid = (M - wave_col0 < 64 ? (M - wave_col0 > 0 ? M - wave_col0 : 0) : 64) * NCH;
+    int32_t* out_stage = reinterpret_cast<int32_t*>(st);         // 64 * 18 * 4 = 4608 B <= STAGE_BYTES
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) out_stage[lane * NCH + k] = t[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n_valid = n_live * NCH;
     int32_t* __restrict__ dst = counts + wave_col0 * NCH;
-    for (int k = lane; k < n_valid; k += 64) dst[k] = stage[wave][k];
+    for (int k = lane; k < n_valid; k += 64) dst[k] = out_stage[k];
     if (live) {
         depth_out[c] = depth;
         uint8_t f = 0;

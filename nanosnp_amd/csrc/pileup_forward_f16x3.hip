@@ -1,0 +1,543 @@
+// pileup_forward_f16x3.hip -- PileupModel forward with every fp32 matrix product evaluated as three
+// fp16 MFMAs with fp32 accumulation ("f16x3"):
+//
+//     w = w_hi + w_lo,  x = x_hi + x_lo   (hi = fp16(v), lo = fp16(v - hi); 21-22 significant bits)
+//     w.x  ~=  w_hi.x_hi + w_lo.x_hi + w_hi.x_lo          (dropped term w_lo.x_lo <= 2^-22 |w.x|)
+//
+// fp16 products are exact in the fp32 accumulator and v_mfma_f32_16x16x32_f16 honours fp16
+// subnormals (probed on gfx950: tools/probes/denorm_probe.hip), so the result differs from the exact-fp32
+// path (pileup_forward.hip) by ~1e-6 in the probabilities (measured; tolerance 1e-4) while the matrix
+// pipe runs at the fp16 rate: 3 MFMAs of 16 cycles replace 8 of 32 cycles per 32-deep K block.
+// Same reference functions, same four-kernel structure and the same register-resident recurrence as
+// the fp32 path: the accumulator layout of tile i (lane = site + 16*q holds unit 4*i+q) is packed
+// straight into the next step's B fragments (K position (kb, q, j) <-> unit 4*(8*kb+j)+q).
+#include "nsnp_common.hpp"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sigmoid_f(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x));
+}
+__device__ __forceinline__ float tanh_f(float x)
+{
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f);
+}
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// acc[t] += W(tile TB+t, K block kb) . b for t < NT, three MFMAs per (tile, block), walked in groups of
+// G tiles term-major so that MFMAs on one accumulator are G issue slots apart.
+// img: h8 elements [tile][kb][part][lane] with NKB blocks per tile.
+template <int NT, int NKB, int KB0, int KBN, int TB, int G, typename WP>
+__device__ __forceinline__ void wave_gemm_h(WP img, int lane, const h8* bh, const h8* bl, f32x4* acc)
+{
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+#pragma unroll
+        for (int ig = 0; ig < NT; ig += G) {
+            h8 ah[G], al[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                ah[u] = img[(((TB + ig + u) * NKB + (KB0 + kb)) * 2 + 0) * 64 + lane];
+                al[u] = img[(((TB + ig + u) * NKB + (KB0 + kb)) * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(ah[u], bh[kb], acc[ig + u]);
+#pragma unroll
+            for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(al[u], bh[kb], acc[ig + u]);
+#pragma unroll
+            for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(ah[u], bl[kb], acc[ig + u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// LSTM cell for 8 units; the new h values become one K block of next step's B fragments
+__device__ __forceinline__ void lstm_pointwise8_h(const f32x4* acc, float* c, h8& nh, h8& nl)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float ig = sigmoid_f(acc[i][0]);
+        const float fg = sigmoid_f(acc[i][1]);
+        const float gg = tanh_f(acc[i][2]);
+        const float og = sigmoid_f(acc[i][3]);
+        c[i] = __builtin_fmaf(fg, c[i], ig * gg);
+        const float h = og * tanh_f(c[i]);
+        _Float16 hi, lo;
+        split1(h, hi, lo);
+        nh[i] = hi; nl[i] = lo;
+    }
+}
+
+__device__ __forceinline__ void copy_to_lds_h(h8* dst, const _Float16* __restrict__ src, int n_h8, int tid, int nthreads)
+{
+    const h8* s8 = reinterpret_cast<const h8*>(src);
+    for (int i = tid; i < n_h8; i += nthreads) dst[i] = s8[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: layer 0.  LDS: W_hh image (64 KB: [16][2][2][64] h8) + hi part of the W_ih image (16 KB) = 80 KB;
+// the lo part of W_ih (16 KB) is read through L1.  H0 layout: [site][t][dir][q][16 hi | 16 lo] fp16.
+// ---------------------------------------------------------------------------------------------
+constexpr int HH_H8 = 16 * 2 * 2 * 64;       // h8 elements of a recurrent image
+constexpr int IH_H8 = 16 * 64;               // one part of the input image
+constexpr int L0H_LDS_BYTES = (HH_H8 + IH_H8) * 16;
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))) void k_pileup_l0_h(
+    const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
+    const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
+    const _Float16* __restrict__ wih_hi0, const _Float16* __restrict__ wih_hi1,
+    const _Float16* __restrict__ wih_lo0, const _Float16* __restrict__ wih_lo1,
+    _Float16* __restrict__ H0)
+{
+    extern __shared__ h8 ldsh[];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds_h(ldsh, dir ? whh1 : whh0, HH_H8, tid, 64 * WAVES);
+    copy_to_lds_h(ldsh + HH_H8, dir ? wih_hi1 : wih_hi0, IH_H8, tid, 64 * WAVES);
+    const h8* __restrict__ wlo = reinterpret_cast<const h8*>(dir ? wih_lo1 : wih_lo0);
+    __syncthreads();
+
+    const int64_t site = (int64_t)blockIdx.x * (16 * WAVES) + wave * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    const int32_t* __restrict__ xs = center_idx ? x + (center_idx[sc] - PCENTER) * PC : x + sc * (PW * PC);
+    _Float16* __restrict__ hout = H0 + ((sc * PW * 2 + dir) * 4 + q) * 32;
+
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    h8 bh[2], bl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bh[k][j] = (_Float16)0.f; bl[k][j] = (_Float16)0.f; }
+
+    // lane q supplies channels 8q..8q+7 (q = 2: channels 16,17 and the constant 1 the bias rides on)
+    int xi[8];
+    auto load_x = [&](int t) {
+        const int32_t* p = xs + t * PC;
+        if (q < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xi[j] = p[8 * q + j];
+        } else {
+            xi[0] = p[16]; xi[1] = p[17];
+#pragma unroll
+            for (int j = 2; j < 8; ++j) xi[j] = 0;
+        }
+    };
+    load_x(dir ? PW - 1 : 0);
+    for (int s = 0; s < PW; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        h8 xh, xl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (float)xi[j];                       // predict.py:49 int -> float
+            if (q == 2 && j == 2) v = 1.0f;
+            if (q == 3) v = 0.0f;
+            _Float16 hi, lo; split1(v, hi, lo);
+            xh[j] = hi; xl[j] = lo;
+        }
+        if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);
+        h8 nh[2], nl[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // input part: hi image from LDS, lo image through L1
+#pragma unroll
+            for (int ig = 0; ig < 8; ig += 2) {
+                h8 ah[2], al[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ah[u] = ldsh[HH_H8 + (hf * 8 + ig + u) * 64 + lane];
+                    al[u] = wlo[(hf * 8 + ig + u) * 64 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ig + u] = mfma_h(ah[u], xh, acc[ig + u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ig + u] = mfma_h(al[u], xh, acc[ig + u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ig + u] = mfma_h(ah[u], xl, acc[ig + u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s > 0) {
+                if (hf == 0) wave_gemm_h<8, 2, 0, 2, 0, 2>(ldsh, lane, bh, bl, acc);
+                else         wave_gemm_h<8, 2, 0, 2, 8, 2>(ldsh, lane, bh, bl, acc);
+            }
+            lstm_pointwise8_h(acc, c + hf * 8, nh[hf], nl[hf]);
+        }
+        bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
+        if (live) {
+            h8* o = reinterpret_cast<h8*>(hout + (int64_t)t * (2 * 4 * 32));
+            o[0] = bh[0]; o[1] = bh[1]; o[2] = bl[0]; o[3] = bl[1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: layer-1 input projection.  LDS: W_ih1 image 128 KB ([16][4][2][64] h8) + fp32 bias image 4 KB.
+// ---------------------------------------------------------------------------------------------
+constexpr int P1H_W_H8 = 16 * 4 * 2 * 64;
+constexpr int P1H_LDS_BYTES = P1H_W_H8 * 16 + 16 * 64 * 16;
+
+__global__ __launch_bounds__(1024, 4) void k_pileup_proj1_h(
+    const _Float16* __restrict__ H0, int64_t N,
+    const _Float16* __restrict__ w0, const _Float16* __restrict__ w1,
+    const float* __restrict__ b0, const float* __restrict__ b1,
+    float* __restrict__ Xp1)
+{
+    extern __shared__ h8 ldsh[];
+    f32x4* lbias = reinterpret_cast<f32x4*>(ldsh + P1H_W_H8);
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds_h(ldsh, dir ? w1 : w0, P1H_W_H8, tid, 1024);
+    {
+        const f32x4* sb = reinterpret_cast<const f32x4*>(dir ? b1 : b0);
+        for (int i = tid; i < 16 * 64; i += 1024) lbias[i] = sb[i];
+    }
+    __syncthreads();
+    const int64_t M = N * PSTEPS1;
+    const int64_t n_rt = NSNP_CDIV(M, 16);
+    float* __restrict__ out = Xp1 + (int64_t)dir * M * 256;
+    for (int64_t rt = (int64_t)blockIdx.x * 16 + wave; rt < n_rt; rt += (int64_t)gridDim.x * 16) {
+        const int64_t m = rt * 16 + (lane & 15);
+        const bool live = m < M;
+        const int64_t mc = live ? m : M - 1;
+        const int64_t site = mc / PSTEPS1;
+        const int u = (int)(mc - site * PSTEPS1);
+        const int t = dir ? PW - 1 - u : u;
+        // K block kb = (source direction d', half): hi at [d'][q][half*8..], lo 16 halfs further
+        const h8* __restrict__ hin = reinterpret_cast<const h8*>(H0 + ((site * PW + t) * 2 * 4 + q) * 32);
+        h8 bh[4], bl[4];
+#pragma unroll
+        for (int dp = 0; dp < 2; ++dp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bh[dp * 2 + half] = hin[dp * 16 + half];          // 4 q-blocks x 4 h8 per direction
+                bl[dp * 2 + half] = hin[dp * 16 + 2 + half];
+            }
+        f32x4* o = reinterpret_cast<f32x4*>(out + mc * 256 + q * 4);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = lbias[(hf * 8 + i) * 64 + lane];
+            if (hf == 0) wave_gemm_h<8, 4, 0, 4, 0, 4>(ldsh, lane, bh, bl, acc);
+            else         wave_gemm_h<8, 4, 0, 4, 8, 4>(ldsh, lane, bh, bl, acc);
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[(hf * 8 + i) * 4] = acc[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: layer-1 recurrence, 17 steps; LDS: W_hh1 image 64 KB.  H1c: [site][dir][q][16 hi | 16 lo] fp16.
+// ---------------------------------------------------------------------------------------------
+constexpr int L1H_LDS_BYTES = HH_H8 * 16;
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))) void k_pileup_l1_h(
+    const float* __restrict__ Xp1, int64_t N,
+    const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
+    _Float16* __restrict__ H1c)
+{
+    extern __shared__ h8 ldsh[];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds_h(ldsh, dir ? whh1 : whh0, HH_H8, tid, 64 * WAVES);
+    __syncthreads();
+    const int64_t site = (int64_t)blockIdx.x * (16 * WAVES) + wave * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    const int64_t M = N * PSTEPS1;
+    const f32x4* __restrict__ xin =
+        reinterpret_cast<const f32x4*>(Xp1 + ((int64_t)dir * M + sc * PSTEPS1) * 256 + q * 4);
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    h8 bh[2], bl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bh[k][j] = (_Float16)0.f; bl[k][j] = (_Float16)0.f; }
+    for (int u = 0; u < PSTEPS1; ++u) {
+        h8 nh[2], nl[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = xin[(int64_t)u * 64 + (hf * 8 + i) * 4];
+            if (u > 0) {
+                if (hf == 0) wave_gemm_h<8, 2, 0, 2, 0, 2>(ldsh, lane, bh, bl, acc);
+                else         wave_gemm_h<8, 2, 0, 2, 8, 2>(ldsh, lane, bh, bl, acc);
+            }
+            lstm_pointwise8_h(acc, c + hf * 8, nh[hf], nl[hf]);
+        }
+        bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
+    }
+    if (live) {
+        h8* o = reinterpret_cast<h8*>(H1c + ((site * 2 + dir) * 4 + q) * 32);
+        o[0] = bh[0]; o[1] = bh[1]; o[2] = bl[0]; o[3] = bl[1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: heads, weights from L2 as fp16 hi/lo images.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pileup_head_h(
+    const _Float16* __restrict__ H1c, int64_t N,
+    const _Float16* __restrict__ proj_w, const float* __restrict__ proj_b,
+    const _Float16* __restrict__ dense_w, const float* __restrict__ dense_b,
+    const _Float16* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ gt_prob, float* __restrict__ zy_prob)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    const int64_t site = ((int64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    const h8* __restrict__ hin = reinterpret_cast<const h8*>(H1c + (sc * 2 * 4 + q) * 32);
+    h8 bh[4], bl[4];
+#pragma unroll
+    for (int dp = 0; dp < 2; ++dp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) { bh[dp * 2 + half] = hin[dp * 16 + half]; bl[dp * 2 + half] = hin[dp * 16 + 2 + half]; }
+    // output_proj 128 -> 128
+    f32x4 ap[8];
+    {
+        const f32x4* pb = reinterpret_cast<const f32x4*>(proj_b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ap[i] = pb[i * 64 + lane];
+        wave_gemm_h<8, 4, 0, 4, 0, 4>(reinterpret_cast<const h8*>(proj_w), lane, bh, bl, ap);
+    }
+    // dense 128 -> 256 + tanh: K position (kb, q, j) <-> proj feature 16*(2kb + (j>>2)) + 4q + (j&3)
+    h8 dh[4], dl[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 hi, lo; split1(ap[2 * kb + (j >> 2)][j & 3], hi, lo); dh[kb][j] = hi; dl[kb][j] = lo; }
+    f32x4 ad[16];
+    {
+        const f32x4* db = reinterpret_cast<const f32x4*>(dense_b);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ad[i] = db[i * 64 + lane];
+        wave_gemm_h<16, 4, 0, 4, 0, 4>(reinterpret_cast<const h8*>(dense_w), lane, dh, dl, ad);
+    }
+    h8 eh[8], el[8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 hi, lo; split1(tanh_f(ad[2 * kb + (j >> 2)][j & 3]), hi, lo); eh[kb][j] = hi; el[kb][j] = lo; }
+    f32x4 ah[2];
+    {
+        const f32x4* hb = reinterpret_cast<const f32x4*>(head_b);
+        ah[0] = hb[lane]; ah[1] = hb[64 + lane];
+        wave_gemm_h<2, 8, 0, 8, 0, 2>(reinterpret_cast<const h8*>(head_w), lane, eh, el, ah);
+    }
+    const float NEG = -3.0e38f;
+    float g0[4], g1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        g0[g] = ah[0][g];
+        const bool is_gt = (q == 0) || (q == 1 && g == 0);
+        g1[g] = is_gt ? ah[1][g] : NEG;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3])), fmaxf(fmaxf(g1[0], g1[1]), fmaxf(g1[2], g1[3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float e0[4], e1[4], sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        e0[g] = __expf(g0[g] - mx);
+        e1[g] = g1[g] > -1.0e38f ? __expf(g1[g] - mx) : 0.f;
+        sum += e0[g] + e1[g];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float z1 = ah[1][1], z2 = ah[1][2], z3 = ah[1][3];
+    const float zm = fmaxf(z1, fmaxf(z2, z3));
+    const float ez1 = __expf(z1 - zm), ez2 = __expf(z2 - zm), ez3 = __expf(z3 - zm);
+    const float zs = ez1 + ez2 + ez3;
+    if (live) {
+        float* gp = gt_prob + site * NSNP_GT_CLASSES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gp[4 * q + g] = e0[g] / sum;
+        if (q == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gp[16 + g] = e1[g] / sum;
+        }
+        if (q == 1) {
+            gp[20] = e1[0] / sum;
+            float* zp = zy_prob + site * NSNP_ZY_CLASSES;
+            zp[0] = ez1 / zs; zp[1] = ez2 / zs; zp[2] = ez3 / zs;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side: fp16 hi/lo weight images
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+inline int gate_row(int row) { const int i = row >> 4, r = row & 15; return (r & 3) * PH + 4 * i + (r >> 2); }
+
+// img[tile][kb][part][lane][j]  <-  f(row = 16*tile + (lane & 15), kb, q = lane >> 4, j)
+template <typename F>
+void pack_h(_Float16* img, int n_tiles, int n_kb, F f)
+{
+    for (int tile = 0; tile < n_tiles; ++tile)
+        for (int kb = 0; kb < n_kb; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const float v = f(16 * tile + (lane & 15), kb, lane >> 4, j);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const size_t e = (((size_t)tile * n_kb + kb) * 2) * 64 + lane;
+                    img[e * 8 + j] = hi;
+                    img[(e + 64) * 8 + j] = lo;
+                }
+}
+
+}  // namespace
+
+int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
+{
+    PileupWeightsF16& pw = ctx->pw16;
+    const size_t n_hh = (size_t)HH_H8 * 8, n_ih = (size_t)IH_H8 * 8 * 2, n_p1 = (size_t)P1H_W_H8 * 8;
+    const size_t n_proj = (size_t)8 * 4 * 2 * 64 * 8, n_dense = (size_t)16 * 4 * 2 * 64 * 8, n_head = (size_t)2 * 8 * 2 * 64 * 8;
+    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh) + n_proj + n_dense + n_head;
+    std::vector<_Float16> host(total);
+    size_t off = 0;
+    auto take = [&](size_t n) { _Float16* p = host.data() + off; off += n; return p; };
+    _Float16 *l0_hh[2], *l0_ih[2], *l1_ih[2], *l1_hh[2];
+    for (int d = 0; d < 2; ++d) { l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); }
+    _Float16* proj = take(n_proj); _Float16* dense = take(n_dense); _Float16* head = take(n_head);
+    auto rec_feat = [](int kb, int q, int j) { return 4 * (8 * kb + j) + q; };                     // hidden unit
+    auto h0_feat = [](int kb, int q, int j) { return (kb >> 1) * 64 + 4 * (8 * (kb & 1) + j) + q; };   // [fwd;bwd] feature
+    auto acc_feat = [](int kb, int q, int j) { return 16 * (2 * kb + (j >> 2)) + 4 * q + (j & 3); };
+    for (int d = 0; d < 2; ++d) {
+        const float* const* l0 = w + d * 4;
+        const float* const* l1 = w + 8 + d * 4;
+        pack_h(l0_hh[d], 16, 2, [&](int row, int kb, int q, int j) { return l0[1][gate_row(row) * PH + rec_feat(kb, q, j)]; });
+        // input image: [tile][part][lane] (one K block): split the generic [tile][kb=1][part] layout
+        pack_h(l0_ih[d], 16, 1, [&](int row, int, int q, int j) {
+            const int tr = gate_row(row);
+            if (q < 2) return l0[0][tr * PC + 8 * q + j];
+            if (q == 2) { if (j < 2) return l0[0][tr * PC + 16 + j]; if (j == 2) return l0[2][tr] + l0[3][tr]; }
+            return 0.f;
+        });
+        pack_h(l1_ih[d], 16, 4, [&](int row, int kb, int q, int j) { return l1[0][gate_row(row) * 2 * PH + h0_feat(kb, q, j)]; });
+        pack_h(l1_hh[d], 16, 2, [&](int row, int kb, int q, int j) { return l1[1][gate_row(row) * PH + rec_feat(kb, q, j)]; });
+    }
+    pack_h(proj, 8, 4, [&](int row, int kb, int q, int j) { return w[16][row * 128 + h0_feat(kb, q, j)]; });
+    pack_h(dense, 16, 4, [&](int row, int kb, int q, int j) { return w[18][row * 128 + acc_feat(kb, q, j)]; });
+    pack_h(head, 2, 8, [&](int row, int kb, int q, int j) {
+        const int f = acc_feat(kb, q, j);
+        if (row < 21) return w[20][row * 256 + f];
+        if (row < 24) return w[22][(row - 21) * 256 + f];
+        return 0.f;
+    });
+    // the layer-0 input image is consumed as two separate [tile][lane] part images (hi in LDS, lo via L1)
+    std::vector<_Float16> ih_split(2 * n_ih);
+    for (int d = 0; d < 2; ++d)
+        for (int tile = 0; tile < 16; ++tile)
+            for (int part = 0; part < 2; ++part)
+                memcpy(ih_split.data() + ((size_t)d * 2 + part) * (n_ih / 2) + (size_t)tile * 64 * 8,
+                       l0_ih[d] + ((size_t)tile * 2 + part) * 64 * 8, sizeof(_Float16) * 64 * 8);
+    for (int d = 0; d < 2; ++d) memcpy(l0_ih[d], ih_split.data() + (size_t)d * n_ih, sizeof(_Float16) * n_ih);
+
+    const size_t bytes = total * sizeof(_Float16);
+    if (pw.arena && pw.arena_bytes != bytes) { (void)hipFree(pw.arena); pw.arena = nullptr; }
+    if (!pw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&pw.arena, bytes)); pw.arena_bytes = bytes; }
+    NSNP_HIP(ctx, hipMemcpy(pw.arena, host.data(), bytes, hipMemcpyHostToDevice));
+    auto dev = [&](const _Float16* hp) { return (void*)((char*)pw.arena + (hp - host.data()) * sizeof(_Float16)); };
+    for (int d = 0; d < 2; ++d) {
+        pw.l0_whh[d] = dev(l0_hh[d]); pw.l0_wih_hi[d] = dev(l0_ih[d]); pw.l0_wih_lo[d] = dev(l0_ih[d] + n_ih / 2);
+        pw.l1_wih[d] = dev(l1_ih[d]); pw.l1_whh[d] = dev(l1_hh[d]);
+    }
+    pw.proj_w = dev(proj); pw.dense_w = dev(dense); pw.head_w = dev(head);
+    pw.loaded = true;
+    return NSNP_OK;
+}
+
+static int set_lds_attr_f16(nsnp_ctx* ctx)
+{
+    if (ctx->attr_set_f16) return NSNP_OK;
+#define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
+    SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
+    SET(k_pileup_proj1_h, P1H_LDS_BYTES);
+    SET(k_pileup_l1_h<8>, L1H_LDS_BYTES); SET(k_pileup_l1_h<4>, L1H_LDS_BYTES); SET(k_pileup_l1_h<2>, L1H_LDS_BYTES); SET(k_pileup_l1_h<1>, L1H_LDS_BYTES);
+#undef SET
+    ctx->attr_set_f16 = true;
+    return NSNP_OK;
+}
+
+int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
+                              int64_t N, float* gt, float* zy, hipStream_t s)
+{
+    if (!ctx->pw16.loaded || !ctx->pw.loaded) return NSNP_ENOWEIGHTS;
+    if (N == 0) return NSNP_OK;
+    int rc = set_lds_attr_f16(ctx);
+    if (rc) return rc;
+    if (!ctx->ws_h0) { rc = nsnp_ctx_reserve(ctx, ctx->chunk_sites); if (rc) return rc; }
+    const PileupWeightsF16& pw = ctx->pw16;
+    const PileupWeightsDev& p32 = ctx->pw;            // fp32 bias images are shared with the fp32 path
+    _Float16* H0 = reinterpret_cast<_Float16*>(ctx->ws_h0);       // same bytes per site as the fp32 layout
+    _Float16* H1c = reinterpret_cast<_Float16*>(ctx->ws_h1c);
+    for (int64_t base = 0; base < N; base += ctx->chunk_sites) {
+        const int64_t n = (N - base < ctx->chunk_sites) ? N - base : ctx->chunk_sites;
+        const int32_t* xc = center_idx ? x : x + base * (PW * PC);
+        const int64_t* cc = center_idx ? center_idx + base : nullptr;
+        const int64_t waves_total = NSNP_CDIV(n, 16) * 2;
+        int wpb = 8;
+        while (wpb > 1 && waves_total / wpb < (int64_t)ctx->n_cu / 2) wpb >>= 1;
+        if (ctx->force_wpb) wpb = ctx->force_wpb;
+        const dim3 g_rec((unsigned)NSNP_CDIV(n, 16 * wpb), 2);
+        { ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
+#define LAUNCH_L0(W) hipLaunchKernelGGL(k_pileup_l0_h<W>, g_rec, dim3(64 * W), L0H_LDS_BYTES, s, xc, cc, n, \
+            (const _Float16*)pw.l0_whh[0], (const _Float16*)pw.l0_whh[1], (const _Float16*)pw.l0_wih_hi[0], (const _Float16*)pw.l0_wih_hi[1], \
+            (const _Float16*)pw.l0_wih_lo[0], (const _Float16*)pw.l0_wih_lo[1], H0)
+        if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
+#undef LAUNCH_L0
+        }
+        const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
+        int64_t gp = NSNP_CDIV(n_rt, 16);
+        if (gp > ctx->n_cu) gp = ctx->n_cu;
+        { ScopedKernelTimer tm(ctx, NSNP_K_PROJ1, s);
+        hipLaunchKernelGGL(k_pileup_proj1_h, dim3((unsigned)gp, 2), dim3(1024), P1H_LDS_BYTES, s, H0, n,
+                           (const _Float16*)pw.l1_wih[0], (const _Float16*)pw.l1_wih[1], p32.l1_bias[0], p32.l1_bias[1], ctx->ws_xp1); }
+        { ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
+#define LAUNCH_L1(W) hipLaunchKernelGGL(k_pileup_l1_h<W>, g_rec, dim3(64 * W), L1H_LDS_BYTES, s, ctx->ws_xp1, n, \
+            (const _Float16*)pw.l1_whh[0], (const _Float16*)pw.l1_whh[1], H1c)
+        if (wpb == 8) LAUNCH_L1(8); else if (wpb == 4) LAUNCH_L1(4); else if (wpb == 2) LAUNCH_L1(2); else LAUNCH_L1(1);
+#undef LAUNCH_L1
+        }
+        ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
+        hipLaunchKernelGGL(k_pileup_head_h, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, H1c, n,
+                           (const _Float16*)pw.proj_w, p32.proj_b, (const _Float16*)pw.dense_w, p32.dense_b,
+                           (const _Float16*)pw.head_w, p32.head_b, gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);
+    }
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}

@@ -158,3 +158,48 @@ def test_workgroup_shape_does_not_change_results(model, pileup_weights):
     with pytest.raises(_lib.NanoSNPError):
         c.set_option("recurrence_waves", 3)
     c.close()
+
+
+def test_f16x3_precision_mode(pileup_weights):
+    """every product as 3 fp16 MFMAs with fp32 accumulation (pileup_forward_f16x3.hip): same goldens,
+    same 1e-4 tolerance; measured ~1e-6"""
+    import torch
+    from nanosnp_amd import _lib
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    z = np.load(golden("pileup_fwd.npz"))
+    x = torch.from_numpy(z["x"].astype(np.int32)).cuda()
+    g32, z32 = c.pileup_forward(x)
+    c.set_option("pileup_precision", 1)
+    g16, z16 = c.pileup_forward(x)
+    torch.cuda.synchronize()
+    d_gold = max(np.abs(g16.cpu().numpy() - z["gt"]).max(), np.abs(z16.cpu().numpy() - z["zy"]).max())
+    d_32 = max((g16 - g32).abs().max().item(), (z16 - z32).abs().max().item())
+    print("f16x3 vs golden", d_gold, "vs fp32 path", d_32)
+    assert d_gold < PROB_ATOL and d_32 < 2e-5
+    assert np.array_equal(g16.cpu().numpy().argmax(1), z["gt"].argmax(1))
+    # deep counts (> 2048: the fp16 hi part is no longer exact, the lo part carries the rest) and extremes
+    from oracle import oracle
+    xe = np.zeros((8, 33, 18), np.int32)
+    xe[1] = 144; xe[2] = -144; xe[3, :, ::2] = 10000; xe[4, 16] = -60000; xe[5, ::3] = 4099; xe[6] = 2049; xe[7, :, 1] = 33001
+    ge, ze = c.pileup_forward(torch.from_numpy(xe).cuda())
+    oge, oze = oracle.pileup_forward(pileup_weights, xe)
+    assert np.isfinite(ge.cpu().numpy()).all()
+    assert np.abs(ge.cpu().numpy() - oge).max() < PROB_ATOL and np.abs(ze.cpu().numpy() - oze).max() < PROB_ATOL
+    # ragged sizes, wave shapes, windows entry point
+    rng = np.random.default_rng(5)
+    xr = torch.from_numpy((rng.integers(0, 50, (1000, 33, 18)) - 10).astype(np.int32)).cuda()
+    ref = c.pileup_forward(xr)
+    for w in (1, 2, 4, 8):
+        # (the exact-fp32 path is bit-identical across workgroup shapes; here the compiler's code for the
+        #  8/4-wave variants differs from the 2/1-wave ones by one ulp in a few rows)
+        c.set_option("recurrence_waves", w)
+        got = c.pileup_forward(xr)
+        assert (got[0] - ref[0]).abs().max().item() < 5e-7 and (got[1] - ref[1]).abs().max().item() < 5e-7, w
+        again = c.pileup_forward(xr)
+        assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])      # run-to-run deterministic
+    c.set_option("recurrence_waves", 0)
+    for n in (1, 17, 129):
+        gn, zn = c.pileup_forward(xr[:n].contiguous())
+        assert torch.equal(gn, ref[0][:n])
+    c.close()
