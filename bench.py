@@ -40,6 +40,7 @@ ALG_FLOP_PER_SITE = {
 }
 assert sum(ALG_FLOP_PER_SITE.values()) == 2 * 6_274_560          # 12.55 MFLOP/site
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (the f16x3 path issues 3 fp16 MFMAs per fp32 product)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -67,7 +68,6 @@ def cpu_baseline(cols, batch, weights, target_s):
     host cores, on a bounded sample of the same windows: encode + forward, all cores."""
     from oracle import oracle
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
 
     def run(n):
         m = n * 33
@@ -95,6 +95,8 @@ def main():
 
     if args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)      # must be set before HIP initialises
+    # the host-side generator / CPU baseline use OpenMP: share the cores between the ranks of a node
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, world))))
     import torch
     import torch.distributed as dist
     from nanosnp_amd import _lib, host
@@ -225,8 +227,13 @@ def main():
         dom = max(avg_ms, key=lambda k: tot[k][0])
         if dom in ALG_FLOP_PER_SITE:
             achieved = ALG_FLOP_PER_SITE[dom] * batch / (avg_ms[dom] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS}
+            peak = PEAK_F16_MFMA_TFLOPS if args.precision == 1 else PEAK_F32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak}
+            if args.precision == 1:
+                roof["note"] = ("f16x3: 3 fp16 MFMAs per fp32 product, priced against the fp16 dense peak; at this rate "
+                                "the recurrence is bound by sigmoid/tanh VALU issue and the forward by HBM traffic of its "
+                                "intermediates (DESIGN.md section 4), not by the matrix pipe")
         else:
             nbytes = (int(cols.col_off[mcols]) + mcols * (1 + 72))        # bytes in + ref + 18 int32 out
             achieved = nbytes / (avg_ms[dom] * 1e-3) / 1e9
@@ -248,11 +255,13 @@ def main():
             "metric": METRIC, "value": world * K * batch / dt, "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f16x3 (fp32 split into two fp16, 3 MFMAs per product, fp32 accumulate)" if args.precision == 1 else "f32",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: pileup encode + PileupModel fwd, synthetic 30x "
                                    "windows (G2) resident in HBM, batch=4096",
                        "batch": batch, "windows_resident_per_gpu": n_windows, "streams": S,
-                       "coverage": args.coverage, "weights": "ont_pileup.chkpt values (tests/golden fixture)",
+                       "coverage": args.coverage, "precision": "f16x3" if args.precision == 1 else "fp32",
+                       "weights": "ont_pileup.chkpt values (tests/golden fixture)",
                        "parallelism": f"site-sharded x{world}, rooted gather of calls"},
             "roofline": roof,
             "kernel_avg_ms": {k: round(v, 5) for k, v in sorted(avg_ms.items())},
@@ -260,7 +269,7 @@ def main():
         }
         if extra:
             out["repeats_before"] = [round(v) for v in extra]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cols, batch, weights, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None

@@ -13,6 +13,15 @@
 // straight into the next step's B fragments (K position (kb, q, j) <-> unit 4*(8*kb+j)+q).
 #include "nsnp_common.hpp"
 
+#ifndef NSNP_F16_PIN
+#define NSNP_F16_PIN 1
+#endif
+#if NSNP_F16_PIN
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PIN() do {} while (0)
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -58,7 +67,7 @@ __device__ __forceinline__ void wave_gemm_h(WP img, int lane, const h8* bh, cons
             for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(al[u], bh[kb], acc[ig + u]);
 #pragma unroll
             for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(ah[u], bl[kb], acc[ig + u]);
-            __builtin_amdgcn_sched_barrier(0);
+            PIN();
         }
     }
 }
@@ -77,6 +86,57 @@ __device__ __forceinline__ void lstm_pointwise8_h(const f32x4* acc, float* c, h8
         _Float16 hi, lo;
         split1(h, hi, lo);
         nh[i] = hi; nl[i] = lo;
+    }
+}
+
+// Same contraction as wave_gemm_h with the weight fragments of group g+1 requested before the MFMAs of
+// group g are issued (G = 2 tiles per group), so the LDS latency hides behind the previous group's
+// matrix work instead of in front of every group.
+template <int NT, int NKB, int KBN, int TB, typename WP>
+__device__ __forceinline__ void wave_gemm_h_pipe(WP img, int lane, const h8* bh, const h8* bl, f32x4* acc)
+{
+    constexpr int G = 2;
+    constexpr int NG = KBN * (NT / G);
+    h8 ah[2][G], al[2][G];
+    auto fetch = [&](int g, int buf) {
+        const int kb = g / (NT / G), ig = (g % (NT / G)) * G;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            ah[buf][u] = img[(((TB + ig + u) * NKB + kb) * 2 + 0) * 64 + lane];
+            al[buf][u] = img[(((TB + ig + u) * NKB + kb) * 2 + 1) * 64 + lane];
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int buf = g & 1;
+        const int kb = g / (NT / G), ig = (g % (NT / G)) * G;
+        if (g + 1 < NG) fetch(g + 1, buf ^ 1);
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(ah[buf][u], bh[kb], acc[ig + u]);
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(al[buf][u], bh[kb], acc[ig + u]);
+#pragma unroll
+        for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(ah[buf][u], bl[kb], acc[ig + u]);
+        PIN();
+    }
+}
+
+// LSTM cell for 4 units (a quarter pass); the new h values fill half of one K block of next step's B fragments
+template <int J0>
+__device__ __forceinline__ void lstm_pointwise4_h(const f32x4* acc, float* c, h8& nh, h8& nl)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float ig = sigmoid_f(acc[i][0]);
+        const float fg = sigmoid_f(acc[i][1]);
+        const float gg = tanh_f(acc[i][2]);
+        const float og = sigmoid_f(acc[i][3]);
+        c[i] = __builtin_fmaf(fg, c[i], ig * gg);
+        const float h = og * tanh_f(c[i]);
+        _Float16 hi, lo;
+        split1(h, hi, lo);
+        nh[J0 + i] = hi; nl[J0 + i] = lo;
     }
 }
 
@@ -153,34 +213,27 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))
         }
         if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);
         h8 nh[2], nl[2];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            f32x4 acc[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // input part: hi image from LDS, lo image through L1
-#pragma unroll
-            for (int ig = 0; ig < 8; ig += 2) {
-                h8 ah[2], al[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    ah[u] = ldsh[HH_H8 + (hf * 8 + ig + u) * 64 + lane];
-                    al[u] = wlo[(hf * 8 + ig + u) * 64 + lane];
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[ig + u] = mfma_h(ah[u], xh, acc[ig + u]);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[ig + u] = mfma_h(al[u], xh, acc[ig + u]);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[ig + u] = mfma_h(ah[u], xl, acc[ig + u]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (s > 0) {
-                if (hf == 0) wave_gemm_h<8, 2, 0, 2, 0, 2>(ldsh, lane, bh, bl, acc);
-                else         wave_gemm_h<8, 2, 0, 2, 8, 2>(ldsh, lane, bh, bl, acc);
-            }
-            lstm_pointwise8_h(acc, c + hf * 8, nh[hf], nl[hf]);
+        // four quarter passes of 4 gate tiles: the lo fragments of the input image (read through L1) are
+        // requested first and consumed last, behind the LDS-fed recurrent MFMAs of the same quarter
+#define QUARTER(QP)                                                                                        \
+        {                                                                                                  \
+            PIN();                                                             \
+            h8 ilo[4];                                                                                     \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) ilo[u] = wlo[((QP) * 4 + u) * 64 + lane];        \
+            f32x4 acc[4];                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};             \
+            if (s > 0) wave_gemm_h_pipe<4, 2, 2, (QP) * 4>(ldsh, lane, bh, bl, acc);                       \
+            h8 ihi[4];                                                                                     \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) ihi[u] = ldsh[HH_H8 + ((QP) * 4 + u) * 64 + lane]; \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma_h(ihi[u], xh, acc[u]);             \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma_h(ilo[u], xh, acc[u]);             \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma_h(ihi[u], xl, acc[u]);             \
+            PIN();                                                             \
+            lstm_pointwise4_h<((QP) & 1) * 4>(acc, c + (QP) * 4, nh[(QP) >> 1], nl[(QP) >> 1]);            \
+            PIN();                                                             \
         }
+        QUARTER(0) QUARTER(1) QUARTER(2) QUARTER(3)
+#undef QUARTER
         bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
         if (live) {
             h8* o = reinterpret_cast<h8*>(hout + (int64_t)t * (2 * 4 * 32));
@@ -509,8 +562,10 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         const int64_t n = (N - base < ctx->chunk_sites) ? N - base : ctx->chunk_sites;
         const int32_t* xc = center_idx ? x : x + base * (PW * PC);
         const int64_t* cc = center_idx ? center_idx + base : nullptr;
+        // 4 waves per recurrence workgroup at most: the 8-wave variant has to fit 128 VGPRs and spills
+        // (measured 2.4 ms vs 1.6 ms for layer 0 at 131072 sites); fewer for small batches as in the fp32 path
         const int64_t waves_total = NSNP_CDIV(n, 16) * 2;
-        int wpb = 8;
+        int wpb = 4;
         while (wpb > 1 && waves_total / wpb < (int64_t)ctx->n_cu / 2) wpb >>= 1;
         if (ctx->force_wpb) wpb = ctx->force_wpb;
         const dim3 g_rec((unsigned)NSNP_CDIV(n, 16 * wpb), 2);
