@@ -48,8 +48,9 @@ __device__ __forceinline__ int nt4(int b)            // cpp_aux.cpp:85-102 (only
 // Iterator over the counted indels of a column (those with length <= 60), following exactly
 // the scan of tensor_maker.cpp:83-114: '^' swallows the next byte; '+'/'-' read decimal digits,
 // then skip `advance` bytes (advance == 0 re-examines the byte after the sign/digits).
-struct IndelIter {
-    const uint8_t* base; int64_t i, end;
+template <typename P>
+struct IndelIterT {
+    P base; int64_t i, end;
     __device__ __forceinline__ bool next(int64_t& off, int& len, int& sign)
     {
         while (i < end) {
@@ -72,6 +73,28 @@ struct IndelIter {
         return false;
     }
 };
+typedef IndelIterT<const uint8_t*> IndelIter;
+
+template <typename P>
+__device__ __forceinline__ void rescan_maxima(P base, int64_t begin, int64_t end, int32_t* mx)
+{
+    // exact distinct-allele maxima by comparing every counted indel with every other one: O(k^2)
+    mx[0] = mx[1] = mx[2] = mx[3] = 0;
+    IndelIterT<P> a{base, begin, end};
+    int64_t ao; int al, as;
+    while (a.next(ao, al, as)) {
+        const int kind = (as == '-' ? 2 : 0) + (al > 0 && is_fwd_char(base[ao]) ? 0 : 1);
+        IndelIterT<P> b2{base, begin, end};
+        int64_t bo; int bl, bs; int same = 0;
+        while (b2.next(bo, bl, bs)) {
+            if (bs != as || bl != al) continue;
+            bool eq = true;
+            for (int k = 0; k < al; ++k) if (base[ao + k] != base[bo + k]) { eq = false; break; }
+            same += eq;
+        }
+        if (same > mx[kind]) mx[kind] = same;
+    }
+}
 
 __device__ __forceinline__ bool same_bytes(const uint8_t* base, int64_t a, int64_t b, int len)
 {
@@ -104,16 +127,7 @@ __device__ __noinline__ void scan_column_global(const uint8_t* __restrict__ base
         } else if (cls == 13) i += 2;
         else ++i;
     }
-    IndelIter a{bases, begin, end};
-    int64_t ao; int al, as;
-    while (a.next(ao, al, as)) {
-        const int kind = (as == '-' ? 2 : 0) + (al > 0 && is_fwd_char(bases[ao]) ? 0 : 1);
-        IndelIter b2{bases, begin, end};
-        int64_t bo; int bl, bs; int same = 0;
-        while (b2.next(bo, bl, bs))
-            if (bs == as && bl == al && same_bytes(bases, ao, bo, al)) ++same;
-        if (same > mx[kind]) mx[kind] = same;
-    }
+    rescan_maxima(bases, begin, end, mx);
 }
 
 // ---- main kernel ----------------------------------------------------------------------------------------
@@ -123,8 +137,14 @@ __device__ __noinline__ void scan_column_global(const uint8_t* __restrict__ base
 // list, byte-exact, so the main scan stays short and the lanes of a wave diverge as little as the grammar
 // allows.
 constexpr int ENC_WAVES = ENC_BLOCK / 64;
-constexpr int STAGE_BYTES = 7168;          // per wave; 64 columns at 60x average ~4.4 KB
-constexpr int KLIST = 12;                  // recorded indels per column before the slow path takes over
+#ifndef NSNP_ENC_STAGE
+#define NSNP_ENC_STAGE 5120
+#endif
+#ifndef NSNP_ENC_KLIST
+#define NSNP_ENC_KLIST 12
+#endif
+constexpr int STAGE_BYTES = NSNP_ENC_STAGE;          // per wave; 64 columns at 60x average ~4.4 KB
+constexpr int KLIST = NSNP_ENC_KLIST;                  // recorded indels per column before the slow path takes over
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
@@ -133,10 +153,17 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
     __shared__ uint32_t ilist[ENC_WAVES][KLIST][64];      // off (16) | len (8) | sign (8)
-    __shared__ uint8_t lut[256];
-
+    __shared__ uint4 ctab[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    lut[tid] = (uint8_t)byte_class(tid);
+    {
+        const int cls = byte_class(tid);      // ENC_BLOCK == 256: one table row per thread
+        uint4 r = {0u, 0u, 0u, 0u};
+        if (cls < 4) r.x = 1u << (8 * cls);
+        else if (cls < 8) r.y = 1u << (8 * (cls - 4));
+        else if (cls < 10) r.z = 1u << (8 * (cls - 8));
+        r.w = (cls == 11 || cls == 12 ? 1u : 0u) | (cls == 13 ? 2u : 0u) | (tid >= '0' && tid <= '9' ? 4u : 0u);
+        ctab[tid] = r;
+    }
     __syncthreads();
     const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
     if (wave_col0 >= M) return;                                   // whole wave idle (no later block barrier)
@@ -145,83 +172,114 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     int64_t begin = 0, end = 0;
     if (live) { begin = col_off[c]; end = col_off[c + 1]; }
     const int n_live = (int)(M - wave_col0 < 64 ? M - wave_col0 : 64);
-    const int64_t b0 = __shfl(begin, 0);
-    const int64_t b1 = __shfl(end, n_live - 1);
     const int64_t total = col_off[M];
 
-    // ---- stage [b0, b1) ------------------------------------------------------------------------------
     uint8_t* st = stage_b[wave];
     const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
-    const uintptr_t a_first = (uintptr_t)(bases + b0) & ~(uintptr_t)15;      // 16-byte aligned global address
-    const int mis = (int)((uintptr_t)(bases + b0) - a_first);
-    const bool staged = (b1 - b0) + mis + 16 <= STAGE_BYTES;                  // wave-uniform
-    if (staged) {
-        const uintptr_t a_end = (uintptr_t)(bases + b1);
-        const uintptr_t a_total = (uintptr_t)(bases + total);
-        for (uintptr_t a = a_first + (uintptr_t)lane * 16; a < a_end; a += 64 * 16) {
-            uint4 v;
-            if (a + 16 <= a_total && a >= (uintptr_t)bases) v = *reinterpret_cast<const uint4*>(a);
-            else {                                                               // buffer edge: byte loads
-                uint8_t tmp[16];
-                for (int k = 0; k < 16; ++k) { const uintptr_t p = a + k; tmp[k] = (p >= (uintptr_t)bases && p < a_total) ? *reinterpret_cast<const uint8_t*>(p) : 0; }
-                v = *reinterpret_cast<uint4*>(tmp);
-            }
-            *reinterpret_cast<uint4*>(st + (a - a_first)) = v;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
     int32_t cnt[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt[k] = 0;
     int32_t tot[4] = {0, 0, 0, 0};      // I, i, D, d   (kind = (sign=='-')*2 + reverse)
     int32_t mx[4] = {0, 0, 0, 0};
-    bool slow = live && !staged;
+    bool slow = false;
 
-    if (live && staged) {
-        // LDS byte index of global offset g: (g - b0) + mis
-        const int lbeg = (int)(begin - b0) + mis, lend = (int)(end - b0) + mis;
-        int cur_wi = -1; uint32_t cur_w = 0;
-        auto rd = [&](int li) -> int {
-            const int wi = li >> 2;
-            if (wi != cur_wi) { cur_w = st32[wi]; cur_wi = wi; }
-            return (int)((cur_w >> ((li & 3) * 8)) & 0xffu);
-        };
-        int n_list = 0;
-        for (int i = lbeg; i < lend;) {
-            const int b = rd(i);
-            const int cls = lut[b];
-            if (cls < 10) {
-#pragma unroll
-                for (int k = 0; k < 10; ++k) cnt[k] += (cls == k);
-                ++i;
-            } else if (cls == 11 || cls == 12) {
-                ++i;
-                int adv = 0; bool huge = false;
-                while (i < lend) {
-                    const int d = rd(i);
-                    if (d < '0' || d > '9') break;
-                    if (adv > 100000) huge = true; else adv = adv * 10 + (d - '0');
-                    ++i;
-                }
-                if (huge) { i = lend; }
-                else {
-                    if (adv <= MAX_INDEL) {
-                        const int avail = lend - i;
-                        const int len = adv < avail ? adv : avail;
-                        if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)i | ((uint32_t)len << 16) | ((uint32_t)b << 24);
-                        ++n_list;
-                    }
-                    i += adv;
-                }
-            } else if (cls == 13) i += 2;
-            else ++i;
+    // The wave's 64 columns are one contiguous byte range; it is staged into LDS in as few sub-batches of
+    // consecutive columns as the stage buffer allows (one at 30x, one or two at 60x).  A single column
+    // longer than the buffer takes the global-memory path.
+    for (int first = 0; first < n_live;) {
+        const int64_t b0 = __shfl(begin, first);
+        const uintptr_t a_first = (uintptr_t)(bases + b0) & ~(uintptr_t)15;      // 16-byte aligned global address
+        const int mis = (int)((uintptr_t)(bases + b0) - a_first);
+        const bool fits = live && lane >= first && (end - b0) + mis + 16 <= STAGE_BYTES;
+        const unsigned long long fm = __ballot(fits) >> first;                   // lanes first.. that fit, from bit 0
+        int n_fit = (~fm) ? __builtin_ctzll(~fm) : 64;                           // leading run of fitting columns
+        if (n_fit > n_live - first) n_fit = n_live - first;
+        if (n_fit == 0) {                                                        // column `first` alone exceeds the stage
+            if (lane == first) slow = true;
+            first += 1;
+            continue;
         }
-        if (n_list > KLIST) slow = true;
-        else {
+        const int last = first + n_fit;                                          // sub-batch = lanes [first, last)
+        const int64_t b1 = __shfl(end, last - 1);
+        {
+            const uintptr_t a_end = (uintptr_t)(bases + b1);
+            const uintptr_t a_total = (uintptr_t)(bases + total);
+            for (uintptr_t a = a_first + (uintptr_t)lane * 16; a < a_end; a += 64 * 16) {
+                uint4 v;
+                if (a + 16 <= a_total && a >= (uintptr_t)bases) v = *reinterpret_cast<const uint4*>(a);
+                else {                                                           // buffer edge: byte loads
+                    uint32_t wv[4] = {0u, 0u, 0u, 0u};
+                    for (int k = 0; k < 16; ++k) {
+                        const uintptr_t q = a + k;
+                        if (q >= (uintptr_t)bases && q < a_total) wv[k >> 2] |= (uint32_t)(*reinterpret_cast<const uint8_t*>(q)) << (8 * (k & 3));
+                    }
+                    v = uint4{wv[0], wv[1], wv[2], wv[3]};
+                }
+                *reinterpret_cast<uint4*>(st + (a - a_first)) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        if (lane >= first && lane < last) {
+            // LDS byte index of global offset g: (g - b0) + mis.  All lanes consume exactly one byte of their
+            // own column per inner step (skips are a per-lane state, not a jump), so the 4-byte LDS reads of a
+            // wave stay in lockstep and the control flow does not diverge on the grammar.
+            const int lbeg = (int)(begin - b0) + mis, lend = (int)(end - b0) + mis;
+            int n_list = 0;
+            int skip = 0, adv = 0, sign = 0; bool dig = false;
+            // byte -> {packed 8-bit increments for A C G T | a c g t | * #, flags} from one 16-byte LDS read
+            uint32_t a0 = 0, a1 = 0, a2 = 0;
+            auto flush = [&]() {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { cnt[k] += (a0 >> (8 * k)) & 0xff; cnt[4 + k] += (a1 >> (8 * k)) & 0xff; }
+                cnt[8] += a2 & 0xff; cnt[9] += (a2 >> 8) & 0xff;
+                a0 = a1 = a2 = 0;
+            };
+            int since = 0;
+            for (int p0 = lbeg & ~3; p0 < lend; p0 += 4) {
+                const uint32_t w = st32[p0 >> 2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = p0 + k;
+                    const bool in = p >= lbeg && p < lend;
+                    const int b = (int)((w >> (8 * k)) & 0xffu);
+                    const uint4 row = ctab[b];
+                    const bool isd = (row.w & 4u) != 0;
+                    // one of three things happens to an in-range byte: it is skipped, it extends / ends a digit
+                    // run, or it is examined as a pileup symbol ("normal")
+                    const bool skipping = in && skip > 0;
+                    const bool in_digits = in && !skipping && dig;
+                    const bool ends_digits = in_digits && !isd;
+                    bool normal = in && !skipping && !dig;
+                    if (skipping) --skip;
+                    if (in_digits && isd) adv = adv > 100000 ? adv : adv * 10 + (b - '0');
+                    if (ends_digits) {
+                        dig = false;
+                        if (adv <= MAX_INDEL) {
+                            const int avail = lend - p;
+                            const int len = adv < avail ? adv : avail;
+                            if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)p | ((uint32_t)len << 16) | ((uint32_t)sign << 24);
+                            ++n_list;
+                        }
+                        if (adv > 0) skip = adv - 1; else normal = true;        // advance == 0 re-examines this byte
+                    }
+                    const uint32_t m = normal ? 0xffffffffu : 0u;
+                    a0 += row.x & m; a1 += row.y & m; a2 += row.z & m;
+                    const uint32_t fl = row.w & m;
+                    if (fl & 1u) { dig = true; adv = 0; sign = b; }
+                    if (fl & 2u) skip = 1;
+                }
+                if (++since == 63) { flush(); since = 0; }       // 8-bit fields: at most 252 increments between flushes
+            }
+            flush();
+            if (dig && adv <= MAX_INDEL) {       // the string ended inside "+<digits>": empty key at the end
+                if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)lend | ((uint32_t)sign << 24);
+                ++n_list;
+            }
             // distinct-allele maxima from the recorded list: m(e) = #{f <= e equal to e}
-            for (int e = 0; e < n_list; ++e) {
+            const int n_rec = n_list < KLIST ? n_list : KLIST;
+            for (int e = 0; e < n_rec; ++e) {
                 const uint32_t ve = ilist[wave][e][lane];
                 const int oe = ve & 0xffff, le = (ve >> 16) & 0xff, se = ve >> 24;
                 const int kind = (se == '-' ? 2 : 0) + (le > 0 && is_fwd_char(st[oe]) ? 0 : 1);
@@ -237,7 +295,17 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
                 }
                 if (same > mx[kind]) mx[kind] = same;
             }
+            if (n_list > KLIST) {
+                // more indel reads than the list holds: totals and maxima again, exactly, from the staged bytes
+                tot[0] = tot[1] = tot[2] = tot[3] = 0;
+                IndelIterT<const uint8_t*> it{st, lbeg, lend};
+                int64_t io; int il, is;
+                while (it.next(io, il, is)) tot[(is == '-' ? 2 : 0) + (il > 0 && is_fwd_char(st[io]) ? 0 : 1)]++;
+                rescan_maxima((const uint8_t*)st, (int64_t)lbeg, (int64_t)lend, mx);
+            }
         }
+        __builtin_amdgcn_wave_barrier();            // the stage buffer is reused by the next sub-batch
+        first = last;
     }
     if (slow) {          // private arrays: passing cnt/tot/mx by address would pin them in scratch for every lane
         int32_t c2[10], t2[4], m2[4];

@@ -126,3 +126,34 @@ def test_full_size_invariants_1m_columns(gpu_ctx):
     so = np.concatenate([[0], np.cumsum(cols.col_off[sample + 1] - cols.col_off[sample])]).astype(np.int64)
     oc, od, _ = oracle.encode_columns(sb, so, cols.ref[sample])
     assert np.array_equal(c[sample], oc) and np.array_equal(d[sample], od)
+
+
+def test_deep_and_indel_heavy_columns_take_the_sub_batch_and_rescan_paths(gpu_ctx):
+    """waves whose 64 columns exceed the LDS stage (split into sub-batches), single columns longer than
+    the stage (global path), and columns with more indel reads than the per-lane list (exact rescan)"""
+    from oracle import oracle
+    rng = np.random.default_rng(21)
+    cols = []
+    for c in range(700):
+        kind = c % 7
+        depth = [30, 144, 400, 30, 2000, 60, 30][kind]
+        parts = []
+        for r in range(depth):
+            sym = "ACGTacgt*#"[int(rng.integers(0, 10))]
+            s = sym
+            if kind in (1, 3, 4) and rng.random() < (0.6 if kind != 4 else 0.1):
+                L = int(rng.integers(1, 6))
+                seq = "".join(rng.choice(list("ACGT"), L))
+                if rng.random() < 0.5:
+                    seq = ["A", "AC", "ACG"][int(rng.integers(0, 3))]
+                s += ("+" if rng.random() < 0.5 else "-") + str(len(seq)) + (seq.lower() if sym.islower() else seq)
+            parts.append(s)
+        cols.append("".join(parts).encode())
+    bases = np.frombuffer(b"".join(cols), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    ref = rng.choice(list(b"ACGTN"), len(cols)).astype(np.uint8)
+    c, d, f = _enc(gpu_ctx, bases, off, ref)
+    oc, od, of = oracle.encode_columns(bases, off, ref)
+    bad = np.nonzero((c.cpu().numpy() != oc).any(1))[0]
+    assert bad.size == 0, (bad[:5], c.cpu().numpy()[bad[:2]], oc[bad[:2]])
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
