@@ -39,6 +39,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->last_err = hipSuccess;
     ctx->chunk_sites = 32768;
     ctx->precision = 0;
+    ctx->proj1_tiles = 4;
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -78,6 +79,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "pileup_precision") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->precision = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "proj1_tiles") == 0) {
+        if (value < 1 || value > 64) return NSNP_EINVAL;
+        ctx->proj1_tiles = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "recurrence_waves") == 0) {

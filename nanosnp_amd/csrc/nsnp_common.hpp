@@ -72,6 +72,7 @@ struct nsnp_ctx {
     bool attr_set;
     bool attr_set_f16;
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
+    int proj1_tiles;    // 16-row tiles per wave of the layer-1 projection kernel (persistent grid sizing)
     int force_wpb;      // 0 = automatic; else waves per recurrence workgroup (tuning / tests)
     // workspace (sized by nsnp_ctx_reserve)
     int64_t chunk_sites;

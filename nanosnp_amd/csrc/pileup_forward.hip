@@ -589,8 +589,11 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
 #undef LAUNCH_L0
         }
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
-        int64_t gp = NSNP_CDIV(n_rt, 16);
+        // persistent workgroups: each loads the 128 KB weight image once and then walks
+        // proj1_tiles 16-row tiles per wave, so the load is amortised even at small batches
+        int64_t gp = NSNP_CDIV(n_rt, 16 * (int64_t)ctx->proj1_tiles);
         if (gp > ctx->n_cu) gp = ctx->n_cu;
+        if (gp < 1) gp = 1;
         { ScopedKernelTimer tm(ctx, NSNP_K_PROJ1, s);
         hipLaunchKernelGGL(k_pileup_proj1, dim3((unsigned)gp, 2), dim3(1024), P1_LDS_BYTES, s, ctx->ws_h0, n,
                            pw.l1_wih[0], pw.l1_wih[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_xp1); }
