@@ -273,3 +273,41 @@ def vcf_header(fai_text: str):
     contigs = "".join('##contig=<ID={},length={}>\n'.format(*line.strip().split()[:2])
                       for line in fai_text.splitlines() if line.strip())
     return VCF_HEADER.format(contigs=contigs)
+
+
+# ---- reference rows of the haplotype features (H3) ---------------------------------------------------
+_BASE2INT = {65: 1, 67: 2, 71: 3, 84: 4, 78: 0}      # dataset_dev.py:9 {'A':1,'C':2,'G':3,'T':4,'N':0}
+
+
+def haplotype_ref_rows(references, candidate_positions, length=33, position_lists=None):
+    """PileupFeature / HaplotypeFeature reference rows (HaplotypeModel/dataset_dev.py:106-120,150-162).
+
+    references: {contig: uint8 array or bytes}.  candidate_positions: "ctg:pos" strings.  With
+    position_lists=None the row covers pos-length//2 .. pos+length//2 (the 33-wide pileup window);
+    otherwise position_lists[i] holds the "ctg:pos" strings of the group (the 11 haplotype columns).
+    Any failure -- unknown contig, lower-case or IUPAC base, position past the end -- gives 0 exactly
+    like the reference's bare except; a NEGATIVE 0-based index wraps around like Python indexing does."""
+    lut = np.zeros(256, np.int32)
+    for k, v in _BASE2INT.items():
+        lut[k] = v
+    n = len(candidate_positions)
+    width = length if position_lists is None else len(position_lists[0]) if n else length
+    out = np.zeros((n, width), np.int32)
+    for i in range(n):
+        if position_lists is None:
+            ctg, pos = candidate_positions[i].split(":")
+            cols = [(ctg, j - 1) for j in range(int(pos) - length // 2, int(pos) + length // 2 + 1)]
+        else:
+            cols = []
+            for item in position_lists[i]:
+                ctg, pos = item.split(":")
+                cols.append((ctg, int(pos) - 1))
+        for k, (ctg, rp) in enumerate(cols):
+            seq = references.get(ctg)
+            if seq is None:
+                continue
+            L = len(seq)
+            if rp >= L or rp < -L:
+                continue
+            out[i, k] = lut[seq[rp]]
+    return out

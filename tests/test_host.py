@@ -77,3 +77,28 @@ def test_hap_planes_shape_and_padding():
     for n in range(8):
         hp = hap[n, :, 16]; hp = hp[hp > 0]
         assert np.all(np.diff(hp) >= 0)
+
+
+def test_haplotype_ref_rows_follow_the_reference_quirks():
+    """dataset_dev.py:106-120: {'A':1,'C':2,'G':3,'T':4,'N':0}, anything else / out of range -> 0,
+    negative 0-based indices wrap around (Python indexing)"""
+    seq = b"ACGTNacgtRACGTACGTACGTACGTACGTACGTACGTAC"
+    refs = {"c1": np.frombuffer(seq, np.uint8)}
+    base2int = {"A": 1, "C": 2, "G": 3, "T": 4, "N": 0}
+
+    def ref_impl(ctg, pos, length):        # the reference loop, restated with Python strings
+        row = []
+        for j in range(pos - length // 2, pos + length // 2 + 1):
+            try:
+                row.append(base2int[{"c1": seq.decode()}[ctg][j - 1]])
+            except Exception:
+                row.append(0)
+        return row
+    cands = ["c1:20", "c1:3", "c1:38", "nope:5"]
+    got = host.haplotype_ref_rows(refs, cands, 33)
+    for i, c in enumerate(cands):
+        ctg, pos = c.split(":")
+        assert got[i].tolist() == ref_impl(ctg, int(pos), 33), c
+    groups = [[f"c1:{p}" for p in range(2, 24, 2)]]
+    g = host.haplotype_ref_rows(refs, ["c1:12"], 11, position_lists=groups)
+    assert g.shape == (1, 11) and g[0].tolist() == [base2int.get(seq.decode()[p - 1], 0) for p in range(2, 24, 2)]
