@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave)")
     ap.add_argument("--precision", type=int, default=1, help="PileupModel forward: 0 exact fp32 MFMA, 1 f16x3 split")
+    ap.add_argument("--fused-l1", type=int, default=1, help="f16x3: fused projection + layer-1 recurrence kernel")
     ap.add_argument("--proj1-tiles", type=int, default=0, help="tiles per wave of the projection kernel (0 = library default)")
     ap.add_argument("--rec-waves", type=int, default=0, help="force waves per recurrence workgroup (0 = auto)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (extra values are informational)")
@@ -134,6 +135,7 @@ def main():
             ctx.set_option("recurrence_waves", args.rec_waves)
         if args.proj1_tiles:
             ctx.set_option("proj1_tiles", args.proj1_tiles)
+        ctx.set_option("fused_l1", args.fused_l1)
         ctxs.append(ctx)
         streams.append(torch.cuda.Stream(device=dev))
         bufs.append(dict(

@@ -40,6 +40,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->chunk_sites = 32768;
     ctx->precision = 0;
     ctx->proj1_tiles = 4;
+    ctx->fused_l1 = 1;
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -79,6 +80,16 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "pileup_precision") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->precision = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "fused_l1") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->fused_l1 = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "fused_waves") == 0) {
+        if (value != 0 && value != 4 && value != 8 && value != 12) return NSNP_EINVAL;
+        ctx->fused_waves = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "proj1_tiles") == 0) {
@@ -138,6 +149,7 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     free_ws(ctx);
     if (ctx->pw.arena) (void)hipFree(ctx->pw.arena);
     if (ctx->pw16.arena) (void)hipFree(ctx->pw16.arena);
+    if (ctx->pw16.l1f_bias) (void)hipFree(ctx->pw16.l1f_bias);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
     nsnp_hap_free(ctx);
     if (ctx->timer) {

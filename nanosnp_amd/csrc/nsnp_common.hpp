@@ -51,6 +51,7 @@ struct PileupWeightsDev {
 // fp16 hi/lo images of the same weights for the f16x3 path (pileup_forward_f16x3.hip)
 struct PileupWeightsF16 {
     void* l0_whh[2]; void* l0_wih_hi[2]; void* l0_wih_lo[2]; void* l1_wih[2]; void* l1_whh[2];
+    void* l1f_hi[2]; void* l1f_lo[2]; float* l1f_bias;      // fused projection + recurrence kernel
     void* proj_w; void* dense_w; void* head_w;
     void* arena; size_t arena_bytes; bool loaded;
 };
@@ -72,6 +73,8 @@ struct nsnp_ctx {
     bool attr_set;
     bool attr_set_f16;
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
+    int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
+    int fused_l1;       // f16x3: 1 = fused projection + layer-1 recurrence kernel (default), 0 = two kernels
     int proj1_tiles;    // 16-row tiles per wave of the layer-1 projection kernel (persistent grid sizing)
     int force_wpb;      // 0 = automatic; else waves per recurrence workgroup (tuning / tests)
     // workspace (sized by nsnp_ctx_reserve)

@@ -354,6 +354,128 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))
 }
 
 // ---------------------------------------------------------------------------------------------
+// K23: layer-1 input projection FUSED into the layer-1 recurrence (no Xp1 round trip through HBM:
+// 70 KB/site less traffic).  One 16-wave workgroup per CU keeps in LDS the recurrent image (64 KB), the
+// hi half of the input image (64 KB) and a compact bias table (1 KB); the lo half of the input image
+// (64 KB) is streamed from L2 through a two-slot LDS ring, 8 KB (two gate tiles) per chunk, one
+// workgroup barrier per chunk.  Arithmetic and summation order are those of K2 followed by K3.
+// ---------------------------------------------------------------------------------------------
+constexpr int L1F_IHI_H8 = 16 * 4 * 64;                 // hi half of the input image  [tile][kb][lane]
+constexpr int L1F_CHUNK_H8 = 2 * 4 * 64;                // one ring chunk: 2 tiles x 4 K blocks
+constexpr int L1F_OFF_IHI = HH_H8;
+constexpr int L1F_OFF_RING = HH_H8 + L1F_IHI_H8;
+constexpr int L1F_OFF_BIAS = L1F_OFF_RING + 2 * L1F_CHUNK_H8;      // then 64 f32x4 of bias
+constexpr int L1F_LDS_BYTES = (L1F_OFF_BIAS) * 16 + 64 * 16;
+
+// WAVES = 4 / 8 / 12 waves of 16 sites per workgroup (one workgroup per CU by LDS), picked from the batch.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES + 3) / 4) void k_pileup_l1f_h(
+    const _Float16* __restrict__ H0, int64_t N,
+    const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
+    const _Float16* __restrict__ ihi0, const _Float16* __restrict__ ihi1,
+    const _Float16* __restrict__ ilo0, const _Float16* __restrict__ ilo1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1,
+    _Float16* __restrict__ H1c)
+{
+    extern __shared__ h8 ldsh[];
+    constexpr int NT = 64 * WAVES;
+    constexpr int NP = (L1F_CHUNK_H8 + NT - 1) / NT;        // ring pieces (16 B) each thread moves per chunk
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    copy_to_lds_h(ldsh, dir ? whh1 : whh0, HH_H8, tid, NT);
+    copy_to_lds_h(ldsh + L1F_OFF_IHI, dir ? ihi1 : ihi0, L1F_IHI_H8, tid, NT);
+    const h8* __restrict__ ilo = reinterpret_cast<const h8*>(dir ? ilo1 : ilo0);       // [8 chunks][512] h8
+    f32x4* lbias = reinterpret_cast<f32x4*>(ldsh + L1F_OFF_BIAS);                      // [tile][q]
+    if (tid < 64) lbias[tid] = reinterpret_cast<const f32x4*>(dir ? bias1 : bias0)[tid];
+    // ring: chunk c lives in slot c & 1.  The piece of chunk c+2 is requested at the start of chunk c, held in
+    // registers across two chunks and written to LDS at the end of chunk c+1 (two chunks of latency hiding).
+    h8 pc[2][NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int e = tid + k * NT;
+        if (e < L1F_CHUNK_H8) { ldsh[L1F_OFF_RING + e] = ilo[e]; pc[1][k] = ilo[L1F_CHUNK_H8 + e]; }
+    }
+    __syncthreads();
+
+    const int64_t site = (int64_t)blockIdx.x * (16 * WAVES) + wave * 16 + (lane & 15);
+    const bool live = site < N;
+    const int64_t sc = live ? site : N - 1;
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    h8 bh[2], bl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bh[k][j] = (_Float16)0.f; bl[k][j] = (_Float16)0.f; }
+
+    for (int u = 0; u < PSTEPS1; ++u) {
+        const int t = dir ? PW - 1 - u : u;
+        const h8* __restrict__ hin = reinterpret_cast<const h8*>(H0 + ((sc * PW + t) * 2 * 4 + q) * 32);
+        h8 gh[4], gl[4];
+#pragma unroll
+        for (int dp = 0; dp < 2; ++dp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) { gh[dp * 2 + half] = hin[dp * 16 + half]; gl[dp * 2 + half] = hin[dp * 16 + 2 + half]; }
+        h8 nh[2], nl[2];
+#define CHUNK(C)                                                                                                 \
+        {                                                                                                        \
+            PIN();                                                                                               \
+            _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                                     \
+                const int e = tid + k * NT;                                                                      \
+                if (e < L1F_CHUNK_H8) pc[(C) & 1][k] = ilo[(((C) + 2) & 7) * L1F_CHUNK_H8 + e];                  \
+            }                                                                                                    \
+            f32x4 acc[2];                                                                                        \
+            acc[0] = lbias[(2 * (C)) * 4 + q]; acc[1] = lbias[(2 * (C) + 1) * 4 + q];                            \
+            const h8* ring = ldsh + L1F_OFF_RING + ((C) & 1) * L1F_CHUNK_H8;                                     \
+            h8 ah[2][2], al[2][2];                                                                               \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                                   \
+                ah[0][tt] = ldsh[L1F_OFF_IHI + ((2 * (C) + tt) * 4 + 0) * 64 + lane];                            \
+                al[0][tt] = ring[(tt * 4 + 0) * 64 + lane];                                                      \
+            }                                                                                                    \
+            _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                   \
+                if (kb + 1 < 4) {                                                                                \
+                    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                           \
+                        ah[(kb + 1) & 1][tt] = ldsh[L1F_OFF_IHI + ((2 * (C) + tt) * 4 + kb + 1) * 64 + lane];    \
+                        al[(kb + 1) & 1][tt] = ring[(tt * 4 + kb + 1) * 64 + lane];                              \
+                    }                                                                                            \
+                }                                                                                                \
+                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) acc[tt] = mfma_h(ah[kb & 1][tt], gh[kb], acc[tt]); \
+                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) acc[tt] = mfma_h(al[kb & 1][tt], gh[kb], acc[tt]); \
+                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) acc[tt] = mfma_h(ah[kb & 1][tt], gl[kb], acc[tt]); \
+                PIN();                                                                                           \
+            }                                                                                                    \
+            wave_gemm_h<2, 2, 0, 2, 2 * (C), 2>(ldsh, lane, bh, bl, acc); /* h = 0 at u = 0: adds nothing */   \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                                   \
+                const int i = 2 * (C) + tt;                                                                      \
+                const float ig = sigmoid_f(acc[tt][0]);                                                          \
+                const float fg = sigmoid_f(acc[tt][1]);                                                          \
+                const float gg = tanh_f(acc[tt][2]);                                                             \
+                const float og = sigmoid_f(acc[tt][3]);                                                          \
+                c[i] = __builtin_fmaf(fg, c[i], ig * gg);                                                        \
+                const float h = og * tanh_f(c[i]);                                                               \
+                _Float16 hi, lo;                                                                                 \
+                split1(h, hi, lo);                                                                               \
+                nh[i >> 3][i & 7] = hi; nl[i >> 3][i & 7] = lo;                                                  \
+            }                                                                                                    \
+            _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                                     \
+                const int e = tid + k * NT;                                                                      \
+                if (e < L1F_CHUNK_H8) ldsh[L1F_OFF_RING + (((C) + 1) & 1) * L1F_CHUNK_H8 + e] = pc[((C) + 1) & 1][k]; \
+            }                                                                                                    \
+            __syncthreads();                                                                                     \
+        }
+        CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3) CHUNK(4) CHUNK(5) CHUNK(6) CHUNK(7)
+#undef CHUNK
+        bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
+    }
+    if (live) {
+        h8* o = reinterpret_cast<h8*>(H1c + ((site * 2 + dir) * 4 + q) * 32);
+        o[0] = bh[0]; o[1] = bh[1]; o[2] = bl[0]; o[3] = bl[1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: heads, weights from L2 as fp16 hi/lo images.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pileup_head_h(
@@ -479,12 +601,14 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
     PileupWeightsF16& pw = ctx->pw16;
     const size_t n_hh = (size_t)HH_H8 * 8, n_ih = (size_t)IH_H8 * 8 * 2, n_p1 = (size_t)P1H_W_H8 * 8;
     const size_t n_proj = (size_t)8 * 4 * 2 * 64 * 8, n_dense = (size_t)16 * 4 * 2 * 64 * 8, n_head = (size_t)2 * 8 * 2 * 64 * 8;
-    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh) + n_proj + n_dense + n_head;
+    const size_t n_fhi = (size_t)L1F_IHI_H8 * 8, n_flo = (size_t)8 * L1F_CHUNK_H8 * 8;     // fused-kernel images
+    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh + n_fhi + n_flo) + n_proj + n_dense + n_head;
     std::vector<_Float16> host(total);
     size_t off = 0;
     auto take = [&](size_t n) { _Float16* p = host.data() + off; off += n; return p; };
     _Float16 *l0_hh[2], *l0_ih[2], *l1_ih[2], *l1_hh[2];
-    for (int d = 0; d < 2; ++d) { l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); }
+    _Float16 *f_hi[2], *f_lo[2];
+    for (int d = 0; d < 2; ++d) { l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); f_hi[d] = take(n_fhi); f_lo[d] = take(n_flo); }
     _Float16* proj = take(n_proj); _Float16* dense = take(n_dense); _Float16* head = take(n_head);
     auto rec_feat = [](int kb, int q, int j) { return 4 * (8 * kb + j) + q; };                     // hidden unit
     auto h0_feat = [](int kb, int q, int j) { return (kb >> 1) * 64 + 4 * (8 * (kb & 1) + j) + q; };   // [fwd;bwd] feature
@@ -520,6 +644,14 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
                        l0_ih[d] + ((size_t)tile * 2 + part) * 64 * 8, sizeof(_Float16) * 64 * 8);
     for (int d = 0; d < 2; ++d) memcpy(l0_ih[d], ih_split.data() + (size_t)d * n_ih, sizeof(_Float16) * n_ih);
 
+    // fused layer-1 kernel: hi half as [tile][kb][lane], lo half chunk-major [chunk][tile in chunk][kb][lane]
+    for (int d = 0; d < 2; ++d)
+        for (int tile = 0; tile < 16; ++tile)
+            for (int kb = 0; kb < 4; ++kb) {
+                const _Float16* src = l1_ih[d] + (((size_t)tile * 4 + kb) * 2) * 64 * 8;      // [tile][kb][part][lane][8]
+                memcpy(f_hi[d] + ((size_t)tile * 4 + kb) * 64 * 8, src, sizeof(_Float16) * 64 * 8);
+                memcpy(f_lo[d] + ((((size_t)(tile >> 1) * 2 + (tile & 1)) * 4 + kb) * 64) * 8, src + 64 * 8, sizeof(_Float16) * 64 * 8);
+            }
     const size_t bytes = total * sizeof(_Float16);
     if (pw.arena && pw.arena_bytes != bytes) { (void)hipFree(pw.arena); pw.arena = nullptr; }
     if (!pw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&pw.arena, bytes)); pw.arena_bytes = bytes; }
@@ -528,8 +660,21 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
     for (int d = 0; d < 2; ++d) {
         pw.l0_whh[d] = dev(l0_hh[d]); pw.l0_wih_hi[d] = dev(l0_ih[d]); pw.l0_wih_lo[d] = dev(l0_ih[d] + n_ih / 2);
         pw.l1_wih[d] = dev(l1_ih[d]); pw.l1_whh[d] = dev(l1_hh[d]);
+        pw.l1f_hi[d] = dev(f_hi[d]); pw.l1f_lo[d] = dev(f_lo[d]);
     }
     pw.proj_w = dev(proj); pw.dense_w = dev(dense); pw.head_w = dev(head);
+    {
+        float hb[2][64 * 4];
+        for (int d = 0; d < 2; ++d) {
+            const float* const* l1 = w + 8 + d * 4;
+            for (int tile = 0; tile < 16; ++tile) for (int qq = 0; qq < 4; ++qq) for (int g = 0; g < 4; ++g) {
+                const int tr = gate_row(16 * tile + 4 * qq + g);
+                hb[d][(tile * 4 + qq) * 4 + g] = l1[2][tr] + l1[3][tr];
+            }
+        }
+        if (!pw.l1f_bias) NSNP_HIP(ctx, hipMalloc((void**)&pw.l1f_bias, sizeof hb));
+        NSNP_HIP(ctx, hipMemcpy(pw.l1f_bias, hb, sizeof hb, hipMemcpyHostToDevice));
+    }
     pw.loaded = true;
     return NSNP_OK;
 }
@@ -540,6 +685,7 @@ static int set_lds_attr_f16(nsnp_ctx* ctx)
 #define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
     SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
     SET(k_pileup_proj1_h, P1H_LDS_BYTES);
+    SET(k_pileup_l1f_h<4>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<8>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<12>, L1F_LDS_BYTES);
     SET(k_pileup_l1_h<8>, L1H_LDS_BYTES); SET(k_pileup_l1_h<4>, L1H_LDS_BYTES); SET(k_pileup_l1_h<2>, L1H_LDS_BYTES); SET(k_pileup_l1_h<1>, L1H_LDS_BYTES);
 #undef SET
     ctx->attr_set_f16 = true;
@@ -576,6 +722,21 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
+        if (ctx->fused_l1) {
+            ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
+            // one workgroup per CU: 12 waves when the batch fills the chip that way, else 8 or 4
+            // (the 12-wave build has to fit 168 VGPRs and spills: 1.84 ms vs 1.49 ms at 131072 sites)
+            int fw = 8;
+            if (NSNP_CDIV(n, 128) * 2 < ctx->n_cu) fw = 4;
+            if (ctx->fused_waves) fw = ctx->fused_waves;
+#define LAUNCH_F(W) hipLaunchKernelGGL(k_pileup_l1f_h<W>, dim3((unsigned)NSNP_CDIV(n, 16 * W), 2), dim3(64 * W), L1F_LDS_BYTES, s, H0, n, \
+                               (const _Float16*)pw.l1_whh[0], (const _Float16*)pw.l1_whh[1], \
+                               (const _Float16*)pw.l1f_hi[0], (const _Float16*)pw.l1f_hi[1], \
+                               (const _Float16*)pw.l1f_lo[0], (const _Float16*)pw.l1f_lo[1], \
+                               (const float*)pw.l1f_bias, (const float*)pw.l1f_bias + 256, H1c)
+            if (fw == 12) LAUNCH_F(12); else if (fw == 8) LAUNCH_F(8); else LAUNCH_F(4);
+#undef LAUNCH_F
+        } else {
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
         // persistent workgroups: each loads the 128 KB weight image once and then walks
         // proj1_tiles 16-row tiles per wave, so the load is amortised even at small batches
@@ -590,6 +751,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
             (const _Float16*)pw.l1_whh[0], (const _Float16*)pw.l1_whh[1], H1c)
         if (wpb == 8) LAUNCH_L1(8); else if (wpb == 4) LAUNCH_L1(4); else if (wpb == 2) LAUNCH_L1(2); else LAUNCH_L1(1);
 #undef LAUNCH_L1
+        }
         }
         ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
         hipLaunchKernelGGL(k_pileup_head_h, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, H1c, n,

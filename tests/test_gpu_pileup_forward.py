@@ -203,3 +203,26 @@ def test_f16x3_precision_mode(pileup_weights):
         gn, zn = c.pileup_forward(xr[:n].contiguous())
         assert torch.equal(gn, ref[0][:n])
     c.close()
+
+
+def test_fused_layer1_kernel_equals_the_two_kernel_path(pileup_weights):
+    """f16x3: projection fused into the layer-1 recurrence (no Xp1 round trip) computes the same sums in
+    the same order as projection kernel + recurrence kernel"""
+    import torch
+    from nanosnp_amd import _lib
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    c.set_option("pileup_precision", 1)
+    rng = np.random.default_rng(9)
+    for n in (1, 191, 192, 193, 1000, 5000):
+        x = torch.from_numpy((rng.integers(0, 50, (n, 33, 18)) - 10).astype(np.int32)).cuda()
+        c.set_option("fused_l1", 0)
+        g0, z0 = c.pileup_forward(x)
+        c.set_option("fused_l1", 1)
+        g1, z1 = c.pileup_forward(x)
+        torch.cuda.synchronize()
+        assert (g0 - g1).abs().max().item() < 5e-7 and (z0 - z1).abs().max().item() < 5e-7, n
+    z = np.load(golden("pileup_fwd.npz"))
+    gt, zy = c.pileup_forward(torch.from_numpy(z["x"].astype(np.int32)).cuda())
+    assert np.abs(gt.cpu().numpy() - z["gt"]).max() < PROB_ATOL and np.abs(zy.cpu().numpy() - z["zy"]).max() < PROB_ATOL
+    c.close()
