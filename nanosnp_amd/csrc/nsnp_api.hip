@@ -98,7 +98,7 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         return NSNP_OK;
     }
     if (strcmp(name, "recurrence_waves") == 0) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NSNP_EINVAL;
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return NSNP_EINVAL;
         ctx->force_wpb = (int)value;
         return NSNP_OK;
     }

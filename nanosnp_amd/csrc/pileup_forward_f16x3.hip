@@ -92,7 +92,10 @@ __device__ __forceinline__ void lstm_pointwise8_h(const f32x4* acc, float* c, h8
 // Same contraction as wave_gemm_h with the weight fragments of group g+1 requested before the MFMAs of
 // group g are issued (G = 2 tiles per group), so the LDS latency hides behind the previous group's
 // matrix work instead of in front of every group.
-template <int NT, int NKB, int KBN, int TB, typename WP>
+// PINMASK: which instruction classes may still cross the scheduling pins (0 = none; 0x1 = ALU incl. MFMA and
+// VALU, so that independent sigmoid/tanh work of the previous quarter can be woven between the MFMAs while
+// the LDS / global reads stay where they are).
+template <int NT, int NKB, int KBN, int TB, int PINMASK = 0, typename WP>
 __device__ __forceinline__ void wave_gemm_h_pipe(WP img, int lane, const h8* bh, const h8* bl, f32x4* acc)
 {
     constexpr int G = 2;
@@ -118,7 +121,7 @@ __device__ __forceinline__ void wave_gemm_h_pipe(WP img, int lane, const h8* bh,
         for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(al[buf][u], bh[kb], acc[ig + u]);
 #pragma unroll
         for (int u = 0; u < G; ++u) acc[ig + u] = mfma_h(ah[buf][u], bl[kb], acc[ig + u]);
-        PIN();
+        __builtin_amdgcn_sched_barrier(PINMASK);
     }
 }
 
@@ -155,7 +158,7 @@ constexpr int IH_H8 = 16 * 64;               // one part of the input image
 constexpr int L0H_LDS_BYTES = (HH_H8 + IH_H8) * 16;
 
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))) void k_pileup_l0_h(
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 6 ? 3 : (WAVES == 4 ? 2 : 1)))) void k_pileup_l0_h(
     const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
     const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
     const _Float16* __restrict__ wih_hi0, const _Float16* __restrict__ wih_hi1,
@@ -213,27 +216,33 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))
         }
         if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);
         h8 nh[2], nl[2];
-        // four quarter passes of 4 gate tiles: the lo fragments of the input image (read through L1) are
-        // requested first and consumed last, behind the LDS-fed recurrent MFMAs of the same quarter
-#define QUARTER(QP)                                                                                        \
+        // four quarter passes of 4 gate tiles.  Within a quarter the lo fragments of the input image (read
+        // through L1) are requested first and consumed last, behind the LDS-fed recurrent MFMAs; the LSTM cell
+        // of quarter q is issued together with the MFMAs of quarter q+1 (which only need the previous step's
+        // h), inside one scheduling region whose inner pins let ALU work cross, so the matrix and the vector
+        // pipe overlap inside a single wave.
+#define QMFMA(QP, ACC)                                                                                     \
         {                                                                                                  \
-            PIN();                                                             \
             h8 ilo[4];                                                                                     \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) ilo[u] = wlo[((QP) * 4 + u) * 64 + lane];        \
-            f32x4 acc[4];                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};             \
-            if (s > 0) wave_gemm_h_pipe<4, 2, 2, (QP) * 4>(ldsh, lane, bh, bl, acc);                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) ACC[i] = f32x4{0.f, 0.f, 0.f, 0.f};             \
+            wave_gemm_h_pipe<4, 2, 2, (QP) * 4, 0x1>(ldsh, lane, bh, bl, ACC); /* h = 0 at s = 0 */       \
             h8 ihi[4];                                                                                     \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) ihi[u] = ldsh[HH_H8 + ((QP) * 4 + u) * 64 + lane]; \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma_h(ihi[u], xh, acc[u]);             \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma_h(ilo[u], xh, acc[u]);             \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma_h(ihi[u], xl, acc[u]);             \
-            PIN();                                                             \
-            lstm_pointwise4_h<((QP) & 1) * 4>(acc, c + (QP) * 4, nh[(QP) >> 1], nl[(QP) >> 1]);            \
-            PIN();                                                             \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) ACC[u] = mfma_h(ihi[u], xh, ACC[u]);             \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) ACC[u] = mfma_h(ilo[u], xh, ACC[u]);             \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) ACC[u] = mfma_h(ihi[u], xl, ACC[u]);             \
         }
-        QUARTER(0) QUARTER(1) QUARTER(2) QUARTER(3)
-#undef QUARTER
+#define QPW(QP, ACC) lstm_pointwise4_h<((QP) & 1) * 4>(ACC, c + (QP) * 4, nh[(QP) >> 1], nl[(QP) >> 1]);
+        f32x4 accA[4], accB[4];
+        PIN(); QMFMA(0, accA)
+        PIN(); QMFMA(1, accB) QPW(0, accA)
+        PIN(); QMFMA(2, accA) QPW(1, accB)
+        PIN(); QMFMA(3, accB) QPW(2, accA)
+        PIN(); QPW(3, accB)
+        PIN();
+#undef QMFMA
+#undef QPW
         bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
         if (live) {
             h8* o = reinterpret_cast<h8*>(hout + (int64_t)t * (2 * 4 * 32));
@@ -683,7 +692,7 @@ static int set_lds_attr_f16(nsnp_ctx* ctx)
 {
     if (ctx->attr_set_f16) return NSNP_OK;
 #define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
-    SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
+    SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<6>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
     SET(k_pileup_proj1_h, P1H_LDS_BYTES);
     SET(k_pileup_l1f_h<4>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<8>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<12>, L1F_LDS_BYTES);
     SET(k_pileup_l1_h<8>, L1H_LDS_BYTES); SET(k_pileup_l1_h<4>, L1H_LDS_BYTES); SET(k_pileup_l1_h<2>, L1H_LDS_BYTES); SET(k_pileup_l1_h<1>, L1H_LDS_BYTES);
@@ -719,7 +728,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
 #define LAUNCH_L0(W) hipLaunchKernelGGL(k_pileup_l0_h<W>, g_rec, dim3(64 * W), L0H_LDS_BYTES, s, xc, cc, n, \
             (const _Float16*)pw.l0_whh[0], (const _Float16*)pw.l0_whh[1], (const _Float16*)pw.l0_wih_hi[0], (const _Float16*)pw.l0_wih_hi[1], \
             (const _Float16*)pw.l0_wih_lo[0], (const _Float16*)pw.l0_wih_lo[1], H0)
-        if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
+        if (wpb == 8) LAUNCH_L0(8); else if (wpb == 6) LAUNCH_L0(6); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
         if (ctx->fused_l1) {
