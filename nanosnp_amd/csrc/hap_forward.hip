@@ -56,7 +56,16 @@ struct StepLaunch { StepArgs z[4]; };
 
 enum { MODE_LSTM = 0, MODE_LINEAR = 1, MODE_LINEAR_TANH = 2 };
 
-template <int MODE>
+// F16 = false: operands are fp32, one element per 4 bytes, v_mfma_f32_32x32x2_f32 (exact fp32).
+// F16 = true : "f16x3" - every 4-byte element is a (hi, lo) fp16 pair (hi = fp16(v), lo = fp16(v - hi)); a row
+//              of a tile image holds its 16 hi halves followed by its 16 lo halves, so the two 16-byte LDS reads
+//              of a lane are its hi and lo fragments of v_mfma_f32_32x32x16_f16, and a product is three MFMAs
+//              (hi.hi + lo.hi + hi.lo) with fp32 accumulation.  Same image sizes, strides and launch sequence.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) { hi = (_Float16)v; lo = (_Float16)(v - (float)hi); }
+
+template <int MODE, bool F16>
 __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
 {
     __shared__ float As[2][TR][LDK];
@@ -108,24 +117,38 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
         f32x4 af[2][2], bf[2][2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const float* p = &As[cur][64 * wr + 32 * rt + li][lh * 8];
+            const float* p = &As[cur][64 * wr + 32 * rt + li][F16 ? lh * 4 : lh * 8];
             af[rt][0] = *reinterpret_cast<const f32x4*>(p);
-            af[rt][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            af[rt][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const float* p = &Bs[cur][64 * wc + 32 * ct + li][lh * 8];
+            const float* p = &Bs[cur][64 * wc + 32 * ct + li][F16 ? lh * 4 : lh * 8];
             bf[ct][0] = *reinterpret_cast<const f32x4*>(p);
-            bf[ct][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            bf[ct][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
         }
+        if (F16) {
+            // af[rt][0] / [1] are the lane's 8 hi / 8 lo halves of row (rt), likewise bf for the site
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+                for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3],
-                                                                        acc[rt][ct], 0, 0, 0);
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const h8 av = __builtin_bit_cast(h8, af[rt][term == 1 ? 1 : 0]);
+                        const h8 bv = __builtin_bit_cast(h8, bf[ct][term == 2 ? 1 : 0]);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[rt][ct], 0, 0, 0);
+                    }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3],
+                                                                            acc[rt][ct], 0, 0, 0);
+        }
         if (kc + 1 < nk) lstore(cur ^ 1, ga0, ga1, gb0, gb1);
         __syncthreads();
     }
@@ -161,7 +184,17 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                     hv[rt][r4] = og * tanh_f(cn);
                 }
             *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
-            *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
+            if (F16) {
+                // the lane's 8 positions lh*8.. are 8 consecutive halves of the hi block and of the lo block
+                h8 hh, hl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { _Float16 x, y; split_h(hv[e >> 2][e & 3], x, y); hh[e] = x; hl[e] = y; }
+                _Float16* hrow = reinterpret_cast<_Float16*>(a.out + (size_t)bx * a.out_tile_stride + img + site * BK);
+                *reinterpret_cast<h8*>(hrow + lh * 8) = hh;
+                *reinterpret_cast<h8*>(hrow + 16 + lh * 8) = hl;
+            } else {
+                *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
+            }
         }
     } else {
         // plain rows: feature f = 128*by + 64*wr + 32*rt + (g + 8*r4 + 4*lh); natural order in chunks of 16
@@ -180,8 +213,17 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                         const float t = acc[rt][ct][4 * r4 + g] + bz[g];
                         v[g] = MODE == MODE_LINEAR_TANH ? tanh_f(t) : t;
                     }
-                    float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK + (f & 15);
-                    *reinterpret_cast<f32x4*>(o) = v;
+                    float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK;
+                    if (F16) {
+                        h4 vh, vl;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) { _Float16 x, y; split_h(v[g], x, y); vh[g] = x; vl[g] = y; }
+                        _Float16* orow = reinterpret_cast<_Float16*>(o);
+                        *reinterpret_cast<h4*>(orow + (f & 15)) = vh;
+                        *reinterpret_cast<h4*>(orow + 16 + (f & 15)) = vl;
+                    } else {
+                        *reinterpret_cast<f32x4*>(o + (f & 15)) = v;
+                    }
                 }
         }
     }
@@ -189,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
 
 // x [N][F][L] (predict_dev.py hands [N,105,L]; model_dev.py:136-137 permutes to [N,L,F]) ->
 // per-step tile images xT[t][site_tile][chunk][128][16], features in natural order, zero padded
+template <bool F16>
 __global__ void k_hap_pack_input(const float* __restrict__ x, int64_t N, int F, int L, int n_tiles, int nkc,
                                  float* __restrict__ xT)
 {
@@ -202,11 +245,17 @@ __global__ void k_hap_pack_input(const float* __restrict__ x, int64_t N, int F, 
         const int t = (int)(r / n_tiles);
         const int64_t n = (int64_t)tile * TS + site;
         const int f = kc * 16 + p;
-        xT[e] = (n < N && f < F) ? x[(n * F + f) * L + t] : 0.f;
+        const float v = (n < N && f < F) ? x[(n * F + f) * L + t] : 0.f;
+        if (F16) {
+            _Float16 hi, lo; split_h(v, hi, lo);
+            _Float16* row = reinterpret_cast<_Float16*>(xT + (e & ~(int64_t)15));
+            row[p] = hi; row[16 + p] = lo;
+        } else xT[e] = v;
     }
 }
 
 // heads: logits = W[rows x 256] . inner + b over the dense output image (natural order), softmax
+template <bool F16>
 __global__ __launch_bounds__(256) void k_hap_heads(const float* __restrict__ inner, int64_t N,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     int n_gt, int n_zy, float* __restrict__ gt, float* __restrict__ zy)
@@ -220,7 +269,9 @@ __global__ __launch_bounds__(256) void k_hap_heads(const float* __restrict__ inn
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = lane + 64 * j;
-        v[j] = inner[(tile * 16 + (f >> 4)) * TILE_F + site * BK + (f & 15)];
+        const float* row = inner + (tile * 16 + (f >> 4)) * TILE_F + site * BK;
+        if (F16) { const _Float16* hr = reinterpret_cast<const _Float16*>(row); v[j] = (float)hr[f & 15] + (float)hr[16 + (f & 15)]; }
+        else v[j] = row[f & 15];
     }
     const int rows = n_gt + n_zy;
     float logit[16];
@@ -258,11 +309,16 @@ struct HapWeightsDev {
     float* dense_w; float* dense_b;                    // Linear(2H -> H), inputs natural order (two proj outputs)
     float* head_w; float* head_b;                      // [(n_gt+n_zy) x H] natural order
     float* arena; size_t arena_floats;
+    float* arena16;                                    // the same images with every weight as an fp16 (hi, lo) pair
 };
 
 void nsnp_hap_free(nsnp_ctx* ctx)
 {
-    if (ctx->hw) { if (ctx->hw->arena) (void)hipFree(ctx->hw->arena); delete ctx->hw; ctx->hw = nullptr; }
+    if (ctx->hw) {
+        if (ctx->hw->arena) (void)hipFree(ctx->hw->arena);
+        if (ctx->hw->arena16) (void)hipFree(ctx->hw->arena16);
+        delete ctx->hw; ctx->hw = nullptr;
+    }
     if (ctx->hap_ws) { (void)hipFree(ctx->hap_ws); ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0; }
 }
 
@@ -362,6 +418,30 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
     if (hw.arena && hw.arena_floats != total) { (void)hipFree(hw.arena); hw.arena = nullptr; }
     if (!hw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&hw.arena, total * sizeof(float))); hw.arena_floats = total; }
     NSNP_HIP(ctx, hipMemcpy(hw.arena, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    {
+        // f16x3 images: rows of 16 weights become 16 hi halves + 16 lo halves (same 64 bytes); biases and the
+        // head matrix stay fp32
+        std::vector<float> h16(host);
+        auto conv = [&](size_t off, size_t n_floats) {
+            for (size_t r = 0; r + 16 <= n_floats; r += 16) {
+                _Float16* dst = reinterpret_cast<_Float16*>(h16.data() + off + r);
+                const float* src = host.data() + off + r;
+                for (int k = 0; k < 16; ++k) {
+                    const _Float16 hi = (_Float16)src[k];
+                    dst[k] = hi; dst[16 + k] = (_Float16)(src[k] - (float)hi);
+                }
+            }
+        };
+        for (int e = 0; e < 2; ++e) {
+            for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d)
+                conv(off_w[e][l][d], (size_t)n_rt * ((l == 0 ? nk0 : 2 * H / BK) + H / BK) * TILE_F);
+            conv(off_pw[e], (size_t)(H / TR) * (2 * H / BK) * TILE_F);
+        }
+        conv(off_dw, (size_t)(H / TR) * (2 * H / BK) * TILE_F);
+        if (hw.arena16 && hw.arena_floats != total) { (void)hipFree(hw.arena16); hw.arena16 = nullptr; }
+        if (!hw.arena16) NSNP_HIP(ctx, hipMalloc((void**)&hw.arena16, total * sizeof(float)));
+        NSNP_HIP(ctx, hipMemcpy(hw.arena16, h16.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    }
     hw.F = F; hw.H = H; hw.n_layers = n_layers; hw.n_gt = n_gt; hw.n_zy = n_zy; hw.nk_in0 = nk0;
     for (int e = 0; e < 2; ++e) {
         for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) { hw.w[e][l][d] = hw.arena + off_w[e][l][d]; hw.b[e][l][d] = hw.arena + off_b[e][l][d]; }
@@ -380,6 +460,8 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
     const HapWeightsDev& hw = *ctx->hw;
     hipStream_t s = (hipStream_t)stream;
     const int H = hw.H, F = hw.F;
+    const bool f16 = ctx->hap_precision == 1;
+    const ptrdiff_t wsh = f16 ? hw.arena16 - hw.arena : 0;     // weight images live at the same offsets in both arenas
     const int Lp = 33, Lh = 11;                       // ont_haplotype.yaml:10-11
     const int64_t chunk = 4096;                        // sites per pass (workspace ~0.8 GB)
     const int max_tiles = (int)(chunk / TS);
@@ -412,7 +494,8 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
         for (int e = 0; e < 2; ++e) {
             const int64_t tot = (int64_t)Ls[e] * n_tiles * hw.nk_in0 * TILE_F;
             int blocks = (int)NSNP_CDIV(tot, 256); if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(k_hap_pack_input, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
+            if (f16) hipLaunchKernelGGL(k_hap_pack_input<true>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
+            else     hipLaunchKernelGGL(k_hap_pack_input<false>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
         }
         // h of one layer: [t][site tile][dir][16 chunks][128][16] -> the 32 chunks [h_fwd ; h_bwd] of a site
         // tile at time t are contiguous (what the next layer and output_proj consume)
@@ -430,7 +513,7 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                         const int t = d ? Ls[e] - 1 - st : st;
                         const int tprev = d ? t + 1 : t - 1;
                         StepArgs& a = L.z[nz];
-                        a.w = hw.w[e][l][d]; a.bias = hw.b[e][l][d];
+                        a.w = hw.w[e][l][d] + wsh; a.bias = hw.b[e][l][d];
                         if (l == 0) {
                             a.in0 = xT[e] + (size_t)t * n_tiles * hw.nk_in0 * TILE_F;
                             a.nk0 = hw.nk_in0; a.in0_tile_stride = hw.nk_in0 * TILE_F;
@@ -449,7 +532,8 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                         ++nz;
                     }
                 }
-                hipLaunchKernelGGL(k_hap_gemm<MODE_LSTM>, dim3(n_tiles, 4 * H / TR, nz), dim3(256), 0, s, L);
+                if (f16) hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, true>), dim3(n_tiles, 4 * H / TR, nz), dim3(256), 0, s, L);
+                else     hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, false>), dim3(n_tiles, 4 * H / TR, nz), dim3(256), 0, s, L);
             }
         }
         // output_proj at the centre step of the last layer (which wrote hb[e][0]), both encoders in one
@@ -458,24 +542,28 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
             StepLaunch L;
             for (int e = 0; e < 2; ++e) {
                 StepArgs& a = L.z[e];
-                a.w = hw.proj_w[e]; a.bias = hw.proj_b[e];
+                a.w = hw.proj_w[e] + wsh; a.bias = hw.proj_b[e];
                 a.in0 = hb[e][0] + (size_t)(Ls[e] / 2) * step_h;
                 a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(2 * tile_h);
                 a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0;
                 a.out = cat + (size_t)e * 16 * TILE_F; a.out_tile_stride = 32 * TILE_F;
                 a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
             }
-            hipLaunchKernelGGL(k_hap_gemm<MODE_LINEAR>, dim3(n_tiles, H / TR, 2), dim3(256), 0, s, L);
+            if (f16) hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, true>), dim3(n_tiles, H / TR, 2), dim3(256), 0, s, L);
+            else     hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, false>), dim3(n_tiles, H / TR, 2), dim3(256), 0, s, L);
         }
         {
             StepLaunch L; StepArgs& a = L.z[0];
-            a.w = hw.dense_w; a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
+            a.w = hw.dense_w + wsh; a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
             a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0; a.out = inner; a.out_tile_stride = 16 * TILE_F;
             a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
-            hipLaunchKernelGGL(k_hap_gemm<MODE_LINEAR_TANH>, dim3(n_tiles, H / TR, 1), dim3(256), 0, s, L);
+            if (f16) hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_TANH, true>), dim3(n_tiles, H / TR, 1), dim3(256), 0, s, L);
+            else     hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_TANH, false>), dim3(n_tiles, H / TR, 1), dim3(256), 0, s, L);
         }
-        hipLaunchKernelGGL(k_hap_heads, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
-                           hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
+        if (f16) hipLaunchKernelGGL(k_hap_heads<true>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
+                                    hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
+        else     hipLaunchKernelGGL(k_hap_heads<false>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
+                                    hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
     }
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;

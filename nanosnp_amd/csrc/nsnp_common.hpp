@@ -72,6 +72,7 @@ struct nsnp_ctx {
     hipError_t last_err;
     bool attr_set;
     bool attr_set_f16;
+    int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
     int fused_l1;       // f16x3: 1 = fused projection + layer-1 recurrence kernel (default), 0 = two kernels

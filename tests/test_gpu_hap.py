@@ -149,3 +149,35 @@ def test_hap_arrange_reads_vs_oracle(gpu_ctx):
             for k in range(4):
                 assert np.array_equal(outs[k][n].cpu().numpy(), want[k]), (n, k)
             assert int(outs[4][n]) == want[4]
+
+
+def test_hap_forward_f16x3_mode(gpu_ctx):
+    """every fp32 product as three fp16 MFMAs (hi.hi + lo.hi + hi.lo), fp32 accumulate: same goldens and
+    tolerance as the exact-fp32 mode"""
+    import torch
+    from nanosnp_amd import _lib
+    from oracle import oracle
+    from tests.helpers import PROB_ATOL, seeded_hap_weights
+    ws = seeded_hap_weights(12, H=256)
+    c = _lib.Context(0)
+    c.hap_load_weights(ws)
+    z = np.load(golden("hap_fwd_h256.npz"))
+    g32, z32 = _hfwd(c, z["xp"], z["xh"])
+    c.set_option("hap_precision", 1)
+    g16, z16 = _hfwd(c, z["xp"], z["xh"])
+    assert np.abs(g16 - z["gt"]).max() < PROB_ATOL and np.abs(z16 - z["zy"]).max() < PROB_ATOL
+    assert np.abs(g16 - g32).max() < 2e-5
+    rng = np.random.default_rng(4)
+    for n in (1, 129, 300):
+        xp = (rng.standard_normal((n, 105, 33)) * 300).astype(np.float32)
+        xh = (rng.standard_normal((n, 105, 11)) * 300).astype(np.float32)
+        gt, zy = _hfwd(c, xp, xh)
+        ogt, ozy = oracle.hap_forward(ws, xp, xh, nthreads=8)
+        assert np.abs(gt - ogt).max() < PROB_ATOL and np.abs(zy - ozy).max() < PROB_ATOL, n
+    # count-valued features up to several thousand (beyond fp16's exact integers): the lo half carries the rest
+    pp = host.synth_hap_planes(77, 64, 60, 180, 33); ph = host.synth_hap_planes(78, 64, 60, 180, 11)
+    xp = oracle.hap_features_batch(*pp); xh = oracle.hap_features_batch(*ph)
+    gt, zy = _hfwd(c, xp, xh)
+    ogt, ozy = oracle.hap_forward(ws, xp, xh, nthreads=8)
+    assert np.abs(gt - ogt).max() < PROB_ATOL
+    c.close()

@@ -92,8 +92,9 @@ print("hap features N=4096 D=90 L=33: %.3f ms  %.2f M sites/s  %.1f GB/s" % (t *
 from tests.helpers import seeded_hap_weights
 ws = seeded_hap_weights(12, H=256)
 ctx.hap_load_weights(ws)
-for N in (512, 4096):
+for N, prec in ((512, 0), (4096, 0), (4096, 1), (16384, 1)):
+    ctx.set_option("hap_precision", prec)
     xp = torch.randn((N, 105, 33), device=dev) * 100
     xh = torch.randn((N, 105, 11), device=dev) * 100
     t = bench(lambda: ctx.hap_forward(xp, xh), iters=3)
-    print("hap forward N=%d: %.2f ms  %.1f k sites/s  %.1f TFLOP/s (353.7 MFLOP/site alg)" % (N, t * 1e3, N / t / 1e3, 353.7e6 * N / t / 1e12))
+    print("hap forward precision %d" % prec, end=" "); print("N=%d: %.2f ms  %.1f k sites/s  %.1f TFLOP/s (353.7 MFLOP/site alg)" % (N, t * 1e3, N / t / 1e3, 353.7e6 * N / t / 1e12))
