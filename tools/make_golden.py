@@ -308,7 +308,55 @@ def group_vcf():
         print(k, len(bytes(v).splitlines()), "lines")
 
 
-GROUPS = {"vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
+def group_next():
+    """merge.py and select_hetesnp_homosnp.find_adjacent_sites run on the golden pileup.vcf plus a
+    synthetic haplotype.csv"""
+    import argparse, json
+    z = np.load(os.path.join(GOLD, "pileup_vcf.npz"))
+    vcf = bytes(z["vcf_bs1000"]).decode()
+    rng = np.random.default_rng(17)
+    labels = ["AA", "AC", "AG", "AT", "CC", "CG", "CT", "GG", "GT", "TT", "DD", "AD", "CD", "GD", "TD", "II", "AI", "CI", "GI", "TI", "ID"]
+    rows = []
+    for line in vcf.splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split("\t")
+        if rng.random() < 0.7:
+            gt = labels[int(rng.integers(0, 21))] if rng.random() < 0.25 else labels[int(rng.integers(0, 10))]
+            rows.append(f"{f[0]}\t{f[1]}\t{gt}\t{round(float(rng.uniform(5, 30)), 2)}")
+    csv = "\n".join(rows) + "\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.vcf"), "w").write(vcf); open(os.path.join(d, "h.csv"), "w").write(csv)
+        sys.path.insert(0, os.path.join(REF, "scripts"))
+        import merge as ref_merge            # noqa: E402  (reference module)
+        merged = {}
+        for q in (15.0, 19.0):
+            ref_merge.Run(argparse.Namespace(cat_predict=os.path.join(d, "h.csv"), output=os.path.join(d, "m.vcf"),
+                                             pileup_vcf=os.path.join(d, "p.vcf"), quality=q))
+            merged[str(q)] = open(os.path.join(d, "m.vcf")).read()
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    import select_hetesnp_homosnp as sel     # noqa: E402
+    # contig_dict exactly as select_snp_multiprocess builds it (:82-104), then the per-chunk worker
+    contig_dict = {}
+    for row in vcf.splitlines():
+        if row[0] == "#": continue
+        c = row.strip().split(); g = c[9].split(":")[0].replace("|", "/"); ql = float(c[5])
+        if (g == "0/0" and ql >= 19) or (g == "1/1" and ql >= 19): continue
+        contig_dict.setdefault(c[0], {})[int(c[1])] = (g, ql)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        one = sel.find_adjacent_sites(contig_dict, ["chrS", "chrT"], 5, 19, 14)      # one chunk: the :226 bug drops chrS
+        each = {}
+        for ctg in ("chrS", "chrT"):
+            each.update(sel.find_adjacent_sites(contig_dict, [ctg], 5, 19, 14))
+    ser = lambda gd: {k: [[(it.position, it.homo_hete, it.info) for it in g] for g in v] for k, v in gd.items()}
+    json.dump({"csv": csv, "merged": merged, "groups_one_chunk": ser(one), "groups_each": ser(each)},
+              open(os.path.join(GOLD, "next_rows.json"), "w"))
+    print("next_rows:", {k: len(v.splitlines()) for k, v in merged.items()}, {k: len(v) for k, v in ser(each).items()}, list(ser(one)))
+
+
+GROUPS = {"next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
           "hapfwd": group_hapfwd}
 
 if __name__ == "__main__":
