@@ -15,6 +15,9 @@
  *   nsnp_pileup_postprocess      argmax / max / depth           PileupModel/predict.py:52-65
  *   nsnp_hap_features            get_frequency_feature + ref row HaplotypeModel/dataset_dev.py:55-87,337-349
  *   nsnp_hap_forward             LSTMNetwork.predict            HaplotypeModel/model_dev.py:133-143
+ *   nsnp_cat_forward             legacy CatModel.predict        HaplotypeModel/model.py:332-358 (ResCRNN: crnn.py:84-190)
+ *                                called from                    HaplotypeModel/predict.py:53
+ *   nsnp_cat_groups              PredictDataset.__getitem__     HaplotypeModel/dataset.py:862-915 (g0 / g1 assembly)
  *                                called from                    HaplotypeModel/predict_dev.py:35-39
  *
  * Conventions: every pointer marked "device" is device memory owned by the caller; functions
@@ -155,6 +158,24 @@ int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* host_tensors, int n
 /* xp: device fp32 [N,105,33], xh: device fp32 [N,105,11] -> gt [N,n_gt], zy [N,n_zy]. */
 int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N,
                      float* gt_prob, float* zy_prob, void* stream);
+
+/* ---- legacy haplotype caller (HaplotypeModel/predict.py -> model.CatModel; not run by run_caller.sh) ---- */
+/* host_tensors: the 132 floating-point tensors of CatModel(nc0=5,nc1=5,nc2=2,nclass=10,nh=256).state_dict()
+ * in order, the integer num_batches_tracked entries skipped (6 ResBlocks x 14, haplotype_base.rnn.{0,1} x 10,
+ * haplotype_percentage 26, out_layer 2), HOST pointers.  BatchNorm is applied in eval mode (predict.py:28). */
+int nsnp_cat_load_weights(nsnp_ctx* ctx, const float* const* host_tensors, int n_tensors);
+
+/* g0, g1: device fp32 [N,40,11,5] exactly as predict.py:33-34,42-43 hands them to the model
+ * (g2 / g3 are ignored by CatModel.predict: model.py:332-358) -> gt_prob device fp32 [N,10] (softmax). */
+int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream);
+
+/* Builds one group tensor [N,40,length,5] fp32 from the per-tag matrices the HDF5 bins hold
+ * (dataset.py:862-915): read / base-quality / mapping-quality [N,depth,length] int32 per tag; the first 20
+ * rows of tag 1 then of tag 2; planes (base, baseq, mapq, mask = base != -2, phase = 1 | 2).
+ * depth1, depth2 >= 20 (NSNP_ESHAPE otherwise: the reference's [:20] slicing would yield a ragged tensor). */
+int nsnp_cat_groups(nsnp_ctx* ctx, const int32_t* read1, const int32_t* bq1, const int32_t* mq1, int depth1,
+                    const int32_t* read2, const int32_t* bq2, const int32_t* mq2, int depth2,
+                    int64_t N, int length, float* g, void* stream);
 
 #ifdef __cplusplus
 }

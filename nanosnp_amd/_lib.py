@@ -47,6 +47,10 @@ _SIGNATURES = {
     "nsnp_hap_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int] + [C.c_int] * 5),
     "nsnp_hap_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "nsnp_cat_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
+    "nsnp_cat_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nsnp_cat_groups": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
+                        [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -260,6 +264,39 @@ class Context:
         check(self.lib.nsnp_hap_load_weights(self.handle, ptrs, len(arrs), n_features, hidden, n_layers, n_gt, n_zy),
               self.handle, "nsnp_hap_load_weights")
         self._hap_dims = (n_gt, n_zy)
+
+    # ---- legacy CatModel (HaplotypeModel/predict.py -> model.CatModel) ----
+    def cat_load_weights(self, tensors):
+        """tensors: the 132 floating-point tensors of CatModel.state_dict() in order (num_batches_tracked skipped)."""
+        import numpy as np
+        arrs = [np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+                for t in tensors]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        check(self.lib.nsnp_cat_load_weights(self.handle, ptrs, len(arrs)), self.handle, "nsnp_cat_load_weights")
+
+    def cat_forward(self, g0, g1, stream=None):
+        """g0, g1: float32 cuda [N,40,11,5] -> softmax probabilities [N,10] (model.py:332-358)."""
+        import torch
+        if tuple(g0.shape[1:]) != (40, 11, 5) or g0.shape != g1.shape:
+            raise NanoSNPError(f"cat_forward: g0/g1 must be [N,40,11,5], got {tuple(g0.shape)} / {tuple(g1.shape)}")
+        g0 = g0.contiguous().float(); g1 = g1.contiguous().float()
+        n = g0.shape[0]
+        gt = torch.empty((n, 10), dtype=torch.float32, device=g0.device)
+        check(self.lib.nsnp_cat_forward(self.handle, _dptr(g0), _dptr(g1), n, _dptr(gt), _stream_ptr(stream)),
+              self.handle, "nsnp_cat_forward")
+        return gt
+
+    def cat_groups(self, tag1, tag2, stream=None):
+        """tag1 / tag2: (read, baseq, mapq) int32 cuda [N,depth,L] per tag -> [N,40,L,5] float32 (dataset.py:862-915)."""
+        import torch
+        r1, q1, m1 = [t.contiguous() for t in tag1]
+        r2, q2, m2 = [t.contiguous() for t in tag2]
+        n, d1, l = r1.shape
+        d2 = r2.shape[1]
+        g = torch.empty((n, 40, l, 5), dtype=torch.float32, device=r1.device)
+        check(self.lib.nsnp_cat_groups(self.handle, _dptr(r1), _dptr(q1), _dptr(m1), d1, _dptr(r2), _dptr(q2), _dptr(m2), d2,
+                                       n, l, _dptr(g), _stream_ptr(stream)), self.handle, "nsnp_cat_groups")
+        return g
 
     def hap_forward(self, xp, xh, stream=None):
         import torch

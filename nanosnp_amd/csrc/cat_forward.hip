@@ -1,0 +1,491 @@
+// cat_forward.hip -- the legacy haplotype caller CatModel.predict (HaplotypeModel/model.py:332-358) on gfx950.
+//
+//   g0, g1 [N,40,11,5] fp32 (dataset.py:862-915: per tag 20 read rows x 11 columns x (base, baseq, mapq, mask, phase))
+//     |- calculate_percentage (model.py:186-194) -> [11][N][20] -> 3-layer BiLSTM(20->256) + Linear(512->256), t = 5
+//     |- ResCRNN (crnn.py:118-190): six ResBlocks (crnn.py:84-115) + four max-pools on [N,10,40,11] -> [11][N][256]
+//     |    -> BiLSTM(256) + Linear(512->256) on all columns -> BiLSTM(256) + Linear(512->256), t = 5
+//     `- Linear(512->10) on the two 256-vectors, softmax
+//
+// Design.  A feature map is a "pixel image": pixel p = (site, y, x) flattened, 128 pixels per tile, channels in
+// chunks of 16 -> [pixel tile][channel chunk][128][16] floats, i.e. exactly the B-operand tile image of the
+// 128x128 LDS-tiled fp32 MFMA GEMM of hap_gemm.hpp.  A 3x3 convolution is that GEMM with K = 9 x C_in gathered
+// on the fly (CONV mode: the loader shifts the pixel index per tap and zero-fills outside the 40x11 image), so no
+// im2col buffer ever exists in HBM.  BatchNorm (eval) is folded into the weight rows and bias when the weights are
+// packed; conv2 of a block takes the 1x1 shortcut as C_in/16 extra K chunks read at the pixel itself, so a ResBlock
+// is two launches: relu(bn1(conv1 x)) and relu(bn2(conv2 y) + shortcut(x)).  Max-pools run on the same images; the
+// last one (height 1) writes the per-column LSTM input tiles directly.  The recurrent parts reuse the fused
+// GEMM + LSTM-cell step launches of the HaplotypeModel path (one launch per time step, both directions).
+// The last recurrent layer of each branch only feeds column 5, so it runs 6 steps per direction instead of 11.
+#include "nsnp_common.hpp"
+
+#include <new>
+
+#include "hap_gemm.hpp"
+
+namespace {
+
+constexpr int CAT_ROWS = 40, CAT_L = 11, CAT_PLANES = 5, CAT_NH = 256, CAT_CLASSES = 10;
+constexpr int CAT_CENTER = 5;                         // model.py:350,352 take row [5] of the [11,N,256] outputs
+constexpr int CAT_CH[7] = {10, 32, 64, 128, 128, 256, 256};
+constexpr int CAT_POOL[6] = {2, 2, 0, 3, 0, 2};       // pool height after block i (crnn.py:134-160), width 3 / pad 1
+
+// g0,g1 -> pixel image of torch.cat((g0_s, g1_s), 1): channel g*5 + plane (model.py:333-336,352), 10 of 16 used
+__global__ void k_cat_pack_pixels(const float* __restrict__ g0, const float* __restrict__ g1, int64_t n_pix,
+                                  int64_t n_pix_pad, float* __restrict__ img)
+{
+    const int64_t total = n_pix_pad * 16;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e & 15);
+        const int64_t p = e >> 4;
+        float v = 0.f;
+        if (p < n_pix && c < 10) v = (c < 5 ? g0 : g1)[p * CAT_PLANES + (c < 5 ? c : c - 5)];
+        img[e] = v;
+    }
+}
+
+// calculate_percentage (model.py:186-194) of the four (group, tag) read stacks -> LSTM input tiles
+// xT[t][site tile][2 chunks][128][16], feature (g*2 + tag)*5 + {A,C,G,T,D}, 20 of 32 used
+__global__ void k_cat_percentage(const float* __restrict__ g0, const float* __restrict__ g1, int64_t N, int n_tiles,
+                                 float* __restrict__ xT)
+{
+    const int64_t total = (int64_t)CAT_L * n_tiles * TS * 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int gt = (int)(e & 3);                  // g*2 + tag
+        const int site = (int)((e >> 2) & 127);
+        const int64_t r = e >> 9;
+        const int tile = (int)(r % n_tiles);
+        const int t = (int)(r / n_tiles);
+        const int64_t n = (int64_t)tile * TS + site;
+        float f[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n < N) {
+            const float* g = (gt >> 1) ? g1 : g0;
+            int cnt[5] = {0, 0, 0, 0, 0}, valid = 0;
+            for (int row = 0; row < 20; ++row) {
+                const float v = g[((n * CAT_ROWS + (gt & 1) * 20 + row) * CAT_L + t) * CAT_PLANES];
+                valid += v != -2.0f;
+                cnt[0] += v == 1.0f; cnt[1] += v == 2.0f; cnt[2] += v == 3.0f; cnt[3] += v == 4.0f; cnt[4] += v == -1.0f;
+            }
+            // torch evaluates int64 / (int64 + 1e-9) in float32
+            const float den = (float)valid + 1e-9f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) f[k] = __fdiv_rn((float)cnt[k], den);
+        }
+        float* base = xT + ((size_t)t * n_tiles + tile) * 2 * TILE_F;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int feat = gt * 5 + k;
+            base[(size_t)(feat >> 4) * TILE_F + site * BK + (feat & 15)] = f[k];
+        }
+        if (gt == 3) {
+#pragma unroll
+            for (int feat = 20; feat < 32; ++feat) base[(size_t)TILE_F + site * BK + (feat & 15)] = 0.f;
+        }
+    }
+}
+
+// nn.MaxPool2d(kernel (kh,3), stride (kh,1), padding (0,1)) on a pixel image with cc channel chunks.
+// time_major (Ho == 1): pixel (site, x) goes to xT[x][site tile][cc][site][16], the LSTM input layout.
+__global__ void k_cat_pool(const float* __restrict__ in, int cc, int64_t n_sites, int H, int W, int kh, int Ho,
+                           int time_major, int n_site_tiles, float* __restrict__ out)
+{
+    const int64_t n_out = n_sites * Ho * W;
+    const int64_t n_out_tiles = NSNP_CDIV(n_out, (int64_t)TS);
+    const int64_t total = n_out_tiles * cc * TS * 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(e & 3);
+        const int prow = (int)((e >> 2) & 127);
+        const int64_t r = e >> 9;
+        const int c = (int)(r % cc);
+        const int64_t tile = r / cc;
+        const int64_t po = tile * TS + prow;
+        if (po >= n_out) continue;
+        const int64_t n = po / (Ho * W);
+        const int rem = (int)(po - n * (Ho * W));
+        const int yo = rem / W, xo = rem - yo * W;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int ky = 0; ky < kh; ++ky)
+            for (int kx = -1; kx <= 1; ++kx) {
+                const int sx = xo + kx;
+                if (sx < 0 || sx >= W) continue;
+                const int64_t pi = (n * H + yo * kh + ky) * W + sx;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(pi >> 7) * cc + c) * TILE_F + (size_t)(pi & 127) * BK + q * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        float* o;
+        if (time_major) o = out + (((size_t)xo * n_site_tiles + (size_t)(n >> 7)) * cc + c) * TILE_F + (size_t)(n & 127) * BK + q * 4;
+        else            o = out + ((size_t)tile * cc + c) * TILE_F + (size_t)prow * BK + q * 4;
+        *reinterpret_cast<f32x4*>(o) = m;
+    }
+}
+
+// out_layer Linear(512 -> 10) + softmax (model.py:354-357) over the cat image [site tile][32 chunks][128][16]
+__global__ __launch_bounds__(256) void k_cat_head(const float* __restrict__ cat, int64_t N, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ gt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int64_t tile = n / TS; const int site = (int)(n % TS);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = lane + 64 * j;
+        v[j] = cat[(tile * 32 + (f >> 4)) * TILE_F + site * BK + (f & 15)];
+    }
+    float logit[CAT_CLASSES];
+    for (int r = 0; r < CAT_CLASSES; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += w[r * 512 + lane + 64 * j] * v[j];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        logit[r] = s + b[r];
+    }
+    if (lane == 0) {
+        float m = logit[0];
+        for (int r = 1; r < CAT_CLASSES; ++r) m = fmaxf(m, logit[r]);
+        float sum = 0.f;
+        for (int r = 0; r < CAT_CLASSES; ++r) { logit[r] = __expf(logit[r] - m); sum += logit[r]; }
+        for (int r = 0; r < CAT_CLASSES; ++r) gt[n * CAT_CLASSES + r] = logit[r] / sum;
+    }
+}
+
+// dataset.PredictDataset.__getitem__ (dataset.py:862-915): per-tag read / base-quality / mapping-quality matrices
+// [N][D][L] int32 -> one group tensor [N][40][L][5] float: rows 0..19 tag 1, 20..39 tag 2 (first 20 rows of each),
+// planes (base, baseq, mapq, mask = base != -2, phase = 1 | 2)
+__global__ void k_cat_groups(const int32_t* __restrict__ r1, const int32_t* __restrict__ q1, const int32_t* __restrict__ m1,
+                             const int32_t* __restrict__ r2, const int32_t* __restrict__ q2, const int32_t* __restrict__ m2,
+                             int64_t N, int D1, int D2, int L, float* __restrict__ g)
+{
+    const int64_t total = N * CAT_ROWS * L;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % L);
+        const int64_t r = e / L;
+        const int row = (int)(r % CAT_ROWS);
+        const int64_t n = r / CAT_ROWS;
+        const int tag = row >= 20;
+        const int rr = row - 20 * tag;
+        const int D = tag ? D2 : D1;
+        const size_t src = ((size_t)n * D + rr) * L + x;
+        const int base = (tag ? r2 : r1)[src];
+        float* o = g + (size_t)e * CAT_PLANES;
+        o[0] = (float)base; o[1] = (float)(tag ? q2 : q1)[src]; o[2] = (float)(tag ? m2 : m1)[src];
+        o[3] = base != -2 ? 1.f : 0.f; o[4] = (float)(tag + 1);
+    }
+}
+
+struct LstmDir { float* w; float* b; };
+struct CatBlock { float* w1; float* b1; float* w2; float* b2; int cin, cout, cc_in, cc_out; };
+
+}  // namespace
+
+struct CatWeightsDev {
+    CatBlock blk[6];
+    LstmDir rnn[2][2];                 // haplotype_base.rnn.{0,1}, direction
+    float* emb_w[2]; float* emb_b[2];  // their Linear(512 -> 256)
+    LstmDir pct[3][2];                 // haplotype_percentage.rnn layer, direction
+    float* pct_w; float* pct_b;        // haplotype_percentage.out_layer
+    float* out_w; float* out_b;        // out_layer [10][512], [10]
+    float* arena; size_t arena_floats;
+};
+
+void nsnp_cat_free(nsnp_ctx* ctx)
+{
+    if (ctx->cw) {
+        if (ctx->cw->arena) (void)hipFree(ctx->cw->arena);
+        delete ctx->cw; ctx->cw = nullptr;
+    }
+    if (ctx->cat_ws) { (void)hipFree(ctx->cat_ws); ctx->cat_ws = nullptr; ctx->cat_ws_bytes = 0; }
+}
+
+namespace {
+
+int chunks_of(int channels) { int cc = 1; while (cc * BK < channels) cc <<= 1; return cc; }   // power of two
+int shift_of(int cc) { int s = 0; while ((1 << s) < cc) ++s; return s; }
+
+// LSTM weight image [8 row tiles][nki + 16][128][16]: rows [unit][gate]; input columns natural (prev_lstm = false)
+// or in the storage order of a previous bidirectional layer's h (prev_lstm = true); recurrent columns in storage order
+void pack_lstm(float* img, float* bias, const float* const* q, int I, int nki, bool prev_lstm)
+{
+    const int H = CAT_NH, G = 4 * H, nkh = H / BK, nk = nki + nkh;
+    auto lstm_row = [H](int R) { return (R & 3) * H + (R >> 2); };
+    for (int by = 0; by < G / TR; ++by)
+        for (int kc = 0; kc < nk; ++kc)
+            for (int row = 0; row < TR; ++row)
+                for (int p = 0; p < BK; ++p) {
+                    const int tr = lstm_row(by * TR + row);
+                    float v = 0.f;
+                    if (kc < nki) {
+                        const int col = prev_lstm ? (kc / nkh) * H + (kc % nkh) * BK + unit_of_pos(p) : kc * BK + p;
+                        if (col < I) v = q[0][(size_t)tr * I + col];
+                    } else {
+                        v = q[1][(size_t)tr * H + (kc - nki) * BK + unit_of_pos(p)];
+                    }
+                    img[(((size_t)by * nk + kc) * TR + row) * BK + p] = v;
+                }
+    for (int R = 0; R < G; ++R) bias[R] = q[2][lstm_row(R)] + q[3][lstm_row(R)];
+}
+
+// Linear(512 -> 256) on [h_fwd ; h_bwd] in LSTM storage order: image [2 row tiles][32][128][16]
+void pack_linear_h(float* img, const float* W)
+{
+    const int H = CAT_NH, nkh = H / BK;
+    for (int by = 0; by < H / TR; ++by)
+        for (int kc = 0; kc < 2 * nkh; ++kc)
+            for (int row = 0; row < TR; ++row)
+                for (int p = 0; p < BK; ++p)
+                    img[(((size_t)by * 2 * nkh + kc) * TR + row) * BK + p] =
+                        W[(size_t)(by * TR + row) * 2 * H + (kc / nkh) * H + (kc % nkh) * BK + unit_of_pos(p)];
+}
+
+}  // namespace
+
+extern "C" int nsnp_cat_load_weights(nsnp_ctx* ctx, const float* const* t, int n_tensors)
+{
+    if (!ctx || !t) return NSNP_EINVAL;
+    if (n_tensors < 132) return NSNP_EINVAL;
+    for (int i = 0; i < 132; ++i) if (!t[i]) return NSNP_EINVAL;
+    NSNP_HIP(ctx, hipSetDevice(ctx->device));
+    const int H = CAT_NH, G = 4 * H;
+    size_t total = 0;
+    auto take = [&total](size_t n) { const size_t o = total; total += (n + 15) & ~(size_t)15; return o; };
+    size_t o_w1[6], o_b1[6], o_w2[6], o_b2[6];
+    int cc_in[6], cc_out[6], rt[6];
+    for (int i = 0; i < 6; ++i) {
+        cc_in[i] = chunks_of(CAT_CH[i]); cc_out[i] = chunks_of(CAT_CH[i + 1]); rt[i] = NSNP_CDIV(CAT_CH[i + 1], TR);
+        o_w1[i] = take((size_t)rt[i] * 9 * cc_in[i] * TILE_F);
+        o_b1[i] = take((size_t)rt[i] * TR);
+        o_w2[i] = take((size_t)rt[i] * (9 * cc_out[i] + cc_in[i]) * TILE_F);
+        o_b2[i] = take((size_t)rt[i] * TR);
+    }
+    size_t o_rw[2][2], o_rb[2][2], o_ew[2], o_eb[2], o_pw[3][2], o_pb[3][2];
+    for (int r = 0; r < 2; ++r) {
+        for (int d = 0; d < 2; ++d) { o_rw[r][d] = take((size_t)(G / TR) * 32 * TILE_F); o_rb[r][d] = take(G); }
+        o_ew[r] = take((size_t)(H / TR) * 32 * TILE_F); o_eb[r] = take(H);
+    }
+    for (int l = 0; l < 3; ++l)
+        for (int d = 0; d < 2; ++d) { o_pw[l][d] = take((size_t)(G / TR) * ((l == 0 ? 2 : 32) + 16) * TILE_F); o_pb[l][d] = take(G); }
+    const size_t o_pcw = take((size_t)(H / TR) * 32 * TILE_F), o_pcb = take(H);
+    const size_t o_ow = take((size_t)CAT_CLASSES * 2 * H), o_ob = take(16);
+
+    std::vector<float> host(total, 0.f);
+    for (int i = 0; i < 6; ++i) {
+        const float* const* q = t + 14 * i;
+        const int ci = CAT_CH[i], co = CAT_CH[i + 1];
+        // eval-mode BatchNorm folded into the conv: s = gamma / sqrt(var + eps); w' = s * w; b' = (b - mean) * s + beta
+        std::vector<float> s1(co), s2(co);
+        for (int c = 0; c < co; ++c) { s1[c] = q[2][c] / sqrtf(q[5][c] + 1e-5f); s2[c] = q[8][c] / sqrtf(q[11][c] + 1e-5f); }
+        {
+            float* img = host.data() + o_w1[i]; const int cc = cc_in[i], nk = 9 * cc;
+            for (int by = 0; by < rt[i]; ++by)
+                for (int kc = 0; kc < nk; ++kc)
+                    for (int row = 0; row < TR; ++row)
+                        for (int p = 0; p < BK; ++p) {
+                            const int o = by * TR + row, tap = kc / cc, c = (kc % cc) * BK + p;
+                            float v = 0.f;
+                            if (o < co && c < ci) v = q[0][((size_t)o * ci + c) * 9 + tap] * s1[o];
+                            img[(((size_t)by * nk + kc) * TR + row) * BK + p] = v;
+                        }
+            float* bz = host.data() + o_b1[i];
+            for (int o = 0; o < co; ++o) bz[o] = (q[1][o] - q[4][o]) * s1[o] + q[3][o];
+        }
+        {
+            float* img = host.data() + o_w2[i]; const int cc = cc_out[i], nk0 = 9 * cc, nk = nk0 + cc_in[i];
+            for (int by = 0; by < rt[i]; ++by)
+                for (int kc = 0; kc < nk; ++kc)
+                    for (int row = 0; row < TR; ++row)
+                        for (int p = 0; p < BK; ++p) {
+                            const int o = by * TR + row;
+                            float v = 0.f;
+                            if (o < co) {
+                                if (kc < nk0) { const int tap = kc / cc, c = (kc % cc) * BK + p; if (c < co) v = q[6][((size_t)o * co + c) * 9 + tap] * s2[o]; }
+                                else { const int c = (kc - nk0) * BK + p; if (c < ci) v = q[12][(size_t)o * ci + c]; }
+                            }
+                            img[(((size_t)by * nk + kc) * TR + row) * BK + p] = v;
+                        }
+            float* bz = host.data() + o_b2[i];
+            for (int o = 0; o < co; ++o) bz[o] = (q[7][o] - q[10][o]) * s2[o] + q[9][o] + q[13][o];
+        }
+    }
+    for (int r = 0; r < 2; ++r) {
+        const float* const* q = t + 84 + 10 * r;
+        for (int d = 0; d < 2; ++d) pack_lstm(host.data() + o_rw[r][d], host.data() + o_rb[r][d], q + 4 * d, H, 16, false);
+        pack_linear_h(host.data() + o_ew[r], q[8]);
+        memcpy(host.data() + o_eb[r], q[9], sizeof(float) * H);
+    }
+    {
+        const float* const* q = t + 104;
+        for (int l = 0; l < 3; ++l)
+            for (int d = 0; d < 2; ++d)
+                pack_lstm(host.data() + o_pw[l][d], host.data() + o_pb[l][d], q + (l * 2 + d) * 4, l == 0 ? 20 : 2 * H, l == 0 ? 2 : 32, l > 0);
+        pack_linear_h(host.data() + o_pcw, q[24]);
+        memcpy(host.data() + o_pcb, q[25], sizeof(float) * H);
+    }
+    memcpy(host.data() + o_ow, t[130], sizeof(float) * CAT_CLASSES * 2 * H);
+    memcpy(host.data() + o_ob, t[131], sizeof(float) * CAT_CLASSES);
+
+    if (!ctx->cw) { ctx->cw = new (std::nothrow) CatWeightsDev(); if (!ctx->cw) return NSNP_ENOMEM; memset((void*)ctx->cw, 0, sizeof(CatWeightsDev)); }
+    CatWeightsDev& cw = *ctx->cw;
+    if (!cw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&cw.arena, total * sizeof(float))); cw.arena_floats = total; }
+    NSNP_HIP(ctx, hipMemcpy(cw.arena, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < 6; ++i) {
+        cw.blk[i] = CatBlock{cw.arena + o_w1[i], cw.arena + o_b1[i], cw.arena + o_w2[i], cw.arena + o_b2[i],
+                             CAT_CH[i], CAT_CH[i + 1], cc_in[i], cc_out[i]};
+    }
+    for (int r = 0; r < 2; ++r) {
+        for (int d = 0; d < 2; ++d) cw.rnn[r][d] = LstmDir{cw.arena + o_rw[r][d], cw.arena + o_rb[r][d]};
+        cw.emb_w[r] = cw.arena + o_ew[r]; cw.emb_b[r] = cw.arena + o_eb[r];
+    }
+    for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) cw.pct[l][d] = LstmDir{cw.arena + o_pw[l][d], cw.arena + o_pb[l][d]};
+    cw.pct_w = cw.arena + o_pcw; cw.pct_b = cw.arena + o_pcb; cw.out_w = cw.arena + o_ow; cw.out_b = cw.arena + o_ob;
+    return NSNP_OK;
+}
+
+namespace {
+
+// one bidirectional LSTM layer: `steps` launches, both directions per launch.
+//   in : [t][site tile][nk_in chunks] tile images;  hout: [t][site tile][dir][16 chunks]
+void run_bilstm(hipStream_t s, const LstmDir* dirs, const float* in, int nk_in, float* hout, float* cst,
+                int n_tiles, int T, int steps)
+{
+    const size_t tile_h = (size_t)16 * TILE_F, step_h = (size_t)n_tiles * 2 * tile_h;
+    const size_t in_tile = (size_t)nk_in * TILE_F, in_step = (size_t)n_tiles * in_tile;
+    for (int st = 0; st < steps; ++st) {
+        StepLaunch L;
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - st : st, tprev = d ? t + 1 : t - 1;
+            StepArgs& a = L.z[d];
+            memset(&a, 0, sizeof(a));
+            a.w = dirs[d].w; a.bias = dirs[d].b;
+            a.in0 = in + (size_t)t * in_step; a.nk0 = nk_in; a.in0_tile_stride = (int)in_tile;
+            a.in1 = st ? hout + (size_t)tprev * step_h + (size_t)d * tile_h : nullptr;
+            a.nk1 = st ? 16 : 0; a.in1_tile_stride = (int)(2 * tile_h);
+            a.nk_img = nk_in + 16;
+            a.out = hout + (size_t)t * step_h + (size_t)d * tile_h; a.out_tile_stride = (int)(2 * tile_h);
+            a.cstate = cst + (size_t)d * n_tiles * tile_h; a.c_tile_stride = (int)tile_h;
+            a.first = st == 0;
+        }
+        hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, false>), dim3(n_tiles, 4 * CAT_NH / TR, 2), dim3(256), 0, s, L);
+    }
+}
+
+// Linear(512 -> 256) over `n_in_tiles` consecutive [dir][16 chunks] h tiles
+void run_linear_h(hipStream_t s, const float* w, const float* b, const float* in, int n_in_tiles, float* out, int out_tile_stride)
+{
+    StepLaunch L; StepArgs& a = L.z[0];
+    memset(&a, 0, sizeof(a));
+    a.w = w; a.bias = b; a.in0 = in; a.nk0 = 32; a.in0_tile_stride = 32 * TILE_F; a.nk_img = 32;
+    a.out = out; a.out_tile_stride = out_tile_stride;
+    hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, false>), dim3(n_in_tiles, CAT_NH / TR, 1), dim3(256), 0, s, L);
+}
+
+int grid_for(int64_t total) { int64_t b = NSNP_CDIV(total, (int64_t)256); return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!g0 || !g1 || !gt_prob))) return NSNP_EINVAL;
+    if (!ctx->cw) return NSNP_ENOWEIGHTS;
+    if (N == 0) return NSNP_OK;
+    const CatWeightsDev& cw = *ctx->cw;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t chunk = 4096;                                   // sites per pass
+    const int max_tiles = (int)(chunk / TS);
+    // workspace (floats): three rotating feature-map images, LSTM inputs / states / outputs
+    const size_t map_f = ((size_t)NSNP_CDIV(chunk * CAT_ROWS * CAT_L, TS) * 2 + 16) * TILE_F;   // 32 channels at full resolution = the largest map
+    const size_t xp_f = (size_t)CAT_L * max_tiles * 2 * TILE_F;
+    const size_t seq_f = (size_t)CAT_L * max_tiles * 16 * TILE_F;
+    const size_t hb_f = (size_t)CAT_L * max_tiles * 32 * TILE_F;
+    const size_t c_f = (size_t)2 * max_tiles * 16 * TILE_F;
+    const size_t cat_f = (size_t)max_tiles * 32 * TILE_F;
+    const size_t need = (3 * map_f + xp_f + 2 * seq_f + 2 * hb_f + c_f + cat_f) * sizeof(float);
+    if (ctx->cat_ws_bytes < need) {
+        NSNP_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->cat_ws) (void)hipFree(ctx->cat_ws);
+        ctx->cat_ws = nullptr; ctx->cat_ws_bytes = 0;
+        NSNP_HIP(ctx, hipMalloc(&ctx->cat_ws, need));
+        ctx->cat_ws_bytes = need;
+    }
+    float* base = (float*)ctx->cat_ws;
+    float* map[3] = {base, base + map_f, base + 2 * map_f};
+    float* xp = base + 3 * map_f;
+    float* seq[2] = {xp + xp_f, xp + xp_f + seq_f};
+    float* hb[2] = {seq[1] + seq_f, seq[1] + seq_f + hb_f};
+    float* cst = hb[1] + hb_f;
+    float* cat = cst + c_f;
+
+    for (int64_t n0 = 0; n0 < N; n0 += chunk) {
+        const int64_t n = N - n0 < chunk ? N - n0 : chunk;
+        const int n_tiles = (int)NSNP_CDIV(n, TS);
+        const float* a0 = g0 + n0 * CAT_ROWS * CAT_L * CAT_PLANES;
+        const float* a1 = g1 + n0 * CAT_ROWS * CAT_L * CAT_PLANES;
+        const size_t step_h = (size_t)n_tiles * 32 * TILE_F;
+
+        // ---- percentage branch: 3-layer BiLSTM on [11][n][20], Linear at column 5 -> cat chunks 0..15 ----
+        hipLaunchKernelGGL(k_cat_percentage, dim3(grid_for((int64_t)CAT_L * n_tiles * TS * 4)), dim3(256), 0, s, a0, a1, n, n_tiles, xp);
+        run_bilstm(s, cw.pct[0], xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm(s, cw.pct[1], hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm(s, cw.pct[2], hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h(s, cw.pct_w, cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
+
+        // ---- ResCRNN branch ----
+        int Hc = CAT_ROWS;
+        int64_t n_pix = n * Hc * CAT_L;
+        int64_t n_ptiles = NSNP_CDIV(n_pix, (int64_t)TS);
+        hipLaunchKernelGGL(k_cat_pack_pixels, dim3(grid_for(n_ptiles * TS * 16)), dim3(256), 0, s, a0, a1, n_pix, n_ptiles * TS, map[0]);
+        int cur = 0;                                              // map[cur] holds the block input
+        for (int i = 0; i < 6; ++i) {
+            const CatBlock& b = cw.blk[i];
+            const int rt = NSNP_CDIV(b.cout, TR);
+            float* X = map[cur]; float* Y = map[(cur + 1) % 3]; float* O = map[(cur + 2) % 3];
+            StepLaunch L; StepArgs& a = L.z[0];
+            memset(&a, 0, sizeof(a));
+            a.conv_h = Hc; a.conv_w = CAT_L; a.n_pix = n_pix; a.n_rows = b.cout;
+            // y = relu(bn1(conv1(x)))
+            a.w = b.w1; a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
+            a.nk1 = 0; a.nk_img = a.nk0; a.out = Y; a.out_tile_stride = b.cc_out * TILE_F;
+            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, false, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
+            // out = relu(bn2(conv2(y)) + shortcut(x))
+            a.w = b.w2; a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
+            a.in1 = X; a.nk1 = b.cc_in; a.in1_tile_stride = b.cc_in * TILE_F; a.nk_img = a.nk0 + a.nk1;
+            a.out = O; a.out_tile_stride = b.cc_out * TILE_F;
+            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, false, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
+            cur = (cur + 2) % 3;
+            if (CAT_POOL[i]) {
+                const int kh = CAT_POOL[i], Ho = (Hc - kh) / kh + 1;
+                const bool last = i == 5;
+                const int64_t n_out_tiles = NSNP_CDIV(n * Ho * CAT_L, (int64_t)TS);
+                float* dst = last ? seq[0] : map[(cur + 1) % 3];
+                hipLaunchKernelGGL(k_cat_pool, dim3(grid_for(n_out_tiles * b.cc_out * TS * 4)), dim3(256), 0, s,
+                                   map[cur], b.cc_out, n, Hc, CAT_L, kh, Ho, last ? 1 : 0, n_tiles, dst);
+                Hc = Ho; n_pix = n * Hc * CAT_L; n_ptiles = n_out_tiles;
+                cur = (cur + 1) % 3;
+            }
+        }
+        if (Hc != 1) return NSNP_ESHAPE;                          // crnn.py:183 asserts the same
+        // BidirectionalLSTM 0: all 11 columns, embedding on every column (crnn.py:12-20)
+        run_bilstm(s, cw.rnn[0], seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_linear_h(s, cw.emb_w[0], cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
+        // BidirectionalLSTM 1: only column 5 is used downstream
+        run_bilstm(s, cw.rnn[1], seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h(s, cw.emb_w[1], cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
+        hipLaunchKernelGGL(k_cat_head, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, cat, n, cw.out_w, cw.out_b, gt_prob + n0 * CAT_CLASSES);
+    }
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_cat_groups(nsnp_ctx* ctx, const int32_t* read1, const int32_t* bq1, const int32_t* mq1, int depth1,
+                               const int32_t* read2, const int32_t* bq2, const int32_t* mq2, int depth2,
+                               int64_t N, int length, float* g, void* stream)
+{
+    if (!ctx || N < 0 || length <= 0) return NSNP_EINVAL;
+    if (depth1 < 20 || depth2 < 20) return NSNP_ESHAPE;           // dataset.py:862 slices [:max_depth = 20]
+    if (N == 0) return NSNP_OK;
+    if (!read1 || !bq1 || !mq1 || !read2 || !bq2 || !mq2 || !g) return NSNP_EINVAL;
+    hipLaunchKernelGGL(k_cat_groups, dim3(grid_for(N * CAT_ROWS * length)), dim3(256), 0, (hipStream_t)stream,
+                       read1, bq1, mq1, read2, bq2, mq2, N, depth1, depth2, length, g);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}

@@ -18,216 +18,9 @@
 
 #include <new>
 
+#include "hap_gemm.hpp"
+
 namespace {
-
-constexpr float LOG2E = 1.4426950408889634f;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
-__device__ __forceinline__ float tanh_f(float x) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f); }
-
-constexpr int TS = 128;        // sites per workgroup tile
-constexpr int TR = 128;        // weight rows per workgroup tile
-constexpr int BK = 16;         // K chunk
-constexpr int LDK = BK + 4;    // padded LDS row (80 B: conflict-free 16-byte reads across 16 lanes)
-constexpr int TILE_F = TS * BK;   // floats in one [128][16] tile image (8 KB)
-
-// position p inside a 16-unit chunk of the LSTM storage order <-> hidden unit within the chunk
-// (p = h*8 + 4*rt + r4  <->  unit = 8*rt + 2*r4 + h : what a lane half h owns after the MFMAs)
-__host__ __device__ inline int unit_of_pos(int p) { return 8 * ((p >> 2) & 1) + 2 * (p & 3) + (p >> 3); }
-
-struct StepArgs {
-    // per z-slice (direction / encoder) description of one fused step
-    const float* w;        // weight images  [row_tiles][n_chunks][128][16]
-    const float* bias;     // [rows] in image row order
-    const float* in0;      // input tile images for this step: [site_tiles][nk0][128][16] (may be NULL when nk0 == 0)
-    const float* in1;      // second input block (h_{t-1} in LSTM mode): [site_tiles][nk1][128][16]
-    float* out;            // LSTM: h_t images, 16 chunks per site tile; linear: rows/16 chunks per site tile
-    float* cstate;         // LSTM: c images, 16 chunks per site tile
-    int nk0, nk1;          // chunks taken from in0 / in1 (nk1 == 0 on the first step: h = 0)
-    int nk_img;            // chunks per row tile in the weight image (>= nk0 + nk1)
-    int in0_tile_stride;   // floats between consecutive site tiles of in0
-    int in1_tile_stride;
-    int out_tile_stride;   // floats between consecutive site tiles of out
-    int c_tile_stride;     // ... of cstate
-    int first;             // LSTM: 1 on the first step (c = 0)
-};
-struct StepLaunch { StepArgs z[4]; };
-
-enum { MODE_LSTM = 0, MODE_LINEAR = 1, MODE_LINEAR_TANH = 2 };
-
-// F16 = false: operands are fp32, one element per 4 bytes, v_mfma_f32_32x32x2_f32 (exact fp32).
-// F16 = true : "f16x3" - every 4-byte element is a (hi, lo) fp16 pair (hi = fp16(v), lo = fp16(v - hi)); a row
-//              of a tile image holds its 16 hi halves followed by its 16 lo halves, so the two 16-byte LDS reads
-//              of a lane are its hi and lo fragments of v_mfma_f32_32x32x16_f16, and a product is three MFMAs
-//              (hi.hi + lo.hi + hi.lo) with fp32 accumulation.  Same image sizes, strides and launch sequence.
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) { hi = (_Float16)v; lo = (_Float16)(v - (float)hi); }
-
-template <int MODE, bool F16>
-__global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
-{
-    __shared__ float As[2][TR][LDK];
-    __shared__ float Bs[2][TS][LDK];
-    const StepArgs& a = L.z[blockIdx.z];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int bx = blockIdx.x;          // site tile
-    const int by = blockIdx.y;          // row tile
-    const int nk = a.nk0 + a.nk1;
-
-    const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_F;
-    const float* __restrict__ b0 = a.in0 ? a.in0 + (size_t)bx * a.in0_tile_stride : nullptr;
-    const float* __restrict__ b1 = a.in1 ? a.in1 + (size_t)bx * a.in1_tile_stride : nullptr;
-
-    // each thread moves two 16-byte pieces of each 8 KB tile image: row = tid/2, quarter = (tid&1)*2 + {0,1}
-    const int crow = tid >> 1, cq = (tid & 1) * 2;
-    auto gload = [&](int kc, f32x4& a0, f32x4& a1, f32x4& bb0, f32x4& bb1) {
-        const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_F) + crow * 4 + cq;
-        a0 = pa[0]; a1 = pa[1];
-        const float* src = kc < a.nk0 ? b0 + (size_t)kc * TILE_F : b1 + (size_t)(kc - a.nk0) * TILE_F;
-        const f32x4* pb = reinterpret_cast<const f32x4*>(src) + crow * 4 + cq;
-        bb0 = pb[0]; bb1 = pb[1];
-    };
-    auto lstore = [&](int buf, const f32x4& a0, const f32x4& a1, const f32x4& bb0, const f32x4& bb1) {
-        *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4]) = a0;
-        *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4 + 4]) = a1;
-        *reinterpret_cast<f32x4*>(&Bs[buf][crow][cq * 4]) = bb0;
-        *reinterpret_cast<f32x4*>(&Bs[buf][crow][cq * 4 + 4]) = bb1;
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    f32x4 ga0, ga1, gb0, gb1;
-    gload(0, ga0, ga1, gb0, gb1);
-    lstore(0, ga0, ga1, gb0, gb1);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1, ga0, ga1, gb0, gb1);
-        // fragments: lane (li, lh) takes floats [lh*8, lh*8+8) of its row = 8 k-steps of 32x32x2
-        f32x4 af[2][2], bf[2][2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const float* p = &As[cur][64 * wr + 32 * rt + li][F16 ? lh * 4 : lh * 8];
-            af[rt][0] = *reinterpret_cast<const f32x4*>(p);
-            af[rt][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
-        }
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const float* p = &Bs[cur][64 * wc + 32 * ct + li][F16 ? lh * 4 : lh * 8];
-            bf[ct][0] = *reinterpret_cast<const f32x4*>(p);
-            bf[ct][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
-        }
-        if (F16) {
-            // af[rt][0] / [1] are the lane's 8 hi / 8 lo halves of row (rt), likewise bf for the site
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        const h8 av = __builtin_bit_cast(h8, af[rt][term == 1 ? 1 : 0]);
-                        const h8 bv = __builtin_bit_cast(h8, bf[ct][term == 2 ? 1 : 0]);
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[rt][ct], 0, 0, 0);
-                    }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3],
-                                                                            acc[rt][ct], 0, 0, 0);
-        }
-        if (kc + 1 < nk) lstore(cur ^ 1, ga0, ga1, gb0, gb1);
-        __syncthreads();
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------
-    // accumulator register r = 4*r4 + g of tile (rt, ct), lane (li, lh):
-    //   row within the 32-row tile = g + 8*r4 + 4*lh,  site = 64*wc + 32*ct + li
-    if (MODE == MODE_LSTM) {
-        // rows are [unit][gate]: unit8 = 2*r4 + lh, gate = g.  The wave's 16 units form chunk
-        // kc = 2*by + wr of the output image; a lane writes positions p = lh*8 + 4*rt + r4.
-        const size_t img = (size_t)(2 * by + wr) * TILE_F;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int site = 64 * wc + 32 * ct + li;
-            float* cptr = a.cstate + (size_t)bx * a.c_tile_stride + img + site * BK + lh * 8;
-            float* hptr = a.out + (size_t)bx * a.out_tile_stride + img + site * BK + lh * 8;
-            f32x4 cv[2];
-            if (a.first) { cv[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cv[1] = cv[0]; }
-            else { cv[0] = *reinterpret_cast<const f32x4*>(cptr); cv[1] = *reinterpret_cast<const f32x4*>(cptr + 4); }
-            f32x4 hv[2];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int row = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;   // image row of gate 0
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + row);
-                    const float ig = sigmoid_f(acc[rt][ct][4 * r4 + 0] + bz[0]);
-                    const float fg = sigmoid_f(acc[rt][ct][4 * r4 + 1] + bz[1]);
-                    const float gg = tanh_f(acc[rt][ct][4 * r4 + 2] + bz[2]);
-                    const float og = sigmoid_f(acc[rt][ct][4 * r4 + 3] + bz[3]);
-                    const float cn = __builtin_fmaf(fg, cv[rt][r4], ig * gg);
-                    cv[rt][r4] = cn;
-                    hv[rt][r4] = og * tanh_f(cn);
-                }
-            *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
-            if (F16) {
-                // the lane's 8 positions lh*8.. are 8 consecutive halves of the hi block and of the lo block
-                h8 hh, hl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { _Float16 x, y; split_h(hv[e >> 2][e & 3], x, y); hh[e] = x; hl[e] = y; }
-                _Float16* hrow = reinterpret_cast<_Float16*>(a.out + (size_t)bx * a.out_tile_stride + img + site * BK);
-                *reinterpret_cast<h8*>(hrow + lh * 8) = hh;
-                *reinterpret_cast<h8*>(hrow + 16 + lh * 8) = hl;
-            } else {
-                *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
-            }
-        }
-    } else {
-        // plain rows: feature f = 128*by + 64*wr + 32*rt + (g + 8*r4 + 4*lh); natural order in chunks of 16
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int site = 64 * wc + 32 * ct + li;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int f = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + f);
-                    f32x4 v;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float t = acc[rt][ct][4 * r4 + g] + bz[g];
-                        v[g] = MODE == MODE_LINEAR_TANH ? tanh_f(t) : t;
-                    }
-                    float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK;
-                    if (F16) {
-                        h4 vh, vl;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) { _Float16 x, y; split_h(v[g], x, y); vh[g] = x; vl[g] = y; }
-                        _Float16* orow = reinterpret_cast<_Float16*>(o);
-                        *reinterpret_cast<h4*>(orow + (f & 15)) = vh;
-                        *reinterpret_cast<h4*>(orow + 16 + (f & 15)) = vl;
-                    } else {
-                        *reinterpret_cast<f32x4*>(o + (f & 15)) = v;
-                    }
-                }
-        }
-    }
-}
 
 // x [N][F][L] (predict_dev.py hands [N,105,L]; model_dev.py:136-137 permutes to [N,L,F]) ->
 // per-step tile images xT[t][site_tile][chunk][128][16], features in natural order, zero padded

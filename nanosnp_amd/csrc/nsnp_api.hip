@@ -52,6 +52,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
 }
 
 void nsnp_hap_free(nsnp_ctx* ctx);   // hap_forward.hip
+void nsnp_cat_free(nsnp_ctx* ctx);   // cat_forward.hip
 
 // ---- per-kernel timing ----------------------------------------------------------------------------
 constexpr size_t TIMER_MAX_PAIRS = 8192;
@@ -157,6 +158,7 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     if (ctx->pw16.l1f_bias) (void)hipFree(ctx->pw16.l1f_bias);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
     nsnp_hap_free(ctx);
+    nsnp_cat_free(ctx);
     if (ctx->timer) {
         for (int k = 0; k < NSNP_K_COUNT; ++k) {
             for (hipEvent_t e : ctx->timer->start[k]) (void)hipEventDestroy(e);

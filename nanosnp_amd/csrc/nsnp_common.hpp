@@ -57,6 +57,7 @@ struct PileupWeightsF16 {
 };
 
 struct HapWeightsDev;   // hap_forward.hip
+struct CatWeightsDev;   // cat_forward.hip
 
 // optional per-kernel timing with HIP events on the launch stream (nsnp_ctx_enable_timing)
 enum { NSNP_K_L0 = 0, NSNP_K_PROJ1, NSNP_K_L1, NSNP_K_HEAD, NSNP_K_ENCODE, NSNP_K_HAPFEAT, NSNP_K_COUNT };
@@ -87,6 +88,8 @@ struct nsnp_ctx {
     PileupWeightsF16 pw16;
     HapWeightsDev* hw;
     void*  hap_ws; size_t hap_ws_bytes;
+    CatWeightsDev* cw;
+    void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     KernelTimer* timer;
 };

@@ -19,6 +19,8 @@
  *     dataset_dev.get_frequency_feature run in the development container.
  *   - HaplotypeModel forward (H6): trained weights are absent from the reference tree;
  *     pinned against goldens from the reference module with seeded random weights.
+ *   - legacy CatModel forward (C1/C2): the same (no trained weights in the tree): goldens from
+ *     HaplotypeModel/model.py CatModel with seeded weights and BatchNorm statistics.
  */
 #ifndef NANOSNP_ORACLE_H
 #define NANOSNP_ORACLE_H
@@ -133,6 +135,16 @@ void orc_hap_forward(const float* const* w, const float* xp /*[N,105,33]*/,
                      const float* xh /*[N,105,11]*/, int64_t N, int F, int H, int n_layers,
                      int Lp, int Lh, int n_gt, int n_zy,
                      float* gt_prob, float* zy_prob, int nthreads);
+
+/* ---- legacy CatModel forward (C1/C2): HaplotypeModel/model.py:332-358, crnn.py:84-190 -- */
+/* weights: the 132 floating-point tensors of CatModel.state_dict() in order (see cat_forward_oracle.c);
+ * g0, g1: [N,40,11,5] float32 (predict.py:33-34); gt_prob [N,10]. */
+void orc_cat_forward(const float* const* w, const float* g0, const float* g1, int64_t N,
+                     float* gt_prob, int nthreads);
+
+void orc_cat_groups(const int32_t* r1, const int32_t* q1, const int32_t* m1, int D1,
+                    const int32_t* r2, const int32_t* q2, const int32_t* m2, int D2,
+                    int64_t N, int L, float* g /*[N,40,L,5]*/);
 
 /* ---- P5/H7: QUAL score (PileupModel/predict.py:31-34) --------------------------------- */
 double orc_calculate_score(double p);

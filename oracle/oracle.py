@@ -45,6 +45,10 @@ def _load():
     lib.orc_hap_arrange.argtypes = [p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_int, p, p, p, p, p]
     lib.orc_hap_forward.restype = None
     lib.orc_hap_forward.argtypes = [p, p, p, C.c_int64] + [C.c_int] * 7 + [p, p, C.c_int]
+    lib.orc_cat_forward.restype = None
+    lib.orc_cat_forward.argtypes = [p, p, p, C.c_int64, p, C.c_int]
+    lib.orc_cat_groups.restype = None
+    lib.orc_cat_groups.argtypes = [p, p, p, C.c_int, p, p, p, C.c_int, C.c_int64, C.c_int, p]
     lib.orc_calculate_score.restype = C.c_double
     lib.orc_calculate_score.argtypes = [C.c_double]
     return lib
@@ -149,6 +153,26 @@ def hap_forward(weights, xp, xh, H=256, n_layers=3, n_gt=10, n_zy=3, nthreads=1)
     lib().orc_hap_forward(arr, _p(xp), _p(xh), N, F, H, n_layers, Lp, Lh, n_gt, n_zy,
                           _p(gt), _p(zy), nthreads)
     return gt, zy
+
+
+def cat_forward(weights, g0, g1, nthreads=1):
+    """weights: the 132 float tensors of CatModel.state_dict() in order; g0, g1 [N,40,11,5]."""
+    ws, arr = _wptrs(weights)
+    assert len(ws) == 132
+    g0 = _c(g0, np.float32); g1 = _c(g1, np.float32)
+    N = g0.shape[0]
+    gt = np.empty((N, 10), np.float32)
+    lib().orc_cat_forward(arr, _p(g0), _p(g1), N, _p(gt), nthreads)
+    return gt
+
+
+def cat_groups(tag1, tag2):
+    """tag1 / tag2: (read, baseq, mapq) int32 [N,D,L] -> [N,40,L,5] float32 (dataset.py:862-915)."""
+    a = [_c(t, np.int32) for t in tag1]; b = [_c(t, np.int32) for t in tag2]
+    N, D1, L = a[0].shape
+    g = np.empty((N, 40, L, 5), np.float32)
+    lib().orc_cat_groups(_p(a[0]), _p(a[1]), _p(a[2]), D1, _p(b[0]), _p(b[1]), _p(b[2]), b[0].shape[1], N, L, _p(g))
+    return g
 
 
 def calculate_score(p):

@@ -1,0 +1,92 @@
+"""Legacy CatModel forward (ResCRNN + percentage RNN) on the GPU vs the reference-module golden and the oracle."""
+import numpy as np
+import pytest
+
+from tests.helpers import golden, seeded_cat_weights, synth_cat_groups
+
+pytestmark = pytest.mark.gpu
+
+PROB_ATOL = 1e-4        # BASELINE.json north_star tolerance on probabilities
+
+
+@pytest.fixture(scope="module")
+def cat_model(gpu_ctx):
+    ws = seeded_cat_weights(21)
+    gpu_ctx.cat_load_weights(ws)
+    return gpu_ctx, ws
+
+
+def _fwd(ctx, g0, g1):
+    import torch
+    out = ctx.cat_forward(torch.from_numpy(np.ascontiguousarray(g0, dtype=np.float32)).cuda(),
+                          torch.from_numpy(np.ascontiguousarray(g1, dtype=np.float32)).cuda())
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_cat_forward_golden(cat_model):
+    ctx, _ = cat_model
+    z = np.load(golden("cat_fwd.npz"))
+    assert int(z["seed"]) == 21
+    got = _fwd(ctx, z["g0"], z["g1"])
+    assert np.abs(got - z["gt"]).max() < PROB_ATOL
+    assert np.array_equal(got.argmax(1), z["gt"].argmax(1))
+
+
+@pytest.mark.parametrize("N", [1, 127, 129, 300])
+def test_cat_forward_vs_oracle(cat_model, N):
+    from oracle import oracle
+    ctx, ws = cat_model
+    g0, g1 = synth_cat_groups(1000 + N, N)
+    got = _fwd(ctx, g0, g1)
+    want = oracle.cat_forward(ws, g0, g1, nthreads=8)
+    assert got.shape == (N, 10)
+    assert np.abs(got - want).max() < PROB_ATOL
+    assert np.allclose(got.sum(1), 1.0, atol=1e-5)
+
+
+def test_cat_forward_multi_chunk_consistency(cat_model):
+    """more sites than one internal pass (4096): every site's result is independent of its batch position"""
+    ctx, _ = cat_model
+    g0, g1 = synth_cat_groups(77, 64)
+    reps = 4096 // 64 + 3
+    big0 = np.tile(g0, (reps, 1, 1, 1)); big1 = np.tile(g1, (reps, 1, 1, 1))
+    got = _fwd(ctx, big0, big1)
+    small = _fwd(ctx, g0, g1)
+    assert np.array_equal(got.reshape(reps, 64, 10), np.broadcast_to(small, (reps, 64, 10)))
+
+
+def test_cat_forward_empty_and_errors(cat_model):
+    import torch
+    from nanosnp_amd._lib import NanoSNPError
+    ctx, _ = cat_model
+    out = ctx.cat_forward(torch.empty((0, 40, 11, 5), device="cuda"), torch.empty((0, 40, 11, 5), device="cuda"))
+    assert out.shape == (0, 10)
+    with pytest.raises(NanoSNPError):
+        ctx.cat_forward(torch.zeros((2, 40, 5, 5), device="cuda"), torch.zeros((2, 40, 5, 5), device="cuda"))
+
+
+def test_cat_forward_requires_weights():
+    import torch
+    from nanosnp_amd._lib import Context, NanoSNPError
+    ctx = Context(0)
+    with pytest.raises(NanoSNPError):
+        ctx.cat_forward(torch.zeros((1, 40, 11, 5), device="cuda"), torch.zeros((1, 40, 11, 5), device="cuda"))
+    ctx.close()
+
+
+def test_cat_groups_vs_oracle(gpu_ctx):
+    import torch
+    from nanosnp_amd._lib import NanoSNPError
+    from oracle import oracle
+    rng = np.random.default_rng(9)
+    N, L = 37, 11
+    mk = lambda D: [rng.integers(-2, 5, (N, D, L)).astype(np.int32), rng.integers(0, 61, (N, D, L)).astype(np.int32),
+                    rng.integers(0, 61, (N, D, L)).astype(np.int32)]
+    t1, t2 = mk(24), mk(40)
+    got = gpu_ctx.cat_groups([torch.from_numpy(a).cuda() for a in t1], [torch.from_numpy(a).cuda() for a in t2])
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), oracle.cat_groups(t1, t2))
+    short = [torch.from_numpy(a[:, :10].copy()).cuda() for a in t1]
+    with pytest.raises(NanoSNPError):
+        gpu_ctx.cat_groups(short, [torch.from_numpy(a).cuda() for a in t2])

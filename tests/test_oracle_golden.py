@@ -78,6 +78,29 @@ def test_hap_forward_matches_reference_module_with_seeded_weights(H):
     assert np.abs(gt - z["gt"]).max() < 5e-6
 
 
+def test_cat_forward_matches_reference_module_with_seeded_weights():
+    """legacy CatModel.predict (HaplotypeModel/model.py:332-358): golden from the reference module (tools/make_golden.py cat)"""
+    from tests.helpers import seeded_cat_weights
+    z = np.load(golden("cat_fwd.npz"))
+    ws = seeded_cat_weights(int(z["seed"]))
+    gt = oracle.cat_forward(ws, z["g0"], z["g1"], nthreads=4)
+    assert np.abs(gt - z["gt"]).max() < 1e-5
+    assert len(set(z["gt"].argmax(1))) > 1            # the fixture discriminates between sites
+
+
+def test_cat_groups_layout():
+    """dataset.py:862-915 restated with numpy concatenation"""
+    rng = np.random.default_rng(4)
+    N, L = 5, 11
+    t1 = [rng.integers(-2, 5, (N, 25, L)).astype(np.int32), rng.integers(0, 60, (N, 25, L)).astype(np.int32), rng.integers(0, 60, (N, 25, L)).astype(np.int32)]
+    t2 = [rng.integers(-2, 5, (N, 31, L)).astype(np.int32), rng.integers(0, 60, (N, 31, L)).astype(np.int32), rng.integers(0, 60, (N, 31, L)).astype(np.int32)]
+    g = oracle.cat_groups(t1, t2)
+    r = np.concatenate([t1[0][:, :20], t2[0][:, :20]], 1)
+    want = np.stack([r, np.concatenate([t1[1][:, :20], t2[1][:, :20]], 1), np.concatenate([t1[2][:, :20], t2[2][:, :20]], 1),
+                     (r != -2).astype(int), np.concatenate([np.ones_like(t1[0][:, :20]), np.ones_like(t2[0][:, :20]) + 1], 1)], 3)
+    assert np.array_equal(g, want.astype(np.float32))
+
+
 def test_calculate_score_matches_python_formula():
     from math import e, log
     def ref(p):   # PileupModel/predict.py:31-34 verbatim formula

@@ -253,6 +253,27 @@ def group_hapfwd():
         print(f"hap_fwd_h{H}: gt argmax", gt.numpy().argmax(1))
 
 
+def group_cat():
+    """legacy CatModel.predict (HaplotypeModel/model.py:332-358) with seeded weights -> tests/golden/cat_fwd.npz"""
+    import torch
+    from tests.helpers import cat_weight_names, seeded_cat_weights, synth_cat_groups
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    from model import CatModel              # noqa: E402  (reference module)
+    seed, N = 21, 12
+    m = CatModel(nc0=5, nc1=5, nc2=2, nclass=10, nh=256)     # predict.py:78-86 / config_prev/cat45.yaml
+    ws = seeded_cat_weights(seed)
+    sd = {k: torch.from_numpy(w) for k, w in zip(cat_weight_names(), ws)}
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all("num_batches_tracked" in k or "crit" in k for k in res.missing_keys), res
+    m.eval()                                                  # predict.py:28
+    g0, g1 = synth_cat_groups(300 + seed, N)
+    with torch.no_grad():
+        gt = m.predict(torch.from_numpy(g0), torch.from_numpy(g1), None, None).numpy()
+    np.savez_compressed(os.path.join(GOLD, "cat_fwd.npz"), g0=g0.astype(np.int8), g1=g1.astype(np.int8), gt=gt, seed=seed)
+    print("cat_fwd: argmax", gt.argmax(1), "max p", gt.max(1).round(3))
+
+
 def group_vcf():
     """pileup.vcf exactly as PileupModel/predict.py:37-195 writes it: the reference's own predict()
     is run on CPU with the shipped weights; only PredictDataset (PyTables reader) is replaced by an
@@ -357,7 +378,7 @@ def group_next():
 
 
 GROUPS = {"next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
-          "hapfwd": group_hapfwd}
+          "hapfwd": group_hapfwd, "cat": group_cat}
 
 if __name__ == "__main__":
     if not os.path.isdir(REF):
