@@ -41,6 +41,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->precision = 0;
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
+    ctx->l0_rs = 1;
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -91,6 +92,16 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "fused_l1") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->fused_l1 = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "l0_register_stationary") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->l0_rs = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "l0_site_groups") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return NSNP_EINVAL;
+        ctx->l0_rs_groups = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "fused_waves") == 0) {
@@ -179,9 +190,9 @@ extern "C" int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites)
     free_ws(ctx);
     ctx->chunk_sites = max_sites;
     const size_t n = (size_t)max_sites;
-    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, n * PW * 128 * sizeof(float)));
+    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, (n + 64) * PW * 128 * sizeof(float)));
     NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_xp1, 2 * n * PSTEPS1 * 256 * sizeof(float)));
-    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h1c, n * 128 * sizeof(float)));
+    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h1c, (n + 64) * 128 * sizeof(float)));
     return NSNP_OK;
 }
 

@@ -52,6 +52,8 @@ struct PileupWeightsDev {
 struct PileupWeightsF16 {
     void* l0_whh[2]; void* l0_wih_hi[2]; void* l0_wih_lo[2]; void* l1_wih[2]; void* l1_whh[2];
     void* l1f_hi[2]; void* l1f_lo[2]; float* l1f_bias;      // fused projection + recurrence kernel
+    void* l0_wih_rs[2];
+    void* l0_whh_rs[2];                                      // register-stationary layer-0 kernel (K order of its exchange rows)
     void* proj_w; void* dense_w; void* head_w;
     void* arena; size_t arena_bytes; bool loaded;
 };
@@ -76,6 +78,8 @@ struct nsnp_ctx {
     int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
+    int l0_rs;          // f16x3: 1 = register-stationary layer-0 kernel (default), 0 = LDS-image kernel
+    int l0_rs_groups;   // 0 = automatic, else 1 / 2 / 4 groups of 16 sites per workgroup
     int fused_l1;       // f16x3: 1 = fused projection + layer-1 recurrence kernel (default), 0 = two kernels
     int proj1_tiles;    // 16-row tiles per wave of the layer-1 projection kernel (persistent grid sizing)
     int force_wpb;      // 0 = automatic; else waves per recurrence workgroup (tuning / tests)

@@ -12,6 +12,7 @@
 // the fp32 path: the accumulator layout of tile i (lane = site + 16*q holds unit 4*i+q) is packed
 // straight into the next step's B fragments (K position (kb, q, j) <-> unit 4*(8*kb+j)+q).
 #include "nsnp_common.hpp"
+#include <type_traits>
 
 #ifndef NSNP_F16_PIN
 #define NSNP_F16_PIN 1
@@ -43,6 +44,15 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
 {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+}
+// Input counts: int32 in the ABI, below 2^11 in practice (mpileup depth cap 144, make_predict_data.sh:117) and then
+// exact in the hi half alone.  Both halves saturate at the fp16 maximum instead of overflowing to infinity, so
+// |x| <= 131008 is carried (to ~3e-5 relative beyond 67552) and larger magnitudes act as +-131008: every gate such an
+// input reaches is saturated either way.  pileup_precision = 0 is exact for the whole int32 range.
+__device__ __forceinline__ void split_count(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.0f, 65504.0f);
 }
 
 // acc[t] += W(tile TB+t, K block kb) . b for t < NT, three MFMAs per (tile, block), walked in groups of
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 6 ? 3 : (WA
             float v = (float)xi[j];                       // predict.py:49 int -> float
             if (q == 2 && j == 2) v = 1.0f;
             if (q == 3) v = 0.0f;
-            _Float16 hi, lo; split1(v, hi, lo);
+            _Float16 hi, lo; split_count(v, hi, lo);
             xh[j] = hi; xl[j] = lo;
         }
         if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);
@@ -249,6 +259,224 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 6 ? 3 : (WA
             o[0] = bh[0]; o[1] = bh[1]; o[2] = bl[0]; o[3] = bl[1];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1r: layer 0 with REGISTER-STATIONARY weights (default).  K1 above keeps one wave per 16 sites with all 16
+// gate tiles and re-reads the 80 KB weight images from LDS every step: the LDS image pins one workgroup per CU
+// (one wave per SIMD, nobody to fill MFMA / transcendental / LDS stalls: SQ counters showed 36 % matrix-pipe
+// busy, 38 % issue stalls) and the LDS pipe is 40 % busy.  Here a workgroup is 4 waves x NSG groups of 16 sites;
+// wave w owns gate tiles 4w..4w+3 (hidden units 16w..16w+15, all four gates) and holds their W_hh / W_ih hi+lo
+// fragments in 96 VGPRs for the whole kernel.  Only h_t (and the staged x_t) cross waves, through a
+// double-buffered LDS exchange (one workgroup barrier per step, 17 KB per buffer), so LDS traffic per site-step
+// drops 5x, a workgroup needs 52 KB of LDS and 2-3 workgroups (independent barriers) share a CU.
+//   exchange row of a site: 16 chunks of 16 bytes; chunk 4w+q = [hi(u=0..3) | lo(u=0..3)] of units 16w+4u+q, the
+//   four units lane (site, q) of wave w leaves the cell with -> one ds_write_b128 per lane and site group.
+//   A B fragment (K block kb, lane quarter kq) is chunks 8kb+2kq and 8kb+2kq+1 (32 contiguous bytes): their hi
+//   halves form the hi fragment, their lo halves the lo fragment (register renaming only).
+//   The per-step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain
+//   the H0 stores to HBM every step.
+// H0 is written in the layout K1 writes (entries m = 4w+u of row q), so the layer-1 kernels are unchanged.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_HROW = 136;                 // halves per exchange row (256 B + 16 B pad: 16-byte accesses of 16 lanes hit distinct banks)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr float RS_K = 2.0f * LOG2E;         // scale of the cell state kept by K1r
+constexpr int RS_XROW = 72;                  // halves per staged-input row: 32 hi | 32 lo | pad (144 B)
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+template <int NSG>
+__global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
+    const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
+    const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
+    const _Float16* __restrict__ wih0, const _Float16* __restrict__ wih1,
+    _Float16* __restrict__ H0 /* padded to a multiple of 64 sites: stores are unconditional */)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 hx[2][16 * NSG][RS_HROW];
+    __shared__ __attribute__((aligned(16))) _Float16 xx[2][16 * NSG][RS_XROW];
+    __shared__ int xflag[2][4];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+
+    // ---- weights of this wave's four gate tiles -> registers -------------------------------------
+    h8 Whh[4][2][2], Wih[4][2];
+    {
+        const h8* __restrict__ ghh = reinterpret_cast<const h8*>(dir ? whh1 : whh0);
+        const h8* __restrict__ gih = reinterpret_cast<const h8*>(dir ? wih1 : wih0);       // [tile][part][lane]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) Whh[u][kb][part] = ghh[(((4 * wave + u) * 2 + kb) * 2 + part) * 64 + lane];
+            Wih[u][0] = gih[((4 * wave + u) * 2 + 0) * 64 + lane];
+            Wih[u][1] = gih[((4 * wave + u) * 2 + 1) * 64 + lane];
+        }
+    }
+
+    // ---- input staging: wave w (< NSG) converts x_t of site group w to fp16 hi/lo rows --------------
+    const int64_t base_site = (int64_t)blockIdx.x * (16 * NSG);
+    const bool stager = NSG >= 4 || wave < NSG;
+    const int64_t xsite = base_site + wave * 16 + n;
+    const int64_t xsc = (stager && xsite < N) ? xsite : N - 1;
+    const int32_t* __restrict__ xs = center_idx ? x + (center_idx[xsc] - PCENTER) * PC : x + xsc * (PW * PC);
+    int xi[8];
+    auto load_x = [&](int t) {
+        if (!stager) return;
+        const int32_t* p = xs + t * PC;
+        if (q < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xi[j] = p[8 * q + j];
+        } else {
+            xi[0] = p[16]; xi[1] = p[17];
+#pragma unroll
+            for (int j = 2; j < 8; ++j) xi[j] = 0;
+        }
+    };
+    auto stage_x = [&](int buf) {
+        if (!stager) return;
+        h8 xh, xl; bool nz = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (float)xi[j];                       // predict.py:49 int -> float
+            if (q == 2 && j == 2) v = 1.0f;               // the bias column of the input image
+            if (q == 3) v = 0.0f;
+            _Float16 hi, lo; split_count(v, hi, lo);
+            xh[j] = hi; xl[j] = lo; nz |= lo != (_Float16)0.f;
+        }
+        _Float16* row = &xx[buf][wave * 16 + n][0];
+        *reinterpret_cast<h8*>(row + 8 * q) = xh;
+        *reinterpret_cast<h8*>(row + 32 + 8 * q) = xl;
+        const bool any = __ballot(nz) != 0ull;             // counts beyond +-2048 are not exact in fp16
+        if (lane == 0) xflag[buf][wave] = any;
+    };
+    if (tid < 8) xflag[tid >> 2][tid & 3] = 0;
+    // h_{-1} = 0: the buffer step 0 reads
+    for (int i = tid; i < 16 * NSG * RS_HROW / 8; i += 256) reinterpret_cast<h8*>(&hx[1][0][0])[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    load_x(dir ? PW - 1 : 0);
+    stage_x(0);
+    __syncthreads();
+
+    float c[4 * NSG];
+#pragma unroll
+    for (int i = 0; i < 4 * NSG; ++i) c[i] = 0.f;
+    // H0 rows leave through the exchange buffer one step late: thread (row = tid / 4, q' = tid % 4) gathers the
+    // four chunks q', 4+q', 8+q', 12+q' of its site (hi and lo of units 4m + q', m = 0..15) and writes the
+    // complete 64-byte row [16 hi | 16 lo] that K1 writes
+    auto flush_h = [&](int buf, int t) {
+        if (NSG < 4 && tid >= 64 * NSG) return;
+        const int row = tid >> 2, qq = tid & 3;
+        const _Float16* r = &hx[buf][row][8 * qq];
+        const h8 k0 = *reinterpret_cast<const h8*>(r), k1 = *reinterpret_cast<const h8*>(r + 32);
+        const h8 k2 = *reinterpret_cast<const h8*>(r + 64), k3 = *reinterpret_cast<const h8*>(r + 96);
+        h8* o = reinterpret_cast<h8*>(H0 + ((((base_site + row) * PW + t) * 2 + dir) * 4 + qq) * 32);
+        o[0] = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 8, 9, 10, 11);
+        o[1] = __builtin_shufflevector(k2, k3, 0, 1, 2, 3, 8, 9, 10, 11);
+        o[2] = __builtin_shufflevector(k0, k1, 4, 5, 6, 7, 12, 13, 14, 15);
+        o[3] = __builtin_shufflevector(k2, k3, 4, 5, 6, 7, 12, 13, 14, 15);
+    };
+
+    struct BFrag { h8 c00, c01, c10, c11, xh, xl; };     // raw chunks; the hi / lo fragments are formed at use
+    auto step = [&](auto any_lo_tag, int t, int xb, int hw_) {
+        constexpr bool ANYLO = decltype(any_lo_tag)::value;
+        const int hr = hw_ ^ 1;
+        auto load_b = [&](int sg, BFrag& f) {
+            const _Float16* hrow = &hx[hr][16 * sg + n][16 * q];
+            f.c00 = *reinterpret_cast<const h8*>(hrow);
+            f.c01 = *reinterpret_cast<const h8*>(hrow + 8);
+            f.c10 = *reinterpret_cast<const h8*>(hrow + 64);
+            f.c11 = *reinterpret_cast<const h8*>(hrow + 72);
+            const _Float16* xrow = &xx[xb][16 * sg + n][0];
+            f.xh = *reinterpret_cast<const h8*>(xrow + 8 * q);
+            if (ANYLO) f.xl = *reinterpret_cast<const h8*>(xrow + 32 + 8 * q);
+        };
+        auto gemm = [&](const BFrag& fr_, f32x4* acc) {
+            struct { h8 bh0, bl0, bh1, bl1, xh, xl; } f;
+            f.bh0 = __builtin_shufflevector(fr_.c00, fr_.c01, 0, 1, 2, 3, 8, 9, 10, 11);
+            f.bl0 = __builtin_shufflevector(fr_.c00, fr_.c01, 4, 5, 6, 7, 12, 13, 14, 15);
+            f.bh1 = __builtin_shufflevector(fr_.c10, fr_.c11, 0, 1, 2, 3, 8, 9, 10, 11);
+            f.bl1 = __builtin_shufflevector(fr_.c10, fr_.c11, 4, 5, 6, 7, 12, 13, 14, 15);
+            f.xh = fr_.xh; f.xl = fr_.xl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][0][0], f.bh0, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][0][1], f.bh0, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][0][0], f.bl0, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][1][0], f.bh1, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][1][1], f.bh1, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][1][0], f.bl1, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Wih[u][0], f.xh, acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Wih[u][1], f.xh, acc[u]);
+            if (ANYLO) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Wih[u][0], f.xl, acc[u]);
+            }
+        };
+        auto cell = [&](int sg, const f32x4* acc) {
+            h4 nh, nl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // gate rows are pre-scaled at pack time (i, f, o by -log2 e; g by 2 log2 e) and the cell state is kept
+                // as c' = 2 log2(e) c, so every activation is exp2 -> add -> rcp on the accumulator itself
+                const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][0]));
+                const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][1]));
+                const float gk = __builtin_fmaf(-2.0f * RS_K, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][2])), RS_K);   // K tanh(g)
+                const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][3]));
+                const float cn = __builtin_fmaf(fg, c[4 * sg + u], ig * gk);
+                c[4 * sg + u] = cn;
+                const float h = og * __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn)), 1.0f);
+                _Float16 hi, lo; split1(h, hi, lo);
+                nh[u] = hi; nl[u] = lo;
+            }
+            *reinterpret_cast<h8*>(&hx[hw_][16 * sg + n][8 * (4 * wave + q)]) = __builtin_shufflevector(nh, nl, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        // software pipeline over the site groups: the MFMAs of group g+1 are issued among the sigmoid / tanh
+        // work of group g (one scheduling region; the matrix pipe runs while the vector ALU issues)
+        BFrag fr[2];
+        f32x4 acc[2][4];
+        load_b(0, fr[0]);
+        if (NSG > 1) load_b(1, fr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm(fr[0], acc[0]);
+#pragma unroll
+        for (int sg = 0; sg < NSG; ++sg) {
+            // the fragment reads of group sg+2 are pinned to the top of the phase (their LDS latency hides behind
+            // the whole phase); gemm(sg) which last used these registers was issued in the previous phase
+            __builtin_amdgcn_sched_barrier(0);
+            if (sg + 2 < NSG) load_b(sg + 2, fr[sg & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sg + 1 < NSG) gemm(fr[(sg + 1) & 1], acc[(sg + 1) & 1]);
+            cell(sg, acc[sg & 1]);
+            if (sg + 1 < NSG) {
+#pragma unroll
+                for (int i = 0; i < (ANYLO ? 36 : 32); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three VALU (cell of the previous group)
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int s = 0; s < PW; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        const int xb = s & 1;
+        if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);
+        const bool any_lo = (xflag[xb][0] | xflag[xb][1] | xflag[xb][2] | xflag[xb][3]) != 0;
+        if (s > 0) flush_h((s & 1) ^ 1, dir ? t + 1 : t - 1);
+        if (any_lo) step(std::true_type{}, t, xb, s & 1);
+        else        step(std::false_type{}, t, xb, s & 1);
+        if (s + 1 < PW) stage_x(xb ^ 1);
+        lds_barrier();
+    }
+    flush_h((PW - 1) & 1, dir ? 0 : PW - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,20 +839,31 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
     const size_t n_hh = (size_t)HH_H8 * 8, n_ih = (size_t)IH_H8 * 8 * 2, n_p1 = (size_t)P1H_W_H8 * 8;
     const size_t n_proj = (size_t)8 * 4 * 2 * 64 * 8, n_dense = (size_t)16 * 4 * 2 * 64 * 8, n_head = (size_t)2 * 8 * 2 * 64 * 8;
     const size_t n_fhi = (size_t)L1F_IHI_H8 * 8, n_flo = (size_t)8 * L1F_CHUNK_H8 * 8;     // fused-kernel images
-    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh + n_fhi + n_flo) + n_proj + n_dense + n_head;
+    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh + n_fhi + n_flo + n_hh + n_ih) + n_proj + n_dense + n_head;
     std::vector<_Float16> host(total);
     size_t off = 0;
     auto take = [&](size_t n) { _Float16* p = host.data() + off; off += n; return p; };
     _Float16 *l0_hh[2], *l0_ih[2], *l1_ih[2], *l1_hh[2];
-    _Float16 *f_hi[2], *f_lo[2];
-    for (int d = 0; d < 2; ++d) { l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); f_hi[d] = take(n_fhi); f_lo[d] = take(n_flo); }
+    _Float16 *f_hi[2], *f_lo[2], *l0_rs[2], *l0_rs_ih[2];
+    for (int d = 0; d < 2; ++d) { l0_rs[d] = take(n_hh); l0_rs_ih[d] = take(n_ih); l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); f_hi[d] = take(n_fhi); f_lo[d] = take(n_flo); }
     _Float16* proj = take(n_proj); _Float16* dense = take(n_dense); _Float16* head = take(n_head);
     auto rec_feat = [](int kb, int q, int j) { return 4 * (8 * kb + j) + q; };                     // hidden unit
     auto h0_feat = [](int kb, int q, int j) { return (kb >> 1) * 64 + 4 * (8 * (kb & 1) + j) + q; };   // [fwd;bwd] feature
     auto acc_feat = [](int kb, int q, int j) { return 16 * (2 * kb + (j >> 2)) + 4 * q + (j & 3); };
+    // register-stationary layer 0: B fragment (kb, q, j) <-> chunk c = 8kb + 2q + (j >> 2) of the exchange row = unit 16 (c >> 2) + 4 (j & 3) + (c & 3)
+    auto rs_feat = [](int kb, int q, int j) { const int c = 8 * kb + 2 * q + (j >> 2); return 16 * (c >> 2) + 4 * (j & 3) + (c & 3); };
     for (int d = 0; d < 2; ++d) {
         const float* const* l0 = w + d * 4;
         const float* const* l1 = w + 8 + d * 4;
+        // K1r images: gate rows pre-scaled so that the cell applies exp2 directly (image row r: gate r & 3)
+        auto gscale = [](int row) { return (row & 3) == 2 ? 2.0f * LOG2E : -LOG2E; };
+        pack_h(l0_rs[d], 16, 2, [&](int row, int kb, int q, int j) { return gscale(row) * l0[1][gate_row(row) * PH + rs_feat(kb, q, j)]; });
+        pack_h(l0_rs_ih[d], 16, 1, [&](int row, int, int q, int j) {
+            const int tr = gate_row(row);
+            if (q < 2) return gscale(row) * l0[0][tr * PC + 8 * q + j];
+            if (q == 2) { if (j < 2) return gscale(row) * l0[0][tr * PC + 16 + j]; if (j == 2) return gscale(row) * (l0[2][tr] + l0[3][tr]); }
+            return 0.f;
+        });
         pack_h(l0_hh[d], 16, 2, [&](int row, int kb, int q, int j) { return l0[1][gate_row(row) * PH + rec_feat(kb, q, j)]; });
         // input image: [tile][part][lane] (one K block): split the generic [tile][kb=1][part] layout
         pack_h(l0_ih[d], 16, 1, [&](int row, int, int q, int j) {
@@ -670,6 +909,7 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
         pw.l0_whh[d] = dev(l0_hh[d]); pw.l0_wih_hi[d] = dev(l0_ih[d]); pw.l0_wih_lo[d] = dev(l0_ih[d] + n_ih / 2);
         pw.l1_wih[d] = dev(l1_ih[d]); pw.l1_whh[d] = dev(l1_hh[d]);
         pw.l1f_hi[d] = dev(f_hi[d]); pw.l1f_lo[d] = dev(f_lo[d]);
+        pw.l0_whh_rs[d] = dev(l0_rs[d]); pw.l0_wih_rs[d] = dev(l0_rs_ih[d]);
     }
     pw.proj_w = dev(proj); pw.dense_w = dev(dense); pw.head_w = dev(head);
     {
@@ -724,6 +964,17 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         while (wpb > 1 && waves_total / wpb < (int64_t)ctx->n_cu / 2) wpb >>= 1;
         if (ctx->force_wpb) wpb = ctx->force_wpb;
         const dim3 g_rec((unsigned)NSNP_CDIV(n, 16 * wpb), 2);
+        if (ctx->l0_rs) {
+            ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
+            // 64 sites per workgroup when that still gives every CU two workgroups, else 32 or 16
+            int nsg = 4;
+            while (nsg > 1 && NSNP_CDIV(n, 16 * nsg) * 2 < 2 * (int64_t)ctx->n_cu) nsg >>= 1;
+            if (ctx->l0_rs_groups) nsg = ctx->l0_rs_groups;
+#define LAUNCH_RS(G) hipLaunchKernelGGL(k_pileup_l0_rs<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), 0, s, xc, cc, n, \
+            (const _Float16*)pw.l0_whh_rs[0], (const _Float16*)pw.l0_whh_rs[1], (const _Float16*)pw.l0_wih_rs[0], (const _Float16*)pw.l0_wih_rs[1], H0)
+            if (nsg == 4) LAUNCH_RS(4); else if (nsg == 2) LAUNCH_RS(2); else LAUNCH_RS(1);
+#undef LAUNCH_RS
+        } else
         { ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
 #define LAUNCH_L0(W) hipLaunchKernelGGL(k_pileup_l0_h<W>, g_rec, dim3(64 * W), L0H_LDS_BYTES, s, xc, cc, n, \
             (const _Float16*)pw.l0_whh[0], (const _Float16*)pw.l0_whh[1], (const _Float16*)pw.l0_wih_hi[0], (const _Float16*)pw.l0_wih_hi[1], \

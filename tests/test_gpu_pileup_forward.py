@@ -226,3 +226,44 @@ def test_fused_layer1_kernel_equals_the_two_kernel_path(pileup_weights):
     gt, zy = c.pileup_forward(torch.from_numpy(z["x"].astype(np.int32)).cuda())
     assert np.abs(gt.cpu().numpy() - z["gt"]).max() < PROB_ATOL and np.abs(zy.cpu().numpy() - z["zy"]).max() < PROB_ATOL
     c.close()
+
+
+def test_register_stationary_layer0_kernel(pileup_weights):
+    """f16x3 layer 0: the register-stationary kernel (weights in VGPRs, h exchanged through LDS; default) against the
+    LDS-image kernel and the oracle, for every workgroup shape, ragged sizes and counts beyond the exact fp16 range"""
+    import torch
+    from nanosnp_amd import _lib
+    from oracle import oracle
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    c.set_option("pileup_precision", 1)
+    rng = np.random.default_rng(21)
+    xn = (rng.integers(0, 50, (1003, 33, 18)) - 10).astype(np.int32)
+    xn[5, 3] = 5000; xn[700, 16, 2] = -70000; xn[1002] = 2049          # steps where the lo part of x is needed
+    xn[300, 10, 4] = 200000; xn[301, 20] = -131008                      # beyond what two fp16 halves carry: saturates
+    x = torch.from_numpy(xn).cuda()
+    c.set_option("l0_register_stationary", 0)
+    old = c.pileup_forward(x)
+    c.set_option("l0_register_stationary", 1)
+    ref = None
+    for g in (0, 1, 2, 4):
+        c.set_option("l0_site_groups", g)
+        got = c.pileup_forward(x)
+        if ref is None:
+            ref = got
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), g      # a site never depends on its group
+    with pytest.raises(_lib.NanoSNPError):
+        c.set_option("l0_site_groups", 3)
+    # gate rows are pre-scaled by log2(e) before the fp16 split, so the two kernels differ by rounding only
+    assert (ref[0] - old[0]).abs().max().item() < 5e-6 and (ref[1] - old[1]).abs().max().item() < 5e-6
+    og, oz = oracle.pileup_forward(pileup_weights, xn[:302], nthreads=8)
+    assert np.abs(ref[0][:302].cpu().numpy() - og).max() < PROB_ATOL and np.abs(ref[1][:302].cpu().numpy() - oz).max() < PROB_ATOL
+    og, oz = oracle.pileup_forward(pileup_weights, xn[-3:])
+    assert np.abs(ref[0][-3:].cpu().numpy() - og).max() < PROB_ATOL
+    assert torch.isfinite(ref[0]).all() and torch.isfinite(old[0]).all()
+    og, oz = oracle.pileup_forward(pileup_weights, xn[698:702])
+    assert np.abs(ref[0][698:702].cpu().numpy() - og).max() < PROB_ATOL and np.abs(old[0][698:702].cpu().numpy() - og).max() < PROB_ATOL
+    for n in (1, 15, 63, 65, 300):
+        gn, zn = c.pileup_forward(x[:n].contiguous())
+        assert torch.equal(gn, ref[0][:n]) and torch.equal(zn, ref[1][:n]), n
+    c.close()
