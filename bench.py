@@ -45,6 +45,11 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (the f16x3 path is
 PEAK_HBM_GBS = 8000.0
 
 
+# f16x3 recurrence kernels: SIMD cycles per site = MFMAs x 16.3 / 16 sites + LSTM cells x 82 / 64 lanes
+SERIAL_SIMD_CYCLES_PER_SITE = {"pileup_l0": 66 * 128 * 16.3 / 16 + 66 * 64 * 82 / 64,
+                               "pileup_l1f": 34 * 288 * 16.3 / 16 + 34 * 64 * 82 / 64}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +70,8 @@ def parse_args():
     ap.add_argument("--rec-waves", type=int, default=0, help="force waves per recurrence workgroup (0 = auto)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (extra values are informational)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--timing-streams", type=int, default=8, help="record per-kernel HIP events on this many of the streams "
+                    "(every kernel launch of those streams inside the timed region; event records cost ~6 %% when on all 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     return ap.parse_args()
@@ -134,7 +141,7 @@ def main():
     for s in range(S):
         ctx = _lib.Context(local_rank, chunk_sites=batch)
         ctx.pileup_load_weights(weights)
-        ctx.enable_timing(not args.no_kernel_timing)
+        ctx.enable_timing(not args.no_kernel_timing and s < max(1, args.timing_streams))
         ctx.set_option("pileup_precision", args.precision)
         if args.rec_waves:
             ctx.set_option("recurrence_waves", args.rec_waves)
@@ -256,6 +263,14 @@ def main():
             achieved = nbytes / (avg_ms[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
+        if args.precision == 1 and dom in SERIAL_SIMD_CYCLES_PER_SITE:
+            # measured serial bound of a recurrence kernel on this chip: a SIMD spends 16.3 cycles per
+            # 16x16x32 fp16 MFMA and 82 cycles per 64-lane LSTM cell, and the two do not overlap
+            cyc = SERIAL_SIMD_CYCLES_PER_SITE[dom]
+            bound_ms = cyc * batch / (1024 * 2.0e9) * 1e3
+            roof["serial_bound"] = {"simd_cycles_per_site": cyc, "clock_ghz": 2.0, "simds": 1024, "bound_ms_per_launch": bound_ms,
+                                    "frac": bound_ms / avg_ms[dom],
+                                    "note": "whole-chip bound; launches of 4096 sites share the chip with the other streams' kernels"}
         roof["avg_launch_ms"] = avg_ms[dom]
         roof["traffic"] = None
         tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -282,6 +297,8 @@ def main():
                        "parallelism": f"site-sharded x{world}, rooted gather of calls"},
             "roofline": roof,
             "kernel_avg_ms": {k: round(v, 5) for k, v in sorted(avg_ms.items())},
+            "kernel_timing": {"streams_with_events": min(S, max(1, args.timing_streams)),
+                              "launches_timed": {k: v[1] for k, v in sorted(tot.items()) if v[1]}},
             "forward_alg_tflops": (2 * 6_274_560 * batch / (fwd_ms * 1e-3) / 1e12) if fwd_ms else None,
         }
         if extra:

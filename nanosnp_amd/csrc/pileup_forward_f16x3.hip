@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
 #pragma unroll
                 for (int i = 0; i < (ANYLO ? 36 : 32); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // three VALU (cell of the previous group)
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // one transcendental   (cell of the previous
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two other VALU        group; cell_rate probe)
                 }
             }
         }
