@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES + 3) / 4) void k_pileup_l1f_h(
                 const int e = tid + k * NT;                                                                      \
                 if (e < L1F_CHUNK_H8) ldsh[L1F_OFF_RING + (((C) + 1) & 1) * L1F_CHUNK_H8 + e] = pc[((C) + 1) & 1][k]; \
             }                                                                                                    \
-            __syncthreads();                                                                                     \
+            lds_barrier();   /* LDS only: __syncthreads() would also drain the ring prefetch (vmcnt) */             \
         }
         CHUNK(0) CHUNK(1) CHUNK(2) CHUNK(3) CHUNK(4) CHUNK(5) CHUNK(6) CHUNK(7)
 #undef CHUNK
