@@ -72,8 +72,18 @@ int nsnp_ctx_destroy(nsnp_ctx* ctx);
  * the hot loop (and out of hipGraph capture). */
 int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
 
-/* Tuning knobs (tests / experiments).  "recurrence_waves": 0 = automatic (default), or 1/2/4/8 waves
- * per workgroup of the PileupModel recurrence kernels.  Results do not depend on any option. */
+/* Options (name, value).  Unknown names / values return NSNP_EINVAL.  Precision options choose between the exact
+ * fp32 MFMA path and "f16x3" (every fp32 operand split into two fp16 halves, three fp16 MFMAs per product, fp32
+ * accumulation; ~1e-6 from the fp32 path, tolerance of the port 1e-4); the others only change launch shapes.
+ *   "pileup_precision"        0 fp32 | 1 f16x3 (default)      PileupModel forward
+ *   "hap_precision"           0 fp32 (default) | 1 f16x3      HaplotypeModel forward
+ *   "cat_precision"           0 fp32 (default) | 1 f16x3      legacy CatModel forward
+ *   "recurrence_waves"        0 auto | 1/2/4/6/8               waves per workgroup of the LDS-image recurrence kernels
+ *   "l0_register_stationary"  1 (default) | 0                 f16x3 layer 0: weights in VGPRs + LDS exchange of h, or LDS images
+ *   "l0_site_groups"          0 auto | 1/2/4                   16-site groups per workgroup of that kernel
+ *   "fused_l1"                1 (default) | 0                 f16x3 layer 1: projection fused into the recurrence
+ *   "fused_waves"             0 auto | 4/8/12                  waves per workgroup of the fused kernel
+ *   "proj1_tiles"             1..64                            row tiles per wave of the unfused projection kernel */
 int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
 
 /* Optional per-kernel timing: when enabled every launch of the kernels below is bracketed by a

@@ -30,6 +30,21 @@ constexpr int CAT_CH[7] = {10, 32, 64, 128, 128, 256, 256};
 constexpr int CAT_POOL[6] = {2, 2, 0, 3, 0, 2};       // pool height after block i (crnn.py:134-160), width 3 / pad 1
 
 // g0,g1 -> pixel image of torch.cat((g0_s, g1_s), 1): channel g*5 + plane (model.py:333-336,352), 10 of 16 used
+// F16 (f16x3 mode, as in hap_gemm.hpp): every 16-float row of an image holds 16 hi halves then 16 lo halves
+template <bool F16>
+__device__ __forceinline__ void put_elem(float* row16, int c, float v)
+{
+    if (F16) { _Float16 hi, lo; split_h(v, hi, lo); _Float16* h = reinterpret_cast<_Float16*>(row16); h[c] = hi; h[16 + c] = lo; }
+    else row16[c] = v;
+}
+template <bool F16>
+__device__ __forceinline__ float get_elem(const float* row16, int c)
+{
+    if (F16) { const _Float16* h = reinterpret_cast<const _Float16*>(row16); return (float)h[c] + (float)h[16 + c]; }
+    return row16[c];
+}
+
+template <bool F16>
 __global__ void k_cat_pack_pixels(const float* __restrict__ g0, const float* __restrict__ g1, int64_t n_pix,
                                   int64_t n_pix_pad, float* __restrict__ img)
 {
@@ -39,12 +54,13 @@ __global__ void k_cat_pack_pixels(const float* __restrict__ g0, const float* __r
         const int64_t p = e >> 4;
         float v = 0.f;
         if (p < n_pix && c < 10) v = (c < 5 ? g0 : g1)[p * CAT_PLANES + (c < 5 ? c : c - 5)];
-        img[e] = v;
+        put_elem<F16>(img + (e & ~(int64_t)15), c, v);
     }
 }
 
 // calculate_percentage (model.py:186-194) of the four (group, tag) read stacks -> LSTM input tiles
 // xT[t][site tile][2 chunks][128][16], feature (g*2 + tag)*5 + {A,C,G,T,D}, 20 of 32 used
+template <bool F16>
 __global__ void k_cat_percentage(const float* __restrict__ g0, const float* __restrict__ g1, int64_t N, int n_tiles,
                                  float* __restrict__ xT)
 {
@@ -74,17 +90,18 @@ __global__ void k_cat_percentage(const float* __restrict__ g0, const float* __re
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int feat = gt * 5 + k;
-            base[(size_t)(feat >> 4) * TILE_F + site * BK + (feat & 15)] = f[k];
+            put_elem<F16>(base + (size_t)(feat >> 4) * TILE_F + site * BK, feat & 15, f[k]);
         }
         if (gt == 3) {
 #pragma unroll
-            for (int feat = 20; feat < 32; ++feat) base[(size_t)TILE_F + site * BK + (feat & 15)] = 0.f;
+            for (int feat = 20; feat < 32; ++feat) put_elem<F16>(base + (size_t)TILE_F + site * BK, feat & 15, 0.f);
         }
     }
 }
 
 // nn.MaxPool2d(kernel (kh,3), stride (kh,1), padding (0,1)) on a pixel image with cc channel chunks.
 // time_major (Ho == 1): pixel (site, x) goes to xT[x][site tile][cc][site][16], the LSTM input layout.
+template <bool F16>
 __global__ void k_cat_pool(const float* __restrict__ in, int cc, int64_t n_sites, int H, int W, int kh, int Ho,
                            int time_major, int n_site_tiles, float* __restrict__ out)
 {
@@ -108,18 +125,32 @@ __global__ void k_cat_pool(const float* __restrict__ in, int cc, int64_t n_sites
                 const int sx = xo + kx;
                 if (sx < 0 || sx >= W) continue;
                 const int64_t pi = (n * H + yo * kh + ky) * W + sx;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(pi >> 7) * cc + c) * TILE_F + (size_t)(pi & 127) * BK + q * 4);
+                const float* row = in + ((size_t)(pi >> 7) * cc + c) * TILE_F + (size_t)(pi & 127) * BK;
+                f32x4 v;
+                if (F16) {
+                    const h4 vh = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(row) + q * 4);
+                    const h4 vl = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(row) + 16 + q * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = (float)vh[k] + (float)vl[k];
+                } else v = *reinterpret_cast<const f32x4*>(row + q * 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
             }
-        float* o;
-        if (time_major) o = out + (((size_t)xo * n_site_tiles + (size_t)(n >> 7)) * cc + c) * TILE_F + (size_t)(n & 127) * BK + q * 4;
-        else            o = out + ((size_t)tile * cc + c) * TILE_F + (size_t)prow * BK + q * 4;
-        *reinterpret_cast<f32x4*>(o) = m;
+        float* orow;
+        if (time_major) orow = out + (((size_t)xo * n_site_tiles + (size_t)(n >> 7)) * cc + c) * TILE_F + (size_t)(n & 127) * BK;
+        else            orow = out + ((size_t)tile * cc + c) * TILE_F + (size_t)prow * BK;
+        if (F16) {
+            h4 vh, vl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { _Float16 a, b; split_h(m[k], a, b); vh[k] = a; vl[k] = b; }
+            *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(orow) + q * 4) = vh;
+            *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(orow) + 16 + q * 4) = vl;
+        } else *reinterpret_cast<f32x4*>(orow + q * 4) = m;
     }
 }
 
 // out_layer Linear(512 -> 10) + softmax (model.py:354-357) over the cat image [site tile][32 chunks][128][16]
+template <bool F16>
 __global__ __launch_bounds__(256) void k_cat_head(const float* __restrict__ cat, int64_t N, const float* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ gt)
 {
@@ -131,7 +162,7 @@ __global__ __launch_bounds__(256) void k_cat_head(const float* __restrict__ cat,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int f = lane + 64 * j;
-        v[j] = cat[(tile * 32 + (f >> 4)) * TILE_F + site * BK + (f & 15)];
+        v[j] = get_elem<F16>(cat + (tile * 32 + (f >> 4)) * TILE_F + site * BK, f & 15);
     }
     float logit[CAT_CLASSES];
     for (int r = 0; r < CAT_CLASSES; ++r) {
@@ -187,12 +218,14 @@ struct CatWeightsDev {
     float* pct_w; float* pct_b;        // haplotype_percentage.out_layer
     float* out_w; float* out_b;        // out_layer [10][512], [10]
     float* arena; size_t arena_floats;
+    float* arena16;                    // the same images with every weight as an fp16 (hi, lo) pair (cat_precision 1)
 };
 
 void nsnp_cat_free(nsnp_ctx* ctx)
 {
     if (ctx->cw) {
         if (ctx->cw->arena) (void)hipFree(ctx->cw->arena);
+        if (ctx->cw->arena16) (void)hipFree(ctx->cw->arena16);
         delete ctx->cw; ctx->cw = nullptr;
     }
     if (ctx->cat_ws) { (void)hipFree(ctx->cat_ws); ctx->cat_ws = nullptr; ctx->cat_ws_bytes = 0; }
@@ -328,6 +361,29 @@ extern "C" int nsnp_cat_load_weights(nsnp_ctx* ctx, const float* const* t, int n
     CatWeightsDev& cw = *ctx->cw;
     if (!cw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&cw.arena, total * sizeof(float))); cw.arena_floats = total; }
     NSNP_HIP(ctx, hipMemcpy(cw.arena, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    {
+        // f16x3 images: rows of 16 weights become 16 hi halves + 16 lo halves; biases and out_layer stay fp32
+        std::vector<float> h16(host);
+        auto conv = [&](size_t off, size_t n_floats) {
+            for (size_t r = 0; r + 16 <= n_floats; r += 16) {
+                _Float16* dst = reinterpret_cast<_Float16*>(h16.data() + off + r);
+                const float* src = host.data() + off + r;
+                for (int k = 0; k < 16; ++k) { const _Float16 hi = (_Float16)src[k]; dst[k] = hi; dst[16 + k] = (_Float16)(src[k] - (float)hi); }
+            }
+        };
+        for (int i = 0; i < 6; ++i) {
+            conv(o_w1[i], (size_t)rt[i] * 9 * cc_in[i] * TILE_F);
+            conv(o_w2[i], (size_t)rt[i] * (9 * cc_out[i] + cc_in[i]) * TILE_F);
+        }
+        for (int r = 0; r < 2; ++r) {
+            for (int d = 0; d < 2; ++d) conv(o_rw[r][d], (size_t)(G / TR) * 32 * TILE_F);
+            conv(o_ew[r], (size_t)(H / TR) * 32 * TILE_F);
+        }
+        for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) conv(o_pw[l][d], (size_t)(G / TR) * ((l == 0 ? 2 : 32) + 16) * TILE_F);
+        conv(o_pcw, (size_t)(H / TR) * 32 * TILE_F);
+        if (!cw.arena16) NSNP_HIP(ctx, hipMalloc((void**)&cw.arena16, total * sizeof(float)));
+        NSNP_HIP(ctx, hipMemcpy(cw.arena16, h16.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    }
     for (int i = 0; i < 6; ++i) {
         cw.blk[i] = CatBlock{cw.arena + o_w1[i], cw.arena + o_b1[i], cw.arena + o_w2[i], cw.arena + o_b2[i],
                              CAT_CH[i], CAT_CH[i + 1], cc_in[i], cc_out[i]};
@@ -345,7 +401,8 @@ namespace {
 
 // one bidirectional LSTM layer: `steps` launches, both directions per launch.
 //   in : [t][site tile][nk_in chunks] tile images;  hout: [t][site tile][dir][16 chunks]
-void run_bilstm(hipStream_t s, const LstmDir* dirs, const float* in, int nk_in, float* hout, float* cst,
+template <bool F16>
+void run_bilstm(hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh, const float* in, int nk_in, float* hout, float* cst,
                 int n_tiles, int T, int steps)
 {
     const size_t tile_h = (size_t)16 * TILE_F, step_h = (size_t)n_tiles * 2 * tile_h;
@@ -356,7 +413,7 @@ void run_bilstm(hipStream_t s, const LstmDir* dirs, const float* in, int nk_in, 
             const int t = d ? T - 1 - st : st, tprev = d ? t + 1 : t - 1;
             StepArgs& a = L.z[d];
             memset(&a, 0, sizeof(a));
-            a.w = dirs[d].w; a.bias = dirs[d].b;
+            a.w = dirs[d].w + wsh; a.bias = dirs[d].b;
             a.in0 = in + (size_t)t * in_step; a.nk0 = nk_in; a.in0_tile_stride = (int)in_tile;
             a.in1 = st ? hout + (size_t)tprev * step_h + (size_t)d * tile_h : nullptr;
             a.nk1 = st ? 16 : 0; a.in1_tile_stride = (int)(2 * tile_h);
@@ -365,31 +422,36 @@ void run_bilstm(hipStream_t s, const LstmDir* dirs, const float* in, int nk_in, 
             a.cstate = cst + (size_t)d * n_tiles * tile_h; a.c_tile_stride = (int)tile_h;
             a.first = st == 0;
         }
-        hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, false>), dim3(n_tiles, 4 * CAT_NH / TR, 2), dim3(256), 0, s, L);
+        hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, F16>), dim3(n_tiles, 4 * CAT_NH / TR, 2), dim3(256), 0, s, L);
     }
 }
 
 // Linear(512 -> 256) over `n_in_tiles` consecutive [dir][16 chunks] h tiles
+template <bool F16>
 void run_linear_h(hipStream_t s, const float* w, const float* b, const float* in, int n_in_tiles, float* out, int out_tile_stride)
 {
     StepLaunch L; StepArgs& a = L.z[0];
     memset(&a, 0, sizeof(a));
     a.w = w; a.bias = b; a.in0 = in; a.nk0 = 32; a.in0_tile_stride = 32 * TILE_F; a.nk_img = 32;
     a.out = out; a.out_tile_stride = out_tile_stride;
-    hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, false>), dim3(n_in_tiles, CAT_NH / TR, 1), dim3(256), 0, s, L);
+    hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, F16>), dim3(n_in_tiles, CAT_NH / TR, 1), dim3(256), 0, s, L);
 }
 
 int grid_for(int64_t total) { int64_t b = NSNP_CDIV(total, (int64_t)256); return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 
 }  // namespace
 
-extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream)
+namespace {
+
+template <bool F16>
+int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream)
 {
     if (!ctx || N < 0 || (N > 0 && (!g0 || !g1 || !gt_prob))) return NSNP_EINVAL;
     if (!ctx->cw) return NSNP_ENOWEIGHTS;
     if (N == 0) return NSNP_OK;
     const CatWeightsDev& cw = *ctx->cw;
     hipStream_t s = (hipStream_t)stream;
+    const ptrdiff_t wsh = F16 ? cw.arena16 - cw.arena : 0;      // weight images live at the same offsets in both arenas
     const int64_t chunk = 4096;                                   // sites per pass
     const int max_tiles = (int)(chunk / TS);
     // workspace (floats): three rotating feature-map images, LSTM inputs / states / outputs
@@ -423,17 +485,17 @@ extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1,
         const size_t step_h = (size_t)n_tiles * 32 * TILE_F;
 
         // ---- percentage branch: 3-layer BiLSTM on [11][n][20], Linear at column 5 -> cat chunks 0..15 ----
-        hipLaunchKernelGGL(k_cat_percentage, dim3(grid_for((int64_t)CAT_L * n_tiles * TS * 4)), dim3(256), 0, s, a0, a1, n, n_tiles, xp);
-        run_bilstm(s, cw.pct[0], xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
-        run_bilstm(s, cw.pct[1], hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
-        run_bilstm(s, cw.pct[2], hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
-        run_linear_h(s, cw.pct_w, cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
+        hipLaunchKernelGGL(k_cat_percentage<F16>, dim3(grid_for((int64_t)CAT_L * n_tiles * TS * 4)), dim3(256), 0, s, a0, a1, n, n_tiles, xp);
+        run_bilstm<F16>(s, cw.pct[0], wsh, xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm<F16>(s, cw.pct[1], wsh, hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm<F16>(s, cw.pct[2], wsh, hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h<F16>(s, cw.pct_w + wsh, cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
 
         // ---- ResCRNN branch ----
         int Hc = CAT_ROWS;
         int64_t n_pix = n * Hc * CAT_L;
         int64_t n_ptiles = NSNP_CDIV(n_pix, (int64_t)TS);
-        hipLaunchKernelGGL(k_cat_pack_pixels, dim3(grid_for(n_ptiles * TS * 16)), dim3(256), 0, s, a0, a1, n_pix, n_ptiles * TS, map[0]);
+        hipLaunchKernelGGL(k_cat_pack_pixels<F16>, dim3(grid_for(n_ptiles * TS * 16)), dim3(256), 0, s, a0, a1, n_pix, n_ptiles * TS, map[0]);
         int cur = 0;                                              // map[cur] holds the block input
         for (int i = 0; i < 6; ++i) {
             const CatBlock& b = cw.blk[i];
@@ -443,21 +505,21 @@ extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1,
             memset(&a, 0, sizeof(a));
             a.conv_h = Hc; a.conv_w = CAT_L; a.n_pix = n_pix; a.n_rows = b.cout;
             // y = relu(bn1(conv1(x)))
-            a.w = b.w1; a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
+            a.w = b.w1 + wsh; a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
             a.nk1 = 0; a.nk_img = a.nk0; a.out = Y; a.out_tile_stride = b.cc_out * TILE_F;
-            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, false, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
+            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
             // out = relu(bn2(conv2(y)) + shortcut(x))
-            a.w = b.w2; a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
+            a.w = b.w2 + wsh; a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
             a.in1 = X; a.nk1 = b.cc_in; a.in1_tile_stride = b.cc_in * TILE_F; a.nk_img = a.nk0 + a.nk1;
             a.out = O; a.out_tile_stride = b.cc_out * TILE_F;
-            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, false, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
+            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
             cur = (cur + 2) % 3;
             if (CAT_POOL[i]) {
                 const int kh = CAT_POOL[i], Ho = (Hc - kh) / kh + 1;
                 const bool last = i == 5;
                 const int64_t n_out_tiles = NSNP_CDIV(n * Ho * CAT_L, (int64_t)TS);
                 float* dst = last ? seq[0] : map[(cur + 1) % 3];
-                hipLaunchKernelGGL(k_cat_pool, dim3(grid_for(n_out_tiles * b.cc_out * TS * 4)), dim3(256), 0, s,
+                hipLaunchKernelGGL(k_cat_pool<F16>, dim3(grid_for(n_out_tiles * b.cc_out * TS * 4)), dim3(256), 0, s,
                                    map[cur], b.cc_out, n, Hc, CAT_L, kh, Ho, last ? 1 : 0, n_tiles, dst);
                 Hc = Ho; n_pix = n * Hc * CAT_L; n_ptiles = n_out_tiles;
                 cur = (cur + 1) % 3;
@@ -465,15 +527,23 @@ extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1,
         }
         if (Hc != 1) return NSNP_ESHAPE;                          // crnn.py:183 asserts the same
         // BidirectionalLSTM 0: all 11 columns, embedding on every column (crnn.py:12-20)
-        run_bilstm(s, cw.rnn[0], seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
-        run_linear_h(s, cw.emb_w[0], cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
+        run_bilstm<F16>(s, cw.rnn[0], wsh, seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_linear_h<F16>(s, cw.emb_w[0] + wsh, cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
         // BidirectionalLSTM 1: only column 5 is used downstream
-        run_bilstm(s, cw.rnn[1], seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
-        run_linear_h(s, cw.emb_w[1], cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
-        hipLaunchKernelGGL(k_cat_head, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, cat, n, cw.out_w, cw.out_b, gt_prob + n0 * CAT_CLASSES);
+        run_bilstm<F16>(s, cw.rnn[1], wsh, seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h<F16>(s, cw.emb_w[1] + wsh, cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
+        hipLaunchKernelGGL(k_cat_head<F16>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, cat, n, cw.out_w, cw.out_b, gt_prob + n0 * CAT_CLASSES);
     }
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
+}
+
+}  // namespace
+
+extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream)
+{
+    if (ctx && ctx->cat_precision == 1) return cat_forward_impl<true>(ctx, g0, g1, N, gt_prob, stream);
+    return cat_forward_impl<false>(ctx, g0, g1, N, gt_prob, stream);
 }
 
 extern "C" int nsnp_cat_groups(nsnp_ctx* ctx, const int32_t* read1, const int32_t* bq1, const int32_t* mq1, int depth1,

@@ -75,6 +75,7 @@ struct nsnp_ctx {
     hipError_t last_err;
     bool attr_set;
     bool attr_set_f16;
+    int cat_precision;  // legacy CatModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split
     int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel

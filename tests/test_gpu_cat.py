@@ -45,6 +45,27 @@ def test_cat_forward_vs_oracle(cat_model, N):
     assert np.allclose(got.sum(1), 1.0, atol=1e-5)
 
 
+def test_cat_forward_f16x3_mode(cat_model):
+    """cat_precision = 1: every product as three fp16 MFMAs with fp32 accumulation (as hap_precision = 1), same goldens"""
+    from oracle import oracle
+    ctx, ws = cat_model
+    z = np.load(golden("cat_fwd.npz"))
+    g0, g1 = synth_cat_groups(555, 200)
+    ref32 = _fwd(ctx, g0, g1)
+    ctx.set_option("cat_precision", 1)
+    try:
+        got = _fwd(ctx, z["g0"], z["g1"])
+        assert np.abs(got - z["gt"]).max() < PROB_ATOL and np.array_equal(got.argmax(1), z["gt"].argmax(1))
+        got = _fwd(ctx, g0, g1)
+        d32 = np.abs(got - ref32).max()
+        print("cat f16x3 vs fp32 path", d32)
+        assert d32 < 2e-5
+        assert np.abs(got - oracle.cat_forward(ws, g0, g1, nthreads=8)).max() < PROB_ATOL
+        assert np.array_equal(got, _fwd(ctx, g0, g1))            # run-to-run deterministic
+    finally:
+        ctx.set_option("cat_precision", 0)
+
+
 def test_cat_forward_multi_chunk_consistency(cat_model):
     """more sites than one internal pass (4096): every site's result is independent of its batch position"""
     ctx, _ = cat_model

@@ -10,6 +10,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = _lib.Context(0)
 ctx.cat_load_weights(seeded_cat_weights(21))
+prec = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+ctx.set_option("cat_precision", prec)
 g0, g1 = synth_cat_groups(5, 256)
 reps = (N + 255) // 256
 g0 = torch.from_numpy(np.tile(g0, (reps, 1, 1, 1))[:N]).cuda(); g1 = torch.from_numpy(np.tile(g1, (reps, 1, 1, 1))[:N]).cuda()
@@ -18,4 +20,4 @@ t = time.time()
 for _ in range(iters): ctx.cat_forward(g0, g1)
 torch.cuda.synchronize()
 dt = (time.time() - t) / iters
-print(f"cat_forward N={N}: {dt*1e3:.2f} ms  {N/dt/1e3:.1f} k sites/s")
+print(f"cat_forward precision={prec} N={N}: {dt*1e3:.2f} ms  {N/dt/1e3:.1f} k sites/s")
