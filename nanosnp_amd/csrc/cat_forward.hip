@@ -34,7 +34,7 @@ constexpr int CAT_POOL[6] = {2, 2, 0, 3, 0, 2};       // pool height after block
 template <bool F16>
 __device__ __forceinline__ void put_elem(float* row16, int c, float v)
 {
-    if (F16) { _Float16 hi, lo; split_h(v, hi, lo); _Float16* h = reinterpret_cast<_Float16*>(row16); h[c] = hi; h[16 + c] = lo; }
+    if (F16) { _Float16 hi, lo; split_sat(v, hi, lo); _Float16* h = reinterpret_cast<_Float16*>(row16); h[c] = hi; h[16 + c] = lo; }
     else row16[c] = v;
 }
 template <bool F16>

@@ -40,7 +40,7 @@ __global__ void k_hap_pack_input(const float* __restrict__ x, int64_t N, int F, 
         const int f = kc * 16 + p;
         const float v = (n < N && f < F) ? x[(n * F + f) * L + t] : 0.f;
         if (F16) {
-            _Float16 hi, lo; split_h(v, hi, lo);
+            _Float16 hi, lo; split_sat(v, hi, lo);
             _Float16* row = reinterpret_cast<_Float16*>(xT + (e & ~(int64_t)15));
             row[p] = hi; row[16 + p] = lo;
         } else xT[e] = v;

@@ -57,6 +57,13 @@ enum { MODE_LSTM = 0, MODE_LINEAR = 1, MODE_LINEAR_TANH = 2, MODE_LINEAR_RELU = 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) { hi = (_Float16)v; lo = (_Float16)(v - (float)hi); }
+// for caller-supplied inputs: both halves saturate at the fp16 maximum instead of becoming infinite, so |v| <= 131008
+// is carried and anything larger acts as +-131008 (the fp32 mode has no such limit)
+__device__ __forceinline__ void split_sat(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.0f, 65504.0f);
+}
 
 template <int MODE, bool F16, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)

@@ -180,4 +180,8 @@ def test_hap_forward_f16x3_mode(gpu_ctx):
     gt, zy = _hfwd(c, xp, xh)
     ogt, ozy = oracle.hap_forward(ws, xp, xh, nthreads=8)
     assert np.abs(gt - ogt).max() < PROB_ATOL
+    # features beyond the fp16 range saturate (both halves) instead of turning into infinities / NaNs
+    xb = xp[:4].copy(); xb[0, 3, 5] = 1.0e5; xb[1, 40, 16] = -3.0e6; xb[2, :, 0] = 7.0e4
+    gt, zy = _hfwd(c, xb, xh[:4])
+    assert np.isfinite(gt).all() and np.isfinite(zy).all() and np.allclose(gt.sum(1), 1.0, atol=1e-5)
     c.close()
