@@ -166,10 +166,10 @@ def main():
 
     P = C.c_void_p
 
-    def make_step(i):
+    def make_step(i, s=None):
         """pre-built argument lists: the timed loop is three C-ABI calls per step"""
         b = i % n_batches
-        s = i % S
+        s = i % S if s is None else s
         c0 = b * mcols
         st = P(streams[s].cuda_stream)
         h = ctxs[s].handle
@@ -183,9 +183,9 @@ def main():
                 P(res["gm"].data_ptr() + 4 * n0), P(res["zm"].data_ptr() + 4 * n0), None, st)
         return enc, fwd, post
 
-    def run_steps(first, count):
+    def run_steps(first, count, table=None):
         for i in range(first, first + count):
-            enc, fwd, post = steps[i]
+            enc, fwd, post = (table or steps)[i]
             rc = lib.nsnp_pileup_encode_columns(*enc)
             rc = rc or lib.nsnp_pileup_forward_windows(*fwd)
             rc = rc or lib.nsnp_pileup_postprocess(*post)
@@ -239,6 +239,14 @@ def main():
     for ctx in ctxs:
         for k, (ms, n) in ctx.read_timing().items():
             a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+    # the same kernels with the chip to themselves (one stream, after the timed region): in the timed region up to
+    # --hw-queues launches share the chip, which stretches every launch without saying anything about the kernel
+    excl = {}
+    if not args.no_kernel_timing:
+        solo = [make_step(W + i, 0) for i in range(32)]
+        run_steps(0, 4, solo); sync_all(); ctxs[0].read_timing()
+        run_steps(4, 28, solo); sync_all()
+        excl = {k: ms / n for k, (ms, n) in ctxs[0].read_timing().items() if n}
     if rank == 0:
         if args.precision == 1 and args.fused_l1 and "pileup_l1" in tot:      # the fused kernel is timed in the l1 slot
             tot["pileup_l1f"] = tot.pop("pileup_l1")
@@ -255,9 +263,10 @@ def main():
             roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak}
             if args.precision == 1:
-                roof["note"] = ("f16x3: 3 fp16 MFMAs per fp32 product, priced against the fp16 dense peak; at this rate "
-                                "the recurrence is bound by sigmoid/tanh VALU issue and the forward by HBM traffic of its "
-                                "intermediates (DESIGN.md section 4), not by the matrix pipe")
+                roof["note"] = ("f16x3: 3 fp16 MFMAs per fp32 product; achieved = algorithmic fp32-equivalent flops, priced against "
+                                "the dense fp16 peak.  A SIMD of this chip runs the MFMAs (16.3 cycles per 16x16x32) and the LSTM "
+                                "cell's exp2 / rcp work (82 cycles per 64-lane cell) one after the other, not side by side "
+                                "(tools/probes/cell_rate.hip): serial_bound is the launch time that sum allows (DESIGN.md section 4)")
         else:
             nbytes = (int(cols.col_off[mcols]) + mcols * (1 + 72))        # bytes in + ref + 18 int32 out
             achieved = nbytes / (avg_ms[dom] * 1e-3) / 1e9
@@ -271,6 +280,12 @@ def main():
             roof["serial_bound"] = {"simd_cycles_per_site": cyc, "clock_ghz": 2.0, "simds": 1024, "bound_ms_per_launch": bound_ms,
                                     "frac": bound_ms / avg_ms[dom],
                                     "note": "whole-chip bound; launches of 4096 sites share the chip with the other streams' kernels"}
+        xk = "pileup_l1" if dom == "pileup_l1f" else dom
+        if xk in excl:
+            unit_work = ALG_FLOP_PER_SITE[dom] * batch / 1e12 if dom in ALG_FLOP_PER_SITE else nbytes / 1e9
+            roof["exclusive"] = {"avg_launch_ms": excl[xk], "achieved": unit_work / (excl[xk] * 1e-3), "frac": unit_work / (excl[xk] * 1e-3) / roof["peak"],
+                                 "note": "same kernel, same batch, one stream: no other launch shares the chip (28 launches after the timed region)"}
+        roof["concurrency"] = "up to %d launches of %d streams share the chip in the timed region; avg_launch_ms is per launch, not exclusive" % (args.hw_queues or 4, S)
         roof["avg_launch_ms"] = avg_ms[dom]
         roof["traffic"] = None
         tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
