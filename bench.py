@@ -59,7 +59,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--windows", type=int, default=1 << 20, help="windows resident per GPU")
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--hw-queues", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4; 16 lets more of the 32 streams run kernels side by side: +8 %%, 24 and more collapse)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = runtime default of 4). 16 lets more "
+                    "of the 32 streams run kernels side by side: +8 %% sites/s (34 M vs 31.5 M), but every launch is then stretched by the "
+                    "launches it shares the chip with and the per-launch durations stop being comparable with a rocprofv3 trace of "
+                    "the same command (tracing itself lowers the concurrency); 24 and more collapse")
     ap.add_argument("--precision", type=int, default=1, help="PileupModel forward: 0 exact fp32 MFMA, 1 f16x3 split")
     ap.add_argument("--fused-l1", type=int, default=1, help="f16x3: fused projection + layer-1 recurrence kernel")
     ap.add_argument("--fused-waves", type=int, default=8, help="waves per workgroup of the fused kernel (0 = auto)")
