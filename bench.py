@@ -315,6 +315,8 @@ def main():
                        "parallelism": f"site-sharded x{world}, rooted gather of calls"},
             "roofline": roof,
             "kernel_avg_ms": {k: round(v, 5) for k, v in sorted(avg_ms.items())},
+            "kernel_exclusive_ms": {("pileup_l1f" if (k == "pileup_l1" and args.precision == 1 and args.fused_l1) else k): round(v, 5)
+                                    for k, v in sorted(excl.items())},
             "kernel_timing": {"streams_with_events": min(S, max(1, args.timing_streams)),
                               "launches_timed": {k: v[1] for k, v in sorted(tot.items()) if v[1]}},
             "forward_alg_tflops": (2 * 6_274_560 * batch / (fwd_ms * 1e-3) / 1e12) if fwd_ms else None,
