@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--fused-l1", type=int, default=1, help="f16x3: fused projection + layer-1 recurrence kernel")
     ap.add_argument("--fused-waves", type=int, default=8, help="waves per workgroup of the fused kernel (0 = auto)")
     ap.add_argument("--l0-rs", type=int, default=1, help="f16x3: register-stationary layer-0 kernel (0 = LDS-image kernel)")
+    ap.add_argument("--l1-rs", type=int, default=1, help="f16x3 fused layer 1: register-stationary kernel (0 = LDS-image / ring kernel)")
     ap.add_argument("--l0-groups", type=int, default=4, help="16-site groups per layer-0 workgroup (0 = auto by batch; 4 is the "
                     "throughput choice when many batches are in flight on separate streams)")
     ap.add_argument("--proj1-tiles", type=int, default=0, help="tiles per wave of the projection kernel (0 = library default)")
@@ -152,6 +153,7 @@ def main():
             ctx.set_option("proj1_tiles", args.proj1_tiles)
         ctx.set_option("fused_l1", args.fused_l1)
         ctx.set_option("l0_register_stationary", args.l0_rs)
+        ctx.set_option("l1_register_stationary", args.l1_rs)
         ctx.set_option("l0_site_groups", args.l0_groups)
         if args.fused_waves:
             ctx.set_option("fused_waves", args.fused_waves)

@@ -42,6 +42,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
     ctx->l0_rs = 1;
+    ctx->l1_rs = 1;
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -102,6 +103,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "l0_register_stationary") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->l0_rs = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "l1_register_stationary") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->l1_rs = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "l0_site_groups") == 0) {

@@ -53,6 +53,7 @@ struct PileupWeightsF16 {
     void* l0_whh[2]; void* l0_wih_hi[2]; void* l0_wih_lo[2]; void* l1_wih[2]; void* l1_whh[2];
     void* l1f_hi[2]; void* l1f_lo[2]; float* l1f_bias;      // fused projection + recurrence kernel
     void* l0_wih_rs[2];
+    void* l1_wih_rs[2]; void* l1_whh_rs[2];                  // register-stationary layer-1 kernel
     void* l0_whh_rs[2];                                      // register-stationary layer-0 kernel (K order of its exchange rows)
     void* proj_w; void* dense_w; void* head_w;
     void* arena; size_t arena_bytes; bool loaded;
@@ -80,6 +81,7 @@ struct nsnp_ctx {
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
     int l0_rs;          // f16x3: 1 = register-stationary layer-0 kernel (default), 0 = LDS-image kernel
+    int l1_rs;          // f16x3 fused layer 1: 1 = register-stationary kernel, 0 = LDS-image / ring kernel
     int l0_rs_groups;   // 0 = automatic, else 1 / 2 / 4 groups of 16 sites per workgroup
     int fused_l1;       // f16x3: 1 = fused projection + layer-1 recurrence kernel (default), 0 = two kernels
     int proj1_tiles;    // 16-row tiles per wave of the layer-1 projection kernel (persistent grid sizing)

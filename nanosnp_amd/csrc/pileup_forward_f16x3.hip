@@ -714,6 +714,161 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES + 3) / 4) void k_pileup_l1f_h(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K23r: layer 1 (input projection + recurrence) with REGISTER-STATIONARY weights, the counterpart of K1r.
+// One workgroup = 8 waves x 64 sites; wave w owns gate tiles 2w, 2w+1 (hidden units 8w..8w+7, all four gates) and keeps
+// their W_ih1 (K = 128) and W_hh1 (K = 64) hi+lo fragments in 96 VGPRs, so nothing is streamed through an LDS ring and
+// a step needs ONE workgroup barrier instead of eight.  LDS holds only operands: h0_t of the 64 sites (512 B rows copied
+// from H0 one step ahead, double-buffered) and the h1 exchange rows (64 hi | 64 lo halves; K position p = 8w + 2q + u
+// <-> unit 4(2w+u) + q, the two units lane (site, q) of wave w leaves the cell with).  A step is 24 "pieces" per wave
+// (4 site groups x (4 input + 2 recurrent K blocks)), each piece one hi and one lo fragment from LDS and 6 MFMAs,
+// requested two pieces ahead.  Gate rows are pre-scaled by log2 e as in K1r.
+// ---------------------------------------------------------------------------------------------
+constexpr int R1_H0ROW = 264;                // halves per staged h0 row: [dir][q][16 hi | 16 lo] = 512 B + 16 B pad
+constexpr int R1_HROW = 136;                 // halves per h1 exchange row: 64 hi | 64 lo | pad
+constexpr int R1_LDS_BYTES = 2 * 64 * R1_H0ROW * 2 + 2 * 64 * R1_HROW * 2;
+
+__global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
+    const _Float16* __restrict__ H0 /* padded to a multiple of 64 sites */, int64_t N,
+    const _Float16* __restrict__ wih0, const _Float16* __restrict__ wih1,
+    const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1,
+    _Float16* __restrict__ H1c /* padded likewise */)
+{
+    extern __shared__ h8 ldsh[];
+    _Float16* const h0s = reinterpret_cast<_Float16*>(ldsh);                       // [2][64][R1_H0ROW]
+    _Float16* const h1x = h0s + 2 * 64 * R1_H0ROW;                                 // [2][64][R1_HROW]
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t base_site = (int64_t)blockIdx.x * 64;
+
+    // ---- this wave's two gate tiles -> registers ---------------------------------------------------
+    h8 Wih[2][4][2], Whh[2][2][2];
+    f32x4 bias[2];
+    {
+        const h8* __restrict__ gih = reinterpret_cast<const h8*>(dir ? wih1 : wih0);        // [tile][kb 4][part][lane]
+        const h8* __restrict__ ghh = reinterpret_cast<const h8*>(dir ? whh1 : whh0);        // [tile][kb 2][part][lane]
+        const f32x4* __restrict__ gb = reinterpret_cast<const f32x4*>(dir ? bias1 : bias0);  // [tile][q]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) Wih[u][kb][part] = gih[(((2 * wave + u) * 4 + kb) * 2 + part) * 64 + lane];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) Whh[u][kb][part] = ghh[(((2 * wave + u) * 2 + kb) * 2 + part) * 64 + lane];
+            bias[u] = gb[(2 * wave + u) * 4 + q];
+        }
+    }
+
+    // ---- h0 staging: thread (row = tid / 8, piece = tid % 8) moves 64 bytes of its site's 512-byte row ----
+    const int srow = tid >> 3, spiece = tid & 7;
+    const int64_t ssite = base_site + srow;                         // H0 is padded: rows beyond N hold garbage that only
+    const h8* __restrict__ gsrc = reinterpret_cast<const h8*>(H0 + (ssite * PW) * (2 * 4 * 32)) + spiece * 4;   // feeds dead sites
+    h8 sreg[4];
+    auto load_h0 = [&](int t) {
+        const h8* p = gsrc + (int64_t)t * (2 * 4 * 32 / 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sreg[k] = p[k];
+    };
+    auto store_h0 = [&](int buf) {
+        h8* d = reinterpret_cast<h8*>(h0s + ((size_t)buf * 64 + srow) * R1_H0ROW + spiece * 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = sreg[k];
+    };
+    // h1_{-1} = 0 in the buffer step 0 reads
+    for (int i = tid; i < 64 * R1_HROW / 8; i += 512) reinterpret_cast<h8*>(h1x + (size_t)64 * R1_HROW)[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    load_h0(dir ? PW - 1 : 0);
+    store_h0(0);
+    __syncthreads();
+
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = 0.f;
+    h4 last_h[4];                                                   // [sg]: hi(u0,u1) lo(u0,u1) of the final step
+
+    for (int s = 0; s < PSTEPS1; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        const int cur = s & 1;
+        if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
+        const _Float16* h0b = h0s + (size_t)cur * 64 * R1_H0ROW;
+        const _Float16* hrb = h1x + (size_t)(cur ^ 1) * 64 * R1_HROW;      // h1_{s-1}
+        _Float16* hwb = h1x + (size_t)cur * 64 * R1_HROW;                  // h1_s
+
+        // piece P = sg * 6 + k: k < 4 input K block k (dir = k >> 1, half = k & 1), k >= 4 recurrent K block k - 4
+        h8 fh[3], fl[3];
+        auto fetch = [&](int P, int slot) {
+            const int sg = P / 6, k = P % 6;
+            if (k < 4) {
+                const _Float16* r = h0b + (size_t)(16 * sg + n) * R1_H0ROW + (k >> 1) * 128 + q * 32 + (k & 1) * 8;
+                fh[slot] = *reinterpret_cast<const h8*>(r);
+                fl[slot] = *reinterpret_cast<const h8*>(r + 16);
+            } else {
+                const _Float16* r = hrb + (size_t)(16 * sg + n) * R1_HROW + (k - 4) * 32 + q * 8;
+                fh[slot] = *reinterpret_cast<const h8*>(r);
+                fl[slot] = *reinterpret_cast<const h8*>(r + 64);
+            }
+        };
+        fetch(0, 0);
+        fetch(1, 1);
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int P = 0; P < 24; ++P) {
+            const int sg = P / 6, k = P % 6, slot = P % 3, ab = sg & 1;
+            if (P + 2 < 24) fetch(P + 2, (P + 2) % 3);
+            if (k == 0) { acc[ab][0] = bias[0]; acc[ab][1] = bias[1]; }
+            if (k < 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Wih[u][k][0], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Wih[u][k][1], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Wih[u][k][0], fl[slot], acc[ab][u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Whh[u][k - 4][0], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Whh[u][k - 4][1], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Whh[u][k - 4][0], fl[slot], acc[ab][u]);
+            }
+            if (k == 5) {
+                // cell of site group sg: lane (n, q) holds units 4 (2 wave + u) + q, u = 0, 1
+                _Float16 hi[2], lo[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][0]));
+                    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][1]));
+                    const float gk = __builtin_fmaf(-2.0f * RS_K, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][2])), RS_K);
+                    const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][3]));
+                    const float cn = __builtin_fmaf(fg, c[2 * sg + u], ig * gk);
+                    c[2 * sg + u] = cn;
+                    const float h = og * __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn)), 1.0f);
+                    split1(h, hi[u], lo[u]);
+                }
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                _Float16* w = hwb + (size_t)(16 * sg + n) * R1_HROW + 8 * wave + 2 * q;
+                *reinterpret_cast<h2*>(w) = h2{hi[0], hi[1]};
+                *reinterpret_cast<h2*>(w + 64) = h2{lo[0], lo[1]};
+                last_h[sg] = h4{hi[0], hi[1], lo[0], lo[1]};
+            }
+        }
+        if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
+        lds_barrier();
+    }
+    // H1c: [site][dir][q][16 hi | 16 lo], entries m = 2 wave + u of row q (the layout K3 / K23 write)
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        _Float16* o = H1c + (((base_site + 16 * sg + n) * 2 + dir) * 4 + q) * 32 + 2 * wave;
+        *reinterpret_cast<h2*>(o) = h2{last_h[sg][0], last_h[sg][1]};
+        *reinterpret_cast<h2*>(o + 16) = h2{last_h[sg][2], last_h[sg][3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: heads, weights from L2 as fp16 hi/lo images.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pileup_head_h(
@@ -840,13 +995,13 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
     const size_t n_hh = (size_t)HH_H8 * 8, n_ih = (size_t)IH_H8 * 8 * 2, n_p1 = (size_t)P1H_W_H8 * 8;
     const size_t n_proj = (size_t)8 * 4 * 2 * 64 * 8, n_dense = (size_t)16 * 4 * 2 * 64 * 8, n_head = (size_t)2 * 8 * 2 * 64 * 8;
     const size_t n_fhi = (size_t)L1F_IHI_H8 * 8, n_flo = (size_t)8 * L1F_CHUNK_H8 * 8;     // fused-kernel images
-    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh + n_fhi + n_flo + n_hh + n_ih) + n_proj + n_dense + n_head;
+    const size_t total = 2 * (n_hh + n_ih + n_p1 + n_hh + n_fhi + n_flo + n_hh + n_ih + n_p1 + n_hh) + n_proj + n_dense + n_head;
     std::vector<_Float16> host(total);
     size_t off = 0;
     auto take = [&](size_t n) { _Float16* p = host.data() + off; off += n; return p; };
     _Float16 *l0_hh[2], *l0_ih[2], *l1_ih[2], *l1_hh[2];
-    _Float16 *f_hi[2], *f_lo[2], *l0_rs[2], *l0_rs_ih[2];
-    for (int d = 0; d < 2; ++d) { l0_rs[d] = take(n_hh); l0_rs_ih[d] = take(n_ih); l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); f_hi[d] = take(n_fhi); f_lo[d] = take(n_flo); }
+    _Float16 *f_hi[2], *f_lo[2], *l0_rs[2], *l0_rs_ih[2], *l1_rs_ih[2], *l1_rs_hh[2];
+    for (int d = 0; d < 2; ++d) { l0_rs[d] = take(n_hh); l0_rs_ih[d] = take(n_ih); l1_rs_ih[d] = take(n_p1); l1_rs_hh[d] = take(n_hh); l0_hh[d] = take(n_hh); l0_ih[d] = take(n_ih); l1_ih[d] = take(n_p1); l1_hh[d] = take(n_hh); f_hi[d] = take(n_fhi); f_lo[d] = take(n_flo); }
     _Float16* proj = take(n_proj); _Float16* dense = take(n_dense); _Float16* head = take(n_head);
     auto rec_feat = [](int kb, int q, int j) { return 4 * (8 * kb + j) + q; };                     // hidden unit
     auto h0_feat = [](int kb, int q, int j) { return (kb >> 1) * 64 + 4 * (8 * (kb & 1) + j) + q; };   // [fwd;bwd] feature
@@ -874,6 +1029,10 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
             return 0.f;
         });
         pack_h(l1_ih[d], 16, 4, [&](int row, int kb, int q, int j) { return l1[0][gate_row(row) * 2 * PH + h0_feat(kb, q, j)]; });
+        // K23r images: the same input image and a recurrent image in the K order of its exchange rows, both pre-scaled
+        auto r1_feat = [](int kb, int q, int j) { const int p = 32 * kb + 8 * q + j; return 4 * (2 * (p >> 3) + (p & 1)) + ((p >> 1) & 3); };
+        pack_h(l1_rs_ih[d], 16, 4, [&](int row, int kb, int q, int j) { return gscale(row) * l1[0][gate_row(row) * 2 * PH + h0_feat(kb, q, j)]; });
+        pack_h(l1_rs_hh[d], 16, 2, [&](int row, int kb, int q, int j) { return gscale(row) * l1[1][gate_row(row) * PH + r1_feat(kb, q, j)]; });
         pack_h(l1_hh[d], 16, 2, [&](int row, int kb, int q, int j) { return l1[1][gate_row(row) * PH + rec_feat(kb, q, j)]; });
     }
     pack_h(proj, 8, 4, [&](int row, int kb, int q, int j) { return w[16][row * 128 + h0_feat(kb, q, j)]; });
@@ -911,15 +1070,17 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
         pw.l1_wih[d] = dev(l1_ih[d]); pw.l1_whh[d] = dev(l1_hh[d]);
         pw.l1f_hi[d] = dev(f_hi[d]); pw.l1f_lo[d] = dev(f_lo[d]);
         pw.l0_whh_rs[d] = dev(l0_rs[d]); pw.l0_wih_rs[d] = dev(l0_rs_ih[d]);
+        pw.l1_wih_rs[d] = dev(l1_rs_ih[d]); pw.l1_whh_rs[d] = dev(l1_rs_hh[d]);
     }
     pw.proj_w = dev(proj); pw.dense_w = dev(dense); pw.head_w = dev(head);
     {
-        float hb[2][64 * 4];
+        float hb[4][64 * 4];                       // [0..1]: plain, [2..3]: pre-scaled by log2 e for K23r
         for (int d = 0; d < 2; ++d) {
             const float* const* l1 = w + 8 + d * 4;
             for (int tile = 0; tile < 16; ++tile) for (int qq = 0; qq < 4; ++qq) for (int g = 0; g < 4; ++g) {
                 const int tr = gate_row(16 * tile + 4 * qq + g);
                 hb[d][(tile * 4 + qq) * 4 + g] = l1[2][tr] + l1[3][tr];
+                hb[2 + d][(tile * 4 + qq) * 4 + g] = (g == 2 ? 2.0f * LOG2E : -LOG2E) * (l1[2][tr] + l1[3][tr]);
             }
         }
         if (!pw.l1f_bias) NSNP_HIP(ctx, hipMalloc((void**)&pw.l1f_bias, sizeof hb));
@@ -935,6 +1096,7 @@ static int set_lds_attr_f16(nsnp_ctx* ctx)
 #define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
     SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<6>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
     SET(k_pileup_proj1_h, P1H_LDS_BYTES);
+    SET(k_pileup_l1_rs, R1_LDS_BYTES);
     SET(k_pileup_l1f_h<4>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<8>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<12>, L1F_LDS_BYTES);
     SET(k_pileup_l1_h<8>, L1H_LDS_BYTES); SET(k_pileup_l1_h<4>, L1H_LDS_BYTES); SET(k_pileup_l1_h<2>, L1H_LDS_BYTES); SET(k_pileup_l1_h<1>, L1H_LDS_BYTES);
 #undef SET
@@ -983,7 +1145,13 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         if (wpb == 8) LAUNCH_L0(8); else if (wpb == 6) LAUNCH_L0(6); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
-        if (ctx->fused_l1) {
+        if (ctx->fused_l1 && ctx->l1_rs) {
+            ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
+            hipLaunchKernelGGL(k_pileup_l1_rs, dim3((unsigned)NSNP_CDIV(n, 64), 2), dim3(512), R1_LDS_BYTES, s, H0, n,
+                               (const _Float16*)pw.l1_wih_rs[0], (const _Float16*)pw.l1_wih_rs[1],
+                               (const _Float16*)pw.l1_whh_rs[0], (const _Float16*)pw.l1_whh_rs[1],
+                               (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c);
+        } else if (ctx->fused_l1) {
             ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
             // one workgroup per CU: 12 waves when the batch fills the chip that way, else 8 or 4
             // (the 12-wave build has to fit 168 VGPRs and spills: 1.84 ms vs 1.49 ms at 131072 sites)

@@ -213,6 +213,7 @@ def test_fused_layer1_kernel_equals_the_two_kernel_path(pileup_weights):
     c = _lib.Context(0)
     c.pileup_load_weights(pileup_weights)
     c.set_option("pileup_precision", 1)
+    c.set_option("l1_register_stationary", 0)          # the LDS-image / ring kernel (K23); K23r has its own test below
     rng = np.random.default_rng(9)
     for n in (1, 191, 192, 193, 1000, 5000):
         x = torch.from_numpy((rng.integers(0, 50, (n, 33, 18)) - 10).astype(np.int32)).cuda()
@@ -264,6 +265,38 @@ def test_register_stationary_layer0_kernel(pileup_weights):
     og, oz = oracle.pileup_forward(pileup_weights, xn[698:702])
     assert np.abs(ref[0][698:702].cpu().numpy() - og).max() < PROB_ATOL and np.abs(old[0][698:702].cpu().numpy() - og).max() < PROB_ATOL
     for n in (1, 15, 63, 65, 300):
+        gn, zn = c.pileup_forward(x[:n].contiguous())
+        assert torch.equal(gn, ref[0][:n]) and torch.equal(zn, ref[1][:n]), n
+    c.close()
+
+
+def test_register_stationary_layer1_kernel(pileup_weights):
+    """f16x3 layer 1: the register-stationary kernel (default) against the LDS-image / ring kernel, the unfused two-kernel
+    path and the oracle; ragged sizes; either layer-0 kernel in front of it"""
+    import torch
+    from nanosnp_amd import _lib
+    from oracle import oracle
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    c.set_option("pileup_precision", 1)
+    rng = np.random.default_rng(31)
+    xn = (rng.integers(0, 60, (777, 33, 18)) - 15).astype(np.int32)
+    x = torch.from_numpy(xn).cuda()
+    ref = c.pileup_forward(x)                                   # defaults: both register-stationary kernels
+    c.set_option("l1_register_stationary", 0)
+    ring = c.pileup_forward(x)
+    c.set_option("fused_l1", 0)
+    two = c.pileup_forward(x)
+    c.set_option("fused_l1", 1); c.set_option("l1_register_stationary", 1); c.set_option("l0_register_stationary", 0)
+    mixed = c.pileup_forward(x)
+    c.set_option("l0_register_stationary", 1)
+    for other in (ring, two, mixed):
+        assert (ref[0] - other[0]).abs().max().item() < 5e-6 and (ref[1] - other[1]).abs().max().item() < 5e-6
+    og, oz = oracle.pileup_forward(pileup_weights, xn[:256], nthreads=8)
+    assert np.abs(ref[0][:256].cpu().numpy() - og).max() < PROB_ATOL and np.abs(ref[1][:256].cpu().numpy() - oz).max() < PROB_ATOL
+    again = c.pileup_forward(x)
+    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+    for n in (1, 63, 64, 65, 200):
         gn, zn = c.pileup_forward(x[:n].contiguous())
         assert torch.equal(gn, ref[0][:n]) and torch.equal(zn, ref[1][:n]), n
     c.close()

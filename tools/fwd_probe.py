@@ -19,6 +19,7 @@ ctx.set_option("fused_l1", int(os.environ.get("FUSED", "1")))
 ctx.set_option("fused_waves", int(os.environ.get("FWAVES", "0")))
 ctx.set_option("l0_register_stationary", int(os.environ.get("L0RS", "1")))
 ctx.set_option("l0_site_groups", int(os.environ.get("L0SG", "0")))
+ctx.set_option("l1_register_stationary", int(os.environ.get("L1RS", "1")))
 x = torch.randint(-20, 40, (N, 33, 18), dtype=torch.int32, device=dev)
 gt = torch.empty((N, 21), device=dev); zy = torch.empty((N, 3), device=dev)
 ctx.pileup_forward(x, gt, zy); torch.cuda.synchronize()
