@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--fused-waves", type=int, default=8, help="waves per workgroup of the fused kernel (0 = auto)")
     ap.add_argument("--l0-rs", type=int, default=1, help="f16x3: register-stationary layer-0 kernel (0 = LDS-image kernel)")
     ap.add_argument("--l1-rs", type=int, default=1, help="f16x3 fused layer 1: register-stationary kernel (0 = LDS-image / ring kernel)")
+    ap.add_argument("--l1-groups", type=int, default=0, help="16-site groups per layer-1 workgroup (0 = picked from the batch size)")
     ap.add_argument("--l0-groups", type=int, default=0, help="16-site groups per layer-0 workgroup (0 = picked from the batch size, 1 at 4096 sites)")
     ap.add_argument("--proj1-tiles", type=int, default=0, help="tiles per wave of the projection kernel (0 = library default)")
     ap.add_argument("--rec-waves", type=int, default=0, help="force waves per recurrence workgroup (0 = auto)")
@@ -153,6 +154,7 @@ def main():
         ctx.set_option("fused_l1", args.fused_l1)
         ctx.set_option("l0_register_stationary", args.l0_rs)
         ctx.set_option("l1_register_stationary", args.l1_rs)
+        ctx.set_option("l1_site_groups", args.l1_groups)
         ctx.set_option("l0_site_groups", args.l0_groups)
         if args.fused_waves:
             ctx.set_option("fused_waves", args.fused_waves)

@@ -82,6 +82,7 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "l0_register_stationary"  1 (default) | 0                 f16x3 layer 0: weights in VGPRs + LDS exchange of h, or LDS images
  *   "l0_site_groups"          0 auto | 1/2/4                   16-site groups per workgroup of that kernel
  *   "l1_register_stationary"  1 (default) | 0                 f16x3 fused layer 1: weights in VGPRs + LDS operands, or LDS images + ring
+ *   "l1_site_groups"          0 auto | 2/4                     16-site groups per workgroup of that kernel
  *   "fused_l1"                1 (default) | 0                 f16x3 layer 1: projection fused into the recurrence
  *   "fused_waves"             0 auto | 4/8/12                  waves per workgroup of the fused kernel
  *   "proj1_tiles"             1..64                            row tiles per wave of the unfused projection kernel */

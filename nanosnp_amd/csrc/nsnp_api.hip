@@ -110,6 +110,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         ctx->l1_rs = (int)value;
         return NSNP_OK;
     }
+    if (strcmp(name, "l1_site_groups") == 0) {
+        if (value != 0 && value != 2 && value != 4) return NSNP_EINVAL;
+        ctx->l1_rs_groups = (int)value;
+        return NSNP_OK;
+    }
     if (strcmp(name, "l0_site_groups") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return NSNP_EINVAL;
         ctx->l0_rs_groups = (int)value;

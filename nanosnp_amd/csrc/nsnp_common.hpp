@@ -81,6 +81,7 @@ struct nsnp_ctx {
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
     int l0_rs;          // f16x3: 1 = register-stationary layer-0 kernel (default), 0 = LDS-image kernel
+    int l1_rs_groups;   // 0 = automatic, else 2 / 4 groups of 16 sites per workgroup of that kernel
     int l1_rs;          // f16x3 fused layer 1: 1 = register-stationary kernel, 0 = LDS-image / ring kernel
     int l0_rs_groups;   // 0 = automatic, else 1 / 2 / 4 groups of 16 sites per workgroup
     int fused_l1;       // f16x3: 1 = fused projection + layer-1 recurrence kernel (default), 0 = two kernels

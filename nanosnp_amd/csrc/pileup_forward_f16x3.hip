@@ -725,8 +725,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES + 3) / 4) void k_pileup_l1f_h(
 // ---------------------------------------------------------------------------------------------
 constexpr int R1_H0ROW = 264;                // halves per staged h0 row: [dir][q][16 hi | 16 lo] = 512 B + 16 B pad
 constexpr int R1_HROW = 136;                 // halves per h1 exchange row: 64 hi | 64 lo | pad
-constexpr int R1_LDS_BYTES = 2 * 64 * R1_H0ROW * 2 + 2 * 64 * R1_HROW * 2;
+constexpr int r1_lds_bytes(int nsg) { return 2 * 16 * nsg * R1_H0ROW * 2 + 2 * 16 * nsg * R1_HROW * 2; }
 
+template <int NSG>          // 16-site groups per workgroup: 4 (64 sites) or 2 (32 sites, small batches)
 __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
     const _Float16* __restrict__ H0 /* padded to a multiple of 64 sites */, int64_t N,
     const _Float16* __restrict__ wih0, const _Float16* __restrict__ wih1,
@@ -736,11 +737,12 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
 {
     extern __shared__ h8 ldsh[];
     _Float16* const h0s = reinterpret_cast<_Float16*>(ldsh);                       // [2][64][R1_H0ROW]
-    _Float16* const h1x = h0s + 2 * 64 * R1_H0ROW;                                 // [2][64][R1_HROW]
+    constexpr int NS = 16 * NSG;                                                    // sites per workgroup
+    _Float16* const h1x = h0s + 2 * NS * R1_H0ROW;                                 // [2][NS][R1_HROW]
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
-    const int64_t base_site = (int64_t)blockIdx.x * 64;
+    const int64_t base_site = (int64_t)blockIdx.x * NS;
 
     // ---- this wave's two gate tiles -> registers ---------------------------------------------------
     h8 Wih[2][4][2], Whh[2][2][2];
@@ -763,39 +765,40 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
         }
     }
 
-    // ---- h0 staging: thread (row = tid / 8, piece = tid % 8) moves 64 bytes of its site's 512-byte row ----
-    const int srow = tid >> 3, spiece = tid & 7;
+    // ---- h0 staging: 512 / NS threads per site row, each moves NS bytes (NS / 16 h8) of the 512-byte row ----
+    constexpr int TPR = 512 / NS, SPT = NS / 16;                    // threads per row, h8 pieces per thread
+    const int srow = tid / TPR, spiece = tid % TPR;
     const int64_t ssite = base_site + srow;                         // H0 is padded: rows beyond N hold garbage that only
-    const h8* __restrict__ gsrc = reinterpret_cast<const h8*>(H0 + (ssite * PW) * (2 * 4 * 32)) + spiece * 4;   // feeds dead sites
-    h8 sreg[4];
+    const h8* __restrict__ gsrc = reinterpret_cast<const h8*>(H0 + (ssite * PW) * (2 * 4 * 32)) + spiece * SPT;   // feeds dead sites
+    h8 sreg[SPT];
     auto load_h0 = [&](int t) {
         const h8* p = gsrc + (int64_t)t * (2 * 4 * 32 / 8);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sreg[k] = p[k];
+        for (int k = 0; k < SPT; ++k) sreg[k] = p[k];
     };
     auto store_h0 = [&](int buf) {
-        h8* d = reinterpret_cast<h8*>(h0s + ((size_t)buf * 64 + srow) * R1_H0ROW + spiece * 32);
+        h8* d = reinterpret_cast<h8*>(h0s + ((size_t)buf * NS + srow) * R1_H0ROW + spiece * SPT * 8);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = sreg[k];
+        for (int k = 0; k < SPT; ++k) d[k] = sreg[k];
     };
     // h1_{-1} = 0 in the buffer step 0 reads
-    for (int i = tid; i < 64 * R1_HROW / 8; i += 512) reinterpret_cast<h8*>(h1x + (size_t)64 * R1_HROW)[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < NS * R1_HROW / 8; i += 512) reinterpret_cast<h8*>(h1x + (size_t)NS * R1_HROW)[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
     load_h0(dir ? PW - 1 : 0);
     store_h0(0);
     __syncthreads();
 
-    float c[8];
+    float c[2 * NSG];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) c[i] = 0.f;
-    h4 last_h[4];                                                   // [sg]: hi(u0,u1) lo(u0,u1) of the final step
+    for (int i = 0; i < 2 * NSG; ++i) c[i] = 0.f;
+    h4 last_h[NSG];                                                   // [sg]: hi(u0,u1) lo(u0,u1) of the final step
 
     for (int s = 0; s < PSTEPS1; ++s) {
         const int t = dir ? PW - 1 - s : s;
         const int cur = s & 1;
         if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
-        const _Float16* h0b = h0s + (size_t)cur * 64 * R1_H0ROW;
-        const _Float16* hrb = h1x + (size_t)(cur ^ 1) * 64 * R1_HROW;      // h1_{s-1}
-        _Float16* hwb = h1x + (size_t)cur * 64 * R1_HROW;                  // h1_s
+        const _Float16* h0b = h0s + (size_t)cur * NS * R1_H0ROW;
+        const _Float16* hrb = h1x + (size_t)(cur ^ 1) * NS * R1_HROW;      // h1_{s-1}
+        _Float16* hwb = h1x + (size_t)cur * NS * R1_HROW;                  // h1_s
 
         // piece P = sg * 6 + k: k < 4 input K block k (dir = k >> 1, half = k & 1), k >= 4 recurrent K block k - 4
         h8 fh[3], fl[3];
@@ -815,9 +818,9 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
         fetch(1, 1);
         f32x4 acc[2][2];
 #pragma unroll
-        for (int P = 0; P < 24; ++P) {
+        for (int P = 0; P < 6 * NSG; ++P) {
             const int sg = P / 6, k = P % 6, slot = P % 3, ab = sg & 1;
-            if (P + 2 < 24) fetch(P + 2, (P + 2) % 3);
+            if (P + 2 < 6 * NSG) fetch(P + 2, (P + 2) % 3);
             if (k == 0) { acc[ab][0] = bias[0]; acc[ab][1] = bias[1]; }
             if (k < 4) {
 #pragma unroll
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
     }
     // H1c: [site][dir][q][16 hi | 16 lo], entries m = 2 wave + u of row q (the layout K3 / K23 write)
 #pragma unroll
-    for (int sg = 0; sg < 4; ++sg) {
+    for (int sg = 0; sg < NSG; ++sg) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         _Float16* o = H1c + (((base_site + 16 * sg + n) * 2 + dir) * 4 + q) * 32 + 2 * wave;
         *reinterpret_cast<h2*>(o) = h2{last_h[sg][0], last_h[sg][1]};
@@ -1096,7 +1099,7 @@ static int set_lds_attr_f16(nsnp_ctx* ctx)
 #define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
     SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<6>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
     SET(k_pileup_proj1_h, P1H_LDS_BYTES);
-    SET(k_pileup_l1_rs, R1_LDS_BYTES);
+    SET(k_pileup_l1_rs<4>, r1_lds_bytes(4)); SET(k_pileup_l1_rs<2>, r1_lds_bytes(2));
     SET(k_pileup_l1f_h<4>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<8>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<12>, L1F_LDS_BYTES);
     SET(k_pileup_l1_h<8>, L1H_LDS_BYTES); SET(k_pileup_l1_h<4>, L1H_LDS_BYTES); SET(k_pileup_l1_h<2>, L1H_LDS_BYTES); SET(k_pileup_l1_h<1>, L1H_LDS_BYTES);
 #undef SET
@@ -1147,10 +1150,15 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         }
         if (ctx->fused_l1 && ctx->l1_rs) {
             ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
-            hipLaunchKernelGGL(k_pileup_l1_rs, dim3((unsigned)NSNP_CDIV(n, 64), 2), dim3(512), R1_LDS_BYTES, s, H0, n,
-                               (const _Float16*)pw.l1_wih_rs[0], (const _Float16*)pw.l1_wih_rs[1],
-                               (const _Float16*)pw.l1_whh_rs[0], (const _Float16*)pw.l1_whh_rs[1],
-                               (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c);
+            // 64 sites per workgroup when that still gives every CU a workgroup, else 32
+            int g1 = NSNP_CDIV(n, 64) * 2 >= (int64_t)ctx->n_cu ? 4 : 2;
+            if (ctx->l1_rs_groups) g1 = ctx->l1_rs_groups;
+#define LAUNCH_R1(G) hipLaunchKernelGGL(k_pileup_l1_rs<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(512), r1_lds_bytes(G), s, H0, n, \
+                               (const _Float16*)pw.l1_wih_rs[0], (const _Float16*)pw.l1_wih_rs[1], \
+                               (const _Float16*)pw.l1_whh_rs[0], (const _Float16*)pw.l1_whh_rs[1], \
+                               (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c)
+            if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2);
+#undef LAUNCH_R1
         } else if (ctx->fused_l1) {
             ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
             // one workgroup per CU: 12 waves when the batch fills the chip that way, else 8 or 4

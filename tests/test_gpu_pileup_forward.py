@@ -296,7 +296,13 @@ def test_register_stationary_layer1_kernel(pileup_weights):
     assert np.abs(ref[0][:256].cpu().numpy() - og).max() < PROB_ATOL and np.abs(ref[1][:256].cpu().numpy() - oz).max() < PROB_ATOL
     again = c.pileup_forward(x)
     assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
-    for n in (1, 63, 64, 65, 200):
+    for g in (2, 4, 0):                                         # 32 / 64 sites per workgroup / automatic
+        c.set_option("l1_site_groups", g)
+        got = c.pileup_forward(x)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), g
+    with pytest.raises(_lib.NanoSNPError):
+        c.set_option("l1_site_groups", 1)
+    for n in (1, 31, 32, 33, 63, 64, 65, 200):
         gn, zn = c.pileup_forward(x[:n].contiguous())
         assert torch.equal(gn, ref[0][:n]) and torch.equal(zn, ref[1][:n]), n
     c.close()
