@@ -874,18 +874,28 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
 // ---------------------------------------------------------------------------------------------
 // K4: heads, weights from L2 as fp16 hi/lo images.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pileup_head_h(
+// HW waves of 16 sites per workgroup share every weight image through one 64 KB LDS stage (proj, dense rows 0-127,
+// dense rows 128-255, heads): the images leave L2 once per workgroup instead of once per wave.
+constexpr int HEAD_WAVES = 8;
+constexpr int HEAD_STAGE_H8 = 8 * 4 * 2 * 64;           // 64 KB: 8 gate tiles x 4 K blocks x (hi, lo)
+__global__ __launch_bounds__(64 * HEAD_WAVES) void k_pileup_head_h(
     const _Float16* __restrict__ H1c, int64_t N,
     const _Float16* __restrict__ proj_w, const float* __restrict__ proj_b,
     const _Float16* __restrict__ dense_w, const float* __restrict__ dense_b,
     const _Float16* __restrict__ head_w, const float* __restrict__ head_b,
     float* __restrict__ gt_prob, float* __restrict__ zy_prob)
 {
+    __shared__ h8 wst[HEAD_STAGE_H8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4;
-    const int64_t site = ((int64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const int64_t site = ((int64_t)blockIdx.x * HEAD_WAVES + wave) * 16 + (lane & 15);
     const bool live = site < N;
     const int64_t sc = live ? site : N - 1;
+    auto stage = [&](const _Float16* src, int n_h8) {
+        __syncthreads();                                   // everyone is done with the previous image
+        copy_to_lds_h(wst, src, n_h8, tid, 64 * HEAD_WAVES);
+        __syncthreads();
+    };
     const h8* __restrict__ hin = reinterpret_cast<const h8*>(H1c + (sc * 2 * 4 + q) * 32);
     h8 bh[4], bl[4];
 #pragma unroll
@@ -898,7 +908,8 @@ __global__ __launch_bounds__(256) void k_pileup_head_h(
         const f32x4* pb = reinterpret_cast<const f32x4*>(proj_b);
 #pragma unroll
         for (int i = 0; i < 8; ++i) ap[i] = pb[i * 64 + lane];
-        wave_gemm_h<8, 4, 0, 4, 0, 4>(reinterpret_cast<const h8*>(proj_w), lane, bh, bl, ap);
+        stage(proj_w, 8 * 4 * 2 * 64);
+        wave_gemm_h<8, 4, 0, 4, 0, 4>(wst, lane, bh, bl, ap);
     }
     // dense 128 -> 256 + tanh: K position (kb, q, j) <-> proj feature 16*(2kb + (j>>2)) + 4q + (j&3)
     h8 dh[4], dl[4];
@@ -911,7 +922,10 @@ __global__ __launch_bounds__(256) void k_pileup_head_h(
         const f32x4* db = reinterpret_cast<const f32x4*>(dense_b);
 #pragma unroll
         for (int i = 0; i < 16; ++i) ad[i] = db[i * 64 + lane];
-        wave_gemm_h<16, 4, 0, 4, 0, 4>(reinterpret_cast<const h8*>(dense_w), lane, dh, dl, ad);
+        stage(dense_w, 8 * 4 * 2 * 64);
+        wave_gemm_h<8, 4, 0, 4, 0, 4>(wst, lane, dh, dl, ad);
+        stage(dense_w + (size_t)8 * 4 * 2 * 64 * 8, 8 * 4 * 2 * 64);
+        wave_gemm_h<8, 4, 0, 4, 0, 4>(wst, lane, dh, dl, ad + 8);
     }
     h8 eh[8], el[8];
 #pragma unroll
@@ -922,7 +936,8 @@ __global__ __launch_bounds__(256) void k_pileup_head_h(
     {
         const f32x4* hb = reinterpret_cast<const f32x4*>(head_b);
         ah[0] = hb[lane]; ah[1] = hb[64 + lane];
-        wave_gemm_h<2, 8, 0, 8, 0, 2>(reinterpret_cast<const h8*>(head_w), lane, eh, el, ah);
+        stage(head_w, 2 * 8 * 2 * 64);
+        wave_gemm_h<2, 8, 0, 8, 0, 2>(wst, lane, eh, el, ah);
     }
     const float NEG = -3.0e38f;
     float g0[4], g1[4];
@@ -1191,7 +1206,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         }
         }
         ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
-        hipLaunchKernelGGL(k_pileup_head_h, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, H1c, n,
+        hipLaunchKernelGGL(k_pileup_head_h, dim3((unsigned)NSNP_CDIV(n, 16 * HEAD_WAVES)), dim3(64 * HEAD_WAVES), 0, s, H1c, n,
                            (const _Float16*)pw.proj_w, p32.proj_b, (const _Float16*)pw.dense_w, p32.dense_b,
                            (const _Float16*)pw.head_w, p32.head_b, gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);
     }
