@@ -78,6 +78,14 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
                               const float* gt_prob, const float* zy_prob, const float* cov,
                               int score_mode, char* out, int64_t cap, int64_t* n_rows);
 
+/* All batches of the predict loop at once (N sites cut into consecutive batches of batch_size, the reference's DataLoader
+ * batches): byte-identical to nsnp_vcf_format_batch on each slice, formatted on nthreads OpenMP threads. */
+int64_t nsnp_vcf_format_batches(int64_t N, int64_t batch_size, const char* names_blob, const int64_t* name_off,
+                                const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                                const uint8_t* gt_arg, const uint8_t* zy_arg,
+                                const float* gt_prob, const float* zy_prob, const float* cov,
+                                int score_mode, char* out, int64_t cap, int64_t* n_rows, int nthreads);
+
 /* haplotype.csv rows (HaplotypeModel/predict_dev.py:40-47) */
 int64_t nsnp_hap_csv_format(int64_t N, const char* names_blob, const int64_t* name_off,
                             const int32_t* contig_id, const int64_t* pos, const uint8_t* gt_arg,

@@ -174,6 +174,51 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
 }
 
 /* HaplotypeModel/predict_dev.py:40-47: "ctg \t pos \t GT \t qual" with GT = gt_decoded_labels[argmax] */
+/* Every batch of the predict loop at once: rows of a batch depend only on that batch (the gt_output[ti] quirk indexes
+ * the batch's own argmax array), so the batches are formatted independently on `nthreads` OpenMP threads - a sizing pass,
+ * a prefix sum, a writing pass - and land in `out` in batch order, byte-identical to calling nsnp_vcf_format_batch on
+ * consecutive slices of `batch_size` sites (PileupModel/predict.py:45-47 DataLoader batches). */
+int64_t nsnp_vcf_format_batches(int64_t N, int64_t batch_size, const char* names_blob, const int64_t* name_off,
+                                const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                                const uint8_t* gt_arg, const uint8_t* zy_arg,
+                                const float* gt_prob, const float* zy_prob, const float* cov,
+                                int score_mode, char* out, int64_t cap, int64_t* n_rows, int nthreads)
+{
+    if (N < 0 || batch_size <= 0 || !name_off || !n_rows) return NSNP_HOST_EINVAL;
+    const int64_t nb = (N + batch_size - 1) / batch_size;
+    int64_t* size = (int64_t*)malloc(sizeof(int64_t) * (size_t)(2 * nb + 1));
+    if (!size) return NSNP_HOST_ENOMEM;
+    int64_t* rows = size + nb + 1;
+    if (nthreads <= 0) nthreads = 1;
+    int err = 0;
+    #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t j0 = b * batch_size, B = (N - j0 < batch_size) ? N - j0 : batch_size;
+        int64_t r = 0;
+        const int64_t need = nsnp_vcf_format_batch(B, names_blob, name_off, contig_id + j0, pos + j0, ref_base + j0, gt_arg + j0,
+                                                   zy_arg + j0, gt_prob + j0, zy_prob + j0, cov + j0 * 8, score_mode, NULL, 0, &r);
+        if (need < 0 && need > -16) { err = 1; size[b + 1] = 0; rows[b] = 0; }                  /* a real error code */
+        else { size[b + 1] = need < 0 ? -need - 16 : need; rows[b] = r; }
+    }
+    if (err) { free(size); return NSNP_HOST_EINVAL; }
+    size[0] = 0;
+    int64_t total_rows = 0;
+    for (int64_t b = 0; b < nb; ++b) { size[b + 1] += size[b]; total_rows += rows[b]; }
+    const int64_t total = size[nb];
+    *n_rows = total_rows;
+    if (!out || cap < total) { free(size); return -(total + 16); }
+    #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t j0 = b * batch_size, B = (N - j0 < batch_size) ? N - j0 : batch_size;
+        int64_t r = 0;
+        (void)nsnp_vcf_format_batch(B, names_blob, name_off, contig_id + j0, pos + j0, ref_base + j0, gt_arg + j0,
+                                    zy_arg + j0, gt_prob + j0, zy_prob + j0, cov + j0 * 8, score_mode,
+                                    out + size[b], size[b + 1] - size[b], &r);
+    }
+    free(size);
+    return total;
+}
+
 int64_t nsnp_hap_csv_format(int64_t N, const char* names_blob, const int64_t* name_off,
                             const int32_t* contig_id, const int64_t* pos, const uint8_t* gt_arg,
                             const float* gt_prob, int score_mode, char* out, int64_t cap)

@@ -190,6 +190,9 @@ def _bind_vcf():
     l.nsnp_vcf_format_batch.restype = C.c_int64
     l.nsnp_vcf_format_batch.argtypes = [C.c_int64, C.c_char_p, p, p, p, p, p, p, p, p, p, C.c_int, p, C.c_int64,
                                         C.POINTER(C.c_int64)]
+    l.nsnp_vcf_format_batches.restype = C.c_int64
+    l.nsnp_vcf_format_batches.argtypes = [C.c_int64, C.c_int64, C.c_char_p, p, p, p, p, p, p, p, p, p, C.c_int, p, C.c_int64,
+                                          C.POINTER(C.c_int64), C.c_int]
     l.nsnp_hap_csv_format.restype = C.c_int64
     l.nsnp_hap_csv_format.argtypes = [C.c_int64, C.c_char_p, p, p, p, p, p, C.c_int, p, C.c_int64]
     l.nsnp_calculate_score.restype = C.c_double
@@ -230,6 +233,30 @@ def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, z
             return buf[:n].tobytes(), rows.value
         if n > -16:
             _check(n, "nsnp_vcf_format_batch")
+        cap = -int(n)
+
+
+def vcf_format_batches(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, batch_size=1000,
+                       score_mode=SCORE_FLOAT32, nthreads=None):
+    """All batches of the predict loop in one native call (OpenMP over batches) -> (bytes, n_rows); byte-identical to
+    concatenating vcf_format_batch over consecutive slices of batch_size sites."""
+    l = _bind_vcf()
+    N = len(pos)
+    args = [np.ascontiguousarray(contig_id, np.int32), np.ascontiguousarray(pos, np.int64),
+            np.ascontiguousarray(ref_base, np.uint8), np.ascontiguousarray(gt_arg, np.uint8),
+            np.ascontiguousarray(zy_arg, np.uint8), np.ascontiguousarray(gt_prob, np.float32),
+            np.ascontiguousarray(zy_prob, np.float32), np.ascontiguousarray(cov, np.float32)]
+    nthreads = int(nthreads or min(64, os.cpu_count() or 1))
+    cap = 128 * N + 256
+    rows = C.c_int64(0)
+    while True:
+        buf = np.empty(cap, np.uint8)
+        n = l.nsnp_vcf_format_batches(N, int(batch_size), table.blob, _ptr(table.off), *[_ptr(a) for a in args], int(score_mode),
+                                      _ptr(buf), cap, C.byref(rows), nthreads)
+        if n >= 0:
+            return buf[:n].tobytes(), rows.value
+        if n > -16:
+            _check(n, "nsnp_vcf_format_batches")
         cap = -int(n)
 
 

@@ -17,7 +17,7 @@ COV_CHANNELS = [0, 1, 2, 3, 9, 10, 11, 12]        # predict.py:63
 
 
 def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text, output_file,
-                   batch_size=1000, score_mode=host.SCORE_FLOAT32):
+                   batch_size=1000, score_mode=host.SCORE_FLOAT32, device_batch=65536):
     """model: nanosnp_amd.pileup_model.LSTMNetwork; x: int32 [N,33,18] (numpy or cuda tensor);
     contig_names/positions/reference_bases: what PredictDataset yields (dataset.py:141-146).
     Returns the number of VCF rows written."""
@@ -29,20 +29,25 @@ def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text,
     pos = np.asarray(positions, np.int64)
     refb = np.asarray(reference_bases, np.uint8)
     n = xt.shape[0]
-    rows = 0
     cov_idx = torch.tensor(COV_CHANNELS, device=xt.device)
+    # device part in passes of `device_batch` sites; the text rows are then produced for the reference's batches of
+    # `batch_size` sites (a row can depend on its batch: nsnp_vcf.c) by one native call, OpenMP over the batches
+    outs = []
+    for b0 in range(0, n, device_batch):
+        xb = xt[b0:b0 + device_batch]
+        gt, zy = model.predict(xb)
+        ga, za, gm, zm, _ = ctx.pileup_postprocess(gt, zy)
+        cov = xb[:, 16, :].index_select(1, cov_idx).to(torch.float32)            # predict.py:63 on a FloatTensor
+        outs.append((ga, za, gm, zm, cov))
+    if outs:
+        ga, za, gm, zm, cov = [torch.cat([o[i] for o in outs]).cpu().numpy() for i in range(5)]
+    else:
+        ga = za = np.empty(0, np.uint8); gm = zm = np.empty(0, np.float32); cov = np.empty((0, 8), np.float32)
+    text, rows = host.vcf_format_batches(table, table.ids, pos, refb, ga, za, gm, zm, cov, batch_size=batch_size,
+                                         score_mode=score_mode)
     with open(output_file, "wb") as f:
         f.write(host.vcf_header(fai_text).encode())
-        for b0 in range(0, n, batch_size):
-            xb = xt[b0:b0 + batch_size]
-            gt, zy = model.predict(xb)
-            ga, za, gm, zm, _ = ctx.pileup_postprocess(gt, zy)
-            cov = xb[:, 16, :].index_select(1, cov_idx).to(torch.float32)        # predict.py:63 on a FloatTensor
-            text, r = host.vcf_format_batch(table, table.ids[b0:b0 + batch_size], pos[b0:b0 + batch_size],
-                                            refb[b0:b0 + batch_size], ga.cpu().numpy(), za.cpu().numpy(),
-                                            gm.cpu().numpy(), zm.cpu().numpy(), cov.cpu().numpy(), score_mode)
-            f.write(text)
-            rows += r
+        f.write(text)
     return rows
 
 
