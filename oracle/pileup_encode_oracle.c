@@ -180,12 +180,14 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
         int first = del[k].len ? (unsigned char)del[k].p[0] : 0;
         if (is_fwd(first)) { t[ORC_CH_D] += cnt; if (cnt > max_del_0) max_del_0 = cnt; }
         else               { t[ORC_CH_d] += cnt; if (cnt > max_del_1) max_del_1 = cnt; }
-        if (alts) { /* "D" + the reference bases that follow the position (tensor_maker.cpp:150-155) */
+        if (alts) { /* "D" + the reference bases that follow the position (tensor_maker.cpp:150-155).  Past the end of the
+                     * contig the reference reads the NUL that terminates its sequence buffer; the key keeps that byte
+                     * (it sorts before every base) and the C-string output of alt_info stops there (see below). */
             alt_t_* a = &alts[n_alt++];
             a->len = 1 + del[k].len; a->s = (char*)malloc((size_t)a->len + 1);
             a->s[0] = 'D';
             for (int q = 0; q < del[k].len; ++q)
-                a->s[1 + q] = (next_ref && q < n_next) ? next_ref[q] : 'N';
+                a->s[1 + q] = (next_ref && q < n_next) ? next_ref[q] : '\0';
             a->count = cnt;
         }
     }
@@ -270,16 +272,24 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
         }
         n_alt = m;
         size_t w = 0;
+        int cut = 0;                                   /* a NUL inside a key ends the reference's "%s" output */
         for (int k = 0; k < n_alt; ++k) {
-            char num[16]; int nn = snprintf(num, sizeof num, "%d", alts[k].count);
-            size_t piece = (size_t)alts[k].len + 1 + (size_t)nn + 1;
-            if (w + piece < alt_cap) {
-                memcpy(alt_info + w, alts[k].s, (size_t)alts[k].len); w += (size_t)alts[k].len;
-                alt_info[w++] = ' ';
-                memcpy(alt_info + w, num, (size_t)nn); w += (size_t)nn;
-                alt_info[w++] = ' ';
+            if (!cut) {
+                char num[16]; int nn = snprintf(num, sizeof num, "%d", alts[k].count);
+                const void* z = memchr(alts[k].s, 0, (size_t)alts[k].len);
+                const size_t klen = z ? (size_t)((const char*)z - alts[k].s) : (size_t)alts[k].len;
+                const size_t piece = z ? klen : klen + 1 + (size_t)nn + 1;
+                if (w + piece < alt_cap) {
+                    memcpy(alt_info + w, alts[k].s, klen); w += klen;
+                    if (!z) {
+                        alt_info[w++] = ' ';
+                        memcpy(alt_info + w, num, (size_t)nn); w += (size_t)nn;
+                        alt_info[w++] = ' ';
+                    }
+                }
+                need += piece;
+                if (z) cut = 1;
             }
-            need += piece;
             free(alts[k].s);
         }
         if (alt_cap) alt_info[w < alt_cap ? w : alt_cap - 1] = 0;

@@ -29,7 +29,7 @@ def test_array_container_round_trip(tmp_path):
         sitefile.read_arrays(tmp_path / "junk.bin")
 
 
-@pytest.mark.parametrize("name", ["encode_g1", "encode_adv"])
+@pytest.mark.parametrize("name", ["encode_g1", "encode_adv", "encode_end"])
 def test_pd_to_bin_holds_what_the_reference_bin_holds(tmp_path, name):
     """make_bin_predict_data.py:48-77 (text -> arrays) followed by PileupModel/dataset.py:118-139 (arrays -> fields),
     restated below, against the native .pd parser of the device pipeline"""
@@ -38,7 +38,7 @@ def test_pd_to_bin_holds_what_the_reference_bin_holds(tmp_path, name):
     n = sitefile.pd_to_bin(pd, p)
     names, pos, refb, x = sitefile.read_pileup_bin(p)
     x2, names2, pos2, refb2 = host.pd_parse(pd)
-    assert n == len(names) == x2.shape[0] and n > 100
+    assert n == len(names) == x2.shape[0] and n > 50
     assert np.array_equal(x, x2) and names == names2 and np.array_equal(pos, pos2) and np.array_equal(refb, refb2)
     # the reference's own transformation of each line
     lines = [l for l in pd.decode().split("\n") if l.strip()]

@@ -141,7 +141,16 @@ def group_encode():
     acols = adversarial_columns(rng, M2, seq2)
     text_b = b"".join(b"chrT\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c.encode(), b"I")
                       for i, c in enumerate(acols) if c)
-    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b)):
+    # (c) a short contig whose long deletions run past its end: the reference reads the NUL behind its sequence
+    #     buffer into the alt_dict key and its "%s" output of alt_info stops there (tensor_maker.cpp:150-155)
+    M3 = 240
+    seq3 = rng.choice(list(b"ACGT"), M3).astype(np.uint8)
+    ecols = adversarial_columns(rng, M3, seq3)
+    for i in range(120, M3):
+        if i % 3 == 0:
+            ecols[i] += "".join(f"-{L}{'ACGTN' * 12}"[:len(str(L)) + 1 + L] for L in (int(rng.choice([30, 59, 60])), 45)) * 3
+    text_c = b"".join(b"chrE\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c.encode(), b"I") for i, c in enumerate(ecols) if c)
+    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b), ("end", "chrE", seq3, text_c)):
         with tempfile.TemporaryDirectory() as d:
             fa = os.path.join(d, "ref.fa")
             host.write_fasta(fa, contig, sq)
