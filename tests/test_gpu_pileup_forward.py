@@ -306,3 +306,38 @@ def test_register_stationary_layer1_kernel(pileup_weights):
         gn, zn = c.pileup_forward(x[:n].contiguous())
         assert torch.equal(gn, ref[0][:n]) and torch.equal(zn, ref[1][:n]), n
     c.close()
+
+
+def test_forward_is_capturable_in_a_hip_graph(pileup_weights):
+    """after one warm-up call (workspace, LDS attributes) encode + forward + postprocess make no allocation and no
+    synchronisation: the sequence can be captured once and replayed (include/nanosnp.h: nsnp_ctx_reserve)"""
+    import torch
+    from nanosnp_amd import _lib, host
+    c = _lib.Context(0, chunk_sites=4096)
+    c.pileup_load_weights(pileup_weights)
+    cols = host.synth_columns(5, 33 * 1024, coverage=30, window=33)
+    b = torch.from_numpy(cols.bases).cuda(); off = torch.from_numpy(cols.col_off).cuda(); rf = torch.from_numpy(cols.ref).cuda()
+    centers = (torch.arange(1024, dtype=torch.int64, device="cuda") * 33 + 16)
+    counts, depth, flags = c.pileup_encode_columns(b, off, rf)
+    gt = torch.empty((1024, 21), device="cuda"); zy = torch.empty((1024, 3), device="cuda")
+    c.pileup_forward_windows(counts, centers, gt, zy)            # warm-up
+    want = (gt.clone(), zy.clone())
+    torch.cuda.synchronize()
+    P = __import__("ctypes").c_void_p
+    lib = _lib.load()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            sp = P(torch.cuda.current_stream().cuda_stream)
+            rc = lib.nsnp_pileup_encode_columns(c.handle, P(b.data_ptr()), P(off.data_ptr()), P(rf.data_ptr()), 33 * 1024,
+                                                __import__("ctypes").c_double(0.12), 6, P(counts.data_ptr()), P(depth.data_ptr()),
+                                                P(flags.data_ptr()), sp)
+            rc = rc or lib.nsnp_pileup_forward_windows(c.handle, P(counts.data_ptr()), P(centers.data_ptr()), 1024, P(gt.data_ptr()), P(zy.data_ptr()), sp)
+            assert rc == 0
+    for _ in range(3):
+        gt.zero_(); zy.zero_(); counts.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gt, want[0]) and torch.equal(zy, want[1])
+    c.close()
