@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES + 3) / 4) void k_pileup_l1f_h(
 // ---------------------------------------------------------------------------------------------
 constexpr int R1_H0ROW = 264;                // halves per staged h0 row: [dir][q][16 hi | 16 lo] = 512 B + 16 B pad
 constexpr int R1_HROW = 136;                 // halves per h1 exchange row: 64 hi | 64 lo | pad
-constexpr int r1_lds_bytes(int nsg) { return 3 * 16 * nsg * R1_H0ROW * 2 + 2 * 16 * nsg * R1_HROW * 2 + 64; }
+constexpr int r1_lds_bytes(int nsg) { return 2 * 16 * nsg * R1_H0ROW * 2 + 2 * 16 * nsg * R1_HROW * 2; }
 
 template <int NSG>          // 16-site groups per workgroup: 4 (64 sites) or 2 (32 sites, small batches)
 __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
@@ -738,8 +738,7 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
     extern __shared__ h8 ldsh[];
     _Float16* const h0s = reinterpret_cast<_Float16*>(ldsh);                       // [2][64][R1_H0ROW]
     constexpr int NS = 16 * NSG;                                                    // sites per workgroup
-    _Float16* const h1x = h0s + 3 * NS * R1_H0ROW;                                 // [2][NS][R1_HROW]
-    int* const arrived = reinterpret_cast<int*>(h1x + 2 * NS * R1_HROW);           // waves that finished a step (monotonic)
+    _Float16* const h1x = h0s + 2 * NS * R1_H0ROW;                                 // [2][NS][R1_HROW]
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -782,25 +781,10 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
 #pragma unroll
         for (int k = 0; k < SPT; ++k) d[k] = sreg[k];
     };
-    // Workgroup synchronisation is split: a wave "arrives" (LDS counter) when its h1_s slice and its share of the staged
-    // h0 rows are written, and only waits for the other seven right before it requests its first recurrent fragment of
-    // the next step - the 16 input pieces (96 MFMAs) in front of that point need h0 rows that were staged two steps ago,
-    // so the skew between waves is absorbed by useful work instead of an s_barrier.
-    auto arrive = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto wait_for = [&](int target) {
-        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    if (tid == 0) *arrived = 0;
     // h1_{-1} = 0 in the buffer step 0 reads
     for (int i = tid; i < NS * R1_HROW / 8; i += 512) reinterpret_cast<h8*>(h1x + (size_t)NS * R1_HROW)[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
     load_h0(dir ? PW - 1 : 0);
     store_h0(0);
-    load_h0(dir ? PW - 2 : 1);
-    store_h0(1);
     __syncthreads();
 
     float c[2 * NSG];
@@ -811,65 +795,57 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
     for (int s = 0; s < PSTEPS1; ++s) {
         const int t = dir ? PW - 1 - s : s;
         const int cur = s & 1;
-        if (s + 2 < PSTEPS1) load_h0(dir ? t - 2 : t + 2);
-        const _Float16* h0b = h0s + (size_t)(s % 3) * NS * R1_H0ROW;
+        if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
+        const _Float16* h0b = h0s + (size_t)cur * NS * R1_H0ROW;
         const _Float16* hrb = h1x + (size_t)(cur ^ 1) * NS * R1_HROW;      // h1_{s-1}
         _Float16* hwb = h1x + (size_t)cur * NS * R1_HROW;                  // h1_s
 
-        // piece order: the 4 NSG input pieces (sg, K block k: dir = k >> 1, half = k & 1), then per site group its two
-        // recurrent K blocks followed by its cell.  Fragments are requested two pieces ahead.
-        constexpr int NIH = 4 * NSG, NP = 6 * NSG;
+        // piece P = sg * 6 + k: k < 4 input K block k (dir = k >> 1, half = k & 1), k >= 4 recurrent K block k - 4
         h8 fh[3], fl[3];
         auto fetch = [&](int P, int slot) {
-            if (P < NIH) {
-                const int sg = P >> 2, k = P & 3;
+            const int sg = P / 6, k = P % 6;
+            if (k < 4) {
                 const _Float16* r = h0b + (size_t)(16 * sg + n) * R1_H0ROW + (k >> 1) * 128 + q * 32 + (k & 1) * 8;
                 fh[slot] = *reinterpret_cast<const h8*>(r);
                 fl[slot] = *reinterpret_cast<const h8*>(r + 16);
             } else {
-                const int sg = (P - NIH) >> 1, k = (P - NIH) & 1;
-                const _Float16* r = hrb + (size_t)(16 * sg + n) * R1_HROW + k * 32 + q * 8;
+                const _Float16* r = hrb + (size_t)(16 * sg + n) * R1_HROW + (k - 4) * 32 + q * 8;
                 fh[slot] = *reinterpret_cast<const h8*>(r);
                 fl[slot] = *reinterpret_cast<const h8*>(r + 64);
             }
         };
         fetch(0, 0);
         fetch(1, 1);
-        f32x4 acc[NSG][2];
+        f32x4 acc[2][2];
 #pragma unroll
-        for (int P = 0; P < NP; ++P) {
-            const int slot = P % 3;
-            if (P + 2 < NP) {
-                if (P + 2 == NIH && s > 0) wait_for(8 * s);                 // everyone's h1_{s-1} is in LDS
-                fetch(P + 2, (P + 2) % 3);
+        for (int P = 0; P < 6 * NSG; ++P) {
+            const int sg = P / 6, k = P % 6, slot = P % 3, ab = sg & 1;
+            if (P + 2 < 6 * NSG) fetch(P + 2, (P + 2) % 3);
+            if (k == 0) { acc[ab][0] = bias[0]; acc[ab][1] = bias[1]; }
+            if (k < 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Wih[u][k][0], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Wih[u][k][1], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Wih[u][k][0], fl[slot], acc[ab][u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Whh[u][k - 4][0], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Whh[u][k - 4][1], fh[slot], acc[ab][u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[ab][u] = mfma_h(Whh[u][k - 4][0], fl[slot], acc[ab][u]);
             }
-            if (P < NIH) {
-                const int sg = P >> 2, k = P & 3;
-                if (k == 0) { acc[sg][0] = bias[0]; acc[sg][1] = bias[1]; }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[sg][u] = mfma_h(Wih[u][k][0], fh[slot], acc[sg][u]);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[sg][u] = mfma_h(Wih[u][k][1], fh[slot], acc[sg][u]);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[sg][u] = mfma_h(Wih[u][k][0], fl[slot], acc[sg][u]);
-                continue;
-            }
-            const int sg = (P - NIH) >> 1, k = (P - NIH) & 1;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) acc[sg][u] = mfma_h(Whh[u][k][0], fh[slot], acc[sg][u]);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) acc[sg][u] = mfma_h(Whh[u][k][1], fh[slot], acc[sg][u]);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) acc[sg][u] = mfma_h(Whh[u][k][0], fl[slot], acc[sg][u]);
-            if (k == 1) {
+            if (k == 5) {
                 // cell of site group sg: lane (n, q) holds units 4 (2 wave + u) + q, u = 0, 1
                 _Float16 hi[2], lo[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sg][u][0]));
-                    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sg][u][1]));
-                    const float gk = __builtin_fmaf(-2.0f * RS_K, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sg][u][2])), RS_K);
-                    const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[sg][u][3]));
+                    const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][0]));
+                    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][1]));
+                    const float gk = __builtin_fmaf(-2.0f * RS_K, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][2])), RS_K);
+                    const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[ab][u][3]));
                     const float cn = __builtin_fmaf(fg, c[2 * sg + u], ig * gk);
                     c[2 * sg + u] = cn;
                     const float h = og * __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn)), 1.0f);
@@ -882,8 +858,8 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
                 last_h[sg] = h4{hi[0], hi[1], lo[0], lo[1]};
             }
         }
-        if (s + 2 < PSTEPS1) store_h0((s + 2) % 3);
-        arrive();
+        if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
+        lds_barrier();
     }
     // H1c: [site][dir][q][16 hi | 16 lo], entries m = 2 wave + u of row q (the layout K3 / K23 write)
 #pragma unroll
