@@ -8,10 +8,14 @@ from tests.helpers import PROB_ATOL, golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def model(gpu_ctx, pileup_weights):
+@pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
+def model(request, gpu_ctx, pileup_weights):
+    """the tests of this module that take `model` run in both precision modes: f16x3 (library default) and exact fp32"""
     gpu_ctx.pileup_load_weights(pileup_weights)
-    return gpu_ctx
+    gpu_ctx.set_option("pileup_precision", request.param)
+    gpu_ctx.test_precision = request.param
+    yield gpu_ctx
+    gpu_ctx.set_option("pileup_precision", 1)
 
 
 def _fwd(ctx, x_np):
@@ -72,6 +76,7 @@ def test_sites_are_independent_and_chunking_is_invisible(model, pileup_weights):
     assert torch.equal(gtp, gt[perm]) and torch.equal(zyp, zy[perm])
     small = _lib.Context(0, chunk_sites=1000)        # forces 5 internal chunks
     small.pileup_load_weights(pileup_weights)
+    small.set_option("pileup_precision", model.test_precision)
     gts, zys = small.pileup_forward(x)
     assert torch.equal(gts, gt) and torch.equal(zys, zy)
     sub, _ = model.pileup_forward(x[100:133].contiguous())
@@ -151,6 +156,7 @@ def test_workgroup_shape_does_not_change_results(model, pileup_weights):
     ref_gt, ref_zy = model.pileup_forward(x)
     c = _lib.Context(0)
     c.pileup_load_weights(pileup_weights)
+    c.set_option("pileup_precision", model.test_precision)
     for w in (1, 2, 4, 8):
         c.set_option("recurrence_waves", w)
         gt, zy = c.pileup_forward(x)
