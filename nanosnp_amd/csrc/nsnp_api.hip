@@ -38,7 +38,9 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->device = device;
     ctx->last_err = hipSuccess;
     ctx->chunk_sites = 32768;
-    ctx->precision = 1;
+    ctx->precision = 1;          // f16x3 is the default of all three model forwards; 0 selects the exact fp32 MFMA paths
+    ctx->hap_precision = 1;
+    ctx->cat_precision = 1;
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
     ctx->l0_rs = 1;

@@ -9,11 +9,15 @@ pytestmark = pytest.mark.gpu
 PROB_ATOL = 1e-4        # BASELINE.json north_star tolerance on probabilities
 
 
-@pytest.fixture(scope="module")
-def cat_model(gpu_ctx):
+@pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
+def cat_model(request, gpu_ctx):
+    """the forward tests run in both modes: f16x3 (library default) and exact fp32"""
     ws = seeded_cat_weights(21)
     gpu_ctx.cat_load_weights(ws)
-    return gpu_ctx, ws
+    gpu_ctx.set_option("cat_precision", request.param)
+    gpu_ctx.test_cat_precision = request.param
+    yield gpu_ctx, ws
+    gpu_ctx.set_option("cat_precision", 1)
 
 
 def _fwd(ctx, g0, g1):
@@ -51,6 +55,7 @@ def test_cat_forward_f16x3_mode(cat_model):
     ctx, ws = cat_model
     z = np.load(golden("cat_fwd.npz"))
     g0, g1 = synth_cat_groups(555, 200)
+    ctx.set_option("cat_precision", 0)
     ref32 = _fwd(ctx, g0, g1)
     ctx.set_option("cat_precision", 1)
     try:
@@ -63,7 +68,7 @@ def test_cat_forward_f16x3_mode(cat_model):
         assert np.abs(got - oracle.cat_forward(ws, g0, g1, nthreads=8)).max() < PROB_ATOL
         assert np.array_equal(got, _fwd(ctx, g0, g1))            # run-to-run deterministic
     finally:
-        ctx.set_option("cat_precision", 0)
+        ctx.set_option("cat_precision", ctx.test_cat_precision)
 
 
 def test_cat_forward_multi_chunk_consistency(cat_model):

@@ -51,12 +51,15 @@ def test_mixed_hp_rows_and_large_values(gpu_ctx):
 
 
 # ---- HaplotypeModel forward -------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def hap_model(gpu_ctx):
+@pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
+def hap_model(request, gpu_ctx):
+    """the forward tests run in both modes: f16x3 (library default) and exact fp32"""
     from tests.helpers import seeded_hap_weights
     ws = seeded_hap_weights(12, H=256)
     gpu_ctx.hap_load_weights(ws)
-    return gpu_ctx, ws
+    gpu_ctx.set_option("hap_precision", request.param)
+    yield gpu_ctx, ws
+    gpu_ctx.set_option("hap_precision", 1)
 
 
 def _hfwd(ctx, xp, xh):
@@ -162,6 +165,7 @@ def test_hap_forward_f16x3_mode(gpu_ctx):
     c = _lib.Context(0)
     c.hap_load_weights(ws)
     z = np.load(golden("hap_fwd_h256.npz"))
+    c.set_option("hap_precision", 0)
     g32, z32 = _hfwd(c, z["xp"], z["xh"])
     c.set_option("hap_precision", 1)
     g16, z16 = _hfwd(c, z["xp"], z["xh"])
