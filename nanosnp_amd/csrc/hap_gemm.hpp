@@ -72,7 +72,13 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
     __shared__ float Bs[2][TS][LDK];
     const StepArgs& a = L.z[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    // Wave mapping: 2 x 2 waves of 64 rows x 64 sites; CONV launches with at most 64 output rows (C_out 32 / 64) use
+    // 1 x 4 waves of 64 rows x 32 sites instead, so that no wave multiplies padding rows (and one row tile at C_out <= 32).
+    const bool small_rows = CONV && L.z[blockIdx.z].n_rows <= 64;
+    const int wr = small_rows ? 0 : wave >> 1, wc = wave & 1;
+    const int nct = small_rows ? 1 : 2;
+    const int nrt = (CONV && L.z[blockIdx.z].n_rows <= 32) ? 1 : 2;
+    const int site0 = small_rows ? 32 * wave : 64 * wc;              // first site of the wave's tile(s)
     const int li = lane & 31, lh = lane >> 5;
     const int bx = blockIdx.x;          // site tile
     const int by = blockIdx.y;          // row tile
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const float* p = &Bs[cur][64 * wc + 32 * ct + li][F16 ? lh * 4 : lh * 8];
+            const float* p = &Bs[cur][site0 + 32 * ct + li][F16 ? lh * 4 : lh * 8];
             bf[ct][0] = *reinterpret_cast<const f32x4*>(p);
             bf[ct][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
         }
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
+                        if (CONV && (ct >= nct || rt >= nrt)) continue;
                         const h8 av = __builtin_bit_cast(h8, af[rt][term == 1 ? 1 : 0]);
                         const h8 bv = __builtin_bit_cast(h8, bf[ct][term == 2 ? 1 : 0]);
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[rt][ct], 0, 0, 0);
@@ -166,9 +173,11 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (CONV && (ct >= nct || rt >= nrt)) continue;
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3],
                                                                             acc[rt][ct], 0, 0, 0);
+                    }
         }
         if (kc + 1 < nk) lstore(cur ^ 1, ga0, ga1, gb0, gb1);
         __syncthreads();
@@ -221,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
         // plain rows: feature f = 128*by + 64*wr + 32*rt + (g + 8*r4 + 4*lh); natural order in chunks of 16
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const int site = 64 * wc + 32 * ct + li;
+            if (CONV && ct >= nct) continue;
+            const int site = site0 + 32 * ct + li;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
