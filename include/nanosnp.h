@@ -153,6 +153,12 @@ int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_t* bq, cons
                       const int32_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
                       float* out, void* stream);
 
+/* The same reduction on int8 read planes (every value of the four planes fits: base codes -2..4, HP -2..3, base
+ * quality <= 93, mapping quality <= 60 with -2 as padding): a quarter of the bytes over PCIe and from HBM.  Results are
+ * bit-identical to nsnp_hap_features on the widened planes.  ref_row stays int32 [N,L]. */
+int nsnp_hap_features_i8(nsnp_ctx* ctx, const int8_t* seq, const int8_t* bq, const int8_t* mq, const int8_t* hap,
+                         const int32_t* ref_row, int64_t N, int D, int L, float* out, void* stream);
+
 /* Read arrangement of the stage-4 generator (create_pileup_haplotype.py:140-207, write_to_bins.py:15-61):
  * per site keep the reads whose base at the centre column is non-zero, order them by the HP tag at
  * the centre column (ties keep input order), pad with -2 to D_out rows, cut at D_out.  Inputs are

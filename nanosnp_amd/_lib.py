@@ -43,6 +43,7 @@ _SIGNATURES = {
     "nsnp_pileup_gather_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p]),
     "nsnp_hap_features": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nsnp_hap_features_i8": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nsnp_hap_arrange_reads": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "nsnp_hap_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int] + [C.c_int] * 5),
     "nsnp_hap_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -237,9 +238,19 @@ class Context:
 
     # ---- HaplotypeModel ----------------------------------------------------------------------
     def hap_features(self, seq, bq, mq, hap, ref_row, stream=None):
+        """int32 planes (the reference's bins) or int8 planes (nsnp_hap_features_i8: a quarter of the bytes); ref_row int32"""
         import torch
         n, d, l = seq.shape
         out = torch.empty((n, 105, l), dtype=torch.float32, device=seq.device)
+        if seq.dtype == torch.int8:
+            if not (bq.dtype == mq.dtype == hap.dtype == torch.int8):
+                raise NanoSNPError("hap_features: the four read planes must share one dtype (int32 or int8)")
+            if ref_row.dtype != torch.int32:
+                raise NanoSNPError("hap_features: ref_row must be int32")
+            check(self.lib.nsnp_hap_features_i8(self.handle, _dptr(seq), _dptr(bq), _dptr(mq), _dptr(hap), _dptr(ref_row),
+                                                n, d, l, _dptr(out), _stream_ptr(stream)),
+                  self.handle, "nsnp_hap_features_i8")
+            return out
         check(self.lib.nsnp_hap_features(self.handle, _dptr(seq), _dptr(bq), _dptr(mq), _dptr(hap), _dptr(ref_row),
                                          n, d, l, _dptr(out), _stream_ptr(stream)),
               self.handle, "nsnp_hap_features")

@@ -18,9 +18,12 @@ constexpr int HF_BLOCK = 256;
 constexpr int HF_MAX_L = 64;
 constexpr int NSTAT = 13;          // per read set: cnt A C G T D, baseq sum A C G T, mapq sum A C G T
 
+// PT: element type of the read planes, int32 (what the reference's bins hold) or int8 (every value of the four planes
+// fits: base codes -2..4, HP -2..3, base quality <= 93, mapping quality <= 60; a quarter of the PCIe and HBM bytes)
+template <typename PT>
 __global__ __launch_bounds__(HF_BLOCK) void k_hap_features(
-    const int32_t* __restrict__ seq, const int32_t* __restrict__ bq, const int32_t* __restrict__ mq,
-    const int32_t* __restrict__ hap, const int32_t* __restrict__ ref_row, int D, int L, float* __restrict__ out)
+    const PT* __restrict__ seq, const PT* __restrict__ bq, const PT* __restrict__ mq,
+    const PT* __restrict__ hap, const int32_t* __restrict__ ref_row, int D, int L, float* __restrict__ out)
 {
     extern __shared__ unsigned long long hf_lds[];
     unsigned long long* sums = hf_lds;                                   // [4][NSTAT][L] int64
@@ -101,9 +104,10 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hap_features(
 
 }  // namespace
 
-extern "C" int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_t* bq, const int32_t* mq,
-                                 const int32_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
-                                 float* out, void* stream)
+namespace {
+template <typename PT>
+int hap_features_impl(nsnp_ctx* ctx, const PT* seq, const PT* bq, const PT* mq, const PT* hap, const int32_t* ref_row,
+                      int64_t N, int D, int L, float* out, void* stream)
 {
     if (!ctx || N < 0 || D <= 0 || L <= 0 || L > HF_MAX_L) return NSNP_EINVAL;
     if (N > 0 && (!seq || !bq || !mq || !hap || !ref_row || !out)) return NSNP_EINVAL;
@@ -111,8 +115,23 @@ extern "C" int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_
     const size_t lds = (size_t)4 * NSTAT * L * 8 + (size_t)D * 4;
     if (lds > 64 * 1024) return NSNP_ESHAPE;
     ScopedKernelTimer tm(ctx, NSNP_K_HAPFEAT, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_hap_features, dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_hap_features<PT>, dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream,
                        seq, bq, mq, hap, ref_row, D, L, out);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
+}
+}  // namespace
+
+extern "C" int nsnp_hap_features(nsnp_ctx* ctx, const int32_t* seq, const int32_t* bq, const int32_t* mq,
+                                 const int32_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
+                                 float* out, void* stream)
+{
+    return hap_features_impl<int32_t>(ctx, seq, bq, mq, hap, ref_row, N, D, L, out, stream);
+}
+
+extern "C" int nsnp_hap_features_i8(nsnp_ctx* ctx, const int8_t* seq, const int8_t* bq, const int8_t* mq,
+                                    const int8_t* hap, const int32_t* ref_row, int64_t N, int D, int L,
+                                    float* out, void* stream)
+{
+    return hap_features_impl<int8_t>(ctx, seq, bq, mq, hap, ref_row, N, D, L, out, stream);
 }

@@ -60,11 +60,17 @@ def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions,
     ctgs, poss = zip(*[p.split(":") for p in candidate_positions]) if n else ((), ())
     table = host.ContigTable(list(ctgs))
     pos = np.array([int(p) for p in poss], np.int64)
+    # read planes handed over as int8 arrays (every value fits: base codes, HP, qualities <= 93, padding -2) cross PCIe
+    # and HBM at a quarter of the bytes, same features bit for bit (nsnp_hap_features_i8); reference rows stay int32
+    def dtypes(planes):
+        narrow = all(a.dtype == np.int8 for a in planes[:4])
+        return [np.dtype(np.int8 if narrow else np.int32)] * 4 + [np.dtype(np.int32)]
+    tp, th = dtypes(planes_pileup), dtypes(planes_haplotype)
     with open(output_file, "wb") as f:
         for b0 in range(0, n, batch_size):
             sl = slice(b0, b0 + batch_size)
-            dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=np.int32)).cuda() for a in planes_pileup]
-            dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=np.int32)).cuda() for a in planes_haplotype]
+            dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).cuda() for a, t in zip(planes_pileup, tp)]
+            dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).cuda() for a, t in zip(planes_haplotype, th)]
             xp = ctx.hap_features(*dp)
             xh = ctx.hap_features(*dh)
             gt, _ = ctx.hap_forward(xp, xh)

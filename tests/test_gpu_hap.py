@@ -34,6 +34,20 @@ def test_random_planes_vs_oracle(gpu_ctx, cov, D, L):
     assert np.array_equal(got, want)
 
 
+def test_int8_planes_give_the_same_features(gpu_ctx):
+    """nsnp_hap_features_i8: the planes as int8 (all values fit), a quarter of the bytes, bit-identical features"""
+    import torch
+    planes = host.synth_hap_planes(4242, 300, coverage=60, depth=180, length=33)
+    want = _feat(gpu_ctx, planes)
+    narrow = [torch.from_numpy(a.astype(np.int8)).cuda() for a in planes[:4]] + [torch.from_numpy(planes[4]).cuda()]
+    got = gpu_ctx.hap_features(*narrow)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    from nanosnp_amd._lib import NanoSNPError
+    with pytest.raises(NanoSNPError):
+        gpu_ctx.hap_features(narrow[0], narrow[1].to(torch.int32), narrow[2], narrow[3], narrow[4])
+
+
 def test_mixed_hp_rows_and_large_values(gpu_ctx):
     """a row with several HP values belongs to several read sets (np.any semantics); int32-range
     qualities need 64-bit sums"""

@@ -60,6 +60,11 @@ def test_haplotype_csv_end_to_end(tmp_path, gpu_ctx):
             assert gt == labels[int(ogt[j].argmax())]
         want_q, ok = host.calculate_score(ogt[j].max())
         assert ok and abs(float(q) - want_q) <= 0.0101
+    # the same planes handed over as int8: identical csv
+    out8 = tmp_path / "haplotype8.csv"
+    predict_haplotype(gpu_ctx, [a.astype(np.int8) for a in pp[:4]] + [pp[4]], [a.astype(np.int8) for a in ph[:4]] + [ph[4]],
+                      cands, str(out8), batch_size=32)
+    assert out8.read_bytes() == out.read_bytes()
 
 
 def test_mpileup_to_vcf_pipeline(tmp_path, pileup_weights):

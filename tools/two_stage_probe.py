@@ -75,6 +75,8 @@ n5 = int(cand.size)
 pp = host.synth_hap_planes(100, max(n5, 1), 30, 90, 33); ph = host.synth_hap_planes(200, max(n5, 1), 30, 90, 11)
 hctx = _lib.Context(0); hctx.hap_load_weights(seeded_hap_weights(12, H=256)); hctx.set_option("hap_precision", hap_prec)
 cpos = [f"ctgS:{p}" for p in cand]
+if len(sys.argv) > 4 and sys.argv[4] == "i8":                      # planes as a reader would produce them: int8
+    pp = [a.astype(np.int8) for a in pp[:4]] + [pp[4]]; ph = [a.astype(np.int8) for a in ph[:4]] + [ph[4]]
 predict_haplotype(hctx, [a[:256] for a in pp], [a[:256] for a in ph], cpos[:256], os.path.join(tmp, "warm.csv"), batch_size=4096)   # warm-up
 torch.cuda.synchronize(); t0 = time.perf_counter()
 csv_path = os.path.join(tmp, "haplotype.csv")
