@@ -10,7 +10,7 @@
  * with the weight rows stored gate-major (i,f,g,o), h0 = c0 = 0, and the call sites
  * PileupModel/model.py:18-37 and HaplotypeModel/model_dev.py:63-81 (batch_first,
  * bidirectional, dropout inactive in eval).  Pinned by golden vectors generated from the
- * reference modules themselves (tools/make_golden.py).
+ * reference modules themselves (tests/golden/make_golden.py).
  */
 #include "oracle.h"
 

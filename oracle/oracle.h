@@ -13,7 +13,7 @@
  *     (tests/test_oracle_vs_ref.py, tests/golden/encode_*.pd.gz).
  *   - PileupModel forward (P2-P4): pinned against golden outputs produced by importing the
  *     reference's PileupModel/model.py with the shipped ont_pileup.chkpt on CPU torch
- *     (tools/make_golden.py -> tests/golden/pileup_fwd_*.npz).  The reference ships no test
+ *     (tests/golden/make_golden.py -> tests/golden/pileup_fwd_*.npz).  The reference ships no test
  *     of its own for this boundary.
  *   - haplotype features (H4/H5): pinned against goldens from the reference's
  *     dataset_dev.get_frequency_feature run in the development container.

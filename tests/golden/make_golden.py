@@ -5,8 +5,8 @@ Runs only in the development container, where the upstream tree is mounted read-
 /root/reference; the fixtures it writes are data (inputs + expected outputs) and are what the
 tests on the GPU box compare against -- the reference does not travel.
 
-    python tools/make_golden.py            # all fixtures
-    python tools/make_golden.py pileup     # one group: encode | pileup | hapfeat | hapfwd
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py pileup     # one group: encode | pileup | hapfeat | hapfwd
 
 Groups (each runs in its own interpreter: the reference's two model packages both define
 top-level modules named model/optim/utils/options):
@@ -29,7 +29,7 @@ import types
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.environ.get("NANOSNP_REFERENCE", "/root/reference")
 sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")

@@ -1,7 +1,7 @@
 """Shared test helpers: fixture paths, seeded weight generators, tolerance constants.
 
 The seeded weight generators stand in for the HaplotypeModel checkpoints that are absent from
-the reference tree (.MISSING_LARGE_BLOBS): tools/make_golden.py loads these exact arrays
+the reference tree (.MISSING_LARGE_BLOBS): tests/golden/make_golden.py loads these exact arrays
 into the reference's model_dev.LSTMNetwork and records its outputs; the tests regenerate the
 same arrays (numpy PCG64 streams are stable across platforms) instead of committing 33 MB.
 """

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""One-off fuzz on the GPU box: adversarial mpileup columns (tools/make_golden.py generator, fresh seeds) through the HIP
+"""One-off fuzz on the GPU box: adversarial mpileup columns (tests/golden/make_golden.py generator, fresh seeds) through the HIP
 encode kernel against the oracle, bit for bit, plus completely random byte strings over the mpileup alphabet."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import numpy as np, torch
 from nanosnp_amd import _lib
 from oracle import oracle

@@ -2,10 +2,10 @@
 """Development-container fuzz of the CPU restatements against the reference's own code (needs /root/reference; never
 runs on the GPU box): random and extreme inputs beyond the committed goldens.
 
-    python tools/fuzz_vs_reference.py hapfeat    oracle.hap_features        vs dataset_dev.get_frequency_feature   (bit-exact)
-    python tools/fuzz_vs_reference.py pileup     oracle.pileup_forward      vs PileupModel/model.py + ont_pileup.chkpt
-    python tools/fuzz_vs_reference.py vcf        host.vcf_format_batches    vs PileupModel/predict.py predict()    (byte-exact)
-    python tools/fuzz_vs_reference.py encode     oracle.mpileup_to_pd       vs oracle/_ref programs                (byte-exact)
+    python tests/manual/fuzz_vs_reference.py hapfeat    oracle.hap_features        vs dataset_dev.get_frequency_feature   (bit-exact)
+    python tests/manual/fuzz_vs_reference.py pileup     oracle.pileup_forward      vs PileupModel/model.py + ont_pileup.chkpt
+    python tests/manual/fuzz_vs_reference.py vcf        host.vcf_format_batches    vs PileupModel/predict.py predict()    (byte-exact)
+    python tests/manual/fuzz_vs_reference.py encode     oracle.mpileup_to_pd       vs oracle/_ref programs                (byte-exact)
 
 One group per process (the reference's PileupModel and HaplotypeModel module names collide)."""
 import os
@@ -14,8 +14,8 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_golden as mg                      # noqa: E402
 
 

@@ -2,7 +2,7 @@
 """Development probe run through gpurun: parity of every HIP entry point against the goldens /
 oracle plus rough timings.  Not part of the test suite (tests/ holds the real checks)."""
 import gzip, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -2,7 +2,7 @@
 """One-off soak on the GPU box: random sizes / inputs through every kernel variant of the pileup forward, f16x3 against the
 exact fp32 path and the oracle; then eight contexts on eight streams concurrently against their sequential results."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

@@ -1,4 +1,4 @@
-"""merge.py and stage-4 group selection vs the reference functions' own output (tools/make_golden.py next)."""
+"""merge.py and stage-4 group selection vs the reference functions' own output (tests/golden/make_golden.py next)."""
 import json
 
 import numpy as np

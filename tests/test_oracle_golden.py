@@ -1,5 +1,5 @@
 """The CPU oracle against the golden vectors generated from the reference itself
-(tools/make_golden.py), and against the reference's own compiled programs when oracle/_ref is
+(tests/golden/make_golden.py), and against the reference's own compiled programs when oracle/_ref is
 present.  Integer results bit-exact; probabilities within 1e-4 (measured ~1e-6)."""
 import gzip
 import os
@@ -79,7 +79,7 @@ def test_hap_forward_matches_reference_module_with_seeded_weights(H):
 
 
 def test_cat_forward_matches_reference_module_with_seeded_weights():
-    """legacy CatModel.predict (HaplotypeModel/model.py:332-358): golden from the reference module (tools/make_golden.py cat)"""
+    """legacy CatModel.predict (HaplotypeModel/model.py:332-358): golden from the reference module (tests/golden/make_golden.py cat)"""
     from tests.helpers import seeded_cat_weights
     z = np.load(golden("cat_fwd.npz"))
     ws = seeded_cat_weights(int(z["seed"]))
