@@ -270,10 +270,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 6 ? 3 : (WA
 // fragments in 96 VGPRs for the whole kernel.  Only h_t (and the staged x_t) cross waves, through a
 // double-buffered LDS exchange (one workgroup barrier per step, 17 KB per buffer), so LDS traffic per site-step
 // drops 5x, a workgroup needs 52 KB of LDS and 2-3 workgroups (independent barriers) share a CU.
-//   exchange row of a site: 16 chunks of 16 bytes; chunk 4w+q = [hi(u=0..3) | lo(u=0..3)] of units 16w+4u+q, the
-//   four units lane (site, q) of wave w leaves the cell with -> one ds_write_b128 per lane and site group.
-//   A B fragment (K block kb, lane quarter kq) is chunks 8kb+2kq and 8kb+2kq+1 (32 contiguous bytes): their hi
-//   halves form the hi fragment, their lo halves the lo fragment (register renaming only).
+//   exchange row of a site: 64 hi halves | 64 lo halves; K position p = 16w + 4q + u <-> unit 16w + 4u + q, the four
+//   units lane (site, q) of wave w leaves the cell with (two 8-byte writes); a B fragment (K block kb, lane quarter kq)
+//   is one 16-byte read per plane at position 32kb + 8kq - no register shuffles.
 //   The per-step barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also drain
 //   the H0 stores to HBM every step.
 // H0 is written in the layout K1 writes (entries m = 4w+u of row q), so the layer-1 kernels are unchanged.
@@ -335,19 +334,34 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
     };
     auto stage_x = [&](int buf) {
         if (!stager) return;
-        h8 xh, xl; bool nz = false;
+        h8 xh, xl;
+        bool big = false;                                  // counts are exact in one fp16 up to +-2048 (always, in practice)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = (float)xi[j];                       // predict.py:49 int -> float
-            if (q == 2 && j == 2) v = 1.0f;               // the bias column of the input image
-            if (q == 3) v = 0.0f;
-            _Float16 hi, lo; split_count(v, hi, lo);
-            xh[j] = hi; xl[j] = lo; nz |= lo != (_Float16)0.f;
+        for (int j = 0; j < 8; ++j) big |= (unsigned)(xi[j] + 2048) > 4096u;
+        bool any = __ballot(big) != 0ull;
+        if (!any) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (float)xi[j];                       // predict.py:49 int -> float
+                if (q == 2 && j == 2) v = 1.0f;               // the bias column of the input image
+                if (q == 3) v = 0.0f;
+                xh[j] = (_Float16)v; xl[j] = (_Float16)0.f;
+            }
+        } else {
+            bool nz = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (float)xi[j];
+                if (q == 2 && j == 2) v = 1.0f;
+                if (q == 3) v = 0.0f;
+                _Float16 hi, lo; split_count(v, hi, lo);
+                xh[j] = hi; xl[j] = lo; nz |= lo != (_Float16)0.f;
+            }
+            any = __ballot(nz) != 0ull;
         }
         _Float16* row = &xx[buf][wave * 16 + n][0];
         *reinterpret_cast<h8*>(row + 8 * q) = xh;
         *reinterpret_cast<h8*>(row + 32 + 8 * q) = xl;
-        const bool any = __ballot(nz) != 0ull;             // counts beyond +-2048 are not exact in fp16
         if (lane == 0) xflag[buf][wave] = any;
     };
     if (tid < 8) xflag[tid >> 2][tid & 3] = 0;
@@ -367,37 +381,33 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
     auto flush_h = [&](int buf, int t) {
         if (NSG < 4 && tid >= 64 * NSG) return;
         const int row = tid >> 2, qq = tid & 3;
-        const _Float16* r = &hx[buf][row][8 * qq];
-        const h8 k0 = *reinterpret_cast<const h8*>(r), k1 = *reinterpret_cast<const h8*>(r + 32);
-        const h8 k2 = *reinterpret_cast<const h8*>(r + 64), k3 = *reinterpret_cast<const h8*>(r + 96);
+        const _Float16* r = &hx[buf][row][4 * qq];                  // positions 16w + 4qq + u, w = 0..3: units 4m + qq, m = 4w + u
         h8* o = reinterpret_cast<h8*>(H0 + ((((base_site + row) * PW + t) * 2 + dir) * 4 + qq) * 32);
-        o[0] = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 8, 9, 10, 11);
-        o[1] = __builtin_shufflevector(k2, k3, 0, 1, 2, 3, 8, 9, 10, 11);
-        o[2] = __builtin_shufflevector(k0, k1, 4, 5, 6, 7, 12, 13, 14, 15);
-        o[3] = __builtin_shufflevector(k2, k3, 4, 5, 6, 7, 12, 13, 14, 15);
+        h4 a0 = *reinterpret_cast<const h4*>(r), a1 = *reinterpret_cast<const h4*>(r + 16);
+        h4 a2 = *reinterpret_cast<const h4*>(r + 32), a3 = *reinterpret_cast<const h4*>(r + 48);
+        o[0] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[1] = __builtin_shufflevector(a2, a3, 0, 1, 2, 3, 4, 5, 6, 7);
+        a0 = *reinterpret_cast<const h4*>(r + 64); a1 = *reinterpret_cast<const h4*>(r + 80);
+        a2 = *reinterpret_cast<const h4*>(r + 96); a3 = *reinterpret_cast<const h4*>(r + 112);
+        o[2] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[3] = __builtin_shufflevector(a2, a3, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    struct BFrag { h8 c00, c01, c10, c11, xh, xl; };     // raw chunks; the hi / lo fragments are formed at use
+    struct BFrag { h8 bh0, bh1, bl0, bl1, xh, xl; };
     auto step = [&](auto any_lo_tag, int t, int xb, int hw_) {
         constexpr bool ANYLO = decltype(any_lo_tag)::value;
         const int hr = hw_ ^ 1;
         auto load_b = [&](int sg, BFrag& f) {
-            const _Float16* hrow = &hx[hr][16 * sg + n][16 * q];
-            f.c00 = *reinterpret_cast<const h8*>(hrow);
-            f.c01 = *reinterpret_cast<const h8*>(hrow + 8);
-            f.c10 = *reinterpret_cast<const h8*>(hrow + 64);
-            f.c11 = *reinterpret_cast<const h8*>(hrow + 72);
+            const _Float16* hrow = &hx[hr][16 * sg + n][8 * q];
+            f.bh0 = *reinterpret_cast<const h8*>(hrow);            // positions 8q.. of K block 0 (hi plane)
+            f.bh1 = *reinterpret_cast<const h8*>(hrow + 32);
+            f.bl0 = *reinterpret_cast<const h8*>(hrow + 64);       // lo plane
+            f.bl1 = *reinterpret_cast<const h8*>(hrow + 96);
             const _Float16* xrow = &xx[xb][16 * sg + n][0];
             f.xh = *reinterpret_cast<const h8*>(xrow + 8 * q);
             if (ANYLO) f.xl = *reinterpret_cast<const h8*>(xrow + 32 + 8 * q);
         };
-        auto gemm = [&](const BFrag& fr_, f32x4* acc) {
-            struct { h8 bh0, bl0, bh1, bl1, xh, xl; } f;
-            f.bh0 = __builtin_shufflevector(fr_.c00, fr_.c01, 0, 1, 2, 3, 8, 9, 10, 11);
-            f.bl0 = __builtin_shufflevector(fr_.c00, fr_.c01, 4, 5, 6, 7, 12, 13, 14, 15);
-            f.bh1 = __builtin_shufflevector(fr_.c10, fr_.c11, 0, 1, 2, 3, 8, 9, 10, 11);
-            f.bl1 = __builtin_shufflevector(fr_.c10, fr_.c11, 4, 5, 6, 7, 12, 13, 14, 15);
-            f.xh = fr_.xh; f.xl = fr_.xl;
+        auto gemm = [&](const BFrag& f, f32x4* acc) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][0][0], f.bh0, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
@@ -435,7 +445,8 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
                 _Float16 hi, lo; split1(h, hi, lo);
                 nh[u] = hi; nl[u] = lo;
             }
-            *reinterpret_cast<h8*>(&hx[hw_][16 * sg + n][8 * (4 * wave + q)]) = __builtin_shufflevector(nh, nl, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<h4*>(&hx[hw_][16 * sg + n][16 * wave + 4 * q]) = nh;
+            *reinterpret_cast<h4*>(&hx[hw_][16 * sg + n][64 + 16 * wave + 4 * q]) = nl;
         };
         // software pipeline over the site groups: the MFMAs of group g+1 are issued among the sigmoid / tanh
         // work of group g (one scheduling region; the matrix pipe runs while the vector ALU issues)
@@ -1024,8 +1035,8 @@ int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w)
     auto rec_feat = [](int kb, int q, int j) { return 4 * (8 * kb + j) + q; };                     // hidden unit
     auto h0_feat = [](int kb, int q, int j) { return (kb >> 1) * 64 + 4 * (8 * (kb & 1) + j) + q; };   // [fwd;bwd] feature
     auto acc_feat = [](int kb, int q, int j) { return 16 * (2 * kb + (j >> 2)) + 4 * q + (j & 3); };
-    // register-stationary layer 0: B fragment (kb, q, j) <-> chunk c = 8kb + 2q + (j >> 2) of the exchange row = unit 16 (c >> 2) + 4 (j & 3) + (c & 3)
-    auto rs_feat = [](int kb, int q, int j) { const int c = 8 * kb + 2 * q + (j >> 2); return 16 * (c >> 2) + 4 * (j & 3) + (c & 3); };
+    // register-stationary layer 0: B fragment (kb, q, j) = exchange position p = 32kb + 8q + j <-> unit 16 (p >> 4) + 4 (p & 3) + ((p >> 2) & 3)
+    auto rs_feat = [](int kb, int q, int j) { const int p = 32 * kb + 8 * q + j; return 16 * (p >> 4) + 4 * (p & 3) + ((p >> 2) & 3); };
     for (int d = 0; d < 2; ++d) {
         const float* const* l0 = w + d * 4;
         const float* const* l1 = w + 8 + d * 4;
