@@ -45,14 +45,10 @@ def call_contig(model, mpileup_text: bytes, contig: str, chr_seq: np.ndarray, mi
     site_pos = pos[c_host]
     site_ref = ref[c_host] & 0xDF                                          # make_predict_data/main.cpp:91 upper-cases
     ga, za, gm, zm, cov = (t.cpu().numpy() for t in (ga, za, gm, zm, cov))
-    out, rows = [], 0
-    for b0 in range(0, n_sites, batch_size):                               # the VCF rows depend on the batch boundary
-        sl = slice(b0, b0 + batch_size)
-        text, r = host.vcf_format_batch(table, ids[sl], site_pos[sl], site_ref[sl], ga[sl], za[sl], gm[sl], zm[sl],
-                                        cov[sl], score_mode)
-        out.append(text)
-        rows += r
-    return b"".join(out), n_sites, rows
+    # the VCF rows depend on the batch boundary: one native call formats every batch (OpenMP over the batches)
+    text, rows = host.vcf_format_batches(table, ids, site_pos, site_ref, ga, za, gm, zm, cov, batch_size=batch_size,
+                                         score_mode=score_mode)
+    return text, n_sites, rows
 
 
 def call_variants(model, contigs, fasta_path, fai_text, output_file, **kw):
