@@ -379,8 +379,10 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
     // four chunks q', 4+q', 8+q', 12+q' of its site (hi and lo of units 4m + q', m = 0..15) and writes the
     // complete 64-byte row [16 hi | 16 lo] that K1 writes
     auto flush_h = [&](int buf, int t) {
-        if (NSG < 4 && tid >= 64 * NSG) return;
-        const int row = tid >> 2, qq = tid & 3;
+        // with fewer than four site groups the waves that do not stage x rows do the flushing
+        constexpr int FO = NSG < 4 ? 64 * NSG : 0;
+        if (NSG < 4 && (tid < FO || tid >= FO + 64 * NSG)) return;
+        const int row = (tid - FO) >> 2, qq = tid & 3;
         const _Float16* r = &hx[buf][row][4 * qq];                  // positions 16w + 4qq + u, w = 0..3: units 4m + qq, m = 4w + u
         h8* o = reinterpret_cast<h8*>(H0 + ((((base_site + row) * PW + t) * 2 + dir) * 4 + qq) * 32);
         h4 a0 = *reinterpret_cast<const h4*>(r), a1 = *reinterpret_cast<const h4*>(r + 16);
