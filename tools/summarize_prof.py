@@ -15,7 +15,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
+NAMES = {"k_pileup_l1_rs": "pileup_l1f", "k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
          "k_pileup_head": "pileup_head", "k_encode_columns": "encode_columns", "k_hap_features": "hap_features",
          "k_pileup_post": "pileup_post", "k_select": "select_sites", "k_gather_windows": "gather_windows",
          "k_hap_": "hap_forward"}
