@@ -2,8 +2,8 @@
 """What would cheaper correction terms cost in accuracy?  numpy model of the PileupModel forward (real weights, golden inputs)
 with every product evaluated as f16x3 (what the kernels do), with the two correction terms in fp8 e4m3 (scaled by 2^11), with
 the h_lo term dropped, and in plain fp16.  DESIGN.md section 9."""
-import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import load_pileup_weights, golden
 w = load_pileup_weights()
 z = np.load(golden("pileup_fwd.npz"))
