@@ -19,7 +19,9 @@ def fp8_e4m3(a):
     e = np.maximum(e, -6.0)                      # subnormals share the exponent of 2^-6
     q = 2.0 ** (e - 3)                           # 3 mantissa bits
     return (s * np.round(m / q) * q).astype(np.float32)
-def matvec(W, v, mode):
+SITE_MODES = {}
+def matvec(W, v, mode, site="other"):
+    mode = SITE_MODES.get(site, mode)
     # W [R,K], v [N,K] -> [N,R]
     Wh, Wl = split(W); vh, vl = split(v)
     main = vh @ Wh.T
@@ -33,19 +35,19 @@ def matvec(W, v, mode):
         return main + vh @ Wl.T
     raise ValueError(mode)
 def sig(a): return 1 / (1 + np.exp(-a))
-def lstm_dir(xs, Wih, Whh, bih, bhh, rev, mode, steps=None):
+def lstm_dir(xs, Wih, Whh, bih, bhh, rev, mode, steps=None, site="l0"):
     N, T, _ = xs.shape; H = Whh.shape[1]
     h = np.zeros((N, H), np.float32); c = np.zeros((N, H), np.float32); out = np.zeros((N, T, H), np.float32)
     order = range(T - 1, -1, -1) if rev else range(T)
     for k, t in enumerate(order):
         if steps is not None and k >= steps: break
-        g = matvec(Wih, xs[:, t], mode) + matvec(Whh, h, mode) + bih + bhh
+        g = matvec(Wih, xs[:, t], mode, site + "_ih") + matvec(Whh, h, mode, site + "_hh") + bih + bhh
         i, f, gg, o = sig(g[:, :H]), sig(g[:, H:2*H]), np.tanh(g[:, 2*H:3*H]), sig(g[:, 3*H:])
         c = f * c + i * gg; h = o * np.tanh(c); out[:, t] = h
     return out
 def forward(mode):
     h0 = np.concatenate([lstm_dir(x, *w[0:4], False, mode), lstm_dir(x, *w[4:8], True, mode)], 2)
-    h1 = np.concatenate([lstm_dir(h0, *w[8:12], False, mode, 17), lstm_dir(h0, *w[12:16], True, mode, 17)], 2)[:, 16]
+    h1 = np.concatenate([lstm_dir(h0, *w[8:12], False, mode, 17, "l1"), lstm_dir(h0, *w[12:16], True, mode, 17, "l1")], 2)[:, 16]
     p = matvec(w[16], h1, mode) + w[17]
     d = np.tanh(matvec(w[18], p, mode) + w[19])
     lg = matvec(w[20], d, mode) + w[21]; lz = matvec(w[22], d, mode) + w[23]
@@ -56,3 +58,9 @@ print("numpy fp32 vs golden:", np.abs(ref[0] - z["gt"][:256]).max())
 for mode in ("f16x3", "fp8corr", "f16hi_wlo", "f16x1"):
     g = forward(mode)
     print(f"{mode:10s} max |dp| vs fp32: gt {np.abs(g[0]-ref[0]).max():.2e}  zy {np.abs(g[1]-ref[1]).max():.2e}   argmax flips {int((g[0].argmax(1)!=ref[0].argmax(1)).sum())}")
+
+for name, sm in (("layer-1 input projection without h0_lo", {"l1_ih": "f16hi_wlo"}), ("layer-1 input projection with fp8 corrections", {"l1_ih": "fp8corr"}),
+                 ("layer-1 input projection in plain fp16", {"l1_ih": "f16x1"})):
+    SITE_MODES.clear(); SITE_MODES.update(sm)
+    g = forward("f16x3")
+    print(f"f16x3 except {name}: gt {np.abs(g[0]-ref[0]).max():.2e}  zy {np.abs(g[1]-ref[1]).max():.2e}")
