@@ -8,9 +8,15 @@
 // subnormals (probed on gfx950: tools/probes/denorm_probe.hip), so the result differs from the exact-fp32
 // path (pileup_forward.hip) by ~1e-6 in the probabilities (measured; tolerance 1e-4) while the matrix
 // pipe runs at the fp16 rate: 3 MFMAs of 16 cycles replace 8 of 32 cycles per 32-deep K block.
-// Same reference functions, same four-kernel structure and the same register-resident recurrence as
-// the fp32 path: the accumulator layout of tile i (lane = site + 16*q holds unit 4*i+q) is packed
-// straight into the next step's B fragments (K position (kb, q, j) <-> unit 4*(8*kb+j)+q).
+//
+// Kernels in this file (same reference functions as the fp32 path):
+//   K1r  k_pileup_l0_rs   layer 0, weights in VGPRs, h exchanged through LDS            default
+//   K23r k_pileup_l1_rs   layer 1 projection + recurrence, weights in VGPRs           default
+//   K4   k_pileup_head_h  output_proj, dense + tanh, heads, softmax                   default
+//   K1   k_pileup_l0_h    layer 0 with LDS weight images, h in registers (the accumulator layout of tile i - lane = site +
+//                         16*q holds unit 4*i+q - is packed straight into the next step's B fragments)   l0_register_stationary 0
+//   K23  k_pileup_l1f_h   fused layer 1 with LDS images + a streamed ring             l1_register_stationary 0
+//   K2 / K3               unfused layer-1 projection and recurrence                    fused_l1 0
 #include "nsnp_common.hpp"
 #include <type_traits>
 
