@@ -73,13 +73,14 @@ int nsnp_ctx_destroy(nsnp_ctx* ctx);
 int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
 
 /* Options (name, value).  Unknown names / values return NSNP_EINVAL.  Precision options choose between the exact
- * fp32 MFMA path and "f16x3" (every fp32 operand split into two fp16 halves, three fp16 MFMAs per product, fp32
- * accumulation; ~1e-6 from the fp32 path, tolerance of the port 1e-4; caller-supplied inputs beyond +-131008 saturate,
+ * fp32 MFMA path (the default: the reference computes in fp32) and the opt-in "f16x3" (every fp32 operand split into
+ * two fp16 halves, three fp16 MFMAs per product, fp32 accumulation: 21-22 significand bits per operand, measured ~1e-6
+ * from the fp32 path in the probabilities, tolerance of the port 1e-4; caller-supplied inputs beyond +-131008 saturate,
  * the fp32 mode has no such limit); the others only change launch shapes.
- *   "pileup_precision"        0 fp32 | 1 f16x3 (default)      PileupModel forward
- *   "hap_precision"           0 fp32 | 1 f16x3 (default)      HaplotypeModel forward
- *   "cat_precision"           0 fp32 | 1 f16x3 (default)      legacy CatModel forward
- *   "recurrence_waves"        0 auto | 1/2/4/6/8               waves per workgroup of the LDS-image recurrence kernels
+ *   "pileup_precision"        0 fp32 (default) | 1 f16x3      PileupModel forward
+ *   "hap_precision"           0 fp32 (default) | 1 f16x3      HaplotypeModel forward
+ *   "cat_precision"           0 fp32 (default) | 1 f16x3      legacy CatModel forward
+ *   "recurrence_waves"        0 auto | 1/2/4/8                 waves per workgroup of the LDS-image recurrence kernels
  *   "l0_register_stationary"  1 (default) | 0                 f16x3 layer 0: weights in VGPRs + LDS exchange of h, or LDS images
  *   "l0_site_groups"          0 auto | 1/2/4                   16-site groups per workgroup of that kernel
  *   "l1_register_stationary"  1 (default) | 0                 f16x3 fused layer 1: weights in VGPRs + LDS operands, or LDS images + ring

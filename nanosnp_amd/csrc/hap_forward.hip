@@ -208,8 +208,12 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
 
     if (!ctx->hw) { ctx->hw = new (std::nothrow) HapWeightsDev(); if (!ctx->hw) return NSNP_ENOMEM; memset((void*)ctx->hw, 0, sizeof(HapWeightsDev)); }
     HapWeightsDev& hw = *ctx->hw;
-    if (hw.arena && hw.arena_floats != total) { (void)hipFree(hw.arena); hw.arena = nullptr; }
-    if (!hw.arena) { NSNP_HIP(ctx, hipMalloc((void**)&hw.arena, total * sizeof(float))); hw.arena_floats = total; }
+    if (hw.arena_floats != total) {     // both arenas are sized by `total`: a reload with other dimensions re-allocates both
+        if (hw.arena) { (void)hipFree(hw.arena); hw.arena = nullptr; }
+        if (hw.arena16) { (void)hipFree(hw.arena16); hw.arena16 = nullptr; }
+        hw.arena_floats = 0;
+    }
+    if (!hw.arena) NSNP_HIP(ctx, hipMalloc((void**)&hw.arena, total * sizeof(float)));
     NSNP_HIP(ctx, hipMemcpy(hw.arena, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
     {
         // f16x3 images: rows of 16 weights become 16 hi halves + 16 lo halves (same 64 bytes); biases and the
@@ -231,8 +235,8 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
             conv(off_pw[e], (size_t)(H / TR) * (2 * H / BK) * TILE_F);
         }
         conv(off_dw, (size_t)(H / TR) * (2 * H / BK) * TILE_F);
-        if (hw.arena16 && hw.arena_floats != total) { (void)hipFree(hw.arena16); hw.arena16 = nullptr; }
         if (!hw.arena16) NSNP_HIP(ctx, hipMalloc((void**)&hw.arena16, total * sizeof(float)));
+        hw.arena_floats = total;
         NSNP_HIP(ctx, hipMemcpy(hw.arena16, h16.data(), total * sizeof(float), hipMemcpyHostToDevice));
     }
     hw.F = F; hw.H = H; hw.n_layers = n_layers; hw.n_gt = n_gt; hw.n_zy = n_zy; hw.nk_in0 = nk0;

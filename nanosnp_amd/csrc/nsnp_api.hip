@@ -38,9 +38,9 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->device = device;
     ctx->last_err = hipSuccess;
     ctx->chunk_sites = 32768;
-    ctx->precision = 1;          // f16x3 is the default of all three model forwards; 0 selects the exact fp32 MFMA paths
-    ctx->hap_precision = 1;
-    ctx->cat_precision = 1;
+    ctx->precision = 0;          // exact fp32 MFMA is the default of all three model forwards (the reference computes in
+    ctx->hap_precision = 0;      // fp32); 1 opts into the f16x3 split (3 fp16 MFMAs per product, ~1e-6 from fp32)
+    ctx->cat_precision = 0;
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
     ctx->l0_rs = 1;
@@ -133,7 +133,8 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         return NSNP_OK;
     }
     if (strcmp(name, "recurrence_waves") == 0) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return NSNP_EINVAL;
+        // every kernel the recurrence grid feeds has 1/2/4/8-wave builds only
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return NSNP_EINVAL;
         ctx->force_wpb = (int)value;
         return NSNP_OK;
     }

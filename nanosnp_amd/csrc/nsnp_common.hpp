@@ -76,9 +76,9 @@ struct nsnp_ctx {
     hipError_t last_err;
     bool attr_set;
     bool attr_set_f16;
-    int cat_precision;  // legacy CatModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split
-    int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split
-    int precision;      // PileupModel forward: 0 = exact fp32 MFMA, 1 = f16x3 split (default)
+    int cat_precision;  // legacy CatModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
+    int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
+    int precision;      // PileupModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
     int l0_rs;          // f16x3: 1 = register-stationary layer-0 kernel (default), 0 = LDS-image kernel
     int l1_rs_groups;   // 0 = automatic, else 2 / 4 groups of 16 sites per workgroup of that kernel

@@ -10,12 +10,15 @@
  *     ti in [0,4,7,9] / [1,2,3,5,6,8] (predict.py:102-109,117-125): it reads the classes predicted
  *     for OTHER sites of the batch, and a batch shorter than the index raises IndexError, which the
  *     bare `except: continue` (predict.py:193-194) turns into a skipped site;
- *   - float32 arithmetic of the coverage features (support_count, depth, af);
- *   - calculate_score (predict.py:31-34).  score_mode 0 = the arithmetic NumPy >= 2 performs on
- *     the float32 probability (python floats are weak: everything stays float32, the 1e-300 guards
- *     vanish, p == 1 raises "math domain error" -> site skipped) -- this is what the reference does
- *     when run in this repository's container and what the goldens pin; score_mode 1 = float64
- *     arithmetic (NumPy 1.x value-based promotion, the reference's own py38 environment).
+ *   - scalar arithmetic of the coverage features (support_count, depth, af) and of calculate_score
+ *     (predict.py:31-34) follows the NumPy generation the loop runs under:
+ *       score_mode 1 (the default of the Python wrappers) = NumPy 1.x, the reference's own environment
+ *         (Dockerfile:13-29, Miniconda py38): a float32 scalar combined with a Python int/float promotes to
+ *         float64, so af is a float64 quotient, the 1e-300 guards act and p == 1 scores 3010.3;
+ *       score_mode 0 = NumPy >= 2 (NEP 50, what this repository's container runs): Python scalars are weak,
+ *         everything stays float32, the guards vanish and p == 1 raises "math domain error" -> the site is
+ *         skipped by the bare except (haplotype.csv: the loop has no except, the batch fails).
+ *     Both are pinned by goldens produced by the reference's predict() (tests/golden/make_golden.py vcf).
  */
 #include "nsnp_host.h"
 
@@ -69,13 +72,13 @@ static void sb_put(sbuf* b, const char* s, int64_t n)
 }
 
 static void emit(sbuf* b, const char* ctg, int ctg_len, int64_t pos, char sref, const char* alt,
-                 double qual_field, const char* filter, const char* zy, double gq, float depth, float af)
+                 double qual_field, const char* filter, const char* zy, double gq, float depth, double af)
 {
     char line[512]; char q1[32];
     fmt_pyfloat(q1, qual_field);
     char aftxt[64];
     if (isnan(af)) strcpy(aftxt, "nan");            /* Python prints nan without a sign */
-    else snprintf(aftxt, sizeof aftxt, "%f", (double)af);
+    else snprintf(aftxt, sizeof aftxt, "%f", af);
     int n = snprintf(line, sizeof line, "%.*s\t%lld\t.\t%c\t%s\t%s\t%s\t.\tGT:GQ:DP:AF\t%s:%lld:%lld:%s\n",
                      ctg_len, ctg, (long long)pos, sref, alt, q1, filter, zy, (long long)gq,
                      (long long)depth, aftxt);
@@ -113,8 +116,10 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
             support += c[bi]; support += c[bi + 4];
         }
         if (bad) continue;
-        float af = support / depth;                              /* float32; x/0 -> inf/nan like numpy */
-        if (af > 1.0f) af = 1.0f;
+        /* counts are integers below 2^24: the sums are exact either way, only the quotient depends on the mode */
+        double af = score_mode ? (double)support / (double)depth      /* NumPy 1.x: float64 scalars; x/0 -> inf/nan */
+                               : (double)(support / depth);           /* NumPy 2: float32 quotient */
+        if (af > 1.0) af = 1.0;
         if (isnan(depth) || isinf(depth)) continue;              /* "%d" % nan / inf raises */
         double gt_qual, zy_qual;
         if (calc_score(gt_prob[j], score_mode, &gt_qual)) continue;

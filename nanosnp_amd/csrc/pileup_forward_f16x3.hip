@@ -174,7 +174,7 @@ constexpr int IH_H8 = 16 * 64;               // one part of the input image
 constexpr int L0H_LDS_BYTES = (HH_H8 + IH_H8) * 16;
 
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 6 ? 3 : (WAVES == 4 ? 2 : 1)))) void k_pileup_l0_h(
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))) void k_pileup_l0_h(
     const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
     const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
     const _Float16* __restrict__ wih_hi0, const _Float16* __restrict__ wih_hi1,
@@ -1131,7 +1131,7 @@ static int set_lds_attr_f16(nsnp_ctx* ctx)
 {
     if (ctx->attr_set_f16) return NSNP_OK;
 #define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
-    SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<6>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
+    SET(k_pileup_l0_h<8>, L0H_LDS_BYTES); SET(k_pileup_l0_h<4>, L0H_LDS_BYTES); SET(k_pileup_l0_h<2>, L0H_LDS_BYTES); SET(k_pileup_l0_h<1>, L0H_LDS_BYTES);
     SET(k_pileup_proj1_h, P1H_LDS_BYTES);
     SET(k_pileup_l1_rs<4>, r1_lds_bytes(4)); SET(k_pileup_l1_rs<2>, r1_lds_bytes(2));
     SET(k_pileup_l1f_h<4>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<8>, L1F_LDS_BYTES); SET(k_pileup_l1f_h<12>, L1F_LDS_BYTES);
@@ -1179,7 +1179,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
 #define LAUNCH_L0(W) hipLaunchKernelGGL(k_pileup_l0_h<W>, g_rec, dim3(64 * W), L0H_LDS_BYTES, s, xc, cc, n, \
             (const _Float16*)pw.l0_whh[0], (const _Float16*)pw.l0_whh[1], (const _Float16*)pw.l0_wih_hi[0], (const _Float16*)pw.l0_wih_hi[1], \
             (const _Float16*)pw.l0_wih_lo[0], (const _Float16*)pw.l0_wih_lo[1], H0)
-        if (wpb == 8) LAUNCH_L0(8); else if (wpb == 6) LAUNCH_L0(6); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
+        if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
         if (ctx->fused_l1 && ctx->l1_rs) {

@@ -215,7 +215,7 @@ class ContigTable:
         self.ids = np.array([self.index[n] for n in names], np.int32)
 
 
-def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, score_mode=SCORE_FLOAT32):
+def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, score_mode=SCORE_FLOAT64):
     """One batch of PileupModel/predict.py:66-194 -> (bytes, n_rows)."""
     l = _bind_vcf()
     B = len(pos)
@@ -237,7 +237,7 @@ def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, z
 
 
 def vcf_format_batches(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, batch_size=1000,
-                       score_mode=SCORE_FLOAT32, nthreads=None):
+                       score_mode=SCORE_FLOAT64, nthreads=None):
     """All batches of the predict loop in one native call (OpenMP over batches) -> (bytes, n_rows); byte-identical to
     concatenating vcf_format_batch over consecutive slices of batch_size sites."""
     l = _bind_vcf()
@@ -260,7 +260,7 @@ def vcf_format_batches(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob,
         cap = -int(n)
 
 
-def hap_csv_format(table, contig_id, pos, gt_arg, gt_prob, score_mode=SCORE_FLOAT32):
+def hap_csv_format(table, contig_id, pos, gt_arg, gt_prob, score_mode=SCORE_FLOAT64):
     l = _bind_vcf()
     N = len(pos)
     args = [np.ascontiguousarray(contig_id, np.int32), np.ascontiguousarray(pos, np.int64),
@@ -277,7 +277,7 @@ def hap_csv_format(table, contig_id, pos, gt_arg, gt_prob, score_mode=SCORE_FLOA
         cap = -int(n)
 
 
-def calculate_score(p, score_mode=SCORE_FLOAT32):
+def calculate_score(p, score_mode=SCORE_FLOAT64):
     """(score, ok): ok is False where the reference's calculate_score raises"""
     ok = C.c_int(0)
     v = _bind_vcf().nsnp_calculate_score(float(np.float32(p)), int(score_mode), C.byref(ok))

@@ -17,7 +17,7 @@ from .predict import COV_CHANNELS
 
 
 def call_contig(model, mpileup_text: bytes, contig: str, chr_seq: np.ndarray, min_af=0.12, min_coverage=6,
-                batch_size=1000, score_mode=host.SCORE_FLOAT32):
+                batch_size=1000, score_mode=host.SCORE_FLOAT64):
     """One contig: returns (vcf_rows: bytes, n_sites, n_rows).  model: pileup_model.LSTMNetwork."""
     import torch
     ctx = model.ctx

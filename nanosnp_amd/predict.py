@@ -17,7 +17,7 @@ COV_CHANNELS = [0, 1, 2, 3, 9, 10, 11, 12]        # predict.py:63
 
 
 def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text, output_file,
-                   batch_size=1000, score_mode=host.SCORE_FLOAT32, device_batch=65536):
+                   batch_size=1000, score_mode=host.SCORE_FLOAT64, device_batch=65536):
     """model: nanosnp_amd.pileup_model.LSTMNetwork; x: int32 [N,33,18] (numpy or cuda tensor);
     contig_names/positions/reference_bases: what PredictDataset yields (dataset.py:141-146).
     Returns the number of VCF rows written."""
@@ -52,7 +52,7 @@ def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text,
 
 
 def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions, output_file,
-                      batch_size=1000, score_mode=host.SCORE_FLOAT32):
+                      batch_size=1000, score_mode=host.SCORE_FLOAT64):
     """ctx: a Context with hap weights loaded; planes_*: (seq, baseq, mapq, hap, ref_row) int32
     arrays [N,D,33] / [N,D,11]; candidate_positions: "ctg:pos" strings (dataset_dev.py:331-333)."""
     import torch

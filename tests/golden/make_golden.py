@@ -337,6 +337,55 @@ def group_vcf():
     for k, v in out.items():
         print(k, len(bytes(v).splitlines()), "lines")
 
+    # ---- the same loop under NumPy 1.x scalar promotion (the reference's own environment: Dockerfile:13-29, py38) ----
+    # NumPy >= 2.2 cannot be switched back to legacy promotion, so the float32 arrays the loop reads are widened to
+    # float64 where they enter NumPy (Tensor.numpy()): every scalar expression of predict.py:66-194 then evaluates in
+    # float64 on the exactly widened float32 values, which is what NumPy 1.x's value-based promotion does with
+    # `1.0 - p`, `0 + cov[i]`, `-1 * cov.sum()` and `support / depth` (array-level max / argmax / integer-valued sums are
+    # exact in either width).  Extra sites with saturated windows make the softmax maximum exactly 1.0f, the case the
+    # two modes treat differently (QUAL 3010.3 vs a skipped site).
+    xe = np.zeros((12, 33, 18), np.int32)
+    rng = np.random.default_rng(5)
+    for i in range(12):
+        xe[i, :, 1] = -(80 + 5 * i); xe[i, :, 10] = -(60 + i); xe[i, 16, 0] = 70 + i; xe[i, 16, 9] = 75     # deep, clean het-like columns
+        xe[i, 16, 1] = -(150 + 40 * i)
+    x1 = np.concatenate([x, xe]); pos1 = np.concatenate([pos, 7000 + np.arange(12)]); refb1 = np.concatenate([refb, np.full(12, ord("C"), refb.dtype)])
+    names1 = names + ["chrT"] * 12
+
+    class FakeDataset1(Dataset):
+        def __init__(self, datapath):
+            pass
+        def __getitem__(self, i):
+            return names1[i], pos1[i], refb1[i], x1[i]
+        def __len__(self):
+            return len(x1)
+
+    ref_predict.PredictDataset = FakeDataset1
+    orig_numpy = torch.Tensor.numpy
+    def widened(self, *a, **k):
+        r = orig_numpy(self, *a, **k)
+        return r.astype(np.float64) if r.dtype == np.float32 else r
+    out1 = {}
+    with tempfile.TemporaryDirectory() as d:
+        fai = os.path.join(d, "ref.fa.fai")
+        open(fai, "w").write("chrS\t6100\t6\t60\t61\nchrT\t1600\t6\t60\t61\n")
+        for mode, patch in (("np2", False), ("np1", True)):
+            torch.Tensor.numpy = widened if patch else orig_numpy
+            try:
+                for bs in (1000, 64, 7):
+                    vcf = os.path.join(d, f"q{mode}{bs}.vcf")
+                    ref_predict.predict(m, ["x.bin"], fai, bs, vcf, torch.device("cpu"))
+                    out1[f"vcf_{mode}_bs{bs}"] = np.frombuffer(open(vcf, "rb").read(), np.uint8)
+            finally:
+                torch.Tensor.numpy = orig_numpy
+    with torch.no_grad():
+        gt1, zy1 = m.predict(torch.from_numpy(x1).type(torch.FloatTensor))
+    print("sites with a softmax maximum of exactly 1.0f:", int((gt1.numpy().max(1) == 1.0).sum()), int((zy1.numpy().max(1) == 1.0).sum()))
+    np.savez_compressed(os.path.join(GOLD, "pileup_vcf_modes.npz"), x=x1.astype(np.int16), pos=pos1, refb=refb1, names=np.array(names1),
+                        gt=gt1.numpy(), zy=zy1.numpy(), fai=np.frombuffer(b"chrS\t6100\t6\t60\t61\nchrT\t1600\t6\t60\t61\n", np.uint8), **out1)
+    for k, v in out1.items():
+        print(k, len(bytes(v).splitlines()), "lines")
+
 
 def group_next():
     """merge.py and select_hetesnp_homosnp.find_adjacent_sites run on the golden pileup.vcf plus a

@@ -11,13 +11,13 @@ PROB_ATOL = 1e-4        # BASELINE.json north_star tolerance on probabilities
 
 @pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
 def cat_model(request, gpu_ctx):
-    """the forward tests run in both modes: f16x3 (library default) and exact fp32"""
+    """the forward tests run in both modes: exact fp32 (library default) and the opt-in f16x3"""
     ws = seeded_cat_weights(21)
     gpu_ctx.cat_load_weights(ws)
     gpu_ctx.set_option("cat_precision", request.param)
     gpu_ctx.test_cat_precision = request.param
     yield gpu_ctx, ws
-    gpu_ctx.set_option("cat_precision", 1)
+    gpu_ctx.set_option("cat_precision", 0)
 
 
 def _fwd(ctx, g0, g1):

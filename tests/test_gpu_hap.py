@@ -67,13 +67,13 @@ def test_mixed_hp_rows_and_large_values(gpu_ctx):
 # ---- HaplotypeModel forward -------------------------------------------------------------------------
 @pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
 def hap_model(request, gpu_ctx):
-    """the forward tests run in both modes: f16x3 (library default) and exact fp32"""
+    """the forward tests run in both modes: exact fp32 (library default) and the opt-in f16x3"""
     from tests.helpers import seeded_hap_weights
     ws = seeded_hap_weights(12, H=256)
     gpu_ctx.hap_load_weights(ws)
     gpu_ctx.set_option("hap_precision", request.param)
     yield gpu_ctx, ws
-    gpu_ctx.set_option("hap_precision", 1)
+    gpu_ctx.set_option("hap_precision", 0)
 
 
 def _hfwd(ctx, xp, xh):

@@ -15,13 +15,13 @@ def test_pileup_vcf_end_to_end(tmp_path, pileup_weights):
     QUAL by one unit in its second decimal; everything else must be identical."""
     from nanosnp_amd.pileup_model import LSTMNetwork
     from nanosnp_amd.predict import predict_pileup
-    z = np.load(golden("pileup_vcf.npz"))
+    z = np.load(golden("pileup_vcf_modes.npz"))          # the wrappers default to NumPy 1.x scalar promotion (score_mode 1)
     m = LSTMNetwork().load_weight_list(pileup_weights)
     out = tmp_path / "pileup.vcf"
     rows = predict_pileup(m, z["x"].astype(np.int32), list(z["names"]), z["pos"], z["refb"],
                           bytes(z["fai"]).decode(), str(out), batch_size=1000)
     got = out.read_bytes().decode().splitlines()
-    want = bytes(z["vcf_bs1000"]).decode().splitlines()
+    want = bytes(z["vcf_np1_bs1000"]).decode().splitlines()
     assert len(got) == len(want) and rows == sum(1 for l in want if not l.startswith("#"))
     n_qual_diff = 0
     for g, w in zip(got, want):
