@@ -111,6 +111,10 @@ void orc_softmax(float* v, int n);
  *  [20,21] genotype_layer  [22,23] zygosity_layer  (indel heads are not used by predict) */
 void orc_pileup_forward(const float* const* w, const int32_t* x /*[N,33,18]*/, int64_t N,
                         float* gt_prob /*[N,21]*/, float* zy_prob /*[N,3]*/, int nthreads);
+/* the same function blocked over 32 sites with L1-resident weight panels and AVX2 FMA inner loops
+ * (pileup_forward_blocked.c): only the CPU baseline leg of bench.py times it */
+void orc_pileup_forward_blocked(const float* const* w, const int32_t* x /*[N,33,18]*/, int64_t N,
+                                float* gt_prob /*[N,21]*/, float* zy_prob /*[N,3]*/, int nthreads);
 
 /* ---- haplotype features (H4/H5): HaplotypeModel/dataset_dev.py:11-87,337-349 --------- */
 /* four int32 planes [D][L]; ref_row[L] int32; out double [105][L] (row 104 = ref row) */

@@ -37,6 +37,8 @@ def _load():
                                       C.c_int, C.c_char_p]
     lib.orc_pileup_forward.restype = None
     lib.orc_pileup_forward.argtypes = [p, p, C.c_int64, p, p, C.c_int]
+    lib.orc_pileup_forward_blocked.restype = None
+    lib.orc_pileup_forward_blocked.argtypes = [p, p, C.c_int64, p, p, C.c_int]
     lib.orc_hap_features_batch.restype = None
     lib.orc_hap_features_batch.argtypes = [p, p, p, p, p, C.c_int64, C.c_int, C.c_int, p, C.c_int]
     lib.orc_hap_features.restype = None
@@ -114,13 +116,14 @@ def _wptrs(weights):
     return ws, arr
 
 
-def pileup_forward(weights, x, nthreads=1):
-    """weights: the 24 fp32 arrays of ont_pileup.chkpt in state-dict order."""
+def pileup_forward(weights, x, nthreads=1, blocked=False):
+    """weights: the 24 fp32 arrays of ont_pileup.chkpt in state-dict order.  blocked=True runs the cache-blocked AVX2
+    arrangement of the same schedule that bench.py times as its CPU baseline (never used as the checker)."""
     ws, arr = _wptrs(weights)
     x = _c(x, np.int32)
     N = x.shape[0]
     gt = np.empty((N, 21), np.float32); zy = np.empty((N, 3), np.float32)
-    lib().orc_pileup_forward(arr, _p(x), N, _p(gt), _p(zy), nthreads)
+    (lib().orc_pileup_forward_blocked if blocked else lib().orc_pileup_forward)(arr, _p(x), N, _p(gt), _p(zy), nthreads)
     return gt, zy
 
 
