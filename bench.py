@@ -1,33 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- candidate SNP sites/sec (pileup encode + PileupModel forward) on synthetic 30x windows.
 
-Workload = BASELINE.json configs[1]: a pool of 1M stand-alone 33-column windows (generator G2,
-SURVEY.md 8(d)) resident in HBM, processed in batches of 4096 windows.  One *step* = one batch
-through the hot path: column encode (mpileup bytes -> int32 [M,18] counts) + PileupModel forward
-reading the windows in place (-> softmax probabilities) + argmax/max/depth post-processing.
-Batches are independent, so steps are issued round-robin over `--streams` HIP streams (one
-nsnp_ctx each) to keep all 256 CUs busy at this batch size.
+Workload = BASELINE.json configs[1]: a pool of 1,048,576 stand-alone 33-column windows (generator G2,
+SURVEY.md 8(d)) resident in HBM on every GPU, processed in batches of 4096 windows.  One batch through
+the hot path = column encode (mpileup bytes -> int32 [M,18] counts) + PileupModel forward reading the
+windows in place (-> softmax probabilities) + argmax/max post-processing.  The pool never depends on
+--steps: one *step* = ceil(256 / steps) consecutive batches of the pool (so the timed region always
+sweeps the whole pool at least once), issued round-robin over `--streams` HIP streams (one nsnp_ctx each).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 4096] [--streams 32]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: one process per GPU, every rank owns its own pool (weak scaling, no data-path
-collective); the only exchange is the rooted gather of the compact per-site results at the end
-(inside the timed region).  Rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 and no torchrun environment: this process starts the N ranks itself (a child
+`python -m torch.distributed.run`, before anything touches the GPU), relays rank 0's JSON line and exits
+with the children's status.  One process per GPU, every rank owns its own pool (weak scaling, no
+data-path collective); the only exchange is the rooted gather of the compact per-site calls at the end,
+inside the timed region (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+
+The headline `value` is the exact-fp32 path (the library default, the reference's arithmetic); the
+opt-in f16x3 mode is timed afterwards on the same pool and reported under "f16x3" in the same line.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
 
 METRIC = "candidate SNP sites/sec (pileup encode + model fwd), 30x windows"
 
@@ -39,84 +45,192 @@ ALG_FLOP_PER_SITE = {
     "pileup_head": 2 * 1_645_056,    # output_proj + dense on 33 positions + 4 heads (model.py:37,67-72)
 }
 ALG_FLOP_PER_SITE["pileup_l1f"] = ALG_FLOP_PER_SITE["pileup_proj1"] + ALG_FLOP_PER_SITE["pileup_l1"]   # fused kernel
-assert sum(v for k, v in ALG_FLOP_PER_SITE.items() if k != "pileup_l1f") == 2 * 6_274_560          # 12.55 MFLOP/site
+ALG_FLOP_FORWARD = 2 * 6_274_560                                                                        # 12.55 MFLOP/site
+assert sum(v for k, v in ALG_FLOP_PER_SITE.items() if k != "pileup_l1f") == ALG_FLOP_FORWARD
+# what the kernels execute (exact reduced schedule: layer 1 only on the 17 steps per direction that reach position 16,
+# output_proj / dense / heads only at position 16 -- model.py:68; layer-0 K padded 18 -> 20 incl. the bias column)
+EXEC_FLOP_PER_SITE = {"pileup_l0": 2 * 33 * 256 * (20 + 64) * 2, "pileup_l1f": 2 * 17 * 256 * (128 + 64) * 2,
+                      "pileup_proj1": 2 * 17 * 256 * 128 * 2, "pileup_l1": 2 * 17 * 256 * 64 * 2,
+                      "pileup_head": (128 * 128 + 256 * 128 + 32 * 256) * 2}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (the f16x3 path issues 3 fp16 MFMAs per fp32 product)
 PEAK_HBM_GBS = 8000.0
+N_POOL = 1 << 20
 
 
-# f16x3 recurrence kernels: SIMD cycles per site = MFMAs x 16.3 / 16 sites + LSTM cells x 82 / 64 lanes
-SERIAL_SIMD_CYCLES_PER_SITE = {"pileup_l0": 66 * 128 * 16.3 / 16 + 66 * 64 * 82 / 64,
-                               "pileup_l1f": 34 * 288 * 16.3 / 16 + 34 * 64 * 82 / 64}
-
-
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--streams", type=int, default=32)
-    ap.add_argument("--windows", type=int, default=1 << 20, help="windows resident per GPU")
+    ap.add_argument("--windows", type=int, default=N_POOL, help="windows resident per GPU (BASELINE configs[1]: 1M)")
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = runtime default of 4). 16 lets more "
-                    "of the 32 streams run kernels side by side: +8 %% sites/s (34 M vs 31.5 M), but every launch is then stretched by the "
-                    "launches it shares the chip with and the per-launch durations stop being comparable with a rocprofv3 trace of "
-                    "the same command (tracing itself lowers the concurrency); 24 and more collapse")
-    ap.add_argument("--precision", type=int, default=1, help="PileupModel forward: 0 exact fp32 MFMA, 1 f16x3 split")
-    ap.add_argument("--fused-l1", type=int, default=1, help="f16x3: fused projection + layer-1 recurrence kernel")
-    ap.add_argument("--fused-waves", type=int, default=8, help="waves per workgroup of the fused kernel (0 = auto)")
-    ap.add_argument("--l0-rs", type=int, default=1, help="f16x3: register-stationary layer-0 kernel (0 = LDS-image kernel)")
-    ap.add_argument("--l1-rs", type=int, default=1, help="f16x3 fused layer 1: register-stationary kernel (0 = LDS-image / ring kernel)")
-    ap.add_argument("--l1-groups", type=int, default=0, help="16-site groups per layer-1 workgroup (0 = picked from the batch size)")
-    ap.add_argument("--l0-groups", type=int, default=0, help="16-site groups per layer-0 workgroup (0 = picked from the batch size, 1 at 4096 sites)")
-    ap.add_argument("--proj1-tiles", type=int, default=0, help="tiles per wave of the projection kernel (0 = library default)")
-    ap.add_argument("--rec-waves", type=int, default=0, help="force waves per recurrence workgroup (0 = auto)")
+    ap.add_argument("--workload", default="pileup", choices=["pileup", "two-stage"],
+                    help="pileup = BASELINE configs[1] (the metric's configuration); two-stage = configs[3]: stage 2 + stage 5 on a "
+                         "chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = runtime default of 4)")
+    ap.add_argument("--precision", type=int, default=0, help="headline arithmetic of the PileupModel forward: 0 exact fp32 MFMA "
+                    "(library default), 1 f16x3 split")
+    ap.add_argument("--no-second-precision", action="store_true", help="skip the labelled f16x3 pass after the fp32 headline")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="nsnp_ctx_set_option on every context (tuning)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (extra values are informational)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--timing-streams", type=int, default=8, help="record per-kernel HIP events on this many of the streams "
-                    "(every kernel launch of those streams inside the timed region; event records cost ~6 %% when on all 32)")
+    ap.add_argument("--timing-streams", type=int, default=16, help="record per-kernel HIP events on this many of the streams "
+                    "(every kernel launch of those streams inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
-    return ap.parse_args()
+    ap.add_argument("--selftest-launcher", action="store_true", help="CPU/gloo dry run of the multi-rank plumbing (spawn, barrier, "
+                    "max-over-ranks timing, rooted gather, one JSON line); no kernels, value is null -- tests/test_dist.py")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without a torchrun environment starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def launch_ranks(args):
+    """Parent of a multi-rank run.  Nothing here imports torch or touches the GPU: the ranks are children of a child
+    `python -m torch.distributed.run`, rank 0's JSON line is relayed, the exit status is the children's."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in p.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if p.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: {args.gpus}-rank run failed (exit {p.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return p.returncode or 1
+    print(lines[0])
+    return 0
+
+
+def usable_cores():
+    """cores this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(math.ceil(int(q) / int(per)))))
+    except Exception:
+        pass
+    return n
+
+
+def selftest_launcher(args, rank, world):
+    """The distributed skeleton of main() on CPU tensors over gloo: same barrier / max-over-ranks timing / rooted gather /
+    single JSON line, the timed region sleeps instead of launching kernels."""
+    import torch
+    import torch.distributed as dist
+    from nanosnp_amd.dist import gather_results, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n_total = 1000 * world + 3
+    lo, hi = shard_range(n_total, rank, world)
+    if world > 1: dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.002 * args.steps * (1 + rank))                     # rank r is r+1 times slower: MAX over ranks must pick the last
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    merged = gather_results(torch.stack([idx, idx * 3], 1), n_total)
+    if world > 1: dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        ok = merged.shape[0] == n_total and bool((merged[:, 0] == torch.arange(n_total)).all())
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / max(args.steps, 1) * 1e3, "selftest": True, "gather_ok": ok,
+                          "world_size_observed": dist.get_world_size() if world > 1 else 1,
+                          "slowest_rank_bound_ok": dt >= 0.002 * args.steps * world}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def cpu_baseline(cols, batch, weights, target_s):
-    """The oracle (plain-C port of the reference algorithm, full reference schedule) on this box's
-    host cores, on a bounded sample of the same windows: encode + forward, all cores."""
+    """The oracle's cache-blocked arrangement of the reference algorithm (full reference schedule, AVX2) on this box's
+    host cores, on a bounded sample of the same windows: column encode + forward."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
 
     def run(n):
         m = n * 33
         b1 = int(cols.col_off[m])
         t0 = time.perf_counter()
         counts, depth, flags = oracle.encode_columns(cols.bases[:b1], cols.col_off[:m + 1], cols.ref[:m])
-        gt, zy = oracle.pileup_forward(weights, counts.reshape(n, 33, 18), nthreads=cores)
-        return time.perf_counter() - t0
+        t1 = time.perf_counter()
+        oracle.pileup_forward(weights, counts.reshape(n, 33, 18), nthreads=cores, blocked=True)
+        t2 = time.perf_counter()
+        return t2 - t0, t1 - t0
 
-    n0 = min(1024, batch)
-    t = run(n0)
-    n = int(min(max(n0, n0 * target_s / max(t, 1e-6)), 262144, cols.n_cols // 33))
+    n0 = min(2048, batch)
+    t, _ = run(n0)
+    n = int(min(max(n0, n0 * target_s / max(t, 1e-6)), 1 << 19, cols.n_cols // 33))
     n = max(n0, (n // 64) * 64)
-    t = run(n)
-    return {"value": n / t, "unit": "sites/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the same synthetic windows (encode + full-schedule fp32 forward), "
-                      f"oracle/liboracle.so with OpenMP over {cores} threads, {t:.1f} s"}
+    t, t_enc = run(n)
+    cpu = ""
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                cpu = l.split(":", 1)[1].strip(); break
+    except Exception:
+        pass
+    out = {"value": n / t, "unit": "sites/s", "cores": cores, "kind": "port",
+           "sample": f"{n} of the same synthetic windows: column encode (single thread, {t_enc:.1f} s) + full-schedule fp32 forward "
+                     f"blocked for L1 with AVX2 FMA, OpenMP over {cores} threads ({t - t_enc:.1f} s); oracle/liboracle.so",
+           "host_cpu": cpu, "logical_cpus": os.cpu_count()}
+    ref = os.path.join(ROOT, "profiles", "r02_reference_cpu.json")
+    if os.path.exists(ref):                       # the reference itself, timed in the development container (cannot travel)
+        try:
+            rj = json.load(open(ref))
+            f64 = next(r for r in rj["forward"] if r["batch"] == 64 and r["threads"] == rj["host"]["logical_cpus"])
+            out["reference_in_dev_container"] = {
+                "value": f64["sites_per_s"], "unit": "sites/s", "cores": f64["threads"], "cpu": rj["host"]["cpu"],
+                "what": "the reference's own LSTMNetwork.predict on CPU torch, batch 64, 1,000 windows (BASELINE configs[0]); forward only; "
+                        "tests/manual/time_reference_cpu.py"}
+        except Exception:
+            pass
+    return out
 
 
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.selftest_launcher:
+        sys.exit(selftest_launcher(args, rank, world))
+    if args.workload == "two-stage":
+        from tools.two_stage_bench import run as run_two_stage
+        sys.exit(run_two_stage(args, rank, world, local_rank))
 
     if args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)      # must be set before HIP initialises
     # the host-side generator / CPU baseline use OpenMP: share the cores between the ranks of a node
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, world))))
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, world))))
+    import numpy as np
     import torch
     import torch.distributed as dist
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
+        sys.exit(3)
     from nanosnp_amd import _lib, host
     from nanosnp_amd.dist import gather_results
     from tests.helpers import load_pileup_weights
@@ -128,8 +242,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     batch, S = args.batch, max(1, args.streams)
-    n_windows = max(batch, (min(args.windows, max(args.steps, 1) * batch) // batch) * batch)
+    n_windows = max(batch, (args.windows // batch) * batch)
     n_batches = n_windows // batch
+    W, K = max(0, args.warmup), max(1, args.steps)
+    bps = max(1, -(-n_batches // K))                    # batches per step: K steps sweep the whole pool at least once
     weights = load_pileup_weights()                      # the shipped ont_pileup weights (fixture)
 
     # ---- synthetic pool, resident in HBM before the clock starts ---------------------------------
@@ -142,22 +258,15 @@ def main():
 
     lib = _lib.load()
     ctxs, streams, bufs = [], [], []
+    timed_streams = 0 if args.no_kernel_timing else min(S, max(1, args.timing_streams))
     for s in range(S):
         ctx = _lib.Context(local_rank, chunk_sites=batch)
         ctx.pileup_load_weights(weights)
-        ctx.enable_timing(not args.no_kernel_timing and s < max(1, args.timing_streams))
+        ctx.enable_timing(s < timed_streams)
         ctx.set_option("pileup_precision", args.precision)
-        if args.rec_waves:
-            ctx.set_option("recurrence_waves", args.rec_waves)
-        if args.proj1_tiles:
-            ctx.set_option("proj1_tiles", args.proj1_tiles)
-        ctx.set_option("fused_l1", args.fused_l1)
-        ctx.set_option("l0_register_stationary", args.l0_rs)
-        ctx.set_option("l1_register_stationary", args.l1_rs)
-        ctx.set_option("l1_site_groups", args.l1_groups)
-        ctx.set_option("l0_site_groups", args.l0_groups)
-        if args.fused_waves:
-            ctx.set_option("fused_waves", args.fused_waves)
+        for o in args.opt:
+            name, val = o.split("=")
+            ctx.set_option(name, int(val))
         ctxs.append(ctx)
         streams.append(torch.cuda.Stream(device=dev))
         bufs.append(dict(
@@ -172,8 +281,8 @@ def main():
 
     P = C.c_void_p
 
-    def make_step(i, s=None):
-        """pre-built argument lists: the timed loop is three C-ABI calls per step"""
+    def make_launch(i, s=None):
+        """pre-built argument lists: one batch is three C-ABI calls"""
         b = i % n_batches
         s = i % S if s is None else s
         c0 = b * mcols
@@ -189,9 +298,9 @@ def main():
                 P(res["gm"].data_ptr() + 4 * n0), P(res["zm"].data_ptr() + 4 * n0), None, st)
         return enc, fwd, post
 
-    def run_steps(first, count, table=None):
+    def run_batches(first, count, table):
         for i in range(first, first + count):
-            enc, fwd, post = (table or steps)[i]
+            enc, fwd, post = table[i]
             rc = lib.nsnp_pileup_encode_columns(*enc)
             rc = rc or lib.nsnp_pileup_forward_windows(*fwd)
             rc = rc or lib.nsnp_pileup_postprocess(*post)
@@ -203,133 +312,149 @@ def main():
             st.synchronize()
         torch.cuda.synchronize(dev)
 
-    W, K = args.warmup, args.steps
-    steps = [make_step(i) for i in range(W + K)]
+    launches = [make_launch(i) for i in range((W + K) * bps)]
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def merge_results(n_done):
+    n_done = min(K * bps, n_batches) * batch                # distinct sites whose calls exist after the timed region
+
+    def merge_results():
         """final merge: compact per-site calls of this rank -> rank 0 (RCCL gather over xGMI)"""
         compact = torch.stack([res["ga"][:n_done].float(), res["za"][:n_done].float(),
                                res["gm"][:n_done], res["zm"][:n_done]], dim=1)
         return gather_results(compact, n_done * world) if world > 1 else compact
 
-    n_done = min(K, n_batches) * batch
-    run_steps(0, W)
-    sync_all()
-    merge_results(n_done)               # warm the merge path (first-use module loads) outside the clock
-    sync_all()
+    def timed_pass():
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
+        run_batches(0, W * bps, launches)
+        sync_all()
+        merge_results()                      # warm the merge path (first-use module loads) outside the clock
+        sync_all()
+        for ctx in ctxs:
+            ctx.read_timing()               # drop warm-up launches
+        barrier(); sync_all()
+        t0 = time.perf_counter()
+        run_batches(W * bps, K * bps, launches)
+        t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (informational)
+        sync_all()
+        merged = merge_results()
+        sync_all(); barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        tot = {}
+        for ctx in ctxs:
+            for k, (ms, n) in ctx.read_timing().items():
+                a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+        return dt, t_issue, merged, {k: v for k, v in tot.items() if v[1]}
+
     extra = []
     for rep in range(max(0, args.repeat - 1)):      # informational repeats BEFORE the reported region
-        sync_all(); t0 = time.perf_counter(); run_steps(W, K); sync_all()
-        extra.append(world * K * batch / (time.perf_counter() - t0))
-    for ctx in ctxs:
-        ctx.read_timing()               # drop warm-up launches
-    barrier(); sync_all()
-    t0 = time.perf_counter()
-    run_steps(W, K)
-    t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (informational)
-    sync_all()
-    merged = merge_results(n_done)
-    sync_all(); barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt_r, _, _, _ = timed_pass()
+        extra.append(world * K * bps * batch / dt_r)
+    dt, t_issue, merged, tot = timed_pass()
+    sites_timed = world * K * bps * batch
+    fused = lambda prec: {"pileup_l1": "pileup_l1f"} if "pileup_proj1" not in tot else {}
 
-    # ---- per-kernel durations from HIP events recorded on the launch streams ---------------------
-    tot = {}
-    for ctx in ctxs:
-        for k, (ms, n) in ctx.read_timing().items():
-            a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
-    # the same kernels with the chip to themselves (one stream, after the timed region): in the timed region up to
-    # --hw-queues launches share the chip, which stretches every launch without saying anything about the kernel
+    # the same kernels with the chip to themselves (one stream, after the timed region)
     excl = {}
-    if not args.no_kernel_timing:
-        solo = [make_step(W + i, 0) for i in range(32)]
-        run_steps(0, 4, solo); sync_all(); ctxs[0].read_timing()
-        run_steps(4, 28, solo); sync_all()
+    if timed_streams:
+        solo = [make_launch(i, 0) for i in range(36)]
+        run_batches(0, 4, solo); sync_all(); ctxs[0].read_timing()
+        run_batches(4, 32, solo); sync_all()
         excl = {k: ms / n for k, (ms, n) in ctxs[0].read_timing().items() if n}
+
+    # ---- second, labelled value: the opt-in f16x3 arithmetic on the same pool ----------------------
+    second = None
+    if not args.no_second_precision and args.precision == 0:
+        ref_gt = gt_all[:n_done].clone(); ref_zy = zy_all[:n_done].clone()
+        for ctx in ctxs:
+            ctx.set_option("pileup_precision", 1)
+        dt2, _, _, tot2 = timed_pass()
+        d = max((gt_all[:n_done] - ref_gt).abs().max().item(), (zy_all[:n_done] - ref_zy).abs().max().item())
+        second = {"value": sites_timed / dt2, "unit": "sites/s", "ms_per_step": dt2 / K * 1e3,
+                  "dtype": "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)",
+                  "max_abs_dp_vs_fp32_on_the_pool": d, "tolerance": 1e-4,
+                  "kernel_avg_ms": {("pileup_l1f" if k == "pileup_l1" else k): round(v[0] / v[1], 5) for k, v in sorted(tot2.items())}}
+        del ref_gt, ref_zy
+
     if rank == 0:
-        if args.precision == 1 and args.fused_l1 and "pileup_l1" in tot:      # the fused kernel is timed in the l1 slot
-            tot["pileup_l1f"] = tot.pop("pileup_l1")
-        avg_ms = {k: (v[0] / v[1]) for k, v in tot.items() if v[1]}
-        if not avg_ms:
-            print(json.dumps({"metric": METRIC, "value": world * K * batch / dt, "unit": "sites/s", "n_gpus": world,
-                              "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "host_issue_ms_per_step": t_issue / K * 1e3, "note": "kernel timing disabled",
-                              "repeats_before": [round(v) for v in extra]}))
-            return
-        dom = max(avg_ms, key=lambda k: tot[k][0])
-        if dom in ALG_FLOP_PER_SITE:
-            achieved = ALG_FLOP_PER_SITE[dom] * batch / (avg_ms[dom] * 1e-3) / 1e12
-            peak = PEAK_F16_MFMA_TFLOPS if args.precision == 1 else PEAK_F32_MFMA_TFLOPS
-            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak}
-            if args.precision == 1:
-                roof["note"] = ("f16x3: 3 fp16 MFMAs per fp32 product; achieved = algorithmic fp32-equivalent flops, priced against "
-                                "the dense fp16 peak.  A SIMD of this chip runs the MFMAs (16.3 cycles per 16x16x32) and the LSTM "
-                                "cell's exp2 / rcp work (82 cycles per 64-lane cell) one after the other, not side by side "
-                                "(tools/probes/cell_rate.hip): serial_bound is the launch time that sum allows (DESIGN.md section 4)")
-        else:
-            nbytes = (int(cols.col_off[mcols]) + mcols * (1 + 72))        # bytes in + ref + 18 int32 out
-            achieved = nbytes / (avg_ms[dom] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
-        if args.precision == 1 and dom in SERIAL_SIMD_CYCLES_PER_SITE:
-            # measured serial bound of a recurrence kernel on this chip (DESIGN.md section 4): a SIMD spends 16.3 cycles per
-            # 16x16x32 fp16 MFMA and 82 cycles per 64-lane LSTM cell, and the two do not overlap
-            cyc = SERIAL_SIMD_CYCLES_PER_SITE[dom]
-            bound_ms = cyc * batch / (1024 * 2.0e9) * 1e3
-            roof["serial_bound"] = {"simd_cycles_per_site": cyc, "clock_ghz": 2.0, "simds": 1024, "bound_ms_per_launch": bound_ms,
-                                    "frac": bound_ms / avg_ms[dom],
-                                    "note": "whole-chip bound; launches of 4096 sites share the chip with the other streams' kernels"}
-        xk = "pileup_l1" if dom == "pileup_l1f" else dom
-        if xk in excl:
-            unit_work = ALG_FLOP_PER_SITE[dom] * batch / 1e12 if dom in ALG_FLOP_PER_SITE else nbytes / 1e9
-            roof["exclusive"] = {"avg_launch_ms": excl[xk], "achieved": unit_work / (excl[xk] * 1e-3), "frac": unit_work / (excl[xk] * 1e-3) / roof["peak"],
-                                 "note": "same kernel, same batch, one stream: no other launch shares the chip (28 launches after the timed region)"}
-        roof["concurrency"] = "up to %d launches of %d streams share the chip in the timed region; avg_launch_ms is per launch, not exclusive" % (args.hw_queues or 4, S)
-        roof["avg_launch_ms"] = avg_ms[dom]
-        roof["traffic"] = None
-        tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tp):                       # HBM bytes per launch from the committed PMC passes
-            try:
-                tj = json.load(open(tp))
-                if tj.get("batch") == batch and dom in tj.get("kernels", {}):
-                    roof["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
-            except Exception:
-                pass
-        # whole-forward view (all four forward kernels, same events)
-        fwd_ms = sum(avg_ms.get(k, 0.0) for k in ALG_FLOP_PER_SITE)      # (either l1f or proj1 + l1 is present)
+        names = fused(args.precision)
+        tot = {names.get(k, k): v for k, v in tot.items()}
+        excl = {names.get(k, k): v for k, v in excl.items()}
+        avg_ms = {k: v[0] / v[1] for k, v in tot.items()}
         out = {
-            "metric": METRIC, "value": world * K * batch / dt, "unit": "sites/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "host_issue_ms_per_step": t_issue / K * 1e3,
+            "metric": METRIC, "value": sites_timed / dt, "unit": "sites/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16x3 (fp32 split into two fp16, 3 MFMAs per product, fp32 accumulate)" if args.precision == 1 else "f32",
+            "dtype": "f32" if args.precision == 0 else "f16x3 (fp32 split into two fp16, 3 MFMAs per product, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: pileup encode + PileupModel fwd, synthetic 30x "
-                                   "windows (G2) resident in HBM, batch=4096",
-                       "batch": batch, "windows_resident_per_gpu": n_windows, "streams": S,
-                       "coverage": args.coverage, "precision": "f16x3" if args.precision == 1 else "fp32",
+            "config": {"workload": "BASELINE configs[1]: pileup encode + PileupModel fwd, 1M synthetic 30x windows (G2) resident in HBM, batch=4096",
+                       "batch": batch, "windows_resident_per_gpu": n_windows, "batches_per_step": bps, "sites_per_step": bps * batch,
+                       "streams": S, "coverage": args.coverage, "precision": "fp32" if args.precision == 0 else "f16x3",
                        "weights": "ont_pileup.chkpt values (tests/golden fixture)",
-                       "parallelism": f"site-sharded x{world}, rooted gather of calls"},
-            "roofline": roof,
-            "kernel_avg_ms": {k: round(v, 5) for k, v in sorted(avg_ms.items())},
-            "kernel_exclusive_ms": {("pileup_l1f" if (k == "pileup_l1" and args.precision == 1 and args.fused_l1) else k): round(v, 5)
-                                    for k, v in sorted(excl.items())},
-            "kernel_timing": {"streams_with_events": min(S, max(1, args.timing_streams)),
-                              "launches_timed": {k: v[1] for k, v in sorted(tot.items()) if v[1]}},
-            "forward_alg_tflops": (2 * 6_274_560 * batch / (fwd_ms * 1e-3) / 1e12) if fwd_ms else None,
+                       "parallelism": f"site-sharded x{world}, rooted gather of calls",
+                       "world_size_observed": dist.get_world_size() if world > 1 else 1},
+            "host_issue_ms_per_step": t_issue / K * 1e3,
         }
+        if avg_ms:
+            fwd_keys = [k for k in avg_ms if k in ALG_FLOP_PER_SITE]
+            dom = max(fwd_keys or list(avg_ms), key=lambda k: tot[k][0])               # dominant = most total time in the timed region
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else PEAK_F16_MFMA_TFLOPS
+            achieved = ALG_FLOP_PER_SITE[dom] * batch / (avg_ms[dom] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "avg_launch_ms": avg_ms[dom], "launches_timed": tot[dom][1],
+                    "algorithmic_flop_per_launch": ALG_FLOP_PER_SITE[dom] * batch,
+                    "executed": {"flop_per_launch": EXEC_FLOP_PER_SITE[dom] * batch * (3 if args.precision == 1 else 1),
+                                 "tflops": EXEC_FLOP_PER_SITE[dom] * batch * (3 if args.precision == 1 else 1) / (avg_ms[dom] * 1e-3) / 1e12,
+                                 "frac": EXEC_FLOP_PER_SITE[dom] * batch * (3 if args.precision == 1 else 1) / (avg_ms[dom] * 1e-3) / 1e12 / peak,
+                                 "note": "MFMA flops the kernel issues (reduced exact schedule: only position 16 is consumed, model.py:68); "
+                                         "achieved/frac above price the reference schedule's flops as SURVEY 8(d) prescribes, so frac can exceed "
+                                         "the executed fraction by the schedule reduction"},
+                    "concurrency": "avg_launch_ms is per launch inside the timed region, where launches of up to %d hardware queues (%d streams) "
+                                   "share the chip; `exclusive` = same kernel, one stream" % (args.hw_queues or 4, S),
+                    "traffic": None}
+            if dom in excl:
+                w_alg = ALG_FLOP_PER_SITE[dom] * batch / 1e12
+                roof["exclusive"] = {"avg_launch_ms": excl[dom], "achieved": w_alg / (excl[dom] * 1e-3), "frac": w_alg / (excl[dom] * 1e-3) / peak}
+            # chip-level view of the whole timed region: every forward flop of every site over the wall time
+            roof["chip"] = {"algorithmic_tflops": ALG_FLOP_FORWARD * (sites_timed / world) / dt / 1e12,
+                            "frac": ALG_FLOP_FORWARD * (sites_timed / world) / dt / 1e12 / peak,
+                            "executed_tflops": sum(EXEC_FLOP_PER_SITE[k] for k in fwd_keys) * (3 if args.precision == 1 else 1) * (sites_timed / world) / dt / 1e12,
+                            "note": "per GPU: forward flops of all timed sites / wall time of the timed region (encode, post-processing and the gather included in the time)"}
+            tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tp):                       # HBM bytes per launch from the committed PMC passes
+                try:
+                    tj = json.load(open(tp))
+                    if tj.get("batch") == batch and tj.get("precision", 1) == args.precision and dom in tj.get("kernels", {}):
+                        roof["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+            out["roofline"] = roof
+            if "encode_columns" in avg_ms:               # the HBM-bound kernel of the path, priced the same way
+                nbytes = int(cols.col_off[mcols]) + mcols * (1 + 72)        # column bytes + ref + 18 int32 out (SURVEY 8(d))
+                e = {"bound": "hbm", "kernel": "encode_columns", "achieved": nbytes / (avg_ms["encode_columns"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "avg_launch_ms": avg_ms["encode_columns"], "launches_timed": tot["encode_columns"][1],
+                     "algorithmic_bytes_per_launch": nbytes}
+                e["frac"] = e["achieved"] / PEAK_HBM_GBS
+                if "encode_columns" in excl:
+                    e["exclusive"] = {"avg_launch_ms": excl["encode_columns"], "achieved": nbytes / (excl["encode_columns"] * 1e-3) / 1e9,
+                                      "frac": nbytes / (excl["encode_columns"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                out["roofline_encode"] = e
+            out["kernel_avg_ms"] = {k: round(v, 5) for k, v in sorted(avg_ms.items())}
+            out["kernel_exclusive_ms"] = {k: round(v, 5) for k, v in sorted(excl.items())}
+            out["kernel_timing"] = {"streams_with_events": timed_streams, "launches_timed": {k: v[1] for k, v in sorted(tot.items())}}
+        else:
+            out["roofline"] = None
+        if second:
+            out["f16x3"] = second
         if extra:
             out["repeats_before"] = [round(v) for v in extra]
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cols, batch, weights, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_baseline(cols, batch, weights, args.cpu_seconds) if (not args.no_cpu_baseline and world == 1) else None
         assert merged is not None and merged.shape[0] == n_done * world
         print(json.dumps(out))
     if world > 1:

@@ -117,3 +117,41 @@ def test_sharded_pipeline_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert any(o is True for o in outs)
+
+
+# ---- bench.py's own launcher: `--gpus N` without a torchrun environment starts the N ranks itself -----------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_gpus2_spawns_two_ranks_and_relays_one_line():
+    """the driver's `python bench.py --gpus N`: N ranks are started (CPU / gloo dry run of the same skeleton: barrier,
+    max-over-ranks timing, rooted gather), rank 0's single JSON line comes back through the parent"""
+    import json
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-launcher")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["steps"] == 5 and d["selftest"] is True
+    assert d["gather_ok"] is True and d["slowest_rank_bound_ok"] is True      # the time is the slowest rank's
+
+
+def test_bench_never_reports_fewer_ranks_than_asked_for():
+    # a torchrun environment that disagrees with --gpus is an error, not a silent n_gpus: 1
+    out = _bench("--gpus", "4", "--selftest-launcher", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+    # N > 1 on a machine without N GPUs: the ranks start, find no device, the parent exits non-zero without a result line
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    out = _bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline")
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
