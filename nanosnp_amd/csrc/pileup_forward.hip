@@ -300,6 +300,285 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1r / K23r: REGISTER-STATIONARY fp32 recurrence kernels (default).  K1 / K3 above give one wave 16 sites and ALL 256
+// gate rows, so a 4096-site batch is only 512 waves for 1024 SIMDs and every wave re-reads the weight images from LDS
+// each step.  Here the gate tiles are split over the waves of a workgroup instead: a wave keeps the A fragments of its
+// tiles in VGPRs for the whole kernel (v_mfma_f32_16x16x4_f32 takes ONE VGPR per operand: 84 / 96 registers), and only
+// h_t crosses waves, through a double-buffered LDS exchange row per site with one LDS-only barrier per step.  A batch of
+// 4096 sites then is 2048 (layer 0) / 2048 (layer 1) waves, two per SIMD, and the matrix pipe - the bound of the fp32
+// path - is fed from registers.  Every accumulator sees the same k-ordered MFMA chain as in K1 / K2 + K3, and the cell
+// uses the same expressions, so the results are bit-identical to the LDS-image kernels (tests/test_gpu_pileup_forward.py).
+//
+// Exchange row of a site (layer-0 h_t and layer-1 h_t alike): 64 floats, the unit 16j + 4e + q at position
+// 16j + 4q + e, rows 72 floats apart.  The B fragment of lane (site n, quarter q) for K-steps 4j .. 4j+3 (units
+// 4(4j+e) + q) is then ONE ds_read_b128 at position 16j + 4q, the four units lane (n, q) of wave w leaves the cell with
+// (tiles 4w + u) are ONE ds_write_b128 at 16w + 4q, and with an 18-slot row stride both hit 16 distinct 16-byte bank
+// slots in every 16-lane group of the instruction (MI355X_MICROARCH.md, LDS table).
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_XROW = 72;                  // floats per exchange row: 64 + 8 pad (18 slots of 16 B)
+constexpr int RS_H0ROW = 136;                // floats per staged h0 row: 128 + 8 pad (34 slots)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// K1r: layer 0.  grid = (ceil(N / (16 NSG)), 2 directions), block = 256: wave w owns gate tiles 4w .. 4w+3 (hidden units
+// 16w .. 16w+15, all four gates) for NSG groups of 16 sites.
+template <int NSG>
+__global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
+    const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
+    const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ wih0, const float* __restrict__ wih1,
+    const float* __restrict__ wlast0, const float* __restrict__ wlast1,
+    float* __restrict__ H0)
+{
+    __shared__ __attribute__((aligned(16))) float hx[2][16 * NSG][RS_XROW];
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t base_site = (int64_t)blockIdx.x * (16 * NSG);
+
+    // ---- this wave's four gate tiles -> registers (the images K1 stages in LDS) ----
+    f32x4 Whh[4][4], Wih[4];
+    float Wl[4];
+    {
+        const f32x4* __restrict__ ghh = reinterpret_cast<const f32x4*>(dir ? whh1 : whh0);     // [tile][j4 4][lane]
+        const f32x4* __restrict__ gih = reinterpret_cast<const f32x4*>(dir ? wih1 : wih0);     // [tile][lane]
+        const float* __restrict__ gl = dir ? wlast1 : wlast0;                                   // [tile][lane]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Whh[u][j] = ghh[((4 * wave + u) * 4 + j) * 64 + lane];
+            Wih[u] = gih[(4 * wave + u) * 64 + lane];
+            Wl[u] = gl[(4 * wave + u) * 64 + lane];
+        }
+    }
+
+    // ---- input windows: every wave reads the x rows of all site groups itself (L1-resident after the first wave) ----
+    const int32_t* __restrict__ xs[NSG];
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) {
+        const int64_t site = base_site + 16 * sg + n;
+        const int64_t sc = site < N ? site : N - 1;
+        xs[sg] = center_idx ? x + (center_idx[sc] - PCENTER) * PC : x + sc * (PW * PC);
+    }
+    const int klast = q < 2 ? 16 + q : 16;   // lanes q = 2, 3 feed the bias / a zero instead
+    int xi[NSG][5];
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int sg = 0; sg < NSG; ++sg) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xi[sg][kk] = xs[sg][t * PC + 4 * kk + q];
+            xi[sg][4] = xs[sg][t * PC + klast];
+        }
+    };
+    load_x(dir ? PW - 1 : 0);
+
+    float c[NSG][4];
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[sg][u] = 0.f;
+
+    // H0 rows leave through the exchange buffer one step late: thread (row = tid / 16, chunk = tid % 16 = 4 q' + j) moves the
+    // 16 bytes at exchange position 16 j + 4 q' to H0 position 16 q' + 4 j, so 16 lanes write one 256-byte row [q][16]
+    auto flush_h = [&](int buf, int t) {
+        const int cid = tid & 15, qq = cid >> 2, jj = cid & 3;
+#pragma unroll
+        for (int k = 0; k < NSG; ++k) {
+            const int row = (tid >> 4) + 16 * k;
+            const int64_t site = base_site + row;
+            if (site < N) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&hx[buf][row][16 * jj + 4 * qq]);
+                *reinterpret_cast<f32x4*>(H0 + ((site * PW + t) * 2 + dir) * 64 + 4 * cid) = v;
+            }
+        }
+    };
+
+    for (int s = 0; s < PW; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        const int cur = s & 1;
+        float xb[NSG][4], xl[NSG];
+#pragma unroll
+        for (int sg = 0; sg < NSG; ++sg) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xb[sg][kk] = (float)xi[sg][kk];      // predict.py:49 int -> float
+            xl[sg] = q == 2 ? 1.0f : (q == 3 ? 0.0f : (float)xi[sg][4]);
+        }
+        if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);                            // prefetch the next position
+        if (s > 0) flush_h(cur ^ 1, dir ? t + 1 : t - 1);
+#pragma unroll
+        for (int sg = 0; sg < NSG; ++sg) {
+            // recurrent B fragments are requested one K block (4 K-steps) ahead of the MFMAs that use them, two in flight:
+            // the LDS latency hides behind 16 MFMAs and only 8 registers hold fragments
+            const float* hr = &hx[cur ^ 1][16 * sg + n][4 * q];
+            f32x4 hb0, hb1;
+            if (s > 0) { hb0 = *reinterpret_cast<const f32x4*>(hr); hb1 = *reinterpret_cast<const f32x4*>(hr + 16); }
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wih[u][e], xb[sg][e], acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wl[u], xl[sg], acc[u]);
+            if (s > 0) {
+#define RS_KBLOCK(J, HB)                                                                               \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                          \
+                    _Pragma("unroll") for (int u = 0; u < 4; ++u) acc[u] = mfma4(Whh[u][J][e], HB[e], acc[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                RS_KBLOCK(0, hb0)
+                __builtin_amdgcn_sched_barrier(0);
+                hb0 = *reinterpret_cast<const f32x4*>(hr + 32);
+                RS_KBLOCK(1, hb1)
+                __builtin_amdgcn_sched_barrier(0);
+                hb1 = *reinterpret_cast<const f32x4*>(hr + 48);
+                RS_KBLOCK(2, hb0)
+                __builtin_amdgcn_sched_barrier(0);
+                RS_KBLOCK(3, hb1)
+#undef RS_KBLOCK
+            }
+            // cell: lane (n, q) holds the four gates of unit 4 (4 wave + u) + q in acc[u]
+            f32x4 hn;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ig = sigmoid_f(acc[u][0]);
+                const float fg = sigmoid_f(acc[u][1]);
+                const float gg = tanh_f(acc[u][2]);
+                const float og = sigmoid_f(acc[u][3]);
+                c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
+                hn[u] = og * tanh_f(c[sg][u]);
+            }
+            *reinterpret_cast<f32x4*>(&hx[cur][16 * sg + n][16 * wave + 4 * q]) = hn;
+        }
+        lds_barrier();
+    }
+    flush_h((PW - 1) & 1, dir ? 0 : PW - 1);
+}
+
+// K23r: layer 1, input projection FUSED into the recurrence (no Xp1 round trip: 70 KB/site less HBM traffic than K2 + K3).
+// grid = (ceil(N / (16 NSG)), 2), block = 512: wave w owns gate tiles 2w, 2w+1 (W_ih1 K = 128 and W_hh1 K = 64: 96 VGPRs).
+// LDS: the h0_t rows of the workgroup's sites copied from H0 one step ahead (double-buffered; the 16-byte chunk (d, q, c) of
+// a row is stored at slot 16 d + 4 c + q so that the fragment reads are conflict-free) and the h1 exchange rows.
+constexpr int rs32_l1_lds_bytes(int nsg) { return (2 * 16 * nsg * RS_H0ROW + 2 * 16 * nsg * RS_XROW) * 4; }
+
+template <int NSG>
+__global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
+    const float* __restrict__ H0, int64_t N,
+    const float* __restrict__ wih0, const float* __restrict__ wih1,
+    const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1,
+    float* __restrict__ H1c)
+{
+    extern __shared__ f32x4 lds[];
+    constexpr int NS = 16 * NSG;
+    float* const h0s = reinterpret_cast<float*>(lds);                  // [2][NS][RS_H0ROW]
+    float* const h1x = h0s + 2 * NS * RS_H0ROW;                         // [2][NS][RS_XROW]
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t base_site = (int64_t)blockIdx.x * NS;
+
+    f32x4 Wih[2][8], Whh[2][4], bias[2];
+    {
+        const f32x4* __restrict__ gih = reinterpret_cast<const f32x4*>(dir ? wih1 : wih0);      // [tile][j4 8][lane]
+        const f32x4* __restrict__ ghh = reinterpret_cast<const f32x4*>(dir ? whh1 : whh0);      // [tile][j4 4][lane]
+        const f32x4* __restrict__ gb = reinterpret_cast<const f32x4*>(dir ? bias1 : bias0);     // [tile][lane]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Wih[u][j] = gih[((2 * wave + u) * 8 + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Whh[u][j] = ghh[((2 * wave + u) * 4 + j) * 64 + lane];
+            bias[u] = gb[(2 * wave + u) * 64 + lane];
+        }
+    }
+
+    // ---- h0 staging: a row is 32 chunks of 16 B; thread (row = tid / 32 + 16 k, chunk = tid % 32) moves NSG chunks per step ----
+    const int cid = tid & 31;                                            // H0 order: 16 d + 4 q' + c
+    const int slot = (cid & 16) + 4 * (cid & 3) + ((cid >> 2) & 3);      // LDS order: 16 d + 4 c + q'
+    f32x4 sreg[NSG];
+    auto load_h0 = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < NSG; ++k) {
+            const int64_t site = base_site + (tid >> 5) + 16 * k;
+            const int64_t sc = site < N ? site : N - 1;
+            sreg[k] = *reinterpret_cast<const f32x4*>(H0 + (sc * PW + t) * 128 + 4 * cid);
+        }
+    };
+    auto store_h0 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NSG; ++k)
+            *reinterpret_cast<f32x4*>(h0s + ((size_t)buf * NS + (tid >> 5) + 16 * k) * RS_H0ROW + 4 * slot) = sreg[k];
+    };
+    load_h0(dir ? PW - 1 : 0);
+    store_h0(0);
+    __syncthreads();
+
+    float c[NSG][2], hlast[NSG][2];
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) { c[sg][0] = c[sg][1] = 0.f; hlast[sg][0] = hlast[sg][1] = 0.f; }
+
+    for (int s = 0; s < PSTEPS1; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        const int cur = s & 1;
+        if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
+        const float* h0b = h0s + (size_t)cur * NS * RS_H0ROW;
+        const float* hrb = h1x + (size_t)(cur ^ 1) * NS * RS_XROW;       // h1_{s-1}
+        float* hwb = h1x + (size_t)cur * NS * RS_XROW;                   // h1_s
+#pragma unroll
+        for (int sg = 0; sg < NSG; ++sg) {
+            const float* r0 = h0b + (size_t)(16 * sg + n) * RS_H0ROW + 4 * q;
+            f32x4 acc[2] = {bias[0], bias[1]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                                 // K-steps 4j .. 4j+3: direction j / 4, chunk j % 4
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(r0 + 64 * (j >> 2) + 16 * (j & 3));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = mfma4(Wih[0][j][e], b4[e], acc[0]);
+                    acc[1] = mfma4(Wih[1][j][e], b4[e], acc[1]);
+                }
+            }
+            if (s > 0) {
+                const float* r1 = hrb + (size_t)(16 * sg + n) * RS_XROW + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(r1 + 16 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = mfma4(Whh[0][j][e], b4[e], acc[0]);
+                        acc[1] = mfma4(Whh[1][j][e], b4[e], acc[1]);
+                    }
+                }
+            }
+            // cell: lane (n, q) holds unit 4 (2 wave + u) + q, u = 0, 1 -> exchange positions 16 (w / 2) + 4 q + 2 (w % 2) + u
+            float hn[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float ig = sigmoid_f(acc[u][0]);
+                const float fg = sigmoid_f(acc[u][1]);
+                const float gg = tanh_f(acc[u][2]);
+                const float og = sigmoid_f(acc[u][3]);
+                c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
+                hn[u] = og * tanh_f(c[sg][u]);
+                hlast[sg][u] = hn[u];
+            }
+            float2 w2; w2.x = hn[0]; w2.y = hn[1];
+            *reinterpret_cast<float2*>(hwb + (size_t)(16 * sg + n) * RS_XROW + 16 * (wave >> 1) + 4 * q + 2 * (wave & 1)) = w2;
+        }
+        if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
+        lds_barrier();
+    }
+    // h1 at position 16 -> H1c[site][dir][q][16]: entries 2 wave, 2 wave + 1 of row q
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) {
+        const int64_t site = base_site + 16 * sg + n;
+        if (site < N) {
+            float2 w2; w2.x = hlast[sg][0]; w2.y = hlast[sg][1];
+            *reinterpret_cast<float2*>(H1c + site * 128 + dir * 64 + q * 16 + 2 * wave) = w2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: heads.  block = 256 (4 waves x 16 sites), weights streamed from L2 (216 KB of images).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pileup_head(
@@ -556,6 +835,8 @@ static int set_lds_attr_once(nsnp_ctx* ctx)
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(4)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(2)));
     ctx->attr_set = true;
     return NSNP_OK;
 }
@@ -582,12 +863,33 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         while (wpb > 1 && waves_total / wpb < (int64_t)ctx->n_cu / 2) wpb >>= 1;
         if (ctx->force_wpb) wpb = ctx->force_wpb;
         const dim3 g_rec((unsigned)NSNP_CDIV(n, 16 * wpb), 2);
+        if (ctx->l0_rs) {
+            ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
+            // 64 sites per workgroup when that still gives every CU two workgroups, else 32 or 16
+            int nsg = 4;
+            while (nsg > 1 && NSNP_CDIV(n, 16 * nsg) * 2 < 2 * (int64_t)ctx->n_cu) nsg >>= 1;
+            if (ctx->l0_rs_groups) nsg = ctx->l0_rs_groups;
+#define LAUNCH_RS(G) hipLaunchKernelGGL(k_pileup_l0_rs32<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), 0, s, xc, cc, n, \
+                           pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1], ctx->ws_h0)
+            if (nsg == 4) LAUNCH_RS(4); else if (nsg == 2) LAUNCH_RS(2); else LAUNCH_RS(1);
+#undef LAUNCH_RS
+        } else
         { ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
 #define LAUNCH_L0(W) hipLaunchKernelGGL(k_pileup_l0<W>, g_rec, dim3(64 * W), L0_LDS_BYTES, s, xc, cc, n, \
                            pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1], ctx->ws_h0)
         if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
+        if (ctx->l1_rs) {
+            ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
+            // one 8-wave workgroup per CU (LDS + registers): 64 sites each when that still gives every CU one, else 32
+            int g1 = NSNP_CDIV(n, 64) * 2 >= (int64_t)ctx->n_cu ? 4 : 2;
+            if (ctx->l1_rs_groups) g1 = ctx->l1_rs_groups;
+#define LAUNCH_R1(G) hipLaunchKernelGGL(k_pileup_l1_rs32<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(512), rs32_l1_lds_bytes(G), s, \
+                           ctx->ws_h0, n, pw.l1_wih[0], pw.l1_wih[1], pw.l1_whh[0], pw.l1_whh[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_h1c)
+            if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2);
+#undef LAUNCH_R1
+        } else {
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
         // persistent workgroups: each loads the 128 KB weight image once and then walks
         // proj1_tiles 16-row tiles per wave, so the load is amortised even at small batches
@@ -602,6 +904,7 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
                            pw.l1_whh[0], pw.l1_whh[1], ctx->ws_h1c)
         if (wpb == 8) LAUNCH_L1(8); else if (wpb == 4) LAUNCH_L1(4); else if (wpb == 2) LAUNCH_L1(2); else LAUNCH_L1(1);
 #undef LAUNCH_L1
+        }
         }
         ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
         hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,

@@ -167,6 +167,38 @@ def test_workgroup_shape_does_not_change_results(model, pileup_weights):
     c.close()
 
 
+def test_fp32_register_stationary_kernels_equal_the_lds_image_kernels_bit_for_bit(pileup_weights):
+    """exact fp32: the register-stationary layer-0 / fused layer-1 kernels (default) issue, per accumulator, the same
+    k-ordered MFMA chain and the same cell expressions as the LDS-image kernels K1 / K2 + K3: identical bits for every
+    workgroup shape, ragged sizes, either kernel in front of the other, and the windows entry point"""
+    import torch
+    from nanosnp_amd import _lib
+    from oracle import oracle
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    rng = np.random.default_rng(41)
+    xn = (rng.integers(0, 60, (1003, 33, 18)) - 15).astype(np.int32)
+    xn[5, 3] = 5000; xn[700, 16, 2] = -70000; xn[300, 10, 4] = 2**24 + 3          # the fp32 mode carries the whole int32 -> float cast
+    x = torch.from_numpy(xn).cuda()
+    c.set_option("l0_register_stationary", 0); c.set_option("l1_register_stationary", 0)
+    old = c.pileup_forward(x)
+    for l0, l1 in ((1, 1), (1, 0), (0, 1)):
+        c.set_option("l0_register_stationary", l0); c.set_option("l1_register_stationary", l1)
+        for g0 in ((0, 1, 2, 4) if l0 else (0,)):
+            for g1 in ((0, 2, 4) if l1 else (0,)):
+                c.set_option("l0_site_groups", g0); c.set_option("l1_site_groups", g1)
+                got = c.pileup_forward(x)
+                assert torch.equal(got[0], old[0]) and torch.equal(got[1], old[1]), (l0, l1, g0, g1)
+    c.set_option("l0_register_stationary", 1); c.set_option("l1_register_stationary", 1)
+    c.set_option("l0_site_groups", 0); c.set_option("l1_site_groups", 0)
+    for n in (1, 15, 16, 17, 31, 33, 63, 64, 65, 200):
+        gn, zn = c.pileup_forward(x[:n].contiguous())
+        assert torch.equal(gn, old[0][:n]) and torch.equal(zn, old[1][:n]), n
+    og, oz = oracle.pileup_forward(pileup_weights, xn[:320], nthreads=8)
+    assert np.abs(old[0][:320].cpu().numpy() - og).max() < PROB_ATOL and np.abs(old[1][:320].cpu().numpy() - oz).max() < PROB_ATOL
+    c.close()
+
+
 def test_f16x3_precision_mode(pileup_weights):
     """every product as 3 fp16 MFMAs with fp32 accumulation (pileup_forward_f16x3.hip): same goldens,
     same 1e-4 tolerance; measured ~1e-6"""

@@ -7,7 +7,7 @@ import numpy as np, torch
 from nanosnp_amd import _lib
 from tests.helpers import load_pileup_weights
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
-prec = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 wpb = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device("cuda:0")
@@ -20,6 +20,7 @@ ctx.set_option("fused_waves", int(os.environ.get("FWAVES", "0")))
 ctx.set_option("l0_register_stationary", int(os.environ.get("L0RS", "1")))
 ctx.set_option("l0_site_groups", int(os.environ.get("L0SG", "0")))
 ctx.set_option("l1_register_stationary", int(os.environ.get("L1RS", "1")))
+ctx.set_option("l1_site_groups", int(os.environ.get("L1SG", "0")))
 x = torch.randint(-20, 40, (N, 33, 18), dtype=torch.int32, device=dev)
 gt = torch.empty((N, 21), device=dev); zy = torch.empty((N, 3), device=dev)
 ctx.pileup_forward(x, gt, zy); torch.cuda.synchronize()
@@ -29,4 +30,4 @@ for _ in range(iters): ctx.pileup_forward(x, gt, zy)
 torch.cuda.synchronize()
 dt = (time.time() - t) / iters
 tm = ctx.read_timing()
-print(f"N={N} precision={prec} wpb={wpb}: {dt*1e3:.3f} ms  {N/dt/1e6:.2f} M sites/s ", {k: round(v[0]/max(v[1],1), 4) for k, v in tm.items() if v[1]})
+print(f"N={N} precision={prec} wpb={wpb} L0RS={os.environ.get('L0RS','1')} L1RS={os.environ.get('L1RS','1')} L0SG={os.environ.get('L0SG','0')} L1SG={os.environ.get('L1SG','0')}: {dt*1e3:.3f} ms  {N/dt/1e6:.2f} M sites/s ", {k: round(v[0]/max(v[1],1), 4) for k, v in tm.items() if v[1]})
