@@ -45,6 +45,8 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->fused_l1 = 1;
     ctx->l0_rs = 1;
     ctx->l1_rs = 1;
+    ctx->l1_stagger = 0;
+    ctx->head_rs = 1;
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -108,12 +110,22 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         return NSNP_OK;
     }
     if (strcmp(name, "l1_register_stationary") == 0) {
-        if (value != 0 && value != 1) return NSNP_EINVAL;
+        if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->l1_rs = (int)value;
         return NSNP_OK;
     }
+    if (strcmp(name, "head_split") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->head_rs = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "l1_stagger") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->l1_stagger = (int)value;
+        return NSNP_OK;
+    }
     if (strcmp(name, "l1_site_groups") == 0) {
-        if (value != 0 && value != 2 && value != 4) return NSNP_EINVAL;
+        if (value != 0 && value != 1 && value != 2 && value != 4) return NSNP_EINVAL;
         ctx->l1_rs_groups = (int)value;
         return NSNP_OK;
     }

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
 // a row is stored at slot 16 d + 4 c + q so that the fragment reads are conflict-free) and the h1 exchange rows.
 constexpr int rs32_l1_lds_bytes(int nsg) { return (2 * 16 * nsg * RS_H0ROW + 2 * 16 * nsg * RS_XROW) * 4; }
 
-template <int NSG>
+template <int NSG, bool STAGGER>
 __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
     const float* __restrict__ H0, int64_t N,
     const float* __restrict__ wih0, const float* __restrict__ wih1,
@@ -509,13 +509,163 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
         for (int k = 0; k < NSG; ++k)
             *reinterpret_cast<f32x4*>(h0s + ((size_t)buf * NS + (tid >> 5) + 16 * k) * RS_H0ROW + 4 * slot) = sreg[k];
     };
+    // Software pipeline: the input part of step u+1 (64 of a step's 96 MFMAs per site group) depends on nothing step u
+    // computes, so it is issued in step u behind the recurrent part - beside the sigmoid / tanh work of the cells and in front
+    // of the barrier, which every wave then reaches with its h1 rows long written.  Per accumulator the chain is still
+    // bias -> 32 input K-steps -> 16 recurrent K-steps.  h0 rows are staged two steps ahead (buffer u % 2 holds step u).
+    auto tpos = [&](int u) { return dir ? PW - 1 - u : u; };
+    load_h0(tpos(0)); store_h0(0);
+    load_h0(tpos(1)); store_h0(1);
+    __syncthreads();
+    load_h0(tpos(2));
+
+    f32x4 acc[NSG][2];
+    auto input_part = [&](int sg, int buf, f32x4& a0, f32x4& a1) {
+        const float* r0 = h0s + ((size_t)buf * NS + 16 * sg + n) * RS_H0ROW + 4 * q;
+        a0 = bias[0]; a1 = bias[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                                     // K-steps 4j .. 4j+3: direction j / 4, chunk j % 4
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(r0 + 64 * (j >> 2) + 16 * (j & 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0 = mfma4(Wih[0][j][e], b4[e], a0);
+                a1 = mfma4(Wih[1][j][e], b4[e], a1);
+            }
+        }
+    };
+    // Waves w and w + 4 share a SIMD and its matrix pipe and run in lockstep between barriers.  The second half of the
+    // workgroup therefore issues a group's next-step input part BEFORE that group's recurrent part and cell, the first half
+    // behind it: the sigmoid / tanh work of one wave then sits beside MFMAs of its partner (MI355X_MICROARCH.md, 'Two waves
+    // per SIMD', item 9) instead of both idling the pipe together.
+    const bool late = STAGGER && wave >= 4;
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) input_part(sg, 0, acc[sg][0], acc[sg][1]);
+
+    float c[NSG][2];
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) c[sg][0] = c[sg][1] = 0.f;
+
+    for (int s = 0; s < PSTEPS1; ++s) {
+        const int cur = s & 1;
+        const float* hrb = h1x + (size_t)(cur ^ 1) * NS * RS_XROW;       // h1_{s-1}
+        float* hwb = h1x + (size_t)cur * NS * RS_XROW;                   // h1_s
+#pragma unroll
+        for (int sg = 0; sg < NSG; ++sg) {
+            f32x4 nx0, nx1;
+            if (late && s + 1 < PSTEPS1) input_part(sg, cur ^ 1, nx0, nx1);
+            if (s > 0) {
+                const float* r1 = hrb + (size_t)(16 * sg + n) * RS_XROW + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(r1 + 16 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[sg][0] = mfma4(Whh[0][j][e], b4[e], acc[sg][0]);
+                        acc[sg][1] = mfma4(Whh[1][j][e], b4[e], acc[sg][1]);
+                    }
+                }
+            }
+            // cell: lane (n, q) holds unit 4 (2 wave + u) + q, u = 0, 1 -> exchange positions 16 (w / 2) + 4 q + 2 (w % 2) + u
+            float2 w2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float ig = sigmoid_f(acc[sg][u][0]);
+                const float fg = sigmoid_f(acc[sg][u][1]);
+                const float gg = tanh_f(acc[sg][u][2]);
+                const float og = sigmoid_f(acc[sg][u][3]);
+                c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
+                const float h = og * tanh_f(c[sg][u]);
+                if (u == 0) w2.x = h; else w2.y = h;
+            }
+            *reinterpret_cast<float2*>(hwb + (size_t)(16 * sg + n) * RS_XROW + 16 * (wave >> 1) + 4 * q + 2 * (wave & 1)) = w2;
+            if (s + 1 < PSTEPS1) {                                      // step s+1's input part (reads h0 of step s+1)
+                if (late) { acc[sg][0] = nx0; acc[sg][1] = nx1; }
+                else input_part(sg, cur ^ 1, acc[sg][0], acc[sg][1]);
+            }
+        }
+        if (s + 2 < PSTEPS1) {
+            store_h0(cur);                                               // h0 of step s+2 replaces h0 of step s (last read in step s-1)
+            if (s + 3 < PSTEPS1) load_h0(tpos(s + 3));
+        }
+        lds_barrier();
+    }
+    // h1 at position 16 -> H1c[site][dir][q][16]: entries 2 wave, 2 wave + 1 of row q (read back from the exchange rows)
+    const float* hfin = h1x + (size_t)((PSTEPS1 - 1) & 1) * NS * RS_XROW;
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) {
+        const int64_t site = base_site + 16 * sg + n;
+        if (site < N)
+            *reinterpret_cast<float2*>(H1c + site * 128 + dir * 64 + q * 16 + 2 * wave) =
+                *reinterpret_cast<const float2*>(hfin + (size_t)(16 * sg + n) * RS_XROW + 16 * (wave >> 1) + 4 * q + 2 * (wave & 1));
+    }
+}
+
+// K23r4: the same fused layer 1 with FOUR gate tiles per wave and four waves per workgroup (default).  K23r's eight waves sit
+// two to a SIMD and move in lockstep between the step barriers, so the matrix pipe idles whenever both are in their cells,
+// at the barrier or waiting for fragments (82 % MFMA busy measured).  With W_ih1 + W_hh1 of four tiles in 192 registers
+// (gfx950 gives a wave up to 512 unified VGPR/AGPR; two such waves fit a SIMD) a workgroup is one wave per SIMD, the second
+// wave of a SIMD belongs to ANOTHER workgroup with its own barriers, and every B fragment read from LDS feeds four tiles
+// instead of two.  Same chains per accumulator: bit-identical to K2 + K3.
+constexpr int rs4_l1_lds_bytes(int nsg) { return (2 * 16 * nsg * RS_H0ROW + 2 * 16 * nsg * RS_XROW + 256) * 4; }
+
+template <int NSG>
+__global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
+    const float* __restrict__ H0, int64_t N,
+    const float* __restrict__ wih0, const float* __restrict__ wih1,
+    const float* __restrict__ whh0, const float* __restrict__ whh1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1,
+    float* __restrict__ H1c)
+{
+    extern __shared__ f32x4 lds[];
+    constexpr int NS = 16 * NSG;
+    float* const h0s = reinterpret_cast<float*>(lds);                  // [2][NS][RS_H0ROW]
+    float* const h1x = h0s + 2 * NS * RS_H0ROW;                         // [2][NS][RS_XROW]
+    f32x4* const lbias = reinterpret_cast<f32x4*>(h1x + 2 * NS * RS_XROW);   // [16 tiles][4 q]
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t base_site = (int64_t)blockIdx.x * NS;
+
+    f32x4 Wih[4][8], Whh[4][4];
+    {
+        const f32x4* __restrict__ gih = reinterpret_cast<const f32x4*>(dir ? wih1 : wih0);      // [tile][j4 8][lane]
+        const f32x4* __restrict__ ghh = reinterpret_cast<const f32x4*>(dir ? whh1 : whh0);      // [tile][j4 4][lane]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Wih[u][j] = gih[((4 * wave + u) * 8 + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Whh[u][j] = ghh[((4 * wave + u) * 4 + j) * 64 + lane];
+        }
+        if (tid < 64) lbias[tid] = reinterpret_cast<const f32x4*>(dir ? bias1 : bias0)[(tid >> 2) * 64 + 16 * (tid & 3)];
+    }
+
+    // ---- h0 staging: a row is 32 chunks of 16 B; thread (row = tid / 32 + 8 k, chunk = tid % 32) moves 2 NSG chunks per step ----
+    const int cid = tid & 31;                                            // H0 order: 16 d + 4 q' + c
+    const int slot = (cid & 16) + 4 * (cid & 3) + ((cid >> 2) & 3);      // LDS order: 16 d + 4 c + q'
+    f32x4 sreg[2 * NSG];
+    auto load_h0 = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < 2 * NSG; ++k) {
+            const int64_t site = base_site + (tid >> 5) + 8 * k;
+            const int64_t sc = site < N ? site : N - 1;
+            sreg[k] = *reinterpret_cast<const f32x4*>(H0 + (sc * PW + t) * 128 + 4 * cid);
+        }
+    };
+    auto store_h0 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 2 * NSG; ++k)
+            *reinterpret_cast<f32x4*>(h0s + ((size_t)buf * NS + (tid >> 5) + 8 * k) * RS_H0ROW + 4 * slot) = sreg[k];
+    };
     load_h0(dir ? PW - 1 : 0);
     store_h0(0);
     __syncthreads();
 
-    float c[NSG][2], hlast[NSG][2];
+    float c[NSG][4];
 #pragma unroll
-    for (int sg = 0; sg < NSG; ++sg) { c[sg][0] = c[sg][1] = 0.f; hlast[sg][0] = hlast[sg][1] = 0.f; }
+    for (int sg = 0; sg < NSG; ++sg)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[sg][u] = 0.f;
 
     for (int s = 0; s < PSTEPS1; ++s) {
         const int t = dir ? PW - 1 - s : s;
@@ -527,15 +677,16 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
 #pragma unroll
         for (int sg = 0; sg < NSG; ++sg) {
             const float* r0 = h0b + (size_t)(16 * sg + n) * RS_H0ROW + 4 * q;
-            f32x4 acc[2] = {bias[0], bias[1]};
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = lbias[(4 * wave + u) * 4 + q];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                                 // K-steps 4j .. 4j+3: direction j / 4, chunk j % 4
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(r0 + 64 * (j >> 2) + 16 * (j & 3));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0] = mfma4(Wih[0][j][e], b4[e], acc[0]);
-                    acc[1] = mfma4(Wih[1][j][e], b4[e], acc[1]);
-                }
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wih[u][j][e], b4[e], acc[u]);
             }
             if (s > 0) {
                 const float* r1 = hrb + (size_t)(16 * sg + n) * RS_XROW + 4 * q;
@@ -543,38 +694,35 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(r1 + 16 * j);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[0] = mfma4(Whh[0][j][e], b4[e], acc[0]);
-                        acc[1] = mfma4(Whh[1][j][e], b4[e], acc[1]);
-                    }
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = mfma4(Whh[u][j][e], b4[e], acc[u]);
                 }
             }
-            // cell: lane (n, q) holds unit 4 (2 wave + u) + q, u = 0, 1 -> exchange positions 16 (w / 2) + 4 q + 2 (w % 2) + u
-            float hn[2];
+            // cell: lane (n, q) holds unit 4 (4 wave + u) + q -> exchange positions 16 wave + 4 q + u
+            f32x4 hn;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const float ig = sigmoid_f(acc[u][0]);
                 const float fg = sigmoid_f(acc[u][1]);
                 const float gg = tanh_f(acc[u][2]);
                 const float og = sigmoid_f(acc[u][3]);
                 c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
                 hn[u] = og * tanh_f(c[sg][u]);
-                hlast[sg][u] = hn[u];
             }
-            float2 w2; w2.x = hn[0]; w2.y = hn[1];
-            *reinterpret_cast<float2*>(hwb + (size_t)(16 * sg + n) * RS_XROW + 16 * (wave >> 1) + 4 * q + 2 * (wave & 1)) = w2;
+            *reinterpret_cast<f32x4*>(hwb + (size_t)(16 * sg + n) * RS_XROW + 16 * wave + 4 * q) = hn;
         }
         if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
         lds_barrier();
     }
-    // h1 at position 16 -> H1c[site][dir][q][16]: entries 2 wave, 2 wave + 1 of row q
+    // h1 at position 16 -> H1c[site][dir][q][16]: entries 4 wave .. 4 wave + 3 of row q (read back from the exchange rows)
+    const float* hfin = h1x + (size_t)((PSTEPS1 - 1) & 1) * NS * RS_XROW;
 #pragma unroll
     for (int sg = 0; sg < NSG; ++sg) {
         const int64_t site = base_site + 16 * sg + n;
-        if (site < N) {
-            float2 w2; w2.x = hlast[sg][0]; w2.y = hlast[sg][1];
-            *reinterpret_cast<float2*>(H1c + site * 128 + dir * 64 + q * 16 + 2 * wave) = w2;
-        }
+        if (site < N)
+            *reinterpret_cast<f32x4*>(H1c + site * 128 + dir * 64 + q * 16 + 4 * wave) =
+                *reinterpret_cast<const f32x4*>(hfin + (size_t)(16 * sg + n) * RS_XROW + 16 * wave + 4 * q);
     }
 }
 
@@ -675,6 +823,137 @@ __global__ __launch_bounds__(256) void k_pileup_head(
             float* zp = zy_prob + site * NSNP_ZY_CLASSES;
             zp[0] = ez1 / zs; zp[1] = ez2 / zs; zp[2] = ez3 / zs;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4r: heads with the output tiles split over the 8 waves of a workgroup (default).  K4 above walks 896 dependent-latency
+// bound MFMAs per 16 sites in ONE wave with its weights streamed from L2 (36 us for a 4096-site batch whose matrix work is
+// 3 us).  Here a workgroup still owns 16 sites at a time, but wave w computes output_proj tile w, dense tiles 2w, 2w+1 and
+// (waves 0, 1) one head tile each, with exactly those weight fragments held in VGPRs across a persistent loop over site
+// groups; the 128 / 256 intermediate features cross waves through LDS in the order the next product's B operand wants them
+// (K-step j of lane (n, q) = accumulator register j % 4 of tile j / 4 of the same lane).  Chains per accumulator are those
+// of K4, so the probabilities are bit-identical.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_pileup_head_rs(
+    const float* __restrict__ H1c, int64_t N,
+    const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+    const float* __restrict__ dense_w, const float* __restrict__ dense_b,
+    const float* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ gt_prob, float* __restrict__ zy_prob)
+{
+    __shared__ float x1[32][64];          // output_proj results as dense K-steps
+    __shared__ float x2[64][64];          // tanh(dense) as head K-steps
+    __shared__ f32x4 x3[64];              // head tile 1 (wave 1) for the softmax in wave 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4;
+    // weights of this wave
+    f32x4 Wp[8], Wd[2][8], Wh[16], bp, bd[2], bh;
+    {
+        const f32x4* pw = reinterpret_cast<const f32x4*>(proj_w);      // [8 tiles][8 j4][lane]
+        const f32x4* dw = reinterpret_cast<const f32x4*>(dense_w);     // [16][8][lane]
+        const f32x4* hw = reinterpret_cast<const f32x4*>(head_w);      // [2][16][lane]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            Wp[j] = pw[(wave * 8 + j) * 64 + lane];
+            Wd[0][j] = dw[((2 * wave) * 8 + j) * 64 + lane];
+            Wd[1][j] = dw[((2 * wave + 1) * 8 + j) * 64 + lane];
+        }
+        bp = reinterpret_cast<const f32x4*>(proj_b)[wave * 64 + lane];
+        bd[0] = reinterpret_cast<const f32x4*>(dense_b)[(2 * wave) * 64 + lane];
+        bd[1] = reinterpret_cast<const f32x4*>(dense_b)[(2 * wave + 1) * 64 + lane];
+        if (wave < 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Wh[j] = hw[(wave * 16 + j) * 64 + lane];
+            bh = reinterpret_cast<const f32x4*>(head_b)[wave * 64 + lane];
+        }
+    }
+    const int64_t n_groups = NSNP_CDIV(N, 16);
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int64_t site = grp * 16 + (lane & 15);
+        const bool live = site < N;
+        const int64_t sc = live ? site : N - 1;
+        const f32x4* __restrict__ hin = reinterpret_cast<const f32x4*>(H1c + sc * 128 + q * 16);
+        // output_proj 128 -> 128 (model.py:37): tile `wave`
+        f32x4 ap = bp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 b4 = hin[(j >> 2) * 16 + (j & 3)];            // fwd half, then reverse half (+64 floats)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ap = mfma4(Wp[j][e], b4[e], ap);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x1[4 * wave + g][lane] = ap[g];
+        __syncthreads();
+        // dense 128 -> 256 + tanh (model.py:67): tiles 2 wave, 2 wave + 1
+        f32x4 ad[2] = {bd[0], bd[1]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float b = x1[4 * j + e][lane];
+                ad[0] = mfma4(Wd[0][j][e], b, ad[0]);
+                ad[1] = mfma4(Wd[1][j][e], b, ad[1]);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) x2[4 * (2 * wave + u) + g][lane] = tanh_f(ad[u][g]);
+        __syncthreads();
+        // genotype (rows 0..20) and zygosity (rows 21..23) heads (model.py:69-70): tile 0 in wave 0, tile 1 in wave 1
+        f32x4 ah = bh;
+        if (wave < 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ah = mfma4(Wh[j][e], x2[4 * j + e][lane], ah);
+            if (wave == 1) x3[lane] = ah;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const f32x4 a1 = x3[lane];
+            // lane (site, q) holds rows 4q..4q+3 of tile 0 and rows 16+4q.. of tile 1.
+            // genotype rows: tile0 all 16; tile1 rows 16..19 (q=0, g=0..3) and row 20 (q=1, g=0); zygosity rows 21..23: tile1, q=1, g=1..3
+            const float NEG = -3.0e38f;
+            float g0[4], g1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                g0[g] = ah[g];
+                const bool is_gt = (q == 0) || (q == 1 && g == 0);
+                g1[g] = is_gt ? a1[g] : NEG;
+            }
+            float mx = fmaxf(fmaxf(fmaxf(g0[0], g0[1]), fmaxf(g0[2], g0[3])), fmaxf(fmaxf(g1[0], g1[1]), fmaxf(g1[2], g1[3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float e0[4], e1[4], sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                e0[g] = __expf(g0[g] - mx);
+                e1[g] = g1[g] > -1.0e38f ? __expf(g1[g] - mx) : 0.f;
+                sum += e0[g] + e1[g];
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float z1 = a1[1], z2 = a1[2], z3 = a1[3];
+            const float zm = fmaxf(z1, fmaxf(z2, z3));
+            const float ez1 = __expf(z1 - zm), ez2 = __expf(z2 - zm), ez3 = __expf(z3 - zm);
+            const float zs = ez1 + ez2 + ez3;
+            if (live) {
+                float* gp = gt_prob + site * NSNP_GT_CLASSES;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gp[4 * q + g] = e0[g] / sum;
+                if (q == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gp[16 + g] = e1[g] / sum;
+                }
+                if (q == 1) {
+                    gp[20] = e1[0] / sum;
+                    float* zp = zy_prob + site * NSNP_ZY_CLASSES;
+                    zp[0] = ez1 / zs; zp[1] = ez2 / zs; zp[2] = ez3 / zs;
+                }
+            }
+        }
+        // (x1 / x2 / x3 of this group are not touched again before the next group's first barrier)
     }
 }
 
@@ -835,8 +1114,12 @@ static int set_lds_attr_once(nsnp_ctx* ctx)
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
     NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
-    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(4)));
-    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(2)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs4<1>, hipFuncAttributeMaxDynamicSharedMemorySize, rs4_l1_lds_bytes(1)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs4<2>, hipFuncAttributeMaxDynamicSharedMemorySize, rs4_l1_lds_bytes(2)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(4)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(2)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(4)));
+    NSNP_HIP(ctx, hipFuncSetAttribute((const void*)k_pileup_l1_rs32<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rs32_l1_lds_bytes(2)));
     ctx->attr_set = true;
     return NSNP_OK;
 }
@@ -880,14 +1163,24 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         if (wpb == 8) LAUNCH_L0(8); else if (wpb == 4) LAUNCH_L0(4); else if (wpb == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
-        if (ctx->l1_rs) {
+        if (ctx->l1_rs == 1) {
+            ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
+            // two 4-wave workgroups per CU (registers), 16 sites each
+            int g1 = 1;            // (the 32-site build needs 11 more registers than a wave may hold and spills)
+            if (ctx->l1_rs_groups == 1 || ctx->l1_rs_groups == 2) g1 = ctx->l1_rs_groups;
+#define LAUNCH_R4(G) hipLaunchKernelGGL(k_pileup_l1_rs4<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), rs4_l1_lds_bytes(G), s, \
+                           ctx->ws_h0, n, pw.l1_wih[0], pw.l1_wih[1], pw.l1_whh[0], pw.l1_whh[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_h1c)
+            if (g1 == 2) LAUNCH_R4(2); else LAUNCH_R4(1);
+#undef LAUNCH_R4
+        } else if (ctx->l1_rs == 2) {
             ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
             // one 8-wave workgroup per CU (LDS + registers): 64 sites each when that still gives every CU one, else 32
             int g1 = NSNP_CDIV(n, 64) * 2 >= (int64_t)ctx->n_cu ? 4 : 2;
             if (ctx->l1_rs_groups) g1 = ctx->l1_rs_groups;
-#define LAUNCH_R1(G) hipLaunchKernelGGL(k_pileup_l1_rs32<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(512), rs32_l1_lds_bytes(G), s, \
+#define LAUNCH_R1(G) hipLaunchKernelGGL((k_pileup_l1_rs32<G, ST>), dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(512), rs32_l1_lds_bytes(G), s, \
                            ctx->ws_h0, n, pw.l1_wih[0], pw.l1_wih[1], pw.l1_whh[0], pw.l1_whh[1], pw.l1_bias[0], pw.l1_bias[1], ctx->ws_h1c)
-            if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2);
+            if (ctx->l1_stagger) { constexpr bool ST = true; if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2); }
+            else { constexpr bool ST = false; if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2); }
 #undef LAUNCH_R1
         } else {
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
@@ -907,6 +1200,13 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         }
         }
         ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
+        if (ctx->head_rs) {
+            int64_t gh = NSNP_CDIV(n, 16);
+            if (gh > 2 * (int64_t)ctx->n_cu) gh = 2 * (int64_t)ctx->n_cu;          // persistent: two 8-wave workgroups per CU
+            hipLaunchKernelGGL(k_pileup_head_rs, dim3((unsigned)gh), dim3(512), 0, s, ctx->ws_h1c, n,
+                               pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,
+                               gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);
+        } else
         hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,
                            pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,
                            gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);

@@ -180,12 +180,20 @@ def test_fp32_register_stationary_kernels_equal_the_lds_image_kernels_bit_for_bi
     xn = (rng.integers(0, 60, (1003, 33, 18)) - 15).astype(np.int32)
     xn[5, 3] = 5000; xn[700, 16, 2] = -70000; xn[300, 10, 4] = 2**24 + 3          # the fp32 mode carries the whole int32 -> float cast
     x = torch.from_numpy(xn).cuda()
-    c.set_option("l0_register_stationary", 0); c.set_option("l1_register_stationary", 0)
+    c.set_option("l0_register_stationary", 0); c.set_option("l1_register_stationary", 0); c.set_option("head_split", 0)
     old = c.pileup_forward(x)
-    for l0, l1 in ((1, 1), (1, 0), (0, 1)):
+    c.set_option("head_split", 1)                     # heads with the output tiles split over 8 waves: same chains
+    got = c.pileup_forward(x)
+    assert torch.equal(got[0], old[0]) and torch.equal(got[1], old[1])
+    for st in (0, 1):                                 # waves 4-7 of the eight-wave layer-1 kernel running a group's next input part early
+        c.set_option("l1_stagger", st); c.set_option("l1_register_stationary", 2)
+        got = c.pileup_forward(x)
+        assert torch.equal(got[0], old[0]) and torch.equal(got[1], old[1]), st
+    c.set_option("l1_stagger", 0)
+    for l0, l1 in ((1, 1), (1, 2), (1, 0), (0, 1), (0, 2)):      # layer 1: 1 = four waves x four tiles (default), 2 = eight waves x two tiles
         c.set_option("l0_register_stationary", l0); c.set_option("l1_register_stationary", l1)
         for g0 in ((0, 1, 2, 4) if l0 else (0,)):
-            for g1 in ((0, 2, 4) if l1 else (0,)):
+            for g1 in ({0: (0,), 1: (0, 1, 2), 2: (0, 2, 4)}[l1]):
                 c.set_option("l0_site_groups", g0); c.set_option("l1_site_groups", g1)
                 got = c.pileup_forward(x)
                 assert torch.equal(got[0], old[0]) and torch.equal(got[1], old[1]), (l0, l1, g0, g1)
@@ -340,7 +348,7 @@ def test_register_stationary_layer1_kernel(pileup_weights):
         got = c.pileup_forward(x)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), g
     with pytest.raises(_lib.NanoSNPError):
-        c.set_option("l1_site_groups", 1)
+        c.set_option("l1_site_groups", 3)
     for n in (1, 31, 32, 33, 63, 64, 65, 200):
         gn, zn = c.pileup_forward(x[:n].contiguous())
         assert torch.equal(gn, ref[0][:n]) and torch.equal(zn, ref[1][:n]), n
