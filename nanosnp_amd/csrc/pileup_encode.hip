@@ -75,11 +75,23 @@ struct IndelIterT {
 };
 typedef IndelIterT<const uint8_t*> IndelIter;
 
+// four small counters that are only ever indexed through compile-time selects (a runtime-indexed register array is
+// placed in scratch memory: a dependent round trip to HBM-backed memory per access)
+struct Quad {
+    int32_t v0, v1, v2, v3;
+    __device__ __forceinline__ void inc(int k) { v0 += k == 0; v1 += k == 1; v2 += k == 2; v3 += k == 3; }
+    __device__ __forceinline__ void raise(int k, int32_t x)
+    {
+        v0 = (k == 0 && x > v0) ? x : v0; v1 = (k == 1 && x > v1) ? x : v1;
+        v2 = (k == 2 && x > v2) ? x : v2; v3 = (k == 3 && x > v3) ? x : v3;
+    }
+};
+
 template <typename P>
-__device__ __forceinline__ void rescan_maxima(P base, int64_t begin, int64_t end, int32_t* mx)
+__device__ __forceinline__ Quad rescan_maxima(P base, int64_t begin, int64_t end)
 {
     // exact distinct-allele maxima by comparing every counted indel with every other one: O(k^2)
-    mx[0] = mx[1] = mx[2] = mx[3] = 0;
+    Quad mx{0, 0, 0, 0};
     IndelIterT<P> a{base, begin, end};
     int64_t ao; int al, as;
     while (a.next(ao, al, as)) {
@@ -92,42 +104,43 @@ __device__ __forceinline__ void rescan_maxima(P base, int64_t begin, int64_t end
             for (int k = 0; k < al; ++k) if (base[ao + k] != base[bo + k]) { eq = false; break; }
             same += eq;
         }
-        if (same > mx[kind]) mx[kind] = same;
+        mx.raise(kind, same);
     }
+    return mx;
 }
 
-__device__ __forceinline__ bool same_bytes(const uint8_t* base, int64_t a, int64_t b, int len)
-{
-    for (int k = 0; k < len; ++k) if (base[a + k] != base[b + k]) return false;
-    return true;
-}
+// symbol counters of one column in the order of byte_class(): A C G T a c g t * #
+struct Counts10 { int32_t k0, k1, k2, k3, k4, k5, k6, k7, k8, k9; };
 
 // ---- slow exact path for one column straight from global memory (no size limits) ---------------------
-// Used for columns whose wave does not fit the LDS stage or that carry more indels than the per-lane
-// list holds.  O(k^2) in the number of indel reads k of the column.
-__device__ __noinline__ void scan_column_global(const uint8_t* __restrict__ bases, int64_t begin, int64_t end,
-                                                int32_t* cnt, int32_t* tot, int32_t* mx)
+// Used for columns whose bytes do not fit the LDS stage of their wave.  O(k^2) in the number of indel reads k.
+__device__ __forceinline__ void scan_column_global(const uint8_t* __restrict__ bases, int64_t begin, int64_t end,
+                                                Counts10& cnt, Quad& tot, Quad& mx)
 {
-    for (int k = 0; k < 10; ++k) cnt[k] = 0;
-    for (int k = 0; k < 4; ++k) { tot[k] = 0; mx[k] = 0; }
+    Counts10 c{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Quad t{0, 0, 0, 0};
     for (int64_t i = begin; i < end;) {
         const int b = bases[i];
         const int cls = byte_class(b);
-        if (cls < 10) { cnt[cls]++; ++i; }
-        else if (cls == 11 || cls == 12) {
+        if (cls < 10) {
+            c.k0 += cls == 0; c.k1 += cls == 1; c.k2 += cls == 2; c.k3 += cls == 3; c.k4 += cls == 4;
+            c.k5 += cls == 5; c.k6 += cls == 6; c.k7 += cls == 7; c.k8 += cls == 8; c.k9 += cls == 9;
+            ++i;
+        } else if (cls == 11 || cls == 12) {
             ++i;
             long long adv = 0;
             while (i < end && bases[i] >= '0' && bases[i] <= '9') { adv = adv * 10 + (bases[i] - '0'); ++i; }
             if (adv <= MAX_INDEL) {
                 const int64_t avail = end - i;
                 const int len = (int)(adv < avail ? adv : avail);
-                tot[(b == '-' ? 2 : 0) + (len > 0 && is_fwd_char(bases[i]) ? 0 : 1)]++;
+                t.inc((b == '-' ? 2 : 0) + (len > 0 && is_fwd_char(bases[i]) ? 0 : 1));
             }
             i += adv;
         } else if (cls == 13) i += 2;
         else ++i;
     }
-    rescan_maxima(bases, begin, end, mx);
+    cnt = c; tot = t;
+    mx = rescan_maxima(bases, begin, end);
 }
 
 // ---- main kernel ----------------------------------------------------------------------------------------
@@ -169,18 +182,22 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     if (wave_col0 >= M) return;                                   // whole wave idle (no later block barrier)
     const int64_t c = wave_col0 + lane;
     const bool live = c < M;
-    int64_t begin = 0, end = 0;
-    if (live) { begin = col_off[c]; end = col_off[c + 1]; }
     const int n_live = (int)(M - wave_col0 < 64 ? M - wave_col0 : 64);
+    // one offset load per lane; a column's end is its right neighbour's begin (the last live lane takes the wave's end offset)
+    const int64_t wave_end = col_off[wave_col0 + n_live];
+    int64_t begin = live ? col_off[c] : wave_end;
+    int64_t end = __shfl_down(begin, 1);
+    if (lane == n_live - 1) end = wave_end;
+    if (!live) { begin = 0; end = 0; }
     const int64_t total = col_off[M];
 
     uint8_t* st = stage_b[wave];
     const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
-    int32_t cnt[10];
+    int32_t cnt[10];                     // (every index below is a compile-time constant: registers, not scratch)
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt[k] = 0;
-    int32_t tot[4] = {0, 0, 0, 0};      // I, i, D, d   (kind = (sign=='-')*2 + reverse)
-    int32_t mx[4] = {0, 0, 0, 0};
+    Quad tot{0, 0, 0, 0};                // I, i, D, d   (kind = (sign=='-')*2 + reverse)
+    Quad mx{0, 0, 0, 0};
     bool slow = false;
 
     // The wave's 64 columns are one contiguous byte range; it is staged into LDS in as few sub-batches of
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
                 const uint32_t ve = ilist[wave][e][lane];
                 const int oe = ve & 0xffff, le = (ve >> 16) & 0xff, se = ve >> 24;
                 const int kind = (se == '-' ? 2 : 0) + (le > 0 && is_fwd_char(st[oe]) ? 0 : 1);
-                tot[kind]++;
+                tot.inc(kind);
                 int same = 1;
                 for (int f = 0; f < e; ++f) {
                     const uint32_t vf = ilist[wave][f][lane];
@@ -293,27 +310,26 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
                     for (int k = 0; k < le; ++k) if (st[oe + k] != st[of + k]) { eq = false; break; }
                     same += eq;
                 }
-                if (same > mx[kind]) mx[kind] = same;
+                mx.raise(kind, same);
             }
             if (n_list > KLIST) {
                 // more indel reads than the list holds: totals and maxima again, exactly, from the staged bytes
-                tot[0] = tot[1] = tot[2] = tot[3] = 0;
+                tot = Quad{0, 0, 0, 0};
                 IndelIterT<const uint8_t*> it{st, lbeg, lend};
                 int64_t io; int il, is;
-                while (it.next(io, il, is)) tot[(is == '-' ? 2 : 0) + (il > 0 && is_fwd_char(st[io]) ? 0 : 1)]++;
-                rescan_maxima((const uint8_t*)st, (int64_t)lbeg, (int64_t)lend, mx);
+                while (it.next(io, il, is)) tot.inc((is == '-' ? 2 : 0) + (il > 0 && is_fwd_char(st[io]) ? 0 : 1));
+                mx = rescan_maxima((const uint8_t*)st, (int64_t)lbeg, (int64_t)lend);
             }
         }
         __builtin_amdgcn_wave_barrier();            // the stage buffer is reused by the next sub-batch
         first = last;
     }
-    if (slow) {          // private arrays: passing cnt/tot/mx by address would pin them in scratch for every lane
-        int32_t c2[10], t2[4], m2[4];
+    if (slow) {          // results come back in plain structs: no array of this kernel ever has its address taken
+        Counts10 c2; Quad t2, m2;
         scan_column_global(bases, begin, end, c2, t2, m2);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) cnt[k] = c2[k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { tot[k] = t2[k]; mx[k] = m2[k]; }
+        cnt[0] = c2.k0; cnt[1] = c2.k1; cnt[2] = c2.k2; cnt[3] = c2.k3; cnt[4] = c2.k4;
+        cnt[5] = c2.k5; cnt[6] = c2.k6; cnt[7] = c2.k7; cnt[8] = c2.k8; cnt[9] = c2.k9;
+        tot = t2; mx = m2;
     }
 
     // ---- assemble the 18 channels, flags (tensor_maker.cpp:127-248) ------------------------------
@@ -321,8 +337,8 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     t[CH_A] = cnt[0]; t[CH_C] = cnt[1]; t[CH_G] = cnt[2]; t[CH_T] = cnt[3];
     t[CH_a] = cnt[4]; t[CH_c] = cnt[5]; t[CH_g] = cnt[6]; t[CH_t] = cnt[7];
     t[CH_STAR] = cnt[8]; t[CH_POUND] = cnt[9];
-    t[CH_I] = tot[0]; t[CH_i] = tot[1]; t[CH_D] = tot[2]; t[CH_d] = tot[3];
-    t[CH_I1] = mx[0]; t[CH_i1] = mx[1]; t[CH_D1] = mx[2]; t[CH_d1] = mx[3];
+    t[CH_I] = tot.v0; t[CH_i] = tot.v1; t[CH_D] = tot.v2; t[CH_d] = tot.v3;
+    t[CH_I1] = mx.v0; t[CH_i1] = mx.v1; t[CH_D1] = mx.v2; t[CH_d1] = mx.v3;
     const int up = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     const int lo = cnt[4] + cnt[5] + cnt[6] + cnt[7];
     const int depth = up + lo + cnt[8] + cnt[9];
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const int rb = nt4(refraw);
     const int chr_idx = rb < 4 ? rb : 0;                      // non-ACGT reference counts as 'A'
     // allele list in std::map order A C D G I T; the first maximum is what a stable sort puts first
-    const int lc[6] = {cnt[0] + cnt[4], cnt[1] + cnt[5], tot[2] + tot[3], cnt[2] + cnt[6], tot[0] + tot[1], cnt[3] + cnt[7]};
+    const int lc[6] = {cnt[0] + cnt[4], cnt[1] + cnt[5], tot.v2 + tot.v3, cnt[2] + cnt[6], tot.v0 + tot.v1, cnt[3] + cnt[7]};
     const int lk[6] = {0, 1, 5, 2, 4, 3};                     // 0..3 = base index, 4 = I, 5 = D
     int top = -1, topc = 0;
 #pragma unroll
@@ -352,12 +368,18 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     __builtin_amdgcn_wave_barrier();
     int32_t* out_stage = reinterpret_cast<int32_t*>(st);         // 64 * 18 * 4 = 4608 B <= STAGE_BYTES
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) out_stage[lane * NCH + k] = t[k];
+    for (int k = 0; k < NCH; k += 2) *reinterpret_cast<int2*>(out_stage + lane * NCH + k) = int2{t[k], t[k + 1]};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int n_valid = n_live * NCH;
     int32_t* __restrict__ dst = counts + wave_col0 * NCH;
-    for (int k = lane; k < n_valid; k += 64) dst[k] = out_stage[k];
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {          // a wave's 4608 output bytes as 16-byte stores (4.5 per lane)
+        const int n16 = n_valid >> 2;
+        for (int k = lane; k < n16; k += 64) reinterpret_cast<int4*>(dst)[k] = reinterpret_cast<const int4*>(out_stage)[k];
+        for (int k = (n16 << 2) + lane; k < n_valid; k += 64) dst[k] = out_stage[k];
+    } else {
+        for (int k = lane; k < n_valid; k += 64) dst[k] = out_stage[k];
+    }
     if (live) {
         depth_out[c] = depth;
         uint8_t f = 0;

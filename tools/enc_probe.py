@@ -13,9 +13,11 @@ ctx = _lib.Context(0)
 cols = host.synth_columns(20260001, 33 * n_win, coverage=cov, window=33)
 b = torch.from_numpy(cols.bases).to(dev); co = torch.from_numpy(cols.col_off).to(dev); rf = torch.from_numpy(cols.ref).to(dev)
 ctx.pileup_encode_columns(b, co, rf); torch.cuda.synchronize()
+ctx.enable_timing(True)
 t = time.time()
 for _ in range(iters): ctx.pileup_encode_columns(b, co, rf)
 torch.cuda.synchronize()
 dt = (time.time() - t) / iters
 M = 33 * n_win
-print(f"encode {M} columns cov {cov}: {dt*1e3:.3f} ms  {M/dt/1e9:.2f} G cols/s  {(cols.bases.size + 73*M)/dt/1e9:.0f} GB/s algorithmic")
+ev = ctx.read_timing()["encode_columns"]
+print(f"encode {M} columns cov {cov}: {dt*1e3:.3f} ms  {M/dt/1e9:.2f} G cols/s  {(cols.bases.size + 73*M)/dt/1e9:.0f} GB/s algorithmic;  HIP events: {ev[0]/max(ev[1],1)*1e3:.1f} us per launch = {(cols.bases.size + 73*M)/(ev[0]/max(ev[1],1)*1e-3)/1e9:.0f} GB/s")
