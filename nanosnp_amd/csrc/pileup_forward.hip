@@ -316,6 +316,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8 ? 4 : (WAVES == 4 ? 2 : 1))
 // slots in every 16-lane group of the instruction (MI355X_MICROARCH.md, LDS table).
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_XROW = 72;                  // floats per exchange row: 64 + 8 pad (18 slots of 16 B)
+constexpr int RS_XSROW = 24;                 // floats per staged input row: 20 used (16 + 2 channels, 1, 0) + pad
 constexpr int RS_H0ROW = 136;                // floats per staged h0 row: 128 + 8 pad (34 slots)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
     float* __restrict__ H0)
 {
     __shared__ __attribute__((aligned(16))) float hx[2][16 * NSG][RS_XROW];
+    __shared__ __attribute__((aligned(16))) float xx[2][16 * NSG * RS_XSROW];
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -351,25 +353,47 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
         }
     }
 
-    // ---- input windows: every wave reads the x rows of all site groups itself (L1-resident after the first wave) ----
-    const int32_t* __restrict__ xs[NSG];
+    // ---- input windows: the 18 counts of (site, t) are 72 contiguous bytes; thread i < 144 NSG / 16 ... moves one 8-byte
+    // piece per step (9 pieces per site), converts it to fp32 (predict.py:49) and stores it where the B fragments want it:
+    // xx[site][4 q + e] = channel 4 e + q (e < 4), xx[site][16 + q] = channels 16, 17, the constant 1 the bias rides on, 0.
+    // One workgroup-wide copy per step instead of five scattered dword loads per lane in each of the four waves.
+    constexpr int NPIECE = 9 * 16 * NSG;                       // 8-byte pieces per step
+    constexpr int PPT = (NPIECE + 255) / 256;                  // pieces per thread
+    const int32_t* xsrc[PPT]; int xdst[PPT][2]; bool xon[PPT];
 #pragma unroll
-    for (int sg = 0; sg < NSG; ++sg) {
-        const int64_t site = base_site + 16 * sg + n;
+    for (int k = 0; k < PPT; ++k) {
+        const int pi = tid + 256 * k;
+        xon[k] = pi < NPIECE;
+        const int row = xon[k] ? pi / 9 : 0, piece = xon[k] ? pi % 9 : 0;
+        const int64_t site = base_site + row;
         const int64_t sc = site < N ? site : N - 1;
-        xs[sg] = center_idx ? x + (center_idx[sc] - PCENTER) * PC : x + sc * (PW * PC);
+        xsrc[k] = (center_idx ? x + (center_idx[sc] - PCENTER) * PC : x + sc * (PW * PC)) + 2 * piece;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ch = 2 * piece + h;                       // channel -> position in the staged row
+            xdst[k][h] = row * RS_XSROW + (ch < 16 ? 4 * (ch & 3) + (ch >> 2) : 16 + (ch - 16));
+        }
     }
-    const int klast = q < 2 ? 16 + q : 16;   // lanes q = 2, 3 feed the bias / a zero instead
-    int xi[NSG][5];
+    int2 xi[PPT];
     auto load_x = [&](int t) {
 #pragma unroll
-        for (int sg = 0; sg < NSG; ++sg) {
+        for (int k = 0; k < PPT; ++k) if (xon[k]) xi[k] = *reinterpret_cast<const int2*>(xsrc[k] + t * PC);
+    };
+    auto stage_x = [&](int buf) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xi[sg][kk] = xs[sg][t * PC + 4 * kk + q];
-            xi[sg][4] = xs[sg][t * PC + klast];
+        for (int k = 0; k < PPT; ++k) if (xon[k]) {
+            xx[buf][xdst[k][0]] = (float)xi[k].x;              // predict.py:49 int -> float
+            xx[buf][xdst[k][1]] = (float)xi[k].y;
         }
     };
+    for (int i = tid; i < 2 * 16 * NSG; i += 256) {            // the constant-1 / zero tail of every staged row (both buffers)
+        float* r = &xx[i / (16 * NSG)][(i % (16 * NSG)) * RS_XSROW];
+        r[18] = 1.0f; r[19] = 0.0f;
+    }
     load_x(dir ? PW - 1 : 0);
+    stage_x(0);
+    if (PW > 1) load_x(dir ? PW - 2 : 1);
+    __syncthreads();
 
     float c[NSG][4];
 #pragma unroll
@@ -395,14 +419,7 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
     for (int s = 0; s < PW; ++s) {
         const int t = dir ? PW - 1 - s : s;
         const int cur = s & 1;
-        float xb[NSG][4], xl[NSG];
-#pragma unroll
-        for (int sg = 0; sg < NSG; ++sg) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xb[sg][kk] = (float)xi[sg][kk];      // predict.py:49 int -> float
-            xl[sg] = q == 2 ? 1.0f : (q == 3 ? 0.0f : (float)xi[sg][4]);
-        }
-        if (s + 1 < PW) load_x(dir ? t - 1 : t + 1);                            // prefetch the next position
+        // x_t of this step was staged during the previous one; x_{t+1} is in flight in registers and is stored behind the MFMAs
         if (s > 0) flush_h(cur ^ 1, dir ? t + 1 : t - 1);
 #pragma unroll
         for (int sg = 0; sg < NSG; ++sg) {
@@ -411,15 +428,18 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
             const float* hr = &hx[cur ^ 1][16 * sg + n][4 * q];
             f32x4 hb0, hb1;
             if (s > 0) { hb0 = *reinterpret_cast<const f32x4*>(hr); hb1 = *reinterpret_cast<const f32x4*>(hr + 16); }
+            const float* xr = &xx[cur][(16 * sg + n) * RS_XSROW];
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+            const float xl = xr[16 + q];
             f32x4 acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wih[u][e], xb[sg][e], acc[u]);
+                for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wih[u][e], xb[e], acc[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wl[u], xl[sg], acc[u]);
+            for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wl[u], xl, acc[u]);
             if (s > 0) {
 #define RS_KBLOCK(J, HB)                                                                               \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e)                                          \
@@ -448,6 +468,10 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
                 hn[u] = og * tanh_f(c[sg][u]);
             }
             *reinterpret_cast<f32x4*>(&hx[cur][16 * sg + n][16 * wave + 4 * q]) = hn;
+        }
+        if (s + 1 < PW) {
+            stage_x(cur ^ 1);                                                   // x of step s+1 (its buffer was last read in step s-1)
+            if (s + 2 < PW) load_x(dir ? t - 2 : t + 2);
         }
         lds_barrier();
     }
