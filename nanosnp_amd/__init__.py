@@ -5,8 +5,11 @@ this package holds only the host-side mirror of the reference's interface for th
 
     pileup_model.LSTMNetwork     PileupModel/model.py LSTMNetwork (predict only)
     haplotype_model.LSTMNetwork  HaplotypeModel/model_dev.py LSTMNetwork (predict only)
-    encode                       dna_sv_tensor make_candidate_snp_tensor + make_predict_data
+    pipeline                     mpileup text -> column encode -> windows -> PileupModel -> pileup.vcf in one pass
+                                 (dna_sv_tensor make_candidate_snp_tensor + make_predict_data + predict.py)
     predict                      PileupModel/predict.py / HaplotypeModel/predict_dev.py loops
+    merge                        stage-4 group selection and the final merge (select_hetesnp_homosnp.py, scripts/merge.py)
+    sitefile                     flat binary containers in place of the HDF5 bins
     dist                         static site sharding over the GPUs of a node + result gather
     host                         native readers / synthetic generators (libnanosnp_host.so)
 

@@ -435,7 +435,257 @@ def group_next():
     print("next_rows:", {k: len(v.splitlines()) for k, v in merged.items()}, {k: len(v) for k, v in ser(each).items()}, list(ser(one)))
 
 
-GROUPS = {"next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
+def group_twostage_s2():
+    """stage 2 of the two-stage fixture (own interpreter: PileupModel's modules collide with HaplotypeModel's): the
+    reference's predict() on the chrS sites of encode_g1 alone, NumPy 1.x scalar promotion -> two_stage_s2.npz"""
+    import gzip as _gz
+    import torch
+    import yaml
+    from torch.utils.data import Dataset
+    from nanosnp_amd import host
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "PileupModel"))
+    import predict as ref_predict          # noqa: E402  (reference module)
+    from model import LSTMNetwork          # noqa: E402
+    from utils import AttrDict             # noqa: E402
+    cfg = AttrDict(yaml.load(open(os.path.join(REF, "PileupModel/config/ont_pileup.yaml")), Loader=yaml.FullLoader))
+    m = LSTMNetwork(cfg.model)
+    ck = torch.load(os.path.join(REF, "PileupModel/models/ont_pileup.chkpt"), map_location="cpu", weights_only=False)
+    m.encoder.load_state_dict(ck["encoder"]); m.forward_layer.load_state_dict(ck["forward_layer"]); m.eval()
+    x, names, pos, refb = host.pd_parse(_gz.open(os.path.join(GOLD, "encode_g1.pd.gz")).read())
+
+    class FakeDataset(Dataset):
+        def __init__(self, datapath):
+            pass
+        def __getitem__(self, i):
+            return names[i], pos[i], refb[i], x[i]
+        def __len__(self):
+            return len(x)
+
+    ref_predict.PredictDataset = FakeDataset
+    real_loader = ref_predict.DataLoader
+    ref_predict.DataLoader = lambda ds, batch_size, shuffle, num_workers: real_loader(ds, batch_size=batch_size, shuffle=False, num_workers=0)
+    orig_numpy = torch.Tensor.numpy
+    def widened(self, *a, **k):              # NumPy 1.x scalar promotion (see group_vcf)
+        r = orig_numpy(self, *a, **k)
+        return r.astype(np.float64) if r.dtype == np.float32 else r
+    with tempfile.TemporaryDirectory() as d:
+        fai = os.path.join(d, "ref.fa.fai")
+        open(fai, "w").write("chrS\t6100\t6\t60\t61\n")
+        vcf = os.path.join(d, "p.vcf")
+        torch.Tensor.numpy = widened
+        try:
+            ref_predict.predict(m, ["x.bin"], fai, 1000, vcf, torch.device("cpu"))
+        finally:
+            torch.Tensor.numpy = orig_numpy
+        text = open(vcf, "rb").read()
+    np.savez_compressed(os.path.join(GOLD, "two_stage_s2.npz"), vcf=np.frombuffer(text, np.uint8))
+    print("two_stage_s2:", len(text.splitlines()), "lines")
+
+
+def group_twostage():
+    """BASELINE configs[3] in miniature, every stage by the reference's own code where it can run here
+    (run_caller.sh:109-141):
+      s2  PileupModel/predict.py predict()                               (group twostage_s2, shipped weights)
+      s4  select_hetesnp_homosnp.py: contig_dict as :82-104, find_adjacent_sites(5, 19, 14)
+          read matrices: the BAM pass of create_pileup_haplotype.py needs htslib -> generator G3 planes instead (inputs
+          of the fixture), in the arrays write_to_bins.py stores
+      s5  HaplotypeModel/predict_dev.py predict(): TestDataset + PileupFeature / HaplotypeFeature (reference rows, H3) +
+          get_frequency_feature + model_dev.LSTMNetwork (seeded weights: trained ones are absent upstream) + the csv rows (H7);
+          only tables.open_file is served from memory
+      s6  scripts/merge.py Run
+    -> two_stage.npz (planes, groups, haplotype.csv, final VCF)"""
+    import gzip as _gz
+    subprocess.run([sys.executable, os.path.abspath(__file__), "twostage_s2"], check=True)
+    vcf = bytes(np.load(os.path.join(GOLD, "two_stage_s2.npz"))["vcf"]).decode()
+    import argparse, io, contextlib
+    import torch
+    from nanosnp_amd import host
+    from tests.helpers import hap_weight_names, seeded_hap_weights
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    import select_hetesnp_homosnp as sel     # noqa: E402  (reference module)
+    contig_dict = {}
+    for row in vcf.splitlines():
+        if row[0] == "#": continue
+        c = row.strip().split(); g = c[9].split(":")[0].replace("|", "/"); ql = float(c[5])
+        if (g == "0/0" and ql >= 19) or (g == "1/1" and ql >= 19): continue
+        contig_dict.setdefault(c[0], {})[int(c[1])] = (g, ql)
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = sel.find_adjacent_sites(contig_dict, ["chrS"], 5, 19, 14)["chrS"]
+    G = len(groups)
+    gpos = np.array([[it.position for it in g] for g in groups], np.int64)            # [G, 11], candidate in the middle
+    cand = gpos[:, 5]
+    # read planes of every group (generator G3), as write_to_bins.py stores them
+    pp = host.synth_hap_planes(4100, G, 30, 90, 33)
+    ph = host.synth_hap_planes(4200, G, 30, 90, 11)
+
+    class Root:
+        pass
+    root = Root()
+    root.pileup_sequences, root.pileup_baseq, root.pileup_mapq, root.pileup_hap = pp[0], pp[1], pp[2], pp[3]
+    root.haplotype_sequences, root.haplotype_baseq, root.haplotype_mapq, root.haplotype_hap = ph[0], ph[1], ph[2], ph[3]
+    root.candidate_positions = np.array([[f"chrS:{p}".encode()] for p in cand], dtype="S300")
+    root.haplotype_positions = np.array([[f"chrS:{p}".encode() for p in row] for row in gpos], dtype="S300")
+
+    class FakeFile:
+        def __init__(self):
+            self.root = root
+        def close(self):
+            pass
+    sys.modules["tables"].open_file = lambda path, mode="r": FakeFile()
+    import predict_dev                        # noqa: E402  (reference module)
+    from model_dev import LSTMNetwork         # noqa: E402
+    from utils import AttrDict                # noqa: E402
+    cfg = AttrDict({"model": {"pileup_dim": 105, "haplotype_dim": 105, "pileup_length": 33, "haplotype_length": 11,
+                              "hidden_size": 256, "lstm_layers": 3, "gt_num_class": 10, "zy_num_class": 3, "dropout": 0.1}})
+    m = LSTMNetwork(cfg)
+    # seeded weights scaled so that the 19 sites get different genotypes and half of them a confident call (QUAL >= 13)
+    sd = {k: torch.from_numpy(w) for k, w in zip(hap_weight_names(), seeded_hap_weights(13, H=256, ih_scale=0.03, head_scale=120.0))}
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all("crit" in k for k in res.missing_keys), res
+    real_loader = torch.utils.data.DataLoader
+    predict_dev.torch.utils.data.DataLoader = lambda ds, batch_size, shuffle, num_workers: real_loader(ds, batch_size=batch_size, shuffle=False, num_workers=0)
+    orig_numpy = torch.Tensor.numpy
+    def widened(self, *a, **k):
+        r = orig_numpy(self, *a, **k)
+        return r.astype(np.float64) if r.dtype == np.float32 else r
+    fa_text = _gz.open(os.path.join(GOLD, "encode_g1.fa.gz")).read()
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "ref.fa"); open(fa, "wb").write(fa_text)
+        bins = os.path.join(d, "bins"); os.makedirs(bins); open(os.path.join(bins, "chrS_0_6100.bin"), "w").close()
+        csv_path = os.path.join(d, "haplotype.csv")
+        torch.Tensor.numpy = widened
+        try:
+            with torch.no_grad():
+                predict_dev.predict(m, bins, fa, 7, 33, 11, csv_path, torch.device("cpu"))       # a batch size that does not divide G
+        finally:
+            torch.Tensor.numpy = orig_numpy
+            predict_dev.torch.utils.data.DataLoader = real_loader
+        csv = open(csv_path).read()
+        # reference rows exactly as PileupFeature / HaplotypeFeature build them (dataset_dev.py:106-120,150-162)
+        import dataset_dev                    # noqa: E402
+        from get_truth import load_reference_file      # noqa: E402
+        refs = load_reference_file(fa)
+        pf = dataset_dev.PileupFeature(FakeFile(), refs, 33)
+        hf = dataset_dev.HaplotypeFeature(FakeFile(), refs, 11)
+        open(os.path.join(d, "p.vcf"), "w").write(vcf)
+        sys.path.insert(0, os.path.join(REF, "scripts"))
+        import merge as ref_merge             # noqa: E402  (reference module)
+        merged = {}
+        for ql in (15.0, 19.0):            # s6 default threshold (scripts/merge.py:151) and the candidate threshold of s4
+            ref_merge.Run(argparse.Namespace(cat_predict=csv_path, output=os.path.join(d, "m.vcf"), pileup_vcf=os.path.join(d, "p.vcf"), quality=ql))
+            merged[ql] = open(os.path.join(d, "m.vcf")).read()
+    np.savez_compressed(os.path.join(GOLD, "two_stage.npz"), vcf_s2=np.frombuffer(vcf.encode(), np.uint8), group_pos=gpos,
+                        **{f"p_{n}": a.astype(np.int8) for n, a in zip(("seq", "bq", "mq", "hap"), pp[:4])},
+                        **{f"h_{n}": a.astype(np.int8) for n, a in zip(("seq", "bq", "mq", "hap"), ph[:4])},
+                        ref_rows_pileup=np.asarray(pf.candidate_reference_sequences, np.int32),
+                        ref_rows_haplotype=np.asarray(hf.candidate_reference_sequences, np.int32),
+                        csv=np.frombuffer(csv.encode(), np.uint8), merged_q15=np.frombuffer(merged[15.0].encode(), np.uint8),
+                        merged_q19=np.frombuffer(merged[19.0].encode(), np.uint8))
+    print("two_stage:", G, "groups;", len(csv.splitlines()), "csv rows;", {q: (len(t.splitlines()), sum(1 for l in t.splitlines() if "\tH\t" in l)) for q, t in merged.items()},
+          "(lines, rows from the haplotype model)")
+
+
+
+def group_haparrange():
+    """H1: create_pileup_haplotype.single_group_pileup_haplotype_feature (:22-214) itself, driven by a stand-in for the
+    pysam.AlignmentFile it iterates (only .pileup() columns with .pos / .n / .pileups[*].alignment.{query_name, has_tag,
+    get_tag, query_sequence, query_qualities, mapping_quality}, .is_del, .is_refskip, .query_position are used, :39-47,90-134).
+    The fixture holds, per group, the read x position matrices the function builds internally (re-derived here from the same
+    synthetic reads) and the filtered, HP-sorted matrices it returns -> hap_arrange.npz"""
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    import create_pileup_haplotype as cph        # noqa: E402  (reference module)
+    from select_hetesnp_homosnp import SNPItem   # noqa: E402
+    rng = np.random.default_rng(77)
+    ctg = "c"
+    span = (1, 900)
+    # synthetic reads: (name, first ref position (1-based), per-position op: 'A'/'C'/'G'/'T' or 'D'), HP tag 1 / 2 / none
+    reads = []
+    for r in range(70):
+        a = int(rng.integers(span[0], span[1] - 200)); b = int(min(span[1], a + rng.integers(150, 700)))
+        ops = [("D" if rng.random() < 0.03 else "ACGT"[int(rng.integers(0, 4))]) for _ in range(a, b + 1)]
+        if rng.random() < 0.1: ops = [o.lower() if o != "D" else o for o in ops]     # str.upper() at :121
+        hp = [1, 2, None][int(rng.integers(0, 3))]
+        quals = rng.integers(1, 60, len(ops)).tolist()
+        reads.append(dict(name=f"r{r}", a=a, b=b, ops=ops, hp=hp, quals=quals, mapq=int(rng.integers(0, 61))))
+
+    class Aln:
+        def __init__(self, rd):
+            self.query_name = rd["name"]; self.rd = rd
+            self.query_sequence = "".join(o for o in rd["ops"] if o != "D")
+            self.query_qualities = [q for o, q in zip(rd["ops"], rd["quals"]) if o != "D"]
+            self.mapping_quality = rd["mapq"]
+        def has_tag(self, t):
+            return t == "HP" and self.rd["hp"] is not None
+        def get_tag(self, t):
+            return self.rd["hp"]
+
+    class PRead:
+        def __init__(self, aln, k):
+            self.alignment = aln
+            self.is_del = aln.rd["ops"][k] == "D"
+            self.is_refskip = False
+            self.query_position = None if self.is_del else sum(1 for o in aln.rd["ops"][:k] if o != "D")
+
+    class Col:
+        def __init__(self, pos0, prs):
+            self.pos = pos0; self.pileups = prs; self.n = len(prs)
+
+    alns = [Aln(rd) for rd in reads]
+
+    class FakeSam:
+        def pileup(self, contig, start, end, min_base_quality=0, min_mapping_quality=0):
+            for p in range(max(start - 3, 1), end + 4):           # 1-based p; pysam yields columns around the region too
+                prs = [PRead(a, p - a.rd["a"]) for a in alns if a.rd["a"] <= p <= a.rd["b"]]
+                if prs:
+                    yield Col(p - 1, prs)
+
+    centres = [260, 300, 455, 610]
+    groups = []
+    for c in centres:
+        left = sorted(rng.choice(np.arange(c - 120, c - 2), 5, replace=False).tolist())
+        right = sorted(rng.choice(np.arange(c + 2, c + 120), 5, replace=False).tolist())
+        groups.append([SNPItem(ctg, p, "0/1", 20.0) for p in left] + [SNPItem(ctg, c, "0/1", 10.0)] + [SNPItem(ctg, p, "0/1", 20.0) for p in right])
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = cph.single_group_pileup_haplotype_feature(FakeSam(), groups, 10000, 5, 16)
+    cand, hpos, hseq, hbq, hmq, hhap, maxh, pseq, pbq, pmq, phap, maxp = out
+    assert len(cand) == len(groups) and maxh > 10 and maxp > 10, (len(cand), maxh, maxp)
+    # the read x position matrices of :86-134 for the columns of each group, from the same reads
+    b2i = {"A": 1, "C": 2, "G": 3, "T": 4}
+    def matrices(cols):
+        R = len(reads)
+        m = [np.zeros((R, len(cols)), np.int32) for _ in range(4)]                  # seq, bq, mq, hap
+        for r, rd in enumerate(reads):
+            tag = rd["hp"] if rd["hp"] is not None else 3
+            for j, p in enumerate(cols):
+                if rd["a"] <= p <= rd["b"]:
+                    o = rd["ops"][p - rd["a"]]
+                    if o == "D":
+                        m[0][r, j] = -1; m[3][r, j] = tag; m[2][r, j] = rd["mapq"]
+                    else:
+                        m[0][r, j] = b2i[o.upper()]; m[3][r, j] = tag; m[1][r, j] = rd["quals"][p - rd["a"]]; m[2][r, j] = rd["mapq"]
+        # the reference's dictionaries only hold reads seen in some column of extend_positions: rows of reads that cover none
+        # of them do not exist there; they are all-zero here and are dropped by the centre filter either way
+        return m
+    fx = {"n_groups": len(groups)}
+    for g, grp in enumerate(groups):
+        gp = [int(it.position) for it in grp]
+        wp = list(range(gp[5] - 16, gp[5] + 17))
+        for tag, cols, outs in (("h", gp, (hseq[g], hbq[g], hmq[g], hhap[g])), ("p", wp, (pseq[g], pbq[g], pmq[g], phap[g]))):
+            ms = matrices(cols)
+            for nm, a, o in zip(("seq", "bq", "mq", "hap"), ms, outs):
+                fx[f"g{g}_{tag}_in_{nm}"] = a.astype(np.int16)
+                fx[f"g{g}_{tag}_out_{nm}"] = np.asarray(o, np.int16)
+    fx["candidates"] = np.array(cand)
+    np.savez_compressed(os.path.join(GOLD, "hap_arrange.npz"), **fx)
+    print("hap_arrange:", len(groups), "groups, depths", [np.asarray(a).shape[0] for a in hseq], [np.asarray(a).shape[0] for a in pseq])
+
+
+
+GROUPS = {"haparrange": group_haparrange, "twostage": group_twostage, "twostage_s2": group_twostage_s2, "next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
           "hapfwd": group_hapfwd, "cat": group_cat}
 
 if __name__ == "__main__":

@@ -72,7 +72,7 @@ def hap_weight_shapes(F=105, H=256, n_layers=3, n_gt=10, n_zy=3):
     return shapes
 
 
-def seeded_hap_weights(seed, F=105, H=256, n_layers=3, n_gt=10, n_zy=3):
+def seeded_hap_weights(seed, F=105, H=256, n_layers=3, n_gt=10, n_zy=3, ih_scale=0.002, head_scale=8.0):
     """U(-1/sqrt(H), 1/sqrt(H)) like torch's default LSTM/Linear init, from numpy PCG64.
     The input-layer weights are scaled down so that count-valued features (up to ~5000)
     do not saturate every gate."""
@@ -83,9 +83,9 @@ def seeded_hap_weights(seed, F=105, H=256, n_layers=3, n_gt=10, n_zy=3):
     for name in hap_weight_names(n_layers):
         w = rng.uniform(-k, k, size=shapes[name]).astype(np.float32)
         if name.endswith("weight_ih_l0") or name.endswith("weight_ih_l0_reverse"):
-            w *= np.float32(0.002)
+            w *= np.float32(ih_scale)
         if "genotype_layer.weight" in name or "zygosity_layer.weight" in name:
-            w *= np.float32(8.0)   # spread the logits so that parity errors are visible
+            w *= np.float32(head_scale)   # spread the logits so that parity errors are visible
         out.append(w)
     return out
 

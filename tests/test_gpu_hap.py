@@ -203,3 +203,41 @@ def test_hap_forward_f16x3_mode(gpu_ctx):
     gt, zy = _hfwd(c, xb, xh[:4])
     assert np.isfinite(gt).all() and np.isfinite(zy).all() and np.allclose(gt.sum(1), 1.0, atol=1e-5)
     c.close()
+
+
+def test_hap_arrange_reads_vs_the_reference_function(gpu_ctx):
+    """nsnp_hap_arrange_reads on the read matrices of tests/golden/hap_arrange.npz against what the reference's
+    single_group_pileup_haplotype_feature returned for them (create_pileup_haplotype.py:140-207)"""
+    import torch
+    from tests.test_oracle_golden import _check_arranged_against_reference
+
+    def arrange(seq, bq, mq, hap, D):
+        outs = gpu_ctx.hap_arrange_reads(*[torch.from_numpy(a[None]).cuda() for a in (seq, bq, mq, hap)], D)
+        torch.cuda.synchronize()
+        return tuple(o[0].cpu().numpy() for o in outs[:4]) + (int(outs[4][0].item()),)
+    _check_arranged_against_reference(arrange, np.load(golden("hap_arrange.npz")))
+
+
+def test_reference_style_haplotype_model_interface():
+    """nanosnp_amd.haplotype_model.LSTMNetwork mirrors model_dev.LSTMNetwork as predict_dev.py:35-39,69-71 uses it"""
+    import torch
+    from nanosnp_amd import _lib
+    from nanosnp_amd.haplotype_model import LSTMNetwork, state_dict_keys
+    from tests.helpers import PROB_ATOL, hap_weight_names, seeded_hap_weights
+    assert state_dict_keys() == hap_weight_names()
+    cfg = {"model": {"pileup_dim": 105, "haplotype_dim": 105, "pileup_length": 33, "haplotype_length": 11, "hidden_size": 256,
+                     "lstm_layers": 3, "gt_num_class": 10, "zy_num_class": 3, "dropout": 0.1}}
+    m = LSTMNetwork(cfg).to("cuda")
+    m.load_state_dict({k: torch.from_numpy(w) for k, w in zip(hap_weight_names(), seeded_hap_weights(12, H=256))})
+    m.eval()
+    z = np.load(golden("hap_fwd_h256.npz"))
+    x_pileup = torch.from_numpy(z["xp"]).type(torch.FloatTensor).to("cuda")            # predict_dev.py:35-36
+    x_haplotype = torch.from_numpy(z["xh"]).type(torch.FloatTensor).to("cuda")
+    gt, zy = m.predict(x_pileup, x_haplotype)
+    assert np.abs(gt.cpu().numpy() - z["gt"]).max() < PROB_ATOL and np.abs(zy.cpu().numpy() - z["zy"]).max() < PROB_ATOL
+    with pytest.raises(Exception):
+        LSTMNetwork(cfg).predict(x_pileup, x_haplotype)                               # weights not loaded
+    with pytest.raises(_lib.NanoSNPError):
+        LSTMNetwork({"model": dict(cfg["model"], hidden_size=100)})
+    with pytest.raises(KeyError):
+        LSTMNetwork(cfg).load_state_dict({})

@@ -1,0 +1,78 @@
+"""BASELINE configs[3] in miniature on the GPU: stage 2 (mpileup text -> encode -> PileupModel -> pileup.vcf), stage 4 (group
+selection), stage 5 (read planes -> haplotype features -> HaplotypeModel -> haplotype.csv) and stage 6 (merge) on the encode_g1
+fixture, every stage compared with what the reference's own code produced for it (tests/golden/two_stage.npz;
+run_caller.sh:109-141).  Probabilities differ from CPU torch by ~1e-7, which can move a QUAL by one unit of its second decimal."""
+import gzip
+
+import numpy as np
+import pytest
+
+from nanosnp_amd import host, merge
+from tests.helpers import golden, seeded_hap_weights
+from tests.test_two_stage_host import TWO_STAGE_HAP_WEIGHTS
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_up_to_qual(got_lines, want_lines, qual_col, gq_in_sample=True):
+    assert len(got_lines) == len(want_lines)
+    moved = 0
+    for g, w in zip(got_lines, want_lines):
+        if g == w:
+            continue
+        gf, wf = g.split("\t"), w.split("\t")
+        assert len(gf) == len(wf)
+        for k, (a, b) in enumerate(zip(gf, wf)):
+            if k == qual_col:
+                assert abs(float(a) - float(b)) <= 0.0101, (g, w)
+            elif gq_in_sample and k == len(gf) - 1:
+                sa, sb = a.split(":"), b.split(":")
+                assert sa[0] == sb[0] and sa[2:] == sb[2:] and abs(int(sa[1]) - int(sb[1])) <= 1, (g, w)
+            else:
+                assert a == b, (g, w)
+        moved += 1
+    return moved
+
+
+def test_two_stage_chain_matches_the_reference_stage_by_stage(tmp_path, pileup_weights):
+    from nanosnp_amd import _lib
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_variants
+    from nanosnp_amd.predict import predict_haplotype
+    z = np.load(golden("two_stage.npz"))
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(gzip.open(golden("encode_g1.fa.gz")).read())
+    mp = tmp_path / "chrS.mpileup"
+    mp.write_bytes(gzip.open(golden("encode_g1.mpileup.gz")).read())
+    # ---- stage 2 ----
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    vcf_path = tmp_path / "pileup.vcf"
+    call_variants(m, [("chrS", str(mp))], str(fa), "chrS\t6100\t6\t60\t61\n", str(vcf_path))
+    vcf = vcf_path.read_text()
+    want_vcf = bytes(z["vcf_s2"]).decode()
+    moved = _same_up_to_qual(vcf.splitlines(), want_vcf.splitlines(), 5)
+    assert moved <= 8
+    # ---- stage 4: candidates below QUAL 19 with five confident heterozygous neighbours each side ----
+    groups = merge.select_groups(vcf, quality_threshold=19.0, adjacent_size=5, support_quality=14.0)["chrS"]
+    gpos = np.array([[p for p, _, _ in g] for g in groups], np.int64)
+    assert np.array_equal(gpos, z["group_pos"])
+    # ---- stage 5 ----
+    seq = host.fasta_load_contig(str(fa), "chrS")
+    cands = [f"chrS:{p}" for p in gpos[:, 5]]
+    rp = host.haplotype_ref_rows({"chrS": seq}, cands, 33)
+    rh = host.haplotype_ref_rows({"chrS": seq}, cands, 11, position_lists=[[f"chrS:{p}" for p in row] for row in gpos])
+    pp = [z[f"p_{n}"] for n in ("seq", "bq", "mq", "hap")] + [rp]            # int8 planes, as a reader would hand them over
+    ph = [z[f"h_{n}"] for n in ("seq", "bq", "mq", "hap")] + [rh]
+    hctx = _lib.Context(0)
+    hctx.hap_load_weights(seeded_hap_weights(**TWO_STAGE_HAP_WEIGHTS))
+    csv_path = tmp_path / "haplotype.csv"
+    predict_haplotype(hctx, pp, ph, cands, str(csv_path), batch_size=7)
+    csv = csv_path.read_text()
+    _same_up_to_qual(csv.splitlines(), bytes(z["csv"]).decode().splitlines(), 3, gq_in_sample=False)
+    hctx.close()
+    # ---- stage 6 ----
+    for q in (15.0, 19.0):
+        got = merge.merge_calls(vcf, csv, q).splitlines()
+        want = bytes(z[f"merged_q{int(q)}"]).decode().splitlines()
+        _same_up_to_qual(got, want, 5)
+    assert sum("\tH\t" in l for l in merge.merge_calls(vcf, csv, 19.0).splitlines()) == 9

@@ -147,30 +147,47 @@ def test_oracle_vs_reference_binaries_on_a_fresh_contig(tmp_path):
     assert (tmp_path / "o.pd").read_bytes() == want
 
 
-def test_hap_arrange_matches_pandas_semantics():
-    """create_pileup_haplotype.py:140-165 with pandas itself: rows filtered on the centre base, sorted
-    by the centre HP.  pandas' quicksort leaves ties in an unspecified order, so the comparison is on
-    what is specified: the sorted HP column and the multiset of rows inside each HP group."""
-    import pandas as pd
-    rng = np.random.default_rng(8)
-    for R, L in ((40, 11), (120, 33), (5, 33)):
-        seq = rng.integers(-1, 5, (R, L)).astype(np.int32)
-        seq[rng.random(R) < 0.2, L // 2] = 0
-        hap = np.where(seq != 0, rng.integers(1, 4, (R, 1)), 0).astype(np.int32)
-        bq = rng.integers(0, 60, (R, L)).astype(np.int32); mq = rng.integers(0, 60, (R, L)).astype(np.int32)
-        gpos = list(range(100, 100 + L))
-        df = pd.DataFrame(seq, columns=gpos); hap_df = pd.DataFrame(hap, columns=gpos)
-        keep = [i for i in range(R) if df.iloc[i][gpos[L // 2]] != 0]                       # :145-149
-        sort_idx = hap_df[gpos].iloc[keep].sort_values(by=gpos[L // 2]).index              # :158-160
-        want_seq = df[gpos].iloc[keep].loc[sort_idx].values; want_hap = hap_df[gpos].iloc[keep].loc[sort_idx].values
-        D = len(keep) + 3
-        oseq, obq, omq, ohap, depth = oracle.hap_arrange(seq, bq, mq, hap, D)
-        assert depth == len(keep)
-        assert np.array_equal(ohap[:depth, L // 2], want_hap[:, L // 2])
-        assert (oseq[depth:] == -2).all() and (ohap[depth:] == -2).all() and (obq[depth:] == -2).all()
-        for g in (1, 2, 3):
-            a = oseq[:depth][ohap[:depth, L // 2] == g]; b = want_seq[want_hap[:, L // 2] == g]
-            assert sorted(map(bytes, a)) == sorted(map(bytes, b))
-        # truncation keeps a prefix of the sorted rows (write_to_bins.py:54-61)
-        cseq, _, _, chap, cdepth = oracle.hap_arrange(seq, bq, mq, hap, max(1, depth // 2))
-        assert cdepth == max(1, depth // 2) and np.array_equal(cseq, oseq[:cdepth])
+def _check_arranged_against_reference(arrange, z):
+    """arrange(seq, bq, mq, hap, D) -> (oseq, obq, omq, ohap, depth) against the matrices the reference's
+    single_group_pileup_haplotype_feature returned (tests/golden/hap_arrange.npz).  pandas' default sort leaves ties in an
+    unspecified order, so what is compared is what is specified: the depth, the sorted centre-HP column, and the multiset of
+    (seq, bq, mq, hap) rows inside each HP group; padding rows are -2; a cut keeps a prefix of the sorted rows."""
+    for g in range(int(z["n_groups"])):
+        for tag in ("h", "p"):
+            ins = [z[f"g{g}_{tag}_in_{n}"].astype(np.int32) for n in ("seq", "bq", "mq", "hap")]
+            want = [z[f"g{g}_{tag}_out_{n}"].astype(np.int32) for n in ("seq", "bq", "mq", "hap")]
+            L = ins[0].shape[1]
+            depth_ref = want[0].shape[0]
+            D = depth_ref + 4
+            oseq, obq, omq, ohap, depth = arrange(*ins, D)
+            assert depth == depth_ref, (g, tag)
+            assert np.array_equal(ohap[:depth, L // 2], want[3][:, L // 2])                   # sorted by the centre HP
+            for o in (oseq, obq, omq, ohap):
+                assert (o[depth:] == -2).all()
+            got_rows = np.concatenate([oseq[:depth], obq[:depth], omq[:depth], ohap[:depth]], axis=1)
+            want_rows = np.concatenate(want, axis=1)
+            for hp in (1, 2, 3):
+                a = got_rows[ohap[:depth, L // 2] == hp]; b = want_rows[want[3][:, L // 2] == hp]
+                assert sorted(map(bytes, a)) == sorted(map(bytes, b)), (g, tag, hp)
+            cseq, _, _, _, cdepth = arrange(*ins, max(1, depth // 2))                          # write_to_bins.py:54-61
+            assert cdepth == max(1, depth // 2) and np.array_equal(cseq, oseq[:cdepth])
+
+
+def test_hap_arrange_matches_the_reference_function():
+    """H1 pinned by create_pileup_haplotype.single_group_pileup_haplotype_feature itself (run with a stand-in for the pysam
+    file it iterates: tests/golden/make_golden.py haparrange): centre filter (:145-149,181-185) and HP sort (:158-165,193-200)"""
+    _check_arranged_against_reference(oracle.hap_arrange, np.load(golden("hap_arrange.npz")))
+
+
+def test_blocked_cpu_baseline_equals_the_plain_restatement(pileup_weights=None):
+    """the cache-blocked AVX2 arrangement bench.py times as its CPU baseline computes the same function as the checker"""
+    from tests.helpers import load_pileup_weights
+    w = load_pileup_weights()
+    z = np.load(golden("pileup_fwd.npz"))
+    g0, z0 = oracle.pileup_forward(w, z["x"], nthreads=4)
+    g1, z1 = oracle.pileup_forward(w, z["x"], nthreads=4, blocked=True)
+    assert np.abs(g0 - g1).max() < 5e-6 and np.abs(z0 - z1).max() < 5e-6
+    assert np.abs(g1 - z["gt"]).max() < 1e-5
+    for n in (1, 31, 33, 65):                                   # ragged block sizes
+        ga, _ = oracle.pileup_forward(w, z["x"][:n], nthreads=3, blocked=True)
+        assert np.abs(ga - g0[:n]).max() < 5e-6
