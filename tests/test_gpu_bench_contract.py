@@ -40,3 +40,14 @@ def test_bench_line_schema():
     assert d["roofline_encode"]["bound"] == "hbm"
     # the opt-in arithmetic is a second, labelled value measured on the same pool, within the port's tolerance of fp32
     assert d["f16x3"]["value"] > 1e6 and d["f16x3"]["max_abs_dp_vs_fp32_on_the_pool"] < 1e-4
+
+
+def test_two_stage_workload_line():
+    """bench.py --workload two-stage (BASELINE configs[3]) on a reduced candidate set: both stages run, calls are gathered"""
+    env = dict(os.environ, NSNP_TWO_STAGE_N2="40000", NSNP_TWO_STAGE_N5="5000")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "two-stage", "--steps", "1", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["stage2_sites"] == 40000 and d["config"]["stage5_sites"] == 5000 and d["scaling"] == "strong"
+    assert d["value"] > 1e5 and d["stage5"]["sites_per_s"] > 1e4 and d["dtype"] == "f32"
