@@ -20,6 +20,14 @@
  *   nsnp_cat_groups              PredictDataset.__getitem__     HaplotypeModel/dataset.py:862-915 (g0 / g1 assembly)
  *                                called from                    HaplotypeModel/predict_dev.py:35-39
  *
+ * Result gather (SURVEY.md 8(b) sketches an `nsnp_gather_results(ctx, rccl_comm, ...)` entry): deliberately NOT part of this ABI.
+ * The path's only exchange is one rooted gather of a few bytes per site at the very end (8(e)); the ranks are PyTorch processes
+ * that already own an RCCL communicator through torch.distributed (backend "nccl" = RCCL over xGMI), and PyTorch does not hand its
+ * ncclComm_t to foreign code, so a C entry would have to create a second communicator per process (ncclGetUniqueId / a side channel /
+ * ncclCommInitRank: a second bootstrap, second set of xGMI rings and buffers) to move ~18 MB per rank once.  The gather therefore
+ * lives in the host-side mirror: nanosnp_amd/dist.py gather_results (equal shards) / gather_varlen (per-rank site lists), one
+ * torch.distributed collective each, covered by world-2 / world-3 gloo tests and by the sharded-pipeline GPU test.
+ *
  * Conventions: every pointer marked "device" is device memory owned by the caller; functions
  * are asynchronous on `stream` unless stated, return 0 on success or a negative NSNP_E* code
  * (never abort/throw; the reference's native stage abort()s, cpp_aux.cpp:10-21), and a

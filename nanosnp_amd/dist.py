@@ -53,3 +53,26 @@ def gather_results(local, n_total, root=0, group=None):
     if rank != root:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def gather_varlen(local, root=0, group=None):
+    """Rooted gather of per-rank row blocks of DIFFERENT lengths ([n_r, k] tensors, e.g. the candidate sites a rank found in
+    its column shard) in rank order: sizes travel first (one small all_gather), then one gather of blocks padded to the longest.
+    Returns the concatenation on root, None elsewhere; the input itself without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    counts = [int(s.item()) for s in sizes]
+    maxn = max(max(counts), 1)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+    dist.gather(pad, bufs, dst=root, group=group)
+    if rank != root:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

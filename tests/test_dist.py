@@ -155,3 +155,37 @@ def test_bench_never_reports_fewer_ranks_than_asked_for():
     out = _bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline")
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _varlen_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from nanosnp_amd.dist import gather_varlen
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = [5, 0, 3][rank]                                   # different lengths, one of them empty
+        local = torch.full((n, 2), float(rank), dtype=torch.float64)
+        local[:, 1] = torch.arange(n, dtype=torch.float64)
+        out = gather_varlen(local)
+        q.put(out.numpy() if rank == 0 else None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_varlen_world3_gloo():
+    """the rooted gather of the column-sharded pipeline: per-rank site lists of different lengths, rank order kept"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_varlen_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    merged = next(o for o in outs if o is not None)
+    assert merged.shape == (8, 2)
+    assert merged[:, 0].tolist() == [0.0] * 5 + [2.0] * 3 and merged[:, 1].tolist() == [0, 1, 2, 3, 4, 0, 1, 2]

@@ -76,3 +76,48 @@ def test_two_stage_chain_matches_the_reference_stage_by_stage(tmp_path, pileup_w
         want = bytes(z[f"merged_q{int(q)}"]).decode().splitlines()
         _same_up_to_qual(got, want, 5)
     assert sum("\tH\t" in l for l in merge.merge_calls(vcf, csv, 19.0).splitlines()) == 9
+
+
+def _sharded_worker(rank, world, port, tmp, q):
+    """one of `world` processes of the s1 + s2 pipeline (all on cuda:0 of the one-GPU box; the result gather over gloo)"""
+    import os
+    import torch.distributed as dist
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_variants
+    from tests.helpers import load_pileup_weights
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = LSTMNetwork().load_weight_list(load_pileup_weights())
+        out = os.path.join(tmp, f"sharded_{rank}.vcf")
+        rows = call_variants(m, [("chrS", os.path.join(tmp, "chrS.mpileup"))], os.path.join(tmp, "ref.fa"), "chrS\t6100\t6\t60\t61\n", out)
+        q.put((rank, rows, os.path.exists(out)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_column_sharded_pipeline_writes_the_single_process_vcf(tmp_path, pileup_weights, world):
+    """ranks encode their column range (+ 16-column halo), call the sites centred in it and gather the calls to rank 0:
+    the VCF is byte-identical to the single-process one (nanosnp_amd.pipeline.call_contig under torch.distributed)"""
+    import socket
+    import torch.multiprocessing as mp
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_variants
+    (tmp_path / "ref.fa").write_bytes(gzip.open(golden("encode_g1.fa.gz")).read())
+    (tmp_path / "chrS.mpileup").write_bytes(gzip.open(golden("encode_g1.mpileup.gz")).read())
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    single = tmp_path / "single.vcf"
+    rows1 = call_variants(m, [("chrS", str(tmp_path / "chrS.mpileup"))], str(tmp_path / "ref.fa"), "chrS\t6100\t6\t60\t61\n", str(single))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert outs[0] == (0, rows1, True) and all(o[1] == 0 and not o[2] for o in outs[1:])
+    assert (tmp_path / "sharded_0.vcf").read_bytes() == single.read_bytes()
