@@ -81,7 +81,8 @@ def test_hap_planes_shape_and_padding():
 
 def test_haplotype_ref_rows_follow_the_reference_quirks():
     """dataset_dev.py:106-120: {'A':1,'C':2,'G':3,'T':4,'N':0}, anything else / out of range -> 0,
-    negative 0-based indices wrap around (Python indexing)"""
+    negative 0-based indices wrap around (Python indexing).  (Corner cases on a hand-made sequence; the pin by the reference's
+    own PileupFeature / HaplotypeFeature classes is tests/test_two_stage_host.py.)"""
     seq = b"ACGTNacgtRACGTACGTACGTACGTACGTACGTACGTAC"
     refs = {"c1": np.frombuffer(seq, np.uint8)}
     base2int = {"A": 1, "C": 2, "G": 3, "T": 4, "N": 0}

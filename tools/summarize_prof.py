@@ -4,7 +4,11 @@ profiles/: the --stats kernel table, and per-kernel HBM traffic from the FETCH_S
 PMC passes with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): counters are in KiB,
 FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x, WRITE_SIZE is exact.
 
-    python tools/summarize_prof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>] [--batch 4096]
+    python tools/summarize_prof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>] [--batch 4096] [--precision 0] [--timed SKIP TAKE]
+
+--timed SKIP TAKE: bench.py launches every kernel W x batches_per_step times before the timed region, K x batches_per_step times
+inside it and 36 more times alone afterwards (the `exclusive` figures); the average over launches SKIP .. SKIP+TAKE of each
+kernel (by start time, from the kernel trace of the stats pass) is the figure that corresponds to `roofline.avg_launch_ms`.
 """
 import collections
 import csv
@@ -15,7 +19,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_pileup_l1_rs": "pileup_l1f", "k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
+NAMES = {"k_pileup_l1_rs4": "pileup_l1f", "k_pileup_l1_rs": "pileup_l1f", "k_pileup_head_rs": "pileup_head", "k_pileup_l0_rs32": "pileup_l0", "k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
          "k_pileup_head": "pileup_head", "k_encode_columns": "encode_columns", "k_hap_features": "hap_features",
          "k_pileup_post": "pileup_post", "k_select": "select_sites", "k_gather_windows": "gather_windows",
          "k_hap_": "hap_forward"}
@@ -32,11 +36,15 @@ def one(d, pat):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    batch = 4096
-    if "--batch" in sys.argv:
-        batch = int(sys.argv[sys.argv.index("--batch") + 1])
-        args.remove(str(batch))
+    argv = list(sys.argv[1:])
+    batch, precision, timed = 4096, 0, None
+    if "--batch" in argv:
+        i = argv.index("--batch"); batch = int(argv[i + 1]); del argv[i:i + 2]
+    if "--precision" in argv:
+        i = argv.index("--precision"); precision = int(argv[i + 1]); del argv[i:i + 2]
+    if "--timed" in argv:
+        i = argv.index("--timed"); timed = (int(argv[i + 1]), int(argv[i + 2])); del argv[i:i + 3]
+    args = argv
     tag, stats_dir = args[0], args[1]
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -46,6 +54,23 @@ def main():
         for r in rows:
             f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.1f},"
                     f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+    if timed:
+        tr = collections.defaultdict(list)
+        for r in csv.DictReader(open(one(stats_dir, "*kernel_trace.csv"))):
+            tr[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "a") as f:
+            f.write(f"# launches {timed[0]} .. {timed[0] + timed[1]} of each kernel by start time = bench.py's timed region (kernel,launches,avg_ns); "
+                    f"the launches behind it run alone (bench.py `exclusive`)\n")
+            for k, v in sorted(tr.items()):
+                if not k.startswith("k_"):
+                    continue
+                v.sort()
+                w = v[timed[0]:timed[0] + timed[1]]
+                tail = v[timed[0] + timed[1]:]
+                if w:
+                    f.write(f"timed_region,{k},{len(w)},{sum(e - s for s, e in w) / len(w):.1f}\n")
+                if tail:
+                    f.write(f"alone_after,{k},{len(tail)},{sum(e - s for s, e in tail) / len(tail):.1f}\n")
     print(open(os.path.join(out_dir, f"{tag}_kernel_stats.csv")).read())
     if len(args) >= 4:
         traffic = collections.defaultdict(dict)
@@ -58,7 +83,7 @@ def main():
                 if k.startswith("k_"):
                     traffic[k][cname] = sum(v) / len(v)
                     traffic[k]["launches"] = len(v)
-        summary = {"batch": batch, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
+        summary = {"batch": batch, "precision": precision, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
                    "correction": "KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1",
                    "kernels": {}}
         for k, v in traffic.items():
