@@ -151,7 +151,7 @@ __device__ __forceinline__ void scan_column_global(const uint8_t* __restrict__ b
 // allows.
 constexpr int ENC_WAVES = ENC_BLOCK / 64;
 #ifndef NSNP_ENC_STAGE
-#define NSNP_ENC_STAGE 5120
+#define NSNP_ENC_STAGE 6144
 #endif
 #ifndef NSNP_ENC_KLIST
 #define NSNP_ENC_KLIST 12
