@@ -11,6 +11,7 @@
 // an exact quadratic rescan when a column has more distinct indel alleles than the table holds.
 // Integer outputs are bit-exact with the reference; the AF tests use the same float64 division.
 #include "nsnp_common.hpp"
+#include <math.h>
 
 namespace {
 
@@ -143,6 +144,31 @@ __device__ __forceinline__ void scan_column_global(const uint8_t* __restrict__ b
     mx = rescan_maxima(bases, begin, end);
 }
 
+// The candidate tests compare (double)count / (double)depth with min_af (tensor_maker.cpp:195-228: float64 division).  For
+// integers count, depth < 2^31 the correctly rounded quotient is >= a double a exactly when count / depth >= the midpoint tau
+// between a and its predecessor (the quotient can never BE that midpoint: tau has an odd 54- or 55-bit mantissa, which a
+// denominator below 2^31 cannot produce), i.e. count * 2^k >= T * depth with T = 2 M - 1 (4 M - 1 when a is a power of two),
+// a = M * 2^(e-53), k = 54 - e (55 - e).  One 128-bit comparison per allele instead of six float64 divisions per column, same
+// bits.  mode 1 / 2: always / never (a <= 0 or so small that any positive count passes; NaN or a beyond every quotient).
+struct AfThreshold { uint64_t t; int k; int mode; };
+
+static AfThreshold make_af_threshold(double a)
+{
+    AfThreshold r{0, 0, 0};
+    if (a != a) { r.mode = 2; return r; }
+    if (a <= 0.0) { r.mode = 1; return r; }
+    int e = 0;
+    const double m = frexp(a, &e);                     // a = m 2^e, m in [0.5, 1)
+    if (!(m > 0.0) || e > 40) { r.mode = 2; return r; }          // infinity, or a > 2^39 > any quotient of 31-bit integers
+    const uint64_t M53 = (uint64_t)ldexp(m, 53);       // 2^52 <= M53 < 2^53 (subnormal a: fewer bits, still exact)
+    const bool pow2 = M53 == (1ull << 52);
+    r.t = pow2 ? 4 * M53 - 1 : 2 * M53 - 1;
+    r.k = (pow2 ? 55 : 54) - e;
+    if (r.k >= 88) { r.mode = 1; r.t = 0; r.k = 0; }   // count 2^k >= 2^88 > T depth for every count >= 1
+    if (r.k < 0) { r.mode = 2; }                       // (e > 54: unreachable behind the e > 40 test)
+    return r;
+}
+
 // ---- main kernel ----------------------------------------------------------------------------------------
 // A wave stages the bytes of its 64 columns (one contiguous range) into LDS with 16-byte loads, every lane
 // then walks its own column out of LDS four bytes per read.  Indels met on the way are only RECORDED
@@ -161,21 +187,21 @@ constexpr int KLIST = NSNP_ENC_KLIST;                  // recorded indels per co
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
-    int64_t M, double min_af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
+    int64_t M, AfThreshold af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
     uint8_t* __restrict__ flags)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
     __shared__ uint32_t ilist[ENC_WAVES][KLIST][64];      // off (16) | len (8) | sign (8)
-    __shared__ uint4 ctab[256];
+    // byte -> 64-bit row: a one in the 6-bit field of its symbol class (A C G T a c g t * # = fields 0..9, bits 0..59), bit 63
+    // set for the three bytes that open a construct (+ - ^).  Every other byte maps to zero.
+    __shared__ uint2 ctab[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const int cls = byte_class(tid);      // ENC_BLOCK == 256: one table row per thread
-        uint4 r = {0u, 0u, 0u, 0u};
-        if (cls < 4) r.x = 1u << (8 * cls);
-        else if (cls < 8) r.y = 1u << (8 * (cls - 4));
-        else if (cls < 10) r.z = 1u << (8 * (cls - 8));
-        r.w = (cls == 11 || cls == 12 ? 1u : 0u) | (cls == 13 ? 2u : 0u) | (tid >= '0' && tid <= '9' ? 4u : 0u);
-        ctab[tid] = r;
+        unsigned long long r = 0;
+        if (cls < 10) r = 1ull << (6 * cls);
+        else if (cls >= 11) r = 1ull << 63;
+        ctab[tid] = uint2{(uint32_t)r, (uint32_t)(r >> 32)};
     }
     __syncthreads();
     const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
@@ -238,61 +264,125 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        if (lane >= first && lane < last) {
-            // LDS byte index of global offset g: (g - b0) + mis.  All lanes consume exactly one byte of their
-            // own column per inner step (skips are a per-lane state, not a jump), so the 4-byte LDS reads of a
-            // wave stay in lockstep and the control flow does not diverge on the grammar.
-            const int lbeg = (int)(begin - b0) + mis, lend = (int)(end - b0) + mis;
+        {
+            // every lane runs the passes (they hold wave-level operations); lanes outside the sub-batch have an empty range
+            const bool act = lane >= first && lane < last;
+            // LDS byte index of global offset g: (g - b0) + mis.
+            const int lbeg = act ? (int)(begin - b0) + mis : mis, lend = act ? (int)(end - b0) + mis : mis;
             int n_list = 0;
-            int skip = 0, adv = 0, sign = 0; bool dig = false;
-            // byte -> {packed 8-bit increments for A C G T | a c g t | * #, flags} from one 16-byte LDS read
-            uint32_t a0 = 0, a1 = 0, a2 = 0;
-            auto flush = [&]() {
+            // ---- pass 1: EVERY byte of the column is counted through the table, no grammar state at all; the positions of
+            // the construct openers (+ - ^) are collected in one bit mask per 60-byte chunk (15 words: a 6-bit field cannot
+            // overflow inside a chunk).  The uniform trip counts are the longest column of the sub-batch.
+            int len_here = lend - (lbeg & ~3);
+            int maxlen = len_here;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { cnt[k] += (a0 >> (8 * k)) & 0xff; cnt[4 + k] += (a1 >> (8 * k)) & 0xff; }
-                cnt[8] += a2 & 0xff; cnt[9] += (a2 >> 8) & 0xff;
-                a0 = a1 = a2 = 0;
+            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxlen, o); maxlen = v > maxlen ? v : maxlen; }
+            const int n_chunks = (maxlen + 59) / 60;                              // same in every lane of the sub-batch
+            unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;                         // opener positions of chunks 0, 1, 2
+            bool bad = act && n_chunks > 3 && lend - (lbeg & ~3) > 180;           // longer than 180 bytes: exact path below
+            auto flush6 = [&](unsigned long long a) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) cnt[k] += (int)((a >> (6 * k)) & 63);
             };
-            int since = 0;
-            for (int p0 = lbeg & ~3; p0 < lend; p0 += 4) {
-                const uint32_t w = st32[p0 >> 2];
+            {
+                const int n_ch = n_chunks > 3 ? 3 : n_chunks;                     // (lanes longer than that are `bad` already)
+                for (int ch = 0; ch < n_ch; ++ch) {
+                    const int cb = (lbeg & ~3) + 60 * ch;
+                    int nw = (maxlen - 60 * ch + 3) >> 2; nw = nw > 15 ? 15 : nw;
+                    if (bad) nw = 0;                                              // (per lane: its counts are redone below)
+                    unsigned long long acc = 0, sm = 0;
+                    for (int wi = 0; wi < nw; ++wi) {
+                        const int p0 = cb + 4 * wi;
+                        uint32_t w = st32[(p0 < STAGE_BYTES - 4 ? p0 : STAGE_BYTES - 4) >> 2];
+                        // bytes outside [lbeg, lend) become 0xff (an all-zero row)
+                        const int lo = lbeg - p0, hi = lend - p0;
+                        const uint32_t mlo = lo <= 0 ? 0xffffffffu : (lo >= 4 ? 0u : 0xffffffffu << (8 * lo));
+                        const uint32_t mhi = hi >= 4 ? 0xffffffffu : (hi <= 0 ? 0u : ~(0xffffffffu << (8 * hi)));
+                        w |= ~(mlo & mhi);
+                        uint32_t s4 = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int p = p0 + k;
-                    const bool in = p >= lbeg && p < lend;
-                    const int b = (int)((w >> (8 * k)) & 0xffu);
-                    const uint4 row = ctab[b];
-                    const bool isd = (row.w & 4u) != 0;
-                    // one of three things happens to an in-range byte: it is skipped, it extends / ends a digit
-                    // run, or it is examined as a pileup symbol ("normal")
-                    const bool skipping = in && skip > 0;
-                    const bool in_digits = in && !skipping && dig;
-                    const bool ends_digits = in_digits && !isd;
-                    bool normal = in && !skipping && !dig;
-                    if (skipping) --skip;
-                    if (in_digits && isd) adv = adv > 100000 ? adv : adv * 10 + (b - '0');
-                    if (ends_digits) {
-                        dig = false;
+                        for (int k = 0; k < 4; ++k) {
+                            const uint2 row = ctab[(w >> (8 * k)) & 0xffu];
+                            acc += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
+                            s4 |= (row.y >> 31) << k;
+                        }
+                        sm |= (unsigned long long)s4 << (4 * wi);
+                    }
+                    flush6(acc);
+                    if (ch == 0) sm0 = sm; else if (ch == 1) sm1 = sm; else sm2 = sm;
+                }
+                // ---- pass 2: the openers, in order.  An opener that lies inside the bytes an earlier construct consumes is not an
+                // opener at all (and what it would have skipped is): such a column is re-scanned exactly below.  For the others the
+                // bytes they skip (the byte after ^, the allele behind +n / -n) are taken out of the counts again.
+                unsigned long long cur = sm0, neg = 0;
+                int cbase = lbeg & ~3, ci = 0, consumed = lbeg, nneg = 0;
+                while (true) {
+                    if (cur == 0 && ci < 2) { cur = ci == 0 ? sm1 : sm2; ++ci; cbase += 60; }
+                    const bool have = (cur | (ci == 0 ? (sm1 | sm2) : (ci == 1 ? sm2 : 0ull))) != 0 && !bad;
+                    if (__ballot(have) == 0ull) break;
+                    if (have && cur != 0) {
+                        const int p = cbase + __builtin_ctzll(cur);
+                        cur &= cur - 1;
+                        if (p < consumed) bad = true;
+                        else {
+                            const int b = st[p];
+                            int q = p + 1, e;
+                            if (b == '^') e = q + 1 < lend ? q + 1 : lend;                   // ^ swallows one byte
+                            else {
+                                int adv = 0;
+                                while (q < lend && st[q] >= '0' && st[q] <= '9') { adv = adv > 100000 ? adv : adv * 10 + (st[q] - '0'); ++q; }
+                                if (adv <= MAX_INDEL) {
+                                    const int avail = lend - q;
+                                    const int len = adv < avail ? adv : avail;
+                                    if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)q | ((uint32_t)len << 16) | ((uint32_t)b << 24);
+                                    ++n_list;
+                                }
+                                e = adv < lend - q ? q + adv : lend;
+                                consumed = q + (adv > 1000000 ? 1000000 : adv);
+                            }
+                            if (b == '^') consumed = p + 2;
+                            for (int k = q; k < e; ++k) {                                    // skipped bytes were counted in pass 1
+                                const uint2 row = ctab[st[k]];
+                                neg += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
+                                if (++nneg == 63) {
+#pragma unroll
+                                    for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
+                                    neg = 0; nneg = 0;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
+            }
+            if (bad) {
+                // exact byte-at-a-time scan of this column out of LDS (tensor_maker.cpp:83-114 verbatim in structure): openers inside
+                // skipped bytes, columns beyond 180 bytes.  Divergent, but only the lanes that need it run it.
+#pragma unroll
+                for (int k = 0; k < 10; ++k) cnt[k] = 0;
+                n_list = 0;
+                for (int i = lbeg; i < lend;) {
+                    const int b = st[i];
+                    const int cls = byte_class(b);
+                    if (cls < 10) {
+#pragma unroll
+                        for (int k = 0; k < 10; ++k) cnt[k] += cls == k;
+                        ++i;
+                    } else if (cls == 11 || cls == 12) {
+                        ++i;
+                        int adv = 0;
+                        while (i < lend && st[i] >= '0' && st[i] <= '9') { adv = adv > 100000 ? adv : adv * 10 + (st[i] - '0'); ++i; }
                         if (adv <= MAX_INDEL) {
-                            const int avail = lend - p;
+                            const int avail = lend - i;
                             const int len = adv < avail ? adv : avail;
-                            if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)p | ((uint32_t)len << 16) | ((uint32_t)sign << 24);
+                            if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)i | ((uint32_t)len << 16) | ((uint32_t)b << 24);
                             ++n_list;
                         }
-                        if (adv > 0) skip = adv - 1; else normal = true;        // advance == 0 re-examines this byte
-                    }
-                    const uint32_t m = normal ? 0xffffffffu : 0u;
-                    a0 += row.x & m; a1 += row.y & m; a2 += row.z & m;
-                    const uint32_t fl = row.w & m;
-                    if (fl & 1u) { dig = true; adv = 0; sign = b; }
-                    if (fl & 2u) skip = 1;
+                        i = adv < lend - i ? i + adv : lend;
+                    } else if (cls == 13) i += 2;
+                    else ++i;
                 }
-                if (++since == 63) { flush(); since = 0; }       // 8-bit fields: at most 252 increments between flushes
-            }
-            flush();
-            if (dig && adv <= MAX_INDEL) {       // the string ended inside "+<digits>": empty key at the end
-                if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)lend | ((uint32_t)sign << 24);
-                ++n_list;
             }
             // distinct-allele maxima from the recorded list: m(e) = #{f <= e equal to e}
             const int n_rec = n_list < KLIST ? n_list : KLIST;
@@ -351,12 +441,14 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     int top = -1, topc = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) if (lc[k] > topc) { topc = lc[k]; top = lk[k]; }
-    const double den = (double)(depth ? depth : 1);
+    const uint32_t den = (uint32_t)(depth ? depth : 1);
+    const unsigned __int128 rhs = (unsigned __int128)af.t * den;                 // T x depth, < 2^87
     bool pass_snp = false, pass_indel = false;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         if (lc[k] <= 0 || lk[k] == chr_idx) continue;
-        const bool ok = ((double)lc[k] / den) >= min_af;
+        // ((double)count / depth) >= min_af, decided exactly in integers (AfThreshold below)
+        const bool ok = af.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << af.k) >= rhs) : af.mode == 1;
         if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
     }
     const bool pass_af = (top >= 0 && top != chr_idx) || pass_snp || pass_indel;
@@ -478,7 +570,7 @@ extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, c
     const unsigned grid = (unsigned)NSNP_CDIV(M, ENC_BLOCK);
     ScopedKernelTimer tm(ctx, NSNP_K_ENCODE, (hipStream_t)stream);
     hipLaunchKernelGGL(k_encode_columns, dim3(grid), dim3(ENC_BLOCK), 0, (hipStream_t)stream,
-                       bases, col_off, ref, M, min_af, min_coverage, counts, depth, flags);
+                       bases, col_off, ref, M, make_af_threshold(min_af), min_coverage, counts, depth, flags);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }

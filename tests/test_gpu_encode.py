@@ -157,3 +157,23 @@ def test_deep_and_indel_heavy_columns_take_the_sub_batch_and_rescan_paths(gpu_ct
     bad = np.nonzero((c.cpu().numpy() != oc).any(1))[0]
     assert bad.size == 0, (bad[:5], c.cpu().numpy()[bad[:2]], oc[bad[:2]])
     assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
+
+
+def test_af_test_in_integers_equals_the_float64_division(gpu_ctx):
+    """the kernel decides (double)count / depth >= min_af with one 128-bit integer comparison (pileup_encode.hip: AfThreshold);
+    the oracle divides in float64 as tensor_maker.cpp:195-228 does.  Flags must agree for every threshold class: ordinary values,
+    quotients that hit the threshold exactly (k / depth for many depths), powers of two, zero / negative / tiny / huge / NaN."""
+    from oracle import oracle
+    cols = host.synth_columns(11, 60_000, coverage=30)
+    rng = np.random.default_rng(3)
+    # small depths too, so that simple fractions (1/3, 2/7, ...) occur as quotients
+    cols2 = host.synth_columns(12, 60_000, coverage=6)
+    thresholds = [0.12, 0.3, 0.5, 0.25, 1.0, 0.0, -1.0, 1e-30, 5e-324, 2.5, 1e12, float("inf"), float("nan"),
+                  1 / 3, 2 / 7, 3 / 8, 0.1, 0.2, np.nextafter(0.25, 0), np.nextafter(0.25, 1), np.nextafter(1 / 3, 0), np.nextafter(1 / 3, 1),
+                  float(rng.random()), float(rng.random())]
+    for cs in (cols, cols2):
+        for a in thresholds:
+            c, d, f = _enc(gpu_ctx, cs.bases, cs.col_off, cs.ref, min_af=a, min_coverage=2)
+            oc, od, of = oracle.encode_columns(cs.bases, cs.col_off, cs.ref, a, 2)
+            assert np.array_equal(f.cpu().numpy(), of), a
+            assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(d.cpu().numpy(), od)
