@@ -95,7 +95,13 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "l1_site_groups"          0 auto | 2/4                     16-site groups per workgroup of that kernel
  *   "fused_l1"                1 (default) | 0                 f16x3 layer 1: projection fused into the recurrence
  *   "fused_waves"             0 auto | 4/8/12                  waves per workgroup of the fused kernel
- *   "proj1_tiles"             1..64                            row tiles per wave of the unfused projection kernel */
+ *   "proj1_tiles"             1..64                            row tiles per wave of the unfused projection kernel
+ *   fp32 path (pileup_precision 0): "l0_register_stationary" 1 (default) | 0, "l1_register_stationary" 1 four waves x four gate
+ *   tiles (default) | 2 eight waves x two tiles | 0 LDS-image kernels with the Xp1 round trip, "l1_site_groups" 0 | 1 | 2 | 4,
+ *   "l1_stagger" 0 (default) | 1 (eight-wave kernel: waves 4-7 issue a group's next input part ahead of its cell),
+ *   "head_split" 1 (default) | 0 heads with the output tiles split over eight waves, "static_priority" 0..3 (f16x3
+ *   register-stationary kernels: s_setprio 1 for waves 4-7 of layer 1 / odd workgroups of layer 0; measured without effect).
+ *   Every fp32 combination returns bit-identical probabilities. */
 int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
 
 /* Optional per-kernel timing: when enabled every launch of the kernels below is bracketed by a

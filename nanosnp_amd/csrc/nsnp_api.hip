@@ -47,6 +47,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->l1_rs = 1;
     ctx->l1_stagger = 0;
     ctx->head_rs = 1;
+    ctx->rs_prio = 0;           // measured without effect, kept as an option
     hipDeviceProp_t prop;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -112,6 +113,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "l1_register_stationary") == 0) {
         if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->l1_rs = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "static_priority") == 0) {
+        if (value < 0 || value > 3) return NSNP_EINVAL;
+        ctx->rs_prio = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "head_split") == 0) {

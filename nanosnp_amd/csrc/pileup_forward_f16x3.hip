@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_rs(
     const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
     const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
     const _Float16* __restrict__ wih0, const _Float16* __restrict__ wih1,
-    _Float16* __restrict__ H0 /* padded to a multiple of 64 sites: stores are unconditional */)
+    _Float16* __restrict__ H0 /* padded to a multiple of 64 sites: stores are unconditional */, int prio)
 {
+    if ((prio & 2) && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(1);
     __shared__ __attribute__((aligned(16))) _Float16 hx[2][16 * NSG][RS_HROW];
     __shared__ __attribute__((aligned(16))) _Float16 xx[2][16 * NSG][RS_XROW];
     __shared__ int xflag[2][4];
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
     const _Float16* __restrict__ wih0, const _Float16* __restrict__ wih1,
     const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
     const float* __restrict__ bias0, const float* __restrict__ bias1,
-    _Float16* __restrict__ H1c /* padded likewise */)
+    _Float16* __restrict__ H1c /* padded likewise */, int prio)
 {
     extern __shared__ h8 ldsh[];
     _Float16* const h0s = reinterpret_cast<_Float16*>(ldsh);                       // [2][64][R1_H0ROW]
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int64_t base_site = (int64_t)blockIdx.x * NS;
+    if (prio && wave >= 4) __builtin_amdgcn_s_setprio(1);       // static priority for the younger half (MI355X_MICROARCH.md, 'Two waves per SIMD' item 4)
 
     // ---- this wave's two gate tiles -> registers ---------------------------------------------------
     h8 Wih[2][4][2], Whh[2][2][2];
@@ -1171,7 +1173,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
             while (nsg > 1 && NSNP_CDIV(n, 16 * nsg) * 2 < 2 * (int64_t)ctx->n_cu) nsg >>= 1;
             if (ctx->l0_rs_groups) nsg = ctx->l0_rs_groups;
 #define LAUNCH_RS(G) hipLaunchKernelGGL(k_pileup_l0_rs<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), 0, s, xc, cc, n, \
-            (const _Float16*)pw.l0_whh_rs[0], (const _Float16*)pw.l0_whh_rs[1], (const _Float16*)pw.l0_wih_rs[0], (const _Float16*)pw.l0_wih_rs[1], H0)
+            (const _Float16*)pw.l0_whh_rs[0], (const _Float16*)pw.l0_whh_rs[1], (const _Float16*)pw.l0_wih_rs[0], (const _Float16*)pw.l0_wih_rs[1], H0, ctx->rs_prio)
             if (nsg == 4) LAUNCH_RS(4); else if (nsg == 2) LAUNCH_RS(2); else LAUNCH_RS(1);
 #undef LAUNCH_RS
         } else
@@ -1190,7 +1192,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
 #define LAUNCH_R1(G) hipLaunchKernelGGL(k_pileup_l1_rs<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(512), r1_lds_bytes(G), s, H0, n, \
                                (const _Float16*)pw.l1_wih_rs[0], (const _Float16*)pw.l1_wih_rs[1], \
                                (const _Float16*)pw.l1_whh_rs[0], (const _Float16*)pw.l1_whh_rs[1], \
-                               (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c)
+                               (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c, ctx->rs_prio)
             if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2);
 #undef LAUNCH_R1
         } else if (ctx->fused_l1) {
