@@ -93,6 +93,21 @@ def test_hap_forward_golden_of_the_reference_module(hap_model):
     assert np.abs(gt - z["gt"]).max() < PROB_ATOL and np.abs(zy - z["zy"]).max() < PROB_ATOL
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "f16x3"])
+def test_hap_forward_golden_with_site_dependent_outputs(prec):
+    """hap_fwd_h256x.npz (48 sites, three genotype classes, p_max 0.37 .. 0.90; reference module with scaled seeded weights)"""
+    from nanosnp_amd import _lib
+    from tests.helpers import PROB_ATOL, seeded_hap_weights
+    z = np.load(golden("hap_fwd_h256x.npz"))
+    c = _lib.Context(0)
+    c.hap_load_weights(seeded_hap_weights(int(z["seed"]), H=256, ih_scale=0.03, head_scale=120.0))
+    c.set_option("hap_precision", prec)
+    gt, zy = _hfwd(c, z["xp"], z["xh"])
+    assert np.abs(gt - z["gt"]).max() < PROB_ATOL and np.abs(zy - z["zy"]).max() < PROB_ATOL
+    assert np.array_equal(gt.argmax(1), z["gt"].argmax(1))
+    c.close()
+
+
 @pytest.mark.parametrize("n", [1, 127, 128, 129, 300])
 def test_hap_forward_vs_oracle_ragged(hap_model, n):
     from oracle import oracle

@@ -78,6 +78,16 @@ def test_hap_forward_matches_reference_module_with_seeded_weights(H):
     assert np.abs(gt - z["gt"]).max() < 5e-6
 
 
+def test_hap_forward_golden_with_site_dependent_outputs():
+    """hap_fwd_h256x.npz: model_dev.LSTMNetwork.predict with the scaled seeded weights of the two-stage fixture on 48 sites whose
+    genotypes differ (three classes, p_max 0.37 .. 0.90): a constant-output golden cannot hide a layout error, this one cannot"""
+    z = np.load(golden("hap_fwd_h256x.npz"))
+    ws = seeded_hap_weights(int(z["seed"]), H=256, ih_scale=0.03, head_scale=120.0)
+    gt, zy = oracle.hap_forward(ws, z["xp"], z["xh"], H=256, nthreads=8)
+    assert np.abs(gt - z["gt"]).max() < 2e-5 and np.abs(zy - z["zy"]).max() < 2e-5
+    assert np.array_equal(gt.argmax(1), z["gt"].argmax(1)) and len(set(z["gt"].argmax(1).tolist())) >= 3
+
+
 def test_cat_forward_matches_reference_module_with_seeded_weights():
     """legacy CatModel.predict (HaplotypeModel/model.py:332-358): golden from the reference module (tests/golden/make_golden.py cat)"""
     from tests.helpers import seeded_cat_weights
