@@ -81,6 +81,10 @@ def parse_args(argv=None):
                     "(every kernel launch of those streams inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measured configuration). "
+                    "gloo + --share-gpu is a TEST configuration: the ranks share GPU 0 and the gathered calls cross host memory, so that the "
+                    "whole multi-rank path runs on a one-GPU box (tests/test_gpu_bench_contract.py); its value is not a scaling number")
+    ap.add_argument("--share-gpu", action="store_true", help="test configuration: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU/gloo dry run of the multi-rank plumbing (spawn, barrier, "
                     "max-over-ranks timing, rooted gather, one JSON line); no kernels, value is null -- tests/test_dist.py")
     return ap.parse_args(argv)
@@ -228,7 +232,12 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+    if args.share_gpu:
+        if args.dist_backend != "gloo":
+            print("bench.py: --share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+            sys.exit(2)
+        local_rank = 0
+    elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
         sys.exit(3)
     from nanosnp_amd import _lib, host
@@ -237,9 +246,13 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")       # where collective payloads live
 
     batch, S = args.batch, max(1, args.streams)
     n_windows = max(batch, (args.windows // batch) * batch)
@@ -324,7 +337,7 @@ def main():
         """final merge: compact per-site calls of this rank -> rank 0 (RCCL gather over xGMI)"""
         compact = torch.stack([res["ga"][:n_done].float(), res["za"][:n_done].float(),
                                res["gm"][:n_done], res["zm"][:n_done]], dim=1)
-        return gather_results(compact, n_done * world) if world > 1 else compact
+        return gather_results(compact.to(cdev), n_done * world) if world > 1 else compact
 
     def timed_pass():
         """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
@@ -343,7 +356,7 @@ def main():
         sync_all(); barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         tot = {}
@@ -398,7 +411,8 @@ def main():
                        "streams": S, "coverage": args.coverage, "precision": "fp32" if args.precision == 0 else "f16x3",
                        "weights": "ont_pileup.chkpt values (tests/golden fixture)",
                        "parallelism": f"site-sharded x{world}, rooted gather of calls",
-                       "world_size_observed": dist.get_world_size() if world > 1 else 1},
+                       "world_size_observed": dist.get_world_size() if world > 1 else 1,
+                       **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: not a scaling number"} if args.share_gpu else {})},
             "host_issue_ms_per_step": t_issue / K * 1e3,
         }
         if avg_ms:

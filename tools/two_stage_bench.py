@@ -30,7 +30,12 @@ def run(args, rank, world, local_rank):
     import numpy as np
     import torch
     import torch.distributed as dist
-    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+    if args.share_gpu:
+        if args.dist_backend != "gloo":
+            print("bench.py: --share-gpu needs --dist-backend gloo", file=sys.stderr)
+            return 2
+        local_rank = 0
+    elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
         return 3
     from nanosnp_amd import _lib, host
@@ -38,9 +43,13 @@ def run(args, rank, world, local_rank):
     from tests.helpers import load_pileup_weights, seeded_hap_weights
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     batch = args.batch
     n2_tot = int(os.environ.get("NSNP_TWO_STAGE_N2", N_STAGE2)); n5_tot = int(os.environ.get("NSNP_TWO_STAGE_N5", N_STAGE5))
     lo2, hi2 = shard_range(n2_tot, rank, world); n2 = hi2 - lo2
@@ -97,8 +106,8 @@ def run(args, rank, world, local_rank):
         torch.cuda.synchronize(dev)
 
     def merge():
-        a = gather_results(res2[:n2], n2_tot) if world > 1 else res2[:n2]
-        b = gather_results(res5[:n5], n5_tot) if world > 1 else res5[:n5]
+        a = gather_results(res2[:n2].to(cdev), n2_tot) if world > 1 else res2[:n2]
+        b = gather_results(res5[:n5].to(cdev), n5_tot) if world > 1 else res5[:n5]
         return a, b
 
     def barrier():
@@ -119,7 +128,7 @@ def run(args, rank, world, local_rank):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tm = torch.tensor([dt, t2, t5], dtype=torch.float64, device=dev)
+        tm = torch.tensor([dt, t2, t5], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt, t2, t5 = (float(v) for v in tm.tolist())
     if rank == 0:
