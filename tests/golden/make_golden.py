@@ -595,62 +595,17 @@ def group_haparrange():
     """H1: create_pileup_haplotype.single_group_pileup_haplotype_feature (:22-214) itself, driven by a stand-in for the
     pysam.AlignmentFile it iterates (only .pileup() columns with .pos / .n / .pileups[*].alignment.{query_name, has_tag,
     get_tag, query_sequence, query_qualities, mapping_quality}, .is_del, .is_refskip, .query_position are used, :39-47,90-134).
-    The fixture holds, per group, the read x position matrices the function builds internally (re-derived here from the same
-    synthetic reads) and the filtered, HP-sorted matrices it returns -> hap_arrange.npz"""
+    The reads and groups come from tests/helpers.py (synth_reads(77), synth_groups(78)); the fixture holds, per group, the read x
+    position matrices the function builds internally (re-derived here from the same reads) and the filtered, HP-sorted matrices
+    it returns, plus its position lists -> hap_arrange.npz"""
     _stub_modules()
     sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
     import create_pileup_haplotype as cph        # noqa: E402  (reference module)
     from select_hetesnp_homosnp import SNPItem   # noqa: E402
-    rng = np.random.default_rng(77)
-    ctg = "c"
-    span = (1, 900)
-    # synthetic reads: (name, first ref position (1-based), per-position op: 'A'/'C'/'G'/'T' or 'D'), HP tag 1 / 2 / none
-    reads = []
-    for r in range(70):
-        a = int(rng.integers(span[0], span[1] - 200)); b = int(min(span[1], a + rng.integers(150, 700)))
-        ops = [("D" if rng.random() < 0.03 else "ACGT"[int(rng.integers(0, 4))]) for _ in range(a, b + 1)]
-        if rng.random() < 0.1: ops = [o.lower() if o != "D" else o for o in ops]     # str.upper() at :121
-        hp = [1, 2, None][int(rng.integers(0, 3))]
-        quals = rng.integers(1, 60, len(ops)).tolist()
-        reads.append(dict(name=f"r{r}", a=a, b=b, ops=ops, hp=hp, quals=quals, mapq=int(rng.integers(0, 61))))
-
-    class Aln:
-        def __init__(self, rd):
-            self.query_name = rd["name"]; self.rd = rd
-            self.query_sequence = "".join(o for o in rd["ops"] if o != "D")
-            self.query_qualities = [q for o, q in zip(rd["ops"], rd["quals"]) if o != "D"]
-            self.mapping_quality = rd["mapq"]
-        def has_tag(self, t):
-            return t == "HP" and self.rd["hp"] is not None
-        def get_tag(self, t):
-            return self.rd["hp"]
-
-    class PRead:
-        def __init__(self, aln, k):
-            self.alignment = aln
-            self.is_del = aln.rd["ops"][k] == "D"
-            self.is_refskip = False
-            self.query_position = None if self.is_del else sum(1 for o in aln.rd["ops"][:k] if o != "D")
-
-    class Col:
-        def __init__(self, pos0, prs):
-            self.pos = pos0; self.pileups = prs; self.n = len(prs)
-
-    alns = [Aln(rd) for rd in reads]
-
-    class FakeSam:
-        def pileup(self, contig, start, end, min_base_quality=0, min_mapping_quality=0):
-            for p in range(max(start - 3, 1), end + 4):           # 1-based p; pysam yields columns around the region too
-                prs = [PRead(a, p - a.rd["a"]) for a in alns if a.rd["a"] <= p <= a.rd["b"]]
-                if prs:
-                    yield Col(p - 1, prs)
-
-    centres = [260, 300, 455, 610]
-    groups = []
-    for c in centres:
-        left = sorted(rng.choice(np.arange(c - 120, c - 2), 5, replace=False).tolist())
-        right = sorted(rng.choice(np.arange(c + 2, c + 120), 5, replace=False).tolist())
-        groups.append([SNPItem(ctg, p, "0/1", 20.0) for p in left] + [SNPItem(ctg, c, "0/1", 10.0)] + [SNPItem(ctg, p, "0/1", 20.0) for p in right])
+    from tests.helpers import FakeSamfile, synth_groups, synth_reads
+    reads = synth_reads(77)
+    groups = [[SNPItem(c, p, "0/1", 10.0 if k == 5 else 20.0) for k, (c, p) in enumerate(g)] for g in synth_groups(78)]
+    FakeSam = lambda: FakeSamfile(reads)
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         out = cph.single_group_pileup_haplotype_feature(FakeSam(), groups, 10000, 5, 16)
@@ -683,6 +638,8 @@ def group_haparrange():
                 fx[f"g{g}_{tag}_in_{nm}"] = a.astype(np.int16)
                 fx[f"g{g}_{tag}_out_{nm}"] = np.asarray(o, np.int16)
     fx["candidates"] = np.array(cand)
+    fx["haplotype_positions"] = np.array(hpos)
+    fx["max_depths"] = np.array([maxh, maxp])
     np.savez_compressed(os.path.join(GOLD, "hap_arrange.npz"), **fx)
     print("hap_arrange:", len(groups), "groups, depths", [np.asarray(a).shape[0] for a in hseq], [np.asarray(a).shape[0] for a in pseq])
 
