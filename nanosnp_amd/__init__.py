@@ -8,6 +8,7 @@ this package holds only the host-side mirror of the reference's interface for th
     pipeline                     mpileup text -> column encode -> windows -> PileupModel -> pileup.vcf in one pass
                                  (dna_sv_tensor make_candidate_snp_tensor + make_predict_data + predict.py)
     predict                      PileupModel/predict.py / HaplotypeModel/predict_dev.py loops
+    readmatrix                   stage-4 read x position matrices from a pysam-like alignment file (create_pileup_haplotype.py)
     merge                        stage-4 group selection and the final merge (select_hetesnp_homosnp.py, scripts/merge.py)
     sitefile                     flat binary containers in place of the HDF5 bins
     dist                         static site sharding over the GPUs of a node + result gather
