@@ -115,6 +115,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         ctx->l1_rs = (int)value;
         return NSNP_OK;
     }
+    if (strcmp(name, "l0_input_weights_in_lds") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->l0_wx_lds = (int)value;
+        return NSNP_OK;
+    }
     if (strcmp(name, "static_priority") == 0) {
         if (value < 0 || value > 3) return NSNP_EINVAL;
         ctx->rs_prio = (int)value;

@@ -87,6 +87,7 @@ struct nsnp_ctx {
     int fused_l1;       // f16x3: 1 = fused projection + layer-1 recurrence kernel (default), 0 = two kernels
     int proj1_tiles;    // 16-row tiles per wave of the layer-1 projection kernel (persistent grid sizing)
     int force_wpb;      // 0 = automatic; else waves per recurrence workgroup (tuning / tests)
+    int l0_wx_lds;      // fp32 layer 0 (16-site workgroups): input-part weight fragments in LDS, 128 VGPRs, four workgroups per SIMD set
     int rs_prio;        // f16x3 register-stationary kernels: bit 0 = static s_setprio 1 for waves 4-7 of the layer-1 kernel, bit 1 = for odd layer-0 workgroups
     int head_rs;        // fp32 heads: 1 = output tiles split over the 8 waves of a workgroup, weights in VGPRs (default); 0 = one wave per 16 sites
     int l1_stagger;     // fp32 register-stationary layer 1: waves 4-7 run a group's next-step input part ahead of its cell (default 1)

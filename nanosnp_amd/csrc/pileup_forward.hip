@@ -322,8 +322,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // K1r: layer 0.  grid = (ceil(N / (16 NSG)), 2 directions), block = 256: wave w owns gate tiles 4w .. 4w+3 (hidden units
 // 16w .. 16w+15, all four gates) for NSG groups of 16 sites.
-template <int NSG>
-__global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
+template <int NSG, bool WXL = false>
+__global__ __launch_bounds__(256, (WXL ? 4 : (NSG <= 2 ? 3 : 2))) void k_pileup_l0_rs32(
     const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
     const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ wih0, const float* __restrict__ wih1,
@@ -332,6 +332,9 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
 {
     __shared__ __attribute__((aligned(16))) float hx[2][16 * NSG][RS_XROW];
     __shared__ __attribute__((aligned(16))) float xx[2][16 * NSG * RS_XSROW];
+    // WXL: the input-part fragments (20 of the 84 weight registers) stay in LDS instead, [wave][tile][lane] f32x4 + [wave][tile][lane] float:
+    // the kernel then fits 128 VGPRs and FOUR workgroups share a SIMD set instead of three
+    __shared__ __attribute__((aligned(16))) float wxl[WXL ? 4 * 4 * 64 * 5 : 4];
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -350,6 +353,10 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
             for (int j = 0; j < 4; ++j) Whh[u][j] = ghh[((4 * wave + u) * 4 + j) * 64 + lane];
             Wih[u] = gih[(4 * wave + u) * 64 + lane];
             Wl[u] = gl[(4 * wave + u) * 64 + lane];
+            if (WXL) {
+                *reinterpret_cast<f32x4*>(&wxl[((wave * 4 + u) * 64 + lane) * 4]) = Wih[u];
+                wxl[4 * 4 * 64 * 4 + (wave * 4 + u) * 64 + lane] = Wl[u];
+            }
         }
     }
 
@@ -434,6 +441,13 @@ __global__ __launch_bounds__(256, (NSG <= 2 ? 3 : 2)) void k_pileup_l0_rs32(
             f32x4 acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (WXL) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    Wih[u] = *reinterpret_cast<const f32x4*>(&wxl[((wave * 4 + u) * 64 + lane) * 4]);
+                    Wl[u] = wxl[4 * 4 * 64 * 4 + (wave * 4 + u) * 64 + lane];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1178,6 +1192,10 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
             if (ctx->l0_rs_groups) nsg = ctx->l0_rs_groups;
 #define LAUNCH_RS(G) hipLaunchKernelGGL(k_pileup_l0_rs32<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), 0, s, xc, cc, n, \
                            pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1], ctx->ws_h0)
+            if (ctx->l0_wx_lds && nsg == 1)
+                hipLaunchKernelGGL((k_pileup_l0_rs32<1, true>), dim3((unsigned)NSNP_CDIV(n, 16), 2), dim3(256), 0, s, xc, cc, n,
+                                   pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1], ctx->ws_h0);
+            else
             if (nsg == 4) LAUNCH_RS(4); else if (nsg == 2) LAUNCH_RS(2); else LAUNCH_RS(1);
 #undef LAUNCH_RS
         } else

@@ -190,6 +190,10 @@ def test_fp32_register_stationary_kernels_equal_the_lds_image_kernels_bit_for_bi
         got = c.pileup_forward(x)
         assert torch.equal(got[0], old[0]) and torch.equal(got[1], old[1]), st
     c.set_option("l1_stagger", 0)
+    c.set_option("l0_input_weights_in_lds", 1); c.set_option("l0_register_stationary", 1); c.set_option("l0_site_groups", 1)
+    got = c.pileup_forward(x)                         # layer 0 with its input-part fragments in LDS (four workgroups per SIMD set)
+    assert torch.equal(got[0], old[0]) and torch.equal(got[1], old[1])
+    c.set_option("l0_input_weights_in_lds", 0)
     for l0, l1 in ((1, 1), (1, 2), (1, 0), (0, 1), (0, 2)):      # layer 1: 1 = four waves x four tiles (default), 2 = eight waves x two tiles
         c.set_option("l0_register_stationary", l0); c.set_option("l1_register_stationary", l1)
         for g0 in ((0, 1, 2, 4) if l0 else (0,)):
