@@ -323,7 +323,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // K1r: layer 0.  grid = (ceil(N / (16 NSG)), 2 directions), block = 256: wave w owns gate tiles 4w .. 4w+3 (hidden units
 // 16w .. 16w+15, all four gates) for NSG groups of 16 sites.
 template <int NSG, bool WXL = false>
-__global__ __launch_bounds__(256, (WXL ? 4 : (NSG <= 2 ? 3 : 2))) void k_pileup_l0_rs32(
+__global__ __launch_bounds__(256, (WXL ? 4 : (NSG == 1 ? 3 : 2))) void k_pileup_l0_rs32(
     const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
     const float* __restrict__ whh0, const float* __restrict__ whh1,
     const float* __restrict__ wih0, const float* __restrict__ wih1,
@@ -428,6 +428,74 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG <= 2 ? 3 : 2))) void k_pileup_
         const int cur = s & 1;
         // x_t of this step was staged during the previous one; x_{t+1} is in flight in registers and is stored behind the MFMAs
         if (s > 0) flush_h(cur ^ 1, dir ? t + 1 : t - 1);
+        if constexpr (NSG >= 2) {
+            // Software pipeline over the site groups: the 84 MFMAs of group g+1 are issued AMONG the sigmoid / tanh work of group g
+            // (one scheduling region, one transcendental and one plain vector instruction behind every MFMA: a v_mfma_f32_16x16x4_f32
+            // holds the vector issue port for 8 of its 32 cycles), so a wave keeps the matrix pipe fed through its own cells.
+            struct Frag { f32x4 xb; float xl; f32x4 hb[4]; };
+            auto load_b = [&](int sg, Frag& f) {
+                const float* xr = &xx[cur][(16 * sg + n) * RS_XSROW];
+                f.xb = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+                f.xl = xr[16 + q];
+                if (s > 0) {
+                    const float* hr = &hx[cur ^ 1][16 * sg + n][4 * q];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f.hb[j] = *reinterpret_cast<const f32x4*>(hr + 16 * j);
+                }
+            };
+            auto gemm = [&](const Frag& f, f32x4* acc) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wih[u][e], f.xb[e], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma4(Wl[u], f.xl, acc[u]);
+                if (s > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc[u] = mfma4(Whh[u][j][e], f.hb[j][e], acc[u]);
+                }
+            };
+            auto cell = [&](int sg, const f32x4* acc) {
+                f32x4 hn;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ig = sigmoid_f(acc[u][0]);
+                    const float fg = sigmoid_f(acc[u][1]);
+                    const float gg = tanh_f(acc[u][2]);
+                    const float og = sigmoid_f(acc[u][3]);
+                    c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
+                    hn[u] = og * tanh_f(c[sg][u]);
+                }
+                *reinterpret_cast<f32x4*>(&hx[cur][16 * sg + n][16 * wave + 4 * q]) = hn;
+            };
+            Frag fr[2];
+            f32x4 acc[2][4];
+            load_b(0, fr[0]);
+            gemm(fr[0], acc[0]);
+#pragma unroll
+            for (int sg = 0; sg < NSG; ++sg) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (sg + 1 < NSG) load_b(sg + 1, fr[(sg + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sg + 1 < NSG) gemm(fr[(sg + 1) & 1], acc[(sg + 1) & 1]);
+                cell(sg, acc[sg & 1]);
+                if (sg + 1 < NSG) {
+#pragma unroll
+                    for (int i = 0; i < 84; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // one transcendental  (cell of the previous group)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // one other vector instruction
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int sg = 0; sg < NSG; ++sg) {
             // recurrent B fragments are requested one K block (4 K-steps) ahead of the MFMAs that use them, two in flight:
@@ -482,6 +550,7 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG <= 2 ? 3 : 2))) void k_pileup_
                 hn[u] = og * tanh_f(c[sg][u]);
             }
             *reinterpret_cast<f32x4*>(&hx[cur][16 * sg + n][16 * wave + 4 * q]) = hn;
+        }
         }
         if (s + 1 < PW) {
             stage_x(cur ^ 1);                                                   // x of step s+1 (its buffer was last read in step s-1)
@@ -1186,9 +1255,9 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         const dim3 g_rec((unsigned)NSNP_CDIV(n, 16 * wpb), 2);
         if (ctx->l0_rs) {
             ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
-            // 64 sites per workgroup when that still gives every CU two workgroups, else 32 or 16
-            int nsg = 4;
-            while (nsg > 1 && NSNP_CDIV(n, 16 * nsg) * 2 < 2 * (int64_t)ctx->n_cu) nsg >>= 1;
+            // 16 sites per workgroup (three independent workgroups per SIMD set) measured best at every batch size; 32 / 64
+            // sites (software-pipelined over the site groups) stay available as options
+            int nsg = 1;
             if (ctx->l0_rs_groups) nsg = ctx->l0_rs_groups;
 #define LAUNCH_RS(G) hipLaunchKernelGGL(k_pileup_l0_rs32<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), 0, s, xc, cc, n, \
                            pw.l0_whh[0], pw.l0_whh[1], pw.l0_wih[0], pw.l0_wih[1], pw.l0_wlast[0], pw.l0_wlast[1], ctx->ws_h0)
