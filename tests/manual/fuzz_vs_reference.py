@@ -88,7 +88,7 @@ def fuzz_vcf():
     real_loader = ref_predict.DataLoader
     ref_predict.DataLoader = lambda ds, batch_size, shuffle, num_workers: real_loader(ds, batch_size=batch_size, shuffle=False, num_workers=0)
     COV = [0, 1, 2, 3, 9, 10, 11, 12]
-    bad = 0
+    bad = 0; n_cmp = 0
     for trial in range(12):
         N = int(rng.choice([1, 5, 9, 10, 11, 63, 500, 1500]))
         x = rng.integers(-40, 40, (N, 33, 18)).astype(np.int32)
@@ -115,29 +115,39 @@ def fuzz_vcf():
         for bs in (1000, 64, 7):
             with tempfile.TemporaryDirectory() as d:
                 fai = os.path.join(d, "r.fai"); open(fai, "w").write("chrA\t1000000000\t6\t60\t61\nchr_B.2\t1000000000\t6\t60\t61\n")
-                vcf = os.path.join(d, "p.vcf")
-                try:
-                    ref_predict.predict(FakeModel(), ["x.bin"], fai, bs, vcf, torch.device("cpu"))
-                    want = open(vcf, "rb").read(); ref_err = None
-                except Exception as e:
-                    want = None; ref_err = repr(e)
-                table = host.ContigTable(names)
-                cov = x[:, 16, COV].astype(np.float32)
-                try:
-                    text, rows = host.vcf_format_batches(table, table.ids, pos, refb, gt.argmax(1), zy.argmax(1), gt.max(1), zy.max(1), cov, batch_size=bs)
-                    got = host.vcf_header(open(fai).read()).encode() + text; my_err = None
-                except Exception as e:
-                    got = None; my_err = repr(e)
-            ok = (got == want) if want is not None and got is not None else (want is None and got is None)
-            if not ok:
-                bad += 1
-                print("MISMATCH trial", trial, "N", N, "bs", bs, "ref_err", ref_err, "my_err", my_err)
-                if want is not None and got is not None:
-                    gl, wl = got.split(b"\n"), want.split(b"\n")
-                    print(len(gl), len(wl))
-                    for a, b in zip(gl, wl):
-                        if a != b: print(a, b"|", b); break
-    print("mismatches:", bad)
+                for mode in (host.SCORE_FLOAT32, host.SCORE_FLOAT64):
+                    # mode 0: the reference as this container's NumPy 2 runs it; mode 1: under NumPy 1.x scalar promotion, emulated by
+                    # widening the float32 arrays where they enter NumPy (tests/golden/make_golden.py vcf)
+                    vcf = os.path.join(d, "p.vcf")
+                    orig_numpy = torch.Tensor.numpy
+                    if mode == host.SCORE_FLOAT64:
+                        torch.Tensor.numpy = lambda self, *a, **k: (lambda r: r.astype(np.float64) if r.dtype == np.float32 else r)(orig_numpy(self, *a, **k))
+                    try:
+                        ref_predict.predict(FakeModel(), ["x.bin"], fai, bs, vcf, torch.device("cpu"))
+                        want = open(vcf, "rb").read(); ref_err = None
+                    except Exception as e:
+                        want = None; ref_err = repr(e)
+                    finally:
+                        torch.Tensor.numpy = orig_numpy
+                    table = host.ContigTable(names)
+                    cov = x[:, 16, COV].astype(np.float32)
+                    try:
+                        text, rows = host.vcf_format_batches(table, table.ids, pos, refb, gt.argmax(1), zy.argmax(1), gt.max(1), zy.max(1), cov, batch_size=bs,
+                                                             score_mode=mode)
+                        got = host.vcf_header(open(fai).read()).encode() + text; my_err = None
+                    except Exception as e:
+                        got = None; my_err = repr(e)
+                    ok = (got == want) if want is not None and got is not None else (want is None and got is None)
+                    n_cmp += 1
+                    if not ok:
+                        bad += 1
+                        print("MISMATCH trial", trial, "mode", mode, "N", N, "bs", bs, "ref_err", ref_err, "my_err", my_err)
+                        if want is not None and got is not None:
+                            gl, wl = got.split(b"\n"), want.split(b"\n")
+                            print(len(gl), len(wl))
+                            for a, b in zip(gl, wl):
+                                if a != b: print(a, b"|", b); break
+    print("comparisons:", n_cmp, "mismatches:", bad)
 
 
 def fuzz_encode():

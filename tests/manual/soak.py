@@ -13,6 +13,8 @@ w = load_pileup_weights()
 rng = np.random.default_rng(12345)
 c32 = _lib.Context(0); c32.pileup_load_weights(w); c32.set_option("pileup_precision", 0)
 c16 = _lib.Context(0); c16.pileup_load_weights(w); c16.set_option("pileup_precision", 1)
+cbase = _lib.Context(0); cbase.pileup_load_weights(w)
+for o in ("l0_register_stationary", "l1_register_stationary", "head_split"): cbase.set_option(o, 0)     # round-1 LDS-image fp32 kernels
 worst = 0.0; t0 = time.time()
 for it in range(iters):
     n = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 500, 1000, 4096, 5000, int(rng.integers(1, 9000))]))
@@ -25,7 +27,15 @@ for it in range(iters):
     for opt, val in (("l0_register_stationary", it % 2), ("l1_register_stationary", (it // 2) % 2), ("l0_site_groups", [0, 1, 2, 4][it % 4]),
                      ("l1_site_groups", [0, 2, 4][it % 3]), ("fused_l1", 0 if it % 7 == 6 else 1)):
         c16.set_option(opt, val)
+    # the fp32 path in every launch shape against its LDS-image kernels: bit-identical
+    l1 = [1, 2, 0][it % 3]
+    for opt, val in (("l0_register_stationary", (it // 3) % 2), ("l1_register_stationary", l1), ("l0_site_groups", [0, 1, 2, 4][(it // 2) % 4]),
+                     ("l1_site_groups", {0: 0, 1: [0, 1, 2][it % 3], 2: [0, 2, 4][it % 3]}[l1]), ("l1_stagger", it % 2), ("head_split", (it // 5) % 2),
+                     ("l0_input_weights_in_lds", (it // 7) % 2)):
+        c32.set_option(opt, val)
     g32, z32 = c32.pileup_forward(xt); g16, z16 = c16.pileup_forward(xt)
+    gb, zb = cbase.pileup_forward(xt)
+    assert torch.equal(g32, gb) and torch.equal(z32, zb), (it, n, "fp32 launch shapes differ")
     d = max((g32 - g16).abs().max().item(), (z32 - z16).abs().max().item())
     # kind 3 (|x| up to 3000, far beyond the depth cap of 144): products of ~300 make the fp32 summation order itself worth ~1e-4
     assert torch.isfinite(g16).all() and d < (5e-4 if kind == 3 else 2e-5), (it, n, kind, d)
