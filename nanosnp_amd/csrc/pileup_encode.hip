@@ -325,30 +325,52 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
                         cur &= cur - 1;
                         if (p < consumed) bad = true;
                         else {
+                            // the opener and the eight bytes behind it from three aligned words (no byte loops: digits and the first
+                            // four skipped bytes are taken out of this window, which covers every 1- to 3-digit indel of up to 5 bases)
                             const int b = st[p];
-                            int q = p + 1, e;
-                            if (b == '^') e = q + 1 < lend ? q + 1 : lend;                   // ^ swallows one byte
-                            else {
-                                int adv = 0;
-                                while (q < lend && st[q] >= '0' && st[q] <= '9') { adv = adv > 100000 ? adv : adv * 10 + (st[q] - '0'); ++q; }
-                                if (adv <= MAX_INDEL) {
-                                    const int avail = lend - q;
-                                    const int len = adv < avail ? adv : avail;
-                                    if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)q | ((uint32_t)len << 16) | ((uint32_t)b << 24);
-                                    ++n_list;
-                                }
-                                e = adv < lend - q ? q + adv : lend;
-                                consumed = q + (adv > 1000000 ? 1000000 : adv);
+                            const int w0 = (p + 1) >> 2;
+                            const uint32_t a0 = st32[w0], a1 = st32[w0 + 1], a2 = st32[w0 + 2];
+                            const int sh = (p + 1) & 3;
+                            const uint32_t wlo = __builtin_amdgcn_alignbyte(a1, a0, sh), whi = __builtin_amdgcn_alignbyte(a2, a1, sh);
+                            const unsigned long long win = ((unsigned long long)whi << 32) | wlo;         // byte i = st[p + 1 + i]
+                            const int avail1 = lend - (p + 1);                                              // bytes of the column behind the opener
+                            const bool caret = b == '^';
+                            const uint32_t d0 = (wlo & 0xffu) - '0', d1 = ((wlo >> 8) & 0xffu) - '0', d2 = ((wlo >> 16) & 0xffu) - '0', d3 = (wlo >> 24) - '0';
+                            const bool k0 = !caret && avail1 > 0 && d0 < 10u, k1 = k0 && avail1 > 1 && d1 < 10u, k2 = k1 && avail1 > 2 && d2 < 10u;
+                            if (k2 && avail1 > 3 && d3 < 10u) bad = true;                                   // four digits and more: exact path
+                            const int L = k2 ? 3 : (k1 ? 2 : (k0 ? 1 : 0));
+                            const int adv = caret ? 1 : (k2 ? (int)(d0 * 100 + d1 * 10 + d2) : (k1 ? (int)(d0 * 10 + d1) : (k0 ? (int)d0 : 0)));
+                            const int q = p + 1 + L;
+                            const int avail = lend - q;
+                            const int nskip = adv < avail ? adv : (avail > 0 ? avail : 0);
+                            if (!caret && adv <= MAX_INDEL) {
+                                if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)q | ((uint32_t)nskip << 16) | ((uint32_t)b << 24);
+                                ++n_list;
                             }
-                            if (b == '^') consumed = p + 2;
-                            for (int k = q; k < e; ++k) {                                    // skipped bytes were counted in pass 1
+                            consumed = q + adv;
+                            // skipped bytes were counted in pass 1: the first four out of the window ...
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (i < nskip) {
+                                    const uint2 row = ctab[(uint32_t)(win >> (8 * (L + i))) & 0xffu];
+                                    neg += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
+                                }
+                            }
+                            nneg += nskip < 4 ? nskip : 4;
+                            // ... longer alleles byte by byte (rare; only the lanes that have one)
+                            for (int k = q + 4; k < q + nskip; ++k) {
                                 const uint2 row = ctab[st[k]];
                                 neg += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
-                                if (++nneg == 63) {
+                                if (++nneg >= 59) {
 #pragma unroll
                                     for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
                                     neg = 0; nneg = 0;
                                 }
+                            }
+                            if (nneg >= 59) {
+#pragma unroll
+                                for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
+                                neg = 0; nneg = 0;
                             }
                         }
                     }
