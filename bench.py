@@ -84,6 +84,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measured configuration). "
                     "gloo + --share-gpu is a TEST configuration: the ranks share GPU 0 and the gathered calls cross host memory, so that the "
                     "whole multi-rank path runs on a one-GPU box (tests/test_gpu_bench_contract.py); its value is not a scaling number")
+    ap.add_argument("--gather", default="torch", choices=["torch", "rccl-abi"], help="final merge through one torch.distributed collective "
+                    "(default) or through the library's own RCCL entry nsnp_gather_results (validated at world size 1 only)")
     ap.add_argument("--share-gpu", action="store_true", help="test configuration: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU/gloo dry run of the multi-rank plumbing (spawn, barrier, "
                     "max-over-ranks timing, rooted gather, one JSON line); no kernels, value is null -- tests/test_dist.py")
@@ -241,7 +243,7 @@ def main():
         print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
         sys.exit(3)
     from nanosnp_amd import _lib, host
-    from nanosnp_amd.dist import gather_results
+    from nanosnp_amd.dist import gather_results, gather_results_abi
     from tests.helpers import load_pileup_weights
 
     if world > 1:
@@ -337,6 +339,8 @@ def main():
         """final merge: compact per-site calls of this rank -> rank 0 (RCCL gather over xGMI)"""
         compact = torch.stack([res["ga"][:n_done].float(), res["za"][:n_done].float(),
                                res["gm"][:n_done], res["zm"][:n_done]], dim=1)
+        if args.gather == "rccl-abi":
+            return gather_results_abi(ctxs[0], compact, n_done * world)
         return gather_results(compact.to(cdev), n_done * world) if world > 1 else compact
 
     def timed_pass():
@@ -411,7 +415,7 @@ def main():
                        "streams": S, "coverage": args.coverage, "precision": "fp32" if args.precision == 0 else "f16x3",
                        "weights": "ont_pileup.chkpt values (tests/golden fixture)",
                        "parallelism": f"site-sharded x{world}, rooted gather of calls",
-                       "world_size_observed": dist.get_world_size() if world > 1 else 1,
+                       "world_size_observed": dist.get_world_size() if world > 1 else 1, "gather": args.gather,
                        **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: not a scaling number"} if args.share_gpu else {})},
             "host_issue_ms_per_step": t_issue / K * 1e3,
         }

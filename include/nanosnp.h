@@ -20,13 +20,10 @@
  *   nsnp_cat_groups              PredictDataset.__getitem__     HaplotypeModel/dataset.py:862-915 (g0 / g1 assembly)
  *                                called from                    HaplotypeModel/predict_dev.py:35-39
  *
- * Result gather (SURVEY.md 8(b) sketches an `nsnp_gather_results(ctx, rccl_comm, ...)` entry): deliberately NOT part of this ABI.
- * The path's only exchange is one rooted gather of a few bytes per site at the very end (8(e)); the ranks are PyTorch processes
- * that already own an RCCL communicator through torch.distributed (backend "nccl" = RCCL over xGMI), and PyTorch does not hand its
- * ncclComm_t to foreign code, so a C entry would have to create a second communicator per process (ncclGetUniqueId / a side channel /
- * ncclCommInitRank: a second bootstrap, second set of xGMI rings and buffers) to move ~18 MB per rank once.  The gather therefore
- * lives in the host-side mirror: nanosnp_amd/dist.py gather_results (equal shards) / gather_varlen (per-rank site lists), one
- * torch.distributed collective each, covered by world-2 / world-3 gloo tests and by the sharded-pipeline GPU test.
+ * Result gather: the path's only exchange is one rooted gather of a few bytes per site at the very end.
+ * PyTorch ranks do it with one torch.distributed collective (nanosnp_amd/dist.py gather_results / gather_varlen: PyTorch owns their
+ * RCCL communicator and does not hand it to foreign code); callers that are not PyTorch processes use nsnp_comm_* +
+ * nsnp_gather_results below, which bind a communicator of their own to the context (RCCL resolved at run time, no link dependency).
  *
  * Conventions: every pointer marked "device" is device memory owned by the caller; functions
  * are asynchronous on `stream` unless stated, return 0 on success or a negative NSNP_E* code
@@ -51,6 +48,8 @@ extern "C" {
 #define NSNP_ENOWEIGHTS (-4)   /* forward called before load_weights        */
 #define NSNP_EARCH      (-5)   /* device is not gfx950                      */
 #define NSNP_ESHAPE     (-6)   /* unsupported model dimensions              */
+#define NSNP_ENOTSUP    (-7)   /* optional component unavailable (RCCL not found in the process or on the loader path) */
+#define NSNP_ECOMM      (-8)   /* an RCCL call failed                        */
 
 #define NSNP_PILEUP_WINDOW   33   /* PileupModel/dataset.py:11-12, 2*flanking_base+1 */
 #define NSNP_PILEUP_CHANNELS 18   /* dna_sv_tensor/src/common/tensor.hpp:6-26        */
@@ -210,6 +209,18 @@ int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
 int nsnp_cat_groups(nsnp_ctx* ctx, const int32_t* read1, const int32_t* bq1, const int32_t* mq1, int depth1,
                     const int32_t* read2, const int32_t* bq2, const int32_t* mq2, int depth2,
                     int64_t N, int length, float* g, void* stream);
+
+/* ---- result gather over RCCL (optional; see the note at the top) ---------------------------------------- */
+/* Rank 0 obtains 128 opaque bytes and shares them with the other ranks by any side channel; every rank then binds a
+ * communicator to its context (collective call).  NSNP_ENOTSUP when no RCCL library can be resolved. */
+int nsnp_comm_unique_id(uint8_t* id128);
+int nsnp_comm_init(nsnp_ctx* ctx, const uint8_t* id128, int rank, int world);
+int nsnp_comm_destroy(nsnp_ctx* ctx);
+/* Rooted gather of per-rank byte blocks (device memory) into root_buf (device, root only) at byte_off[r] .. byte_off[r+1]
+ * (HOST array of world + 1 offsets, read on the root only; local_bytes of the root must equal its own slot).  Grouped
+ * ncclSend / ncclRecv on `stream`, asynchronous; rank order = site order, so the merge is a concatenation. */
+int nsnp_gather_results(nsnp_ctx* ctx, const void* local, int64_t local_bytes, void* root_buf,
+                        const int64_t* byte_off, int root, void* stream);
 
 #ifdef __cplusplus
 }

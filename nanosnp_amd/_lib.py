@@ -50,6 +50,10 @@ _SIGNATURES = {
                                    C.c_void_p]),
     "nsnp_cat_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "nsnp_cat_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nsnp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "nsnp_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "nsnp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "nsnp_gather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nsnp_cat_groups": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
                         [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
 }
@@ -150,6 +154,29 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # ---- optional RCCL gather of the C ABI (PyTorch ranks normally use nanosnp_amd.dist instead) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(load().nsnp_comm_unique_id(buf), None, "nsnp_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, id128: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(id128)
+        check(self.lib.nsnp_comm_init(self.handle, buf, int(rank), int(world)), self.handle, "nsnp_comm_init")
+        self._comm = (int(rank), int(world))
+
+    def gather_bytes(self, local, counts_bytes, root=0, stream=None):
+        """local: contiguous cuda tensor of this rank; counts_bytes: bytes of every rank's block -> uint8 cuda tensor on root, else None"""
+        import numpy as np
+        import torch
+        rank, world = self._comm
+        off = np.concatenate([[0], np.cumsum(np.asarray(counts_bytes, np.int64))]).astype(np.int64)
+        out = torch.empty(int(off[-1]), dtype=torch.uint8, device=local.device) if rank == root else None
+        check(self.lib.nsnp_gather_results(self.handle, _dptr(local), int(local.numel() * local.element_size()), _dptr(out),
+                                           off.ctypes.data_as(C.c_void_p), int(root), _stream_ptr(stream)), self.handle, "nsnp_gather_results")
+        return out
 
     # ---- PileupModel -------------------------------------------------------------------------
     def pileup_load_weights(self, tensors):

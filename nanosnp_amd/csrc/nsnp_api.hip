@@ -15,6 +15,8 @@ extern "C" const char* nsnp_strerror(int code)
     case NSNP_ENOWEIGHTS: return "weights not loaded";
     case NSNP_EARCH: return "device is not gfx950";
     case NSNP_ESHAPE: return "unsupported model dimensions";
+    case NSNP_ENOTSUP: return "optional component unavailable (RCCL not found)";
+    case NSNP_ECOMM: return "RCCL call failed";
     default: return "unknown error";
     }
 }
@@ -210,6 +212,7 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     if (ctx->pw16.arena) (void)hipFree(ctx->pw16.arena);
     if (ctx->pw16.l1f_bias) (void)hipFree(ctx->pw16.l1f_bias);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
+    (void)nsnp_comm_destroy(ctx);
     nsnp_hap_free(ctx);
     nsnp_cat_free(ctx);
     if (ctx->timer) {

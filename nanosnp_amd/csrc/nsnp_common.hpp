@@ -104,6 +104,7 @@ struct nsnp_ctx {
     void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     KernelTimer* timer;
+    void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init (nsnp_comm.hip)
 };
 
 // records an event pair around one kernel launch when timing is enabled

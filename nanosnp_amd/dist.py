@@ -76,3 +76,25 @@ def gather_varlen(local, root=0, group=None):
     if rank != root:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def gather_results_abi(ctx, local, n_total, root=0, stream=None):
+    """The same rooted gather through the library's own RCCL entry (nsnp_comm_init + nsnp_gather_results, include/nanosnp.h) instead of
+    a torch.distributed collective: grouped ncclSend / ncclRecv straight into place on the root, no padded copies.  The 128-byte
+    communicator id travels over the existing process group once per context.  Validated on hardware at world size 1 only (the
+    development pool has one-GPU boxes); bench.py uses it with --gather rccl-abi."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if not hasattr(ctx, "_comm"):
+        ids = [ctx.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+    row_bytes = local.element_size() * (local.numel() // max(local.shape[0], 1)) if local.shape[0] else local.element_size() * int(torch.tensor(local.shape[1:]).prod())
+    counts = [(hi - lo) * row_bytes for lo, hi in (shard_range(n_total, r, world) for r in range(world))]
+    out = ctx.gather_bytes(local.contiguous(), counts, root=root, stream=stream)
+    if rank != root:
+        return None
+    return out.view(local.dtype).view((n_total,) + tuple(local.shape[1:]))

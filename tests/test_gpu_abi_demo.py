@@ -44,3 +44,29 @@ def test_plain_c_program_through_the_abi(tmp_path, pileup_weights):
     assert np.allclose([float(r[4]) for r in rows], zm.cpu().numpy(), atol=2e-6)
     assert len(set(int(r[1]) for r in rows)) > 3            # the demo input is not degenerate
     ctx.close()
+
+
+def test_rccl_gather_entry_world_one(gpu_ctx):
+    """nsnp_comm_* / nsnp_gather_results (the optional C-ABI gather over RCCL): a one-rank communicator on the GPU box - the unique
+    id, ncclCommInitRank through the run-time resolved library, the root's own block copied into place, empty blocks allowed.
+    (Two ranks need two GPUs: RCCL refuses a second rank on the same device; the PyTorch ranks of bench.py gather through
+    torch.distributed, see include/nanosnp.h.)"""
+    import torch
+    from nanosnp_amd import _lib
+    c = _lib.Context(0)
+    uid = _lib.Context.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    c.comm_init(uid, 0, 1)
+    x = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+    out = c.gather_bytes(x, [x.numel() * 4])
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.float32), x)
+    empty = torch.empty(0, dtype=torch.float32, device="cuda")
+    out0 = c.gather_bytes(empty, [0])
+    assert out0.numel() == 0
+    with pytest.raises(_lib.NanoSNPError):
+        c.comm_init(uid, 0, 1)                        # one communicator per context
+    with pytest.raises(_lib.NanoSNPError):
+        gpu_ctx.gather_bytes(x, [x.numel() * 4]) if hasattr(gpu_ctx, "_comm") else _lib.check(_lib.load().nsnp_gather_results(
+            gpu_ctx.handle, None, 0, None, None, 0, None), gpu_ctx.handle, "nsnp_gather_results")     # no communicator bound
+    c.close()

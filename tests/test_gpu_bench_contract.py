@@ -74,3 +74,12 @@ def test_two_ranks_through_the_launcher_on_one_gpu(workload):
         assert abs(d["value"] - 2 * d["config"]["sites_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6      # whole-job aggregate
     else:
         assert d["scaling"] == "strong" and d["config"]["stage2_sites"] == 30000 and d["config"]["stage5_sites"] == 3001
+
+
+def test_bench_with_the_library_gather_entry():
+    """--gather rccl-abi: the final merge through nsnp_comm_init + nsnp_gather_results (one rank here)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "65536", "--gather", "rccl-abi",
+                          "--no-cpu-baseline", "--no-second-precision"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["gather"] == "rccl-abi" and d["value"] > 1e6
