@@ -236,8 +236,15 @@ extern "C" int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites)
     ctx->chunk_sites = max_sites;
     const size_t n = (size_t)max_sites;
     NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, (n + 64) * PW * 128 * sizeof(float)));
-    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_xp1, 2 * n * PSTEPS1 * 256 * sizeof(float)));
+    // ws_xp1 (34.8 KB per site) only exists for the legacy unfused layer-1 path: nsnp_ctx_need_xp1 allocates it on first use
     NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h1c, (n + 64) * 128 * sizeof(float)));
+    return NSNP_OK;
+}
+
+int nsnp_ctx_need_xp1(nsnp_ctx* ctx)
+{
+    if (ctx->ws_xp1) return NSNP_OK;
+    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_xp1, 2 * (size_t)ctx->chunk_sites * PSTEPS1 * 256 * sizeof(float)));
     return NSNP_OK;
 }
 

@@ -124,6 +124,8 @@ struct ScopedKernelTimer {
 typedef float (*nsnp_wfun)(const void* user, int row, int k);
 void nsnp_pack_image(float* img, int n_tiles, int n_j4, nsnp_wfun f, const void* user);
 
+int nsnp_ctx_need_xp1(nsnp_ctx* ctx);   // legacy unfused layer-1 path only (synchronous allocation on first use)
+
 // kernels' launchers (pileup_forward.hip)
 int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
                              int64_t N, float* gt, float* zy, hipStream_t s);

@@ -1294,6 +1294,7 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
             else { constexpr bool ST = false; if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2); }
 #undef LAUNCH_R1
         } else {
+        { const int rx = nsnp_ctx_need_xp1(ctx); if (rx) return rx; }
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
         // persistent workgroups: each loads the 128 KB weight image once and then walks
         // proj1_tiles 16-row tiles per wave, so the load is amortised even at small batches

@@ -1210,6 +1210,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
             if (fw == 12) LAUNCH_F(12); else if (fw == 8) LAUNCH_F(8); else LAUNCH_F(4);
 #undef LAUNCH_F
         } else {
+        { const int rx = nsnp_ctx_need_xp1(ctx); if (rx) return rx; }
         const int64_t n_rt = NSNP_CDIV(n * PSTEPS1, 16);
         // persistent workgroups: each loads the 128 KB weight image once and then walks
         // proj1_tiles 16-row tiles per wave, so the load is amortised even at small batches
