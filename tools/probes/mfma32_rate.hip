@@ -1,11 +1,14 @@
 // Probe: how busy can v_mfma_f32_16x16x4_f32 keep a SIMD's matrix pipe in the shape of the fp32 recurrence kernels?  gfx950.
 // A workgroup = 4 waves (one per SIMD); WGS workgroups per CU share the SIMDs.  Per iteration ("step") a wave issues 84 MFMAs on 4
 // accumulators (operands in registers), optionally the LSTM cell of 4 hidden units (5 exp2 + 5 rcp + ~12 plain VALU each), an LDS
-// write + read of 16 B, and a workgroup barrier.  Reports cycles per step and wave (s_memtime) and matrix-pipe utilisation
-// = WGS x 84 x 32 / cycles per step.
+// write + read of 16 B, and a workgroup barrier.  Reports wall time per MFMA and SIMD (build with -DITERS=40000: the default 400 steps
+// make a 0.5-1.5 ms launch whose ramp is 10 % of it).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#ifndef ITERS
+#define ITERS 400
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sg(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695f * x)); }
 __device__ __forceinline__ float th(float x) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539f * x)), 1.0f); }
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 3) void k(float* out, unsigned long long* cyc,
 template <bool CELL, bool BAR, bool LDSX>
 void run(const char* name, int wgs_per_cu)
 {
-    const int iters = 400, grid = 256 * wgs_per_cu;
+    const int iters = ITERS, grid = 256 * wgs_per_cu;
     float* out; unsigned long long* cyc;
     hipMalloc(&out, grid * 256 * sizeof(float)); hipMalloc(&cyc, grid * 4 * sizeof(unsigned long long));
     hipLaunchKernelGGL((k<CELL, BAR, LDSX>), dim3(grid), dim3(256), 0, 0, out, cyc, 10); hipDeviceSynchronize();
@@ -78,8 +81,11 @@ void run(const char* name, int wgs_per_cu)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(grid * 4); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     double a = 0; for (auto v : h) a += (double)v; a /= h.size() * iters;
-    printf("%-46s %d WG/CU: %7.0f cycles per wave-step, matrix pipe %5.1f %% busy, kernel %.3f ms (clock ~%.2f GHz)\n", name, wgs_per_cu, a,
-           100.0 * wgs_per_cu * 84 * 32 / a, ms, a * iters / (ms * 1e-3) / 1e9);
+    // wall time is the honest figure: with several workgroups per CU the age-ordered arbiter lets waves finish at different times, so
+    // the mean per-wave s_memtime span understates the kernel's length
+    const double ns = ms * 1e6 / ((double)iters * 84 * wgs_per_cu);
+    printf("%-46s %d WG/CU: kernel %8.3f ms = %5.2f ns per MFMA and SIMD (13.5 = the pipe's pace at 2.37 GHz: %5.1f %%), mean wave span %7.0f cycles per step\n",
+           name, wgs_per_cu, ms, ns, 100.0 * 13.5 / ns, a);
     hipFree(out); hipFree(cyc);
 }
 int main()
