@@ -4,11 +4,10 @@
 //   TensorMaker::make_tensor        dna_sv_tensor/src/make_candidate_snp_tensor/tensor_maker.cpp:61-249
 //   candidate test / pending queue  dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:174-217
 //   33-column window emission       dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:233-244
-// The reference builds a std::map<string,int> per column; here one lane walks one column's bytes
-// (the +n<seq>/-n<seq>/^q grammar is inherently sequential inside a column), 64 columns per
-// wave, with the byte stream fetched 8 bytes at a time.  Distinct-allele maxima (channels
-// I1/D1/i1/d1) use a small per-lane table in LDS keyed by a hash and verified byte-for-byte, with
-// an exact quadratic rescan when a column has more distinct indel alleles than the table holds.
+// The reference builds a std::map<string,int> per column; here one lane owns one column, 64 columns per wave: every byte is counted
+// through a table, then the +n<seq> / -n<seq> / ^q constructs (whose grammar is sequential inside a column) are decoded one per
+// lane over the whole wave and their skipped bytes taken out again; distinct-allele maxima (channels I1/D1/i1/d1) come from comparing
+// every counted indel with the earlier ones of its column, byte-exact; columns the fast path cannot take are re-scanned exactly.
 // Integer outputs are bit-exact with the reference; the AF tests use the same float64 division.
 #include "nsnp_common.hpp"
 #include <math.h>
@@ -113,10 +112,10 @@ __device__ __forceinline__ Quad rescan_maxima(P base, int64_t begin, int64_t end
 // symbol counters of one column in the order of byte_class(): A C G T a c g t * #
 struct Counts10 { int32_t k0, k1, k2, k3, k4, k5, k6, k7, k8, k9; };
 
-// ---- slow exact path for one column straight from global memory (no size limits) ---------------------
-// Used for columns whose bytes do not fit the LDS stage of their wave.  O(k^2) in the number of indel reads k.
-__device__ __forceinline__ void scan_column_global(const uint8_t* __restrict__ bases, int64_t begin, int64_t end,
-                                                Counts10& cnt, Quad& tot, Quad& mx)
+// ---- exact path for one column, byte at a time (tensor_maker.cpp:83-114 in structure), from global memory (columns whose bytes do
+// not fit the LDS stage of their wave) or from the staged bytes (columns the fast path hands back).  O(k^2) in the indel reads k.
+template <typename P>
+__device__ __forceinline__ void scan_column_exact(P bases, int64_t begin, int64_t end, Counts10& cnt, Quad& tot, Quad& mx)
 {
     Counts10 c{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     Quad t{0, 0, 0, 0};
@@ -130,13 +129,13 @@ __device__ __forceinline__ void scan_column_global(const uint8_t* __restrict__ b
         } else if (cls == 11 || cls == 12) {
             ++i;
             long long adv = 0;
-            while (i < end && bases[i] >= '0' && bases[i] <= '9') { adv = adv * 10 + (bases[i] - '0'); ++i; }
+            while (i < end && bases[i] >= '0' && bases[i] <= '9') { adv = adv > 100000000 ? adv : adv * 10 + (bases[i] - '0'); ++i; }
             if (adv <= MAX_INDEL) {
                 const int64_t avail = end - i;
                 const int len = (int)(adv < avail ? adv : avail);
                 t.inc((b == '-' ? 2 : 0) + (len > 0 && is_fwd_char(bases[i]) ? 0 : 1));
             }
-            i += adv;
+            i = adv < end - i ? i + adv : end;
         } else if (cls == 13) i += 2;
         else ++i;
     }
@@ -170,20 +169,44 @@ static AfThreshold make_af_threshold(double a)
 }
 
 // ---- main kernel ----------------------------------------------------------------------------------------
-// A wave stages the bytes of its 64 columns (one contiguous range) into LDS with 16-byte loads, every lane
-// then walks its own column out of LDS four bytes per read.  Indels met on the way are only RECORDED
-// (offset, length, sign) in a per-lane list; the distinct-allele maxima are worked out afterwards from that
-// list, byte-exact, so the main scan stays short and the lanes of a wave diverge as little as the grammar
-// allows.
+// One lane per column, 64 columns per wave, their bytes (one contiguous range) staged into LDS with 16-byte loads.  The kernel is
+// bound by vector-instruction issue (MFMA-free, four waves per SIMD keep the vector pipe busy), so it is built around the
+// instruction count per column:
+//   pass 1   EVERY byte of the column is counted through a 16-byte table row (three words of 8-bit class counters and the flag
+//            of the construct openers + - ^), whole words at a time: 5 vector instructions per byte, no grammar state, no flushes
+//            (the fast path covers 192 bytes per column), the opener flags gathered in one bit mask per 32 bytes;
+//   openers  compacted over the wave (DPP prefix sum) and decoded ONE PER LANE whatever column they belong to: digits, the bytes
+//            they skip taken out of the column's counts again (LDS atomics on the same packed counters), the record of a counted
+//            indel; an opener inside the bytes an earlier construct consumes, a four-digit length, a column beyond the fast
+//            path: that column is re-scanned by the exact path;
+//   indels   every counted indel finds its multiplicity among the earlier ones of its column (length, sign and the first four
+//            allele bytes in one compare, longer alleles byte by byte); totals and maxima by kind reach the column through LDS
+//            atomics.
 constexpr int ENC_WAVES = ENC_BLOCK / 64;
 #ifndef NSNP_ENC_STAGE
-#define NSNP_ENC_STAGE 6144
+#define NSNP_ENC_STAGE 5120
 #endif
-#ifndef NSNP_ENC_KLIST
-#define NSNP_ENC_KLIST 12
+#ifndef NSNP_ENC_ECAP
+#define NSNP_ENC_ECAP 128
 #endif
 constexpr int STAGE_BYTES = NSNP_ENC_STAGE;          // per wave; 64 columns at 60x average ~4.4 KB
-constexpr int KLIST = NSNP_ENC_KLIST;                  // recorded indels per column before the slow path takes over
+constexpr int ENC_ECAP = NSNP_ENC_ECAP;              // opener entries of one segment of a wave's columns (more: further segments)
+constexpr int ENC_NBLK = 6;                          // 32-byte blocks of a column the fast path covers
+static_assert(STAGE_BYTES >= 64 * NCH * 4, "the stage buffer doubles as the 64 x 18 output transposition buffer");
+static_assert(STAGE_BYTES <= 8192, "staged positions are kept in 13 bits");
+
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (no LDS)
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
 
 __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
@@ -191,17 +214,26 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     uint8_t* __restrict__ flags)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
-    __shared__ uint32_t ilist[ENC_WAVES][KLIST][64];      // off (16) | len (8) | sign (8)
-    // byte -> 64-bit row: a one in the 6-bit field of its symbol class (A C G T a c g t * # = fields 0..9, bits 0..59), bit 63
-    // set for the three bytes that open a construct (+ - ^).  Every other byte maps to zero.
-    __shared__ uint2 ctab[256];
+    // one record per construct opener of the segment.  word 0: position | column << 16 (written by the column), then
+    // q | nskip << 13 | column << 20 | minus << 26 | counted << 27 | fwd << 28 (written by the lane that decoded it);
+    // word 1: the first four allele bytes, zero beyond the allele's length
+    __shared__ uint2 ents[ENC_WAVES][ENC_ECAP];
+    // per column: [0..2] skipped bytes by class (the table's three counter words), [3] indel reads by kind (8-bit fields),
+    // [4..7] largest multiplicity of one allele by kind
+    __shared__ __attribute__((aligned(16))) uint32_t colacc[ENC_WAVES][64][8];
+    __shared__ unsigned long long badmask[ENC_WAVES];
+    // byte -> x: A C G T, y: a c g t, z: * # (8-bit counters) | "ACGTN*" << 24, w: 1 for the construct openers + - ^
+    __shared__ uint4 tab[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const int cls = byte_class(tid);      // ENC_BLOCK == 256: one table row per thread
-        unsigned long long r = 0;
-        if (cls < 10) r = 1ull << (6 * cls);
-        else if (cls >= 11) r = 1ull << 63;
-        ctab[tid] = uint2{(uint32_t)r, (uint32_t)(r >> 32)};
+        uint4 r{0u, 0u, 0u, 0u};
+        if (cls < 4) r.x = 1u << (8 * cls);
+        else if (cls < 8) r.y = 1u << (8 * (cls - 4));
+        else if (cls < 10) r.z = 1u << (8 * (cls - 8));
+        else if (cls >= 11) r.w = 1u;
+        if (is_fwd_char(tid)) r.z |= 1u << 24;
+        tab[tid] = r;
     }
     __syncthreads();
     const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
@@ -209,7 +241,6 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const int64_t c = wave_col0 + lane;
     const bool live = c < M;
     const int n_live = (int)(M - wave_col0 < 64 ? M - wave_col0 : 64);
-    // one offset load per lane; a column's end is its right neighbour's begin (the last live lane takes the wave's end offset)
     const int64_t wave_end = col_off[wave_col0 + n_live];
     int64_t begin = live ? col_off[c] : wave_end;
     int64_t end = __shfl_down(begin, 1);
@@ -219,30 +250,29 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
 
     uint8_t* st = stage_b[wave];
     const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
-    int32_t cnt[10];                     // (every index below is a compile-time constant: registers, not scratch)
+    uint2* ent = ents[wave];
+    uint32_t* acc_mine = colacc[wave][lane];
+    int32_t cnt[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt[k] = 0;
     Quad tot{0, 0, 0, 0};                // I, i, D, d   (kind = (sign=='-')*2 + reverse)
     Quad mx{0, 0, 0, 0};
     bool slow = false;
 
-    // The wave's 64 columns are one contiguous byte range; it is staged into LDS in as few sub-batches of
-    // consecutive columns as the stage buffer allows (one at 30x, one or two at 60x).  A single column
-    // longer than the buffer takes the global-memory path.
     for (int first = 0; first < n_live;) {
         const int64_t b0 = __shfl(begin, first);
-        const uintptr_t a_first = (uintptr_t)(bases + b0) & ~(uintptr_t)15;      // 16-byte aligned global address
+        const uintptr_t a_first = (uintptr_t)(bases + b0) & ~(uintptr_t)15;
         const int mis = (int)((uintptr_t)(bases + b0) - a_first);
         const bool fits = live && lane >= first && (end - b0) + mis + 16 <= STAGE_BYTES;
-        const unsigned long long fm = __ballot(fits) >> first;                   // lanes first.. that fit, from bit 0
-        int n_fit = (~fm) ? __builtin_ctzll(~fm) : 64;                           // leading run of fitting columns
+        const unsigned long long fm = __ballot(fits) >> first;
+        int n_fit = (~fm) ? __builtin_ctzll(~fm) : 64;
         if (n_fit > n_live - first) n_fit = n_live - first;
-        if (n_fit == 0) {                                                        // column `first` alone exceeds the stage
+        if (n_fit == 0) {
             if (lane == first) slow = true;
             first += 1;
             continue;
         }
-        const int last = first + n_fit;                                          // sub-batch = lanes [first, last)
+        const int last = first + n_fit;
         const int64_t b1 = __shfl(end, last - 1);
         {
             const uintptr_t a_end = (uintptr_t)(bases + b1);
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
             for (uintptr_t a = a_first + (uintptr_t)lane * 16; a < a_end; a += 64 * 16) {
                 uint4 v;
                 if (a + 16 <= a_total && a >= (uintptr_t)bases) v = *reinterpret_cast<const uint4*>(a);
-                else {                                                           // buffer edge: byte loads
+                else {
                     uint32_t wv[4] = {0u, 0u, 0u, 0u};
                     for (int k = 0; k < 16; ++k) {
                         const uintptr_t q = a + k;
@@ -261,184 +291,204 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
                 *reinterpret_cast<uint4*>(st + (a - a_first)) = v;
             }
         }
+        *reinterpret_cast<uint4*>(acc_mine) = uint4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<uint4*>(acc_mine + 4) = uint4{0u, 0u, 0u, 0u};
+        if (lane == 0) badmask[wave] = 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         {
-            // every lane runs the passes (they hold wave-level operations); lanes outside the sub-batch have an empty range
             const bool act = lane >= first && lane < last;
-            // LDS byte index of global offset g: (g - b0) + mis.
             const int lbeg = act ? (int)(begin - b0) + mis : mis, lend = act ? (int)(end - b0) + mis : mis;
-            int n_list = 0;
-            // ---- pass 1: EVERY byte of the column is counted through the table, no grammar state at all; the positions of
-            // the construct openers (+ - ^) are collected in one bit mask per 60-byte chunk (15 words: a 6-bit field cannot
-            // overflow inside a chunk).  The uniform trip counts are the longest column of the sub-batch.
-            int len_here = lend - (lbeg & ~3);
-            int maxlen = len_here;
+            // ---- pass 1: every byte counted through the table; the opener flags land in one bit mask per 32-byte block ----
+            const int wb = lbeg & ~3;                                              // the column's first word
+            const int tr = act ? ((lend - 1 - wb) >> 2) : -1;                      // its last word (relative); -1: none
+            bool bad = tr >= 8 * ENC_NBLK;                                          // longer than the fast path covers: exact path
+            const int trp = bad ? -1 : tr;
+            const uint32_t hm = (1u << (8 * (lbeg & 3))) - 1u;                     // bytes of word 0 in front of the column
+            const int rem = lend - (wb + 4 * tr);                                  // bytes of the column in its last word, 1..4
+            const uint32_t tm = rem >= 4 ? 0u : 0xffffffffu << (8 * (rem & 3));
+            const uint32_t* cw = st32 + (wb >> 2);
+            uint32_t ax = 0, ay = 0, az = 0;
+            uint32_t sm[ENC_NBLK];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxlen, o); maxlen = v > maxlen ? v : maxlen; }
-            const int n_chunks = (maxlen + 59) / 60;                              // same in every lane of the sub-batch
-            unsigned long long sm0 = 0, sm1 = 0, sm2 = 0;                         // opener positions of chunks 0, 1, 2
-            bool bad = act && n_chunks > 3 && lend - (lbeg & ~3) > 180;           // longer than 180 bytes: exact path below
-            auto flush6 = [&](unsigned long long a) {
+            for (int b = 0; b < ENC_NBLK; ++b) sm[b] = 0u;
 #pragma unroll
-                for (int k = 0; k < 10; ++k) cnt[k] += (int)((a >> (6 * k)) & 63);
-            };
+            for (int b = 0; b < ENC_NBLK; ++b) {
+                if (__ballot(trp >= 8 * b) == 0ull) break;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int R = 8 * b + r;
+                    if (R <= trp) {
+                        uint32_t w = cw[R];
+                        if (R == 0) w |= hm;
+                        w |= (R == trp) ? tm : 0u;
+                        const uint4 r0 = tab[w & 0xffu], r1 = tab[(w >> 8) & 0xffu], r2 = tab[(w >> 16) & 0xffu], r3 = tab[w >> 24];
+                        ax += r0.x + r1.x; ax += r2.x + r3.x;
+                        ay += r0.y + r1.y; ay += r2.y + r3.y;
+                        az += r0.z + r1.z; az += r2.z + r3.z;
+                        sm[b] |= (r0.w << (4 * r)) | (r1.w << (4 * r + 1));
+                        sm[b] |= (r2.w << (4 * r + 2)) | (r3.w << (4 * r + 3));
+                    }
+                }
+            }
+            // ---- the openers of the sub-batch, compacted over the wave ----
+            int n_op = 0;
+#pragma unroll
+            for (int b = 0; b < ENC_NBLK; ++b) n_op += __builtin_popcount(sm[b]);
+            if (n_op > ENC_ECAP) { bad = true; n_op = 0; }
+            const int incl = wave_scan_incl(n_op);
+            const int excl = incl - n_op;
+            const int total_ops = __builtin_amdgcn_readlane(incl, 63);
+            for (int sfirst = first; total_ops > 0 && sfirst < last;) {
+                // segment = the longest run of columns from sfirst whose openers fit the entry list
+                const int sbase = __shfl(excl, sfirst);
+                const bool sfit = act && lane >= sfirst && incl - sbase <= ENC_ECAP;
+                const unsigned long long sfm = __ballot(sfit) >> sfirst;
+                int n_seg = (~sfm) ? __builtin_ctzll(~sfm) : 64;
+                if (n_seg > last - sfirst) n_seg = last - sfirst;
+                const int slast = sfirst + n_seg;                                  // n_seg >= 1: every column holds <= ECAP openers
+                const int T = __shfl(incl, slast - 1) - sbase;
+                const bool sact = lane >= sfirst && lane < slast;
+                // P2a: every column writes the positions of its openers, in order
+                {
+                    int j = excl - sbase;
+                    const uint32_t tag = (uint32_t)wb | ((uint32_t)lane << 16);
+#pragma unroll
+                    for (int b = 0; b < ENC_NBLK; ++b) {
+                        uint32_t cur = sact ? sm[b] : 0u;
+                        while (__ballot(cur != 0u) != 0ull) {
+                            if (cur != 0u) {
+                                ent[j].x = tag + (uint32_t)(32 * b + __builtin_ctz(cur));
+                                cur &= cur - 1u; ++j;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // P2b: one opener per lane: digits, skipped bytes out of the counts again, the record of a counted indel
+                int carry_end = 0, carry_owner = -1;
+                for (int r0i = 0; r0i < T; r0i += 64) {
+                    const int j = r0i + lane;
+                    const bool valid = j < T;
+                    const uint32_t e0 = valid ? ent[j].x : 0u;
+                    const int p = e0 & 0xffff, owner = valid ? (int)(e0 >> 16) : 64 + lane;
+                    const int lend_o = __shfl(lend, owner & 63);
+                    int endpos = 0;
+                    if (valid) {
+                        const int b = st[p];
+                        const int w0 = (p + 1) >> 2;
+                        const uint32_t a0 = st32[w0], a1 = st32[w0 + 1], a2 = st32[w0 + 2];
+                        const int sh = (p + 1) & 3;
+                        const uint32_t wlo = __builtin_amdgcn_alignbyte(a1, a0, sh), whi = __builtin_amdgcn_alignbyte(a2, a1, sh);   // byte i = st[p + 1 + i]
+                        const int avail1 = lend_o - (p + 1);
+                        const bool caret = b == '^';
+                        const uint32_t d0 = (wlo & 0xffu) - '0', d1 = ((wlo >> 8) & 0xffu) - '0', d2 = ((wlo >> 16) & 0xffu) - '0', d3 = (wlo >> 24) - '0';
+                        const bool k0 = !caret && avail1 > 0 && d0 < 10u, k1 = k0 && avail1 > 1 && d1 < 10u, k2 = k1 && avail1 > 2 && d2 < 10u;
+                        const bool mybad = k2 && avail1 > 3 && d3 < 10u;                              // four digits and more: exact path
+                        const int L = k2 ? 3 : (k1 ? 2 : (k0 ? 1 : 0));
+                        const int adv = caret ? 1 : (k2 ? (int)(d0 * 100 + d1 * 10 + d2) : (k1 ? (int)(d0 * 10 + d1) : (k0 ? (int)d0 : 0)));
+                        const int q = p + 1 + L;
+                        const int avail = lend_o - q;
+                        const int nskip = adv < avail ? adv : (avail > 0 ? avail : 0);
+                        endpos = q + adv;
+                        const uint32_t al = __builtin_amdgcn_alignbyte(whi, wlo, L);                  // the first four skipped bytes
+                        const uint32_t keep = nskip >= 4 ? 0xffffffffu : ((1u << (8 * (nskip & 3))) - 1u);
+                        const uint32_t alm = al | ~keep;                                              // bytes beyond the allele: 0xff (a zero row)
+                        const uint4 r0 = tab[alm & 0xffu], r1 = tab[(alm >> 8) & 0xffu], r2 = tab[(alm >> 16) & 0xffu], r3 = tab[alm >> 24];
+                        uint32_t nx = r0.x + r1.x, ny = r0.y + r1.y, nz = r0.z + r1.z;
+                        nx += r2.x + r3.x; ny += r2.y + r3.y; nz += r2.z + r3.z;
+                        for (int k = q + 4; k < q + nskip; ++k) {                                     // longer alleles (rare)
+                            const uint4 rr = tab[st[k]];
+                            nx += rr.x; ny += rr.y; nz += rr.z;
+                        }
+                        const bool counted = !caret && adv <= MAX_INDEL;
+                        const uint32_t fwd = (r0.z >> 24) & 1u;                                       // first allele byte in "ACGTN*" (0 without allele)
+                        ent[j] = uint2{(uint32_t)q | ((uint32_t)(nskip > 127 ? 127 : nskip) << 13) | ((uint32_t)owner << 20) | ((uint32_t)(b == '-') << 26) |
+                                           ((uint32_t)counted << 27) | (fwd << 28),
+                                       al & keep};
+                        uint32_t* oa = colacc[wave][owner];
+                        atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
+                        if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
+                        if (mybad) atomicOr(&badmask[wave], 1ull << owner);
+                    }
+                    // an opener inside the bytes an earlier construct of its column consumes is not an opener: exact path
+                    int pe = __shfl_up(endpos, 1), po = __shfl_up(owner, 1);
+                    if (lane == 0) { pe = carry_end; po = carry_owner; }
+                    if (valid && po == owner && p < pe) atomicOr(&badmask[wave], 1ull << owner);
+                    carry_end = __shfl(endpos, 63); carry_owner = __shfl(owner, 63);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // P3: multiplicity of every counted indel among the earlier ones of its column, m(e) = #{f <= e equal to e};
+                // the column's totals and maxima by kind through LDS atomics
+                for (int r0i = 0; r0i < T; r0i += 64) {
+                    const int j = r0i + lane;
+                    const uint2 me = j < T ? ent[j] : uint2{0u, 0u};
+                    const bool counted = (me.x >> 27) & 1u;
+                    const uint32_t own_bits = me.x & (63u << 20);
+                    const uint32_t cmp_mask = (127u << 13) | (1u << 26) | (63u << 20) | (1u << 27);   // length, sign, column, counted
+                    const int le = (me.x >> 13) & 127, qe = me.x & 0x1fff;
+                    int same = 1;
+                    int f = j - 1;
+                    bool go = counted && f >= 0;
+                    while (__ballot(go) != 0ull) {
+                        if (go) {
+                            const uint2 o = ent[f];
+                            if ((o.x & (63u << 20)) != own_bits) go = false;
+                            else {
+                                if (((o.x ^ me.x) & cmp_mask) == 0u && o.y == me.y) {
+                                    bool eq = true;
+                                    const int qf = o.x & 0x1fff;
+                                    for (int k = 4; k < le; ++k) if (st[qe + k] != st[qf + k]) { eq = false; break; }
+                                    same += eq;
+                                }
+                                --f;
+                                if (f < 0) go = false;
+                            }
+                        }
+                    }
+                    if (counted) {
+                        const int kind = (int)((me.x >> 26) & 1u) * 2 + (int)(((me.x >> 28) & 1u) ^ 1u);
+                        uint32_t* oa = colacc[wave][(me.x >> 20) & 63u];
+                        atomicAdd(oa + 3, 1u << (8 * kind));
+                        atomicMax(oa + 4 + kind, (uint32_t)same);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                sfirst = slast;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             {
-                const int n_ch = n_chunks > 3 ? 3 : n_chunks;                     // (lanes longer than that are `bad` already)
-                for (int ch = 0; ch < n_ch; ++ch) {
-                    const int cb = (lbeg & ~3) + 60 * ch;
-                    int nw = (maxlen - 60 * ch + 3) >> 2; nw = nw > 15 ? 15 : nw;
-                    if (bad) nw = 0;                                              // (per lane: its counts are redone below)
-                    unsigned long long acc = 0, sm = 0;
-                    for (int wi = 0; wi < nw; ++wi) {
-                        const int p0 = cb + 4 * wi;
-                        uint32_t w = st32[(p0 < STAGE_BYTES - 4 ? p0 : STAGE_BYTES - 4) >> 2];
-                        // bytes outside [lbeg, lend) become 0xff (an all-zero row)
-                        const int lo = lbeg - p0, hi = lend - p0;
-                        const uint32_t mlo = lo <= 0 ? 0xffffffffu : (lo >= 4 ? 0u : 0xffffffffu << (8 * lo));
-                        const uint32_t mhi = hi >= 4 ? 0xffffffffu : (hi <= 0 ? 0u : ~(0xffffffffu << (8 * hi)));
-                        w |= ~(mlo & mhi);
-                        uint32_t s4 = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const uint2 row = ctab[(w >> (8 * k)) & 0xffu];
-                            acc += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
-                            s4 |= (row.y >> 31) << k;
-                        }
-                        sm |= (unsigned long long)s4 << (4 * wi);
-                    }
-                    flush6(acc);
-                    if (ch == 0) sm0 = sm; else if (ch == 1) sm1 = sm; else sm2 = sm;
+                const uint4 a0 = *reinterpret_cast<const uint4*>(acc_mine), a1 = *reinterpret_cast<const uint4*>(acc_mine + 4);
+                ax -= a0.x; ay -= a0.y; az -= a0.z;
+                if (act) {
+                    cnt[0] = ax & 0xff; cnt[1] = (ax >> 8) & 0xff; cnt[2] = (ax >> 16) & 0xff; cnt[3] = ax >> 24;
+                    cnt[4] = ay & 0xff; cnt[5] = (ay >> 8) & 0xff; cnt[6] = (ay >> 16) & 0xff; cnt[7] = ay >> 24;
+                    cnt[8] = az & 0xff; cnt[9] = (az >> 8) & 0xff;
+                    tot = Quad{(int)(a0.w & 0xff), (int)((a0.w >> 8) & 0xff), (int)((a0.w >> 16) & 0xff), (int)(a0.w >> 24)};
+                    mx = Quad{(int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
                 }
-                // ---- pass 2: the openers, in order.  An opener that lies inside the bytes an earlier construct consumes is not an
-                // opener at all (and what it would have skipped is): such a column is re-scanned exactly below.  For the others the
-                // bytes they skip (the byte after ^, the allele behind +n / -n) are taken out of the counts again.
-                unsigned long long cur = sm0, neg = 0;
-                int cbase = lbeg & ~3, ci = 0, consumed = lbeg, nneg = 0;
-                while (true) {
-                    if (cur == 0 && ci < 2) { cur = ci == 0 ? sm1 : sm2; ++ci; cbase += 60; }
-                    const bool have = (cur | (ci == 0 ? (sm1 | sm2) : (ci == 1 ? sm2 : 0ull))) != 0 && !bad;
-                    if (__ballot(have) == 0ull) break;
-                    if (have && cur != 0) {
-                        const int p = cbase + __builtin_ctzll(cur);
-                        cur &= cur - 1;
-                        if (p < consumed) bad = true;
-                        else {
-                            // the opener and the eight bytes behind it from three aligned words (no byte loops: digits and the first
-                            // four skipped bytes are taken out of this window, which covers every 1- to 3-digit indel of up to 5 bases)
-                            const int b = st[p];
-                            const int w0 = (p + 1) >> 2;
-                            const uint32_t a0 = st32[w0], a1 = st32[w0 + 1], a2 = st32[w0 + 2];
-                            const int sh = (p + 1) & 3;
-                            const uint32_t wlo = __builtin_amdgcn_alignbyte(a1, a0, sh), whi = __builtin_amdgcn_alignbyte(a2, a1, sh);
-                            const unsigned long long win = ((unsigned long long)whi << 32) | wlo;         // byte i = st[p + 1 + i]
-                            const int avail1 = lend - (p + 1);                                              // bytes of the column behind the opener
-                            const bool caret = b == '^';
-                            const uint32_t d0 = (wlo & 0xffu) - '0', d1 = ((wlo >> 8) & 0xffu) - '0', d2 = ((wlo >> 16) & 0xffu) - '0', d3 = (wlo >> 24) - '0';
-                            const bool k0 = !caret && avail1 > 0 && d0 < 10u, k1 = k0 && avail1 > 1 && d1 < 10u, k2 = k1 && avail1 > 2 && d2 < 10u;
-                            if (k2 && avail1 > 3 && d3 < 10u) bad = true;                                   // four digits and more: exact path
-                            const int L = k2 ? 3 : (k1 ? 2 : (k0 ? 1 : 0));
-                            const int adv = caret ? 1 : (k2 ? (int)(d0 * 100 + d1 * 10 + d2) : (k1 ? (int)(d0 * 10 + d1) : (k0 ? (int)d0 : 0)));
-                            const int q = p + 1 + L;
-                            const int avail = lend - q;
-                            const int nskip = adv < avail ? adv : (avail > 0 ? avail : 0);
-                            if (!caret && adv <= MAX_INDEL) {
-                                if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)q | ((uint32_t)nskip << 16) | ((uint32_t)b << 24);
-                                ++n_list;
-                            }
-                            consumed = q + adv;
-                            // skipped bytes were counted in pass 1: the first four out of the window ...
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (i < nskip) {
-                                    const uint2 row = ctab[(uint32_t)(win >> (8 * (L + i))) & 0xffu];
-                                    neg += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
-                                }
-                            }
-                            nneg += nskip < 4 ? nskip : 4;
-                            // ... longer alleles byte by byte (rare; only the lanes that have one)
-                            for (int k = q + 4; k < q + nskip; ++k) {
-                                const uint2 row = ctab[st[k]];
-                                neg += ((unsigned long long)(row.y & 0x7fffffffu) << 32) | row.x;
-                                if (++nneg >= 59) {
-#pragma unroll
-                                    for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
-                                    neg = 0; nneg = 0;
-                                }
-                            }
-                            if (nneg >= 59) {
-#pragma unroll
-                                for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
-                                neg = 0; nneg = 0;
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int f = 0; f < 10; ++f) cnt[f] -= (int)((neg >> (6 * f)) & 63);
+                bad = bad || (act && ((badmask[wave] >> lane) & 1ull));
             }
             if (bad) {
-                // exact byte-at-a-time scan of this column out of LDS (tensor_maker.cpp:83-114 verbatim in structure): openers inside
-                // skipped bytes, columns beyond 180 bytes.  Divergent, but only the lanes that need it run it.
-#pragma unroll
-                for (int k = 0; k < 10; ++k) cnt[k] = 0;
-                n_list = 0;
-                for (int i = lbeg; i < lend;) {
-                    const int b = st[i];
-                    const int cls = byte_class(b);
-                    if (cls < 10) {
-#pragma unroll
-                        for (int k = 0; k < 10; ++k) cnt[k] += cls == k;
-                        ++i;
-                    } else if (cls == 11 || cls == 12) {
-                        ++i;
-                        int adv = 0;
-                        while (i < lend && st[i] >= '0' && st[i] <= '9') { adv = adv > 100000 ? adv : adv * 10 + (st[i] - '0'); ++i; }
-                        if (adv <= MAX_INDEL) {
-                            const int avail = lend - i;
-                            const int len = adv < avail ? adv : avail;
-                            if (n_list < KLIST) ilist[wave][n_list][lane] = (uint32_t)i | ((uint32_t)len << 16) | ((uint32_t)b << 24);
-                            ++n_list;
-                        }
-                        i = adv < lend - i ? i + adv : lend;
-                    } else if (cls == 13) i += 2;
-                    else ++i;
-                }
-            }
-            // distinct-allele maxima from the recorded list: m(e) = #{f <= e equal to e}
-            const int n_rec = n_list < KLIST ? n_list : KLIST;
-            for (int e = 0; e < n_rec; ++e) {
-                const uint32_t ve = ilist[wave][e][lane];
-                const int oe = ve & 0xffff, le = (ve >> 16) & 0xff, se = ve >> 24;
-                const int kind = (se == '-' ? 2 : 0) + (le > 0 && is_fwd_char(st[oe]) ? 0 : 1);
-                tot.inc(kind);
-                int same = 1;
-                for (int f = 0; f < e; ++f) {
-                    const uint32_t vf = ilist[wave][f][lane];
-                    if ((vf >> 16) != (ve >> 16)) continue;               // length and sign
-                    const int of = vf & 0xffff;
-                    bool eq = true;
-                    for (int k = 0; k < le; ++k) if (st[oe + k] != st[of + k]) { eq = false; break; }
-                    same += eq;
-                }
-                mx.raise(kind, same);
-            }
-            if (n_list > KLIST) {
-                // more indel reads than the list holds: totals and maxima again, exactly, from the staged bytes
-                tot = Quad{0, 0, 0, 0};
-                IndelIterT<const uint8_t*> it{st, lbeg, lend};
-                int64_t io; int il, is;
-                while (it.next(io, il, is)) tot.inc((is == '-' ? 2 : 0) + (il > 0 && is_fwd_char(st[io]) ? 0 : 1));
-                mx = rescan_maxima((const uint8_t*)st, (int64_t)lbeg, (int64_t)lend);
+                // exact byte-at-a-time scan of this column out of LDS (tensor_maker.cpp:83-114 in structure): openers inside skipped
+                // bytes, four-digit lengths, columns beyond the fast path's length or with more openers than the entry list holds
+                Counts10 c2; Quad t2, m2;
+                scan_column_exact((const uint8_t*)st, (int64_t)lbeg, (int64_t)lend, c2, t2, m2);
+                cnt[0] = c2.k0; cnt[1] = c2.k1; cnt[2] = c2.k2; cnt[3] = c2.k3; cnt[4] = c2.k4;
+                cnt[5] = c2.k5; cnt[6] = c2.k6; cnt[7] = c2.k7; cnt[8] = c2.k8; cnt[9] = c2.k9;
+                tot = t2; mx = m2;
             }
         }
         __builtin_amdgcn_wave_barrier();            // the stage buffer is reused by the next sub-batch
         first = last;
     }
-    if (slow) {          // results come back in plain structs: no array of this kernel ever has its address taken
+    if (slow) {
         Counts10 c2; Quad t2, m2;
-        scan_column_global(bases, begin, end, c2, t2, m2);
+        scan_column_exact(bases, begin, end, c2, t2, m2);
         cnt[0] = c2.k0; cnt[1] = c2.k1; cnt[2] = c2.k2; cnt[3] = c2.k3; cnt[4] = c2.k4;
         cnt[5] = c2.k5; cnt[6] = c2.k6; cnt[7] = c2.k7; cnt[8] = c2.k8; cnt[9] = c2.k9;
         tot = t2; mx = m2;
@@ -456,20 +506,18 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const int depth = up + lo + cnt[8] + cnt[9];
     const int refraw = live ? ref[c] : 'A';
     const int rb = nt4(refraw);
-    const int chr_idx = rb < 4 ? rb : 0;                      // non-ACGT reference counts as 'A'
-    // allele list in std::map order A C D G I T; the first maximum is what a stable sort puts first
+    const int chr_idx = rb < 4 ? rb : 0;
     const int lc[6] = {cnt[0] + cnt[4], cnt[1] + cnt[5], tot.v2 + tot.v3, cnt[2] + cnt[6], tot.v0 + tot.v1, cnt[3] + cnt[7]};
-    const int lk[6] = {0, 1, 5, 2, 4, 3};                     // 0..3 = base index, 4 = I, 5 = D
+    const int lk[6] = {0, 1, 5, 2, 4, 3};
     int top = -1, topc = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) if (lc[k] > topc) { topc = lc[k]; top = lk[k]; }
     const uint32_t den = (uint32_t)(depth ? depth : 1);
-    const unsigned __int128 rhs = (unsigned __int128)af.t * den;                 // T x depth, < 2^87
+    const unsigned __int128 rhs = (unsigned __int128)af.t * den;
     bool pass_snp = false, pass_indel = false;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         if (lc[k] <= 0 || lk[k] == chr_idx) continue;
-        // ((double)count / depth) >= min_af, decided exactly in integers (AfThreshold below)
         const bool ok = af.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << af.k) >= rhs) : af.mode == 1;
         if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
     }
@@ -478,16 +526,15 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (k == chr_idx) { t[up_ch[k]] = -up; t[lo_ch[k]] = -lo; }
 
-    // ---- coalesced write-out through the (now free) stage buffer ---------------------------------
     __builtin_amdgcn_wave_barrier();
-    int32_t* out_stage = reinterpret_cast<int32_t*>(st);         // 64 * 18 * 4 = 4608 B <= STAGE_BYTES
+    int32_t* out_stage = reinterpret_cast<int32_t*>(st);
 #pragma unroll
     for (int k = 0; k < NCH; k += 2) *reinterpret_cast<int2*>(out_stage + lane * NCH + k) = int2{t[k], t[k + 1]};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int n_valid = n_live * NCH;
     int32_t* __restrict__ dst = counts + wave_col0 * NCH;
-    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {          // a wave's 4608 output bytes as 16-byte stores (4.5 per lane)
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
         const int n16 = n_valid >> 2;
         for (int k = lane; k < n16; k += 64) reinterpret_cast<int4*>(dst)[k] = reinterpret_cast<const int4*>(out_stage)[k];
         for (int k = (n16 << 2) + lane; k < n_valid; k += 64) dst[k] = out_stage[k];
@@ -504,6 +551,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
         flags[c] = f;
     }
 }
+
 
 // ---- site selection: candidate && 33 consecutive positions around it -------------------------------
 __device__ __forceinline__ bool site_ok(const int64_t* pos, const uint8_t* flags, int64_t M, int64_t c)
