@@ -208,7 +208,7 @@ __device__ __forceinline__ int wave_scan_incl(int v)
     return x;
 }
 
-__global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
+__global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
     int64_t M, AfThreshold af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
     uint8_t* __restrict__ flags)
@@ -241,12 +241,26 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const int64_t c = wave_col0 + lane;
     const bool live = c < M;
     const int n_live = (int)(M - wave_col0 < 64 ? M - wave_col0 : 64);
-    const int64_t wave_end = col_off[wave_col0 + n_live];
-    int64_t begin = live ? col_off[c] : wave_end;
-    int64_t end = __shfl_down(begin, 1);
-    if (lane == n_live - 1) end = wave_end;
-    if (!live) { begin = 0; end = 0; }
+    const int64_t* __restrict__ woff = col_off + wave_col0;       // (uniform: scalar base + lane offset addressing)
+    // three independent loads, issued back to back (lanes past the last column read the wave's end offset / its last reference byte)
+    const int64_t wave_end = woff[n_live];
+    const int64_t begin64 = woff[lane < n_live ? lane : n_live];
+    const int refraw = (ref + wave_col0)[lane < n_live ? lane : n_live - 1];      // (used at the very end; in flight meanwhile)
     const int64_t total = col_off[M];
+    // everything below works on 32-bit offsets relative to the wave's first byte; a wave whose columns span 1 GB or more has
+    // them saturate, which sends the affected columns to the global-memory path (begin64 / end64 again)
+    const int64_t wave_b0 = __builtin_amdgcn_readfirstlane((int)(begin64 & 0xffffffff)) |
+                            ((int64_t)__builtin_amdgcn_readfirstlane((int)(begin64 >> 32)) << 32);
+    constexpr int REL_SAT = 1 << 30;
+    const int64_t rb64 = begin64 - wave_b0;
+    int rbeg = (int)(rb64 < REL_SAT ? rb64 : REL_SAT);
+    int rend = __shfl_down(rbeg, 1);
+    {
+        const int64_t re64 = wave_end - wave_b0;
+        if (lane == n_live - 1) rend = (int)(re64 < REL_SAT ? re64 : REL_SAT);
+    }
+    if (!live) { rbeg = 0; rend = 0; }
+    const uint8_t* __restrict__ wbase = bases + wave_b0;          // uniform
 
     uint8_t* st = stage_b[wave];
     const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
@@ -260,10 +274,10 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     bool slow = false;
 
     for (int first = 0; first < n_live;) {
-        const int64_t b0 = __shfl(begin, first);
-        const uintptr_t a_first = (uintptr_t)(bases + b0) & ~(uintptr_t)15;
-        const int mis = (int)((uintptr_t)(bases + b0) - a_first);
-        const bool fits = live && lane >= first && (end - b0) + mis + 16 <= STAGE_BYTES;
+        const int b0 = __builtin_amdgcn_readlane(rbeg, first);                    // uniform
+        const int mis = (int)((uintptr_t)(wbase + b0) & 15);
+        const uint8_t* __restrict__ src = wbase + (b0 - mis);                     // 16-byte aligned, uniform
+        const bool fits = live && lane >= first && b0 < REL_SAT && rend <= (STAGE_BYTES - 16 - mis) + b0 && rend >= b0;
         const unsigned long long fm = __ballot(fits) >> first;
         int n_fit = (~fm) ? __builtin_ctzll(~fm) : 64;
         if (n_fit > n_live - first) n_fit = n_live - first;
@@ -273,22 +287,28 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
             continue;
         }
         const int last = first + n_fit;
-        const int64_t b1 = __shfl(end, last - 1);
+        const int span = __builtin_amdgcn_readlane(rend, last - 1) - b0 + mis;    // bytes to stage from src, uniform
         {
-            const uintptr_t a_end = (uintptr_t)(bases + b1);
-            const uintptr_t a_total = (uintptr_t)(bases + total);
-            for (uintptr_t a = a_first + (uintptr_t)lane * 16; a < a_end; a += 64 * 16) {
-                uint4 v;
-                if (a + 16 <= a_total && a >= (uintptr_t)bases) v = *reinterpret_cast<const uint4*>(a);
-                else {
+            // 16-byte pieces; the ones that stick out of the buffer (only ever the first and last pieces of the whole input) byte-wise
+            const bool inside = (uintptr_t)src >= (uintptr_t)bases && (uintptr_t)src + (((uintptr_t)span + 15) & ~(uintptr_t)15) <= (uintptr_t)(bases + total);
+            if (inside) {
+                // all of a lane's pieces in flight together (one memory round trip per sub-batch, not one per kilobyte)
+                constexpr int NP = (STAGE_BYTES + 1023) / 1024;
+                const int o_last = ((span - 1) >> 4) << 4;                         // the last piece (span >= 1: a fitting column ends here)
+                uint4 pc[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) { const int o = (lane + 64 * i) * 16; pc[i] = *reinterpret_cast<const uint4*>(src + (o < span ? o : o_last)); }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) { const int o = (lane + 64 * i) * 16; if (o < span) *reinterpret_cast<uint4*>(st + o) = pc[i]; }
+            } else {
+                for (int o = lane * 16; o < span; o += 64 * 16) {
                     uint32_t wv[4] = {0u, 0u, 0u, 0u};
                     for (int k = 0; k < 16; ++k) {
-                        const uintptr_t q = a + k;
-                        if (q >= (uintptr_t)bases && q < a_total) wv[k >> 2] |= (uint32_t)(*reinterpret_cast<const uint8_t*>(q)) << (8 * (k & 3));
+                        const uint8_t* q = src + o + k;
+                        if (q >= bases && q < bases + total) wv[k >> 2] |= (uint32_t)(*q) << (8 * (k & 3));
                     }
-                    v = uint4{wv[0], wv[1], wv[2], wv[3]};
+                    *reinterpret_cast<uint4*>(st + o) = uint4{wv[0], wv[1], wv[2], wv[3]};
                 }
-                *reinterpret_cast<uint4*>(st + (a - a_first)) = v;
             }
         }
         *reinterpret_cast<uint4*>(acc_mine) = uint4{0u, 0u, 0u, 0u};
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
 
         {
             const bool act = lane >= first && lane < last;
-            const int lbeg = act ? (int)(begin - b0) + mis : mis, lend = act ? (int)(end - b0) + mis : mis;
+            const int lbeg = act ? rbeg - b0 + mis : mis, lend = act ? rend - b0 + mis : mis;
             // ---- pass 1: every byte counted through the table; the opener flags land in one bit mask per 32-byte block ----
             const int wb = lbeg & ~3;                                              // the column's first word
             const int tr = act ? ((lend - 1 - wb) >> 2) : -1;                      // its last word (relative); -1: none
@@ -316,21 +336,27 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
 #pragma unroll
             for (int b = 0; b < ENC_NBLK; ++b) {
                 if (__ballot(trp >= 8 * b) == 0ull) break;
+                uint32_t smb = 0u;
+                // a rolled loop of two words per trip (unrolled, the scheduler hoists every load of the block and the kernel needs 450
+                // registers); straight-line inside: words behind the column's last one become 0xffffffff (four zero rows)
+#pragma nounroll
+                for (int r = 0; r < 8; r += 2) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int R = 8 * b + r;
-                    if (R <= trp) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int R = 8 * b + r + h;
                         uint32_t w = cw[R];
-                        if (R == 0) w |= hm;
-                        w |= (R == trp) ? tm : 0u;
+                        w |= (R == 0) ? hm : 0u;
+                        w |= R < trp ? 0u : (R == trp ? tm : 0xffffffffu);
                         const uint4 r0 = tab[w & 0xffu], r1 = tab[(w >> 8) & 0xffu], r2 = tab[(w >> 16) & 0xffu], r3 = tab[w >> 24];
                         ax += r0.x + r1.x; ax += r2.x + r3.x;
                         ay += r0.y + r1.y; ay += r2.y + r3.y;
                         az += r0.z + r1.z; az += r2.z + r3.z;
-                        sm[b] |= (r0.w << (4 * r)) | (r1.w << (4 * r + 1));
-                        sm[b] |= (r2.w << (4 * r + 2)) | (r3.w << (4 * r + 3));
+                        const uint32_t f4 = (((r3.w << 1) | r2.w) << 2) | ((r1.w << 1) | r0.w);
+                        smb |= f4 << (4 * (r + h));
                     }
+                    if (__ballot(trp > 8 * b + r + 1) == 0ull) break;
                 }
+                sm[b] = smb;
             }
             // ---- the openers of the sub-batch, compacted over the wave ----
             int n_op = 0;
@@ -488,7 +514,7 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     }
     if (slow) {
         Counts10 c2; Quad t2, m2;
-        scan_column_exact(bases, begin, end, c2, t2, m2);
+        scan_column_exact(bases, begin64, lane == n_live - 1 ? wave_end : woff[lane + 1], c2, t2, m2);
         cnt[0] = c2.k0; cnt[1] = c2.k1; cnt[2] = c2.k2; cnt[3] = c2.k3; cnt[4] = c2.k4;
         cnt[5] = c2.k5; cnt[6] = c2.k6; cnt[7] = c2.k7; cnt[8] = c2.k8; cnt[9] = c2.k9;
         tot = t2; mx = m2;
@@ -504,7 +530,6 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
     const int up = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     const int lo = cnt[4] + cnt[5] + cnt[6] + cnt[7];
     const int depth = up + lo + cnt[8] + cnt[9];
-    const int refraw = live ? ref[c] : 'A';
     const int rb = nt4(refraw);
     const int chr_idx = rb < 4 ? rb : 0;
     const int lc[6] = {cnt[0] + cnt[4], cnt[1] + cnt[5], tot.v2 + tot.v3, cnt[2] + cnt[6], tot.v0 + tot.v1, cnt[3] + cnt[7]};
@@ -542,13 +567,13 @@ __global__ __launch_bounds__(ENC_BLOCK) void k_encode_columns(
         for (int k = lane; k < n_valid; k += 64) dst[k] = out_stage[k];
     }
     if (live) {
-        depth_out[c] = depth;
+        (depth_out + wave_col0)[lane] = depth;
         uint8_t f = 0;
         if (pass_af) f |= NSNP_FLAG_PASS_AF;
         if (pass_snp) f |= NSNP_FLAG_PASS_SNP;
         if (pass_indel) f |= NSNP_FLAG_PASS_INDEL;
         if (rb < 4 && pass_af && depth >= min_cov) f |= NSNP_FLAG_CANDIDATE;
-        flags[c] = f;
+        (flags + wave_col0)[lane] = f;
     }
 }
 
