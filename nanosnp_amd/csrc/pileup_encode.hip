@@ -174,7 +174,7 @@ static AfThreshold make_af_threshold(double a)
 // instruction count per column:
 //   pass 1   EVERY byte of the column is counted through a 16-byte table row (three words of 8-bit class counters and the flag
 //            of the construct openers + - ^), whole words at a time: 5 vector instructions per byte, no grammar state, no flushes
-//            (the fast path covers 192 bytes per column), the opener flags gathered in one bit mask per 32 bytes;
+//            (the fast path covers columns of up to 253 bytes), the opener flags gathered in one bit mask per 32 bytes;
 //   openers  compacted over the wave (DPP prefix sum) and decoded ONE PER LANE whatever column they belong to: digits, the bytes
 //            they skip taken out of the column's counts again (LDS atomics on the same packed counters), the record of a counted
 //            indel; an opener inside the bytes an earlier construct consumes, a four-digit length, a column beyond the fast
@@ -191,7 +191,7 @@ constexpr int ENC_WAVES = ENC_BLOCK / 64;
 #endif
 constexpr int STAGE_BYTES = NSNP_ENC_STAGE;          // per wave; 64 columns at 60x average ~4.4 KB
 constexpr int ENC_ECAP = NSNP_ENC_ECAP;              // opener entries of one segment of a wave's columns (more: further segments)
-constexpr int ENC_NBLK = 6;                          // 32-byte blocks of a column the fast path covers
+constexpr int ENC_NBLK = 8;                          // 32-byte blocks of a column the fast path covers (8-bit counters: at most 253 bytes)
 static_assert(STAGE_BYTES >= 64 * NCH * 4, "the stage buffer doubles as the 64 x 18 output transposition buffer");
 static_assert(STAGE_BYTES <= 8192, "staged positions are kept in 13 bits");
 
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
                     const uint32_t tag = (uint32_t)wb | ((uint32_t)lane << 16);
 #pragma unroll
                     for (int b = 0; b < ENC_NBLK; ++b) {
-                        uint32_t cur = sact ? sm[b] : 0u;
+                        uint32_t cur = (sact && n_op > 0) ? sm[b] : 0u;      // (a column handed to the exact path reserved no entries)
                         while (__ballot(cur != 0u) != 0ull) {
                             if (cur != 0u) {
                                 ent[j].x = tag + (uint32_t)(32 * b + __builtin_ctz(cur));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off fuzz on the GPU box: adversarial mpileup columns (tests/golden/make_golden.py generator, fresh seeds) through the HIP
-encode kernel against the oracle, bit for bit, plus completely random byte strings over the mpileup alphabet."""
+encode kernel against the oracle, bit for bit, plus completely random byte strings over the mpileup alphabet and opener-dense ones."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -17,8 +17,12 @@ tot = 0; t0 = time.time()
 for r in range(rounds):
     rng = np.random.default_rng(9000 + r)
     ref = rng.choice(np.frombuffer(b"ACGTacgtNn", np.uint8), n_cols).astype(np.uint8)
-    if r % 2 == 0:
+    if r % 3 == 0:
         cols = [c.encode() for c in mg.adversarial_columns(rng, n_cols, ref)]
+    elif r % 3 == 2:   # opener-dense: mostly + - ^ and digits, lengths around the 253-byte end of the fast path, among ordinary columns
+        dense = np.frombuffer(b"+-^+-^+-^0123ACGTacgt*#", np.uint8)
+        lens = rng.integers(0, 300, n_cols)
+        cols = [bytes(rng.choice(dense if rng.random() < 0.3 else alphabet, int(l))) for l in lens]
     else:       # unstructured: any byte sequence of the alphabet, lengths 0..400 (grammar errors included)
         lens = rng.integers(0, 400, n_cols)
         cols = [bytes(rng.choice(alphabet, int(l))) for l in lens]

@@ -81,6 +81,29 @@ def test_handwritten_edge_columns(gpu_ctx):
     assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
 
 
+def test_opener_dense_columns(gpu_ctx):
+    """columns made of construct openers: more flagged openers in one column than the wave's entry list holds (exact path), a wave
+    whose openers need several segments of the list, openers shadowed by the bytes an earlier one consumes, four-digit lengths,
+    alleles longer than the four bytes the multiplicity compare takes at once, columns at both ends of the 253-byte fast path"""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    cols = [b"^" * 200, b"+" * 150, b"-" * 253, b"^+" * 100, b"A+1^C-1+G", b"A+1000" + b"C" * 30, b"T-0A+0", b"^^^A",
+            b"A+6ACGTAC" * 10 + b"A+6ACGTAG" * 7 + b"A+6ACGTAC", b"c-7acgtacg" * 5 + b"c-7acgtacc" * 6,
+            b"A" * 253, b"A" * 254, b"C" * 250 + b"+1G", b"G" * 249 + b"-2AC", b"^" * 127 + b"A" * 126]
+    for _ in range(120):                                          # a whole wave of indel-only columns: ~ 64 x 40 openers
+        n = int(rng.integers(20, 60))
+        cols.append(b"".join(bytes(rng.choice(list(b"ACGTacgt"), 1)) + (b"+" if rng.random() < .5 else b"-") + b"2" +
+                             bytes(rng.choice(list(b"ACGT"), 2)) for _ in range(n)))
+    bases = np.frombuffer(b"".join(cols), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    ref = rng.choice(list(b"ACGTN"), len(cols)).astype(np.uint8)
+    c, d, f = _enc(gpu_ctx, bases, off, ref)
+    oc, od, of = oracle.encode_columns(bases, off, ref)
+    bad = np.nonzero((c.cpu().numpy() != oc).any(1))[0]
+    assert bad.size == 0, (bad[:5], c.cpu().numpy()[bad[:2]], oc[bad[:2]])
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
+
+
 def test_empty_call(gpu_ctx):
     import torch
     e8 = torch.zeros(1, dtype=torch.uint8, device="cuda")
