@@ -402,7 +402,7 @@ namespace {
 // one bidirectional LSTM layer: `steps` launches, both directions per launch.
 //   in : [t][site tile][nk_in chunks] tile images;  hout: [t][site tile][dir][16 chunks]
 template <bool F16>
-void run_bilstm(hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh, const float* in, int nk_in, float* hout, float* cst,
+void run_bilstm(nsnp_ctx* ctx, hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh, const float* in, int nk_in, float* hout, float* cst,
                 int n_tiles, int T, int steps)
 {
     const size_t tile_h = (size_t)16 * TILE_F, step_h = (size_t)n_tiles * 2 * tile_h;
@@ -422,19 +422,19 @@ void run_bilstm(hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh, const float* 
             a.cstate = cst + (size_t)d * n_tiles * tile_h; a.c_tile_stride = (int)tile_h;
             a.first = st == 0;
         }
-        hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, F16>), dim3(n_tiles, 4 * CAT_NH / TR, 2), dim3(256), 0, s, L);
+        hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, F16>), dim3(n_tiles, 4 * CAT_NH / TR, 2), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (4 * CAT_NH / TR) * (2), ctx->n_cu), s, L);
     }
 }
 
 // Linear(512 -> 256) over `n_in_tiles` consecutive [dir][16 chunks] h tiles
 template <bool F16>
-void run_linear_h(hipStream_t s, const float* w, const float* b, const float* in, int n_in_tiles, float* out, int out_tile_stride)
+void run_linear_h(nsnp_ctx* ctx, hipStream_t s, const float* w, const float* b, const float* in, int n_in_tiles, float* out, int out_tile_stride)
 {
     StepLaunch L; StepArgs& a = L.z[0];
     memset(&a, 0, sizeof(a));
     a.w = w; a.bias = b; a.in0 = in; a.nk0 = 32; a.in0_tile_stride = 32 * TILE_F; a.nk_img = 32;
     a.out = out; a.out_tile_stride = out_tile_stride;
-    hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, F16>), dim3(n_in_tiles, CAT_NH / TR, 1), dim3(256), 0, s, L);
+    hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, F16>), dim3(n_in_tiles, CAT_NH / TR, 1), dim3(256), gemm_lds_ballast((long long)(n_in_tiles) * (CAT_NH / TR) * (1), ctx->n_cu), s, L);
 }
 
 int grid_for(int64_t total) { int64_t b = NSNP_CDIV(total, (int64_t)256); return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
@@ -486,10 +486,10 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
 
         // ---- percentage branch: 3-layer BiLSTM on [11][n][20], Linear at column 5 -> cat chunks 0..15 ----
         hipLaunchKernelGGL(k_cat_percentage<F16>, dim3(grid_for((int64_t)CAT_L * n_tiles * TS * 4)), dim3(256), 0, s, a0, a1, n, n_tiles, xp);
-        run_bilstm<F16>(s, cw.pct[0], wsh, xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
-        run_bilstm<F16>(s, cw.pct[1], wsh, hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
-        run_bilstm<F16>(s, cw.pct[2], wsh, hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
-        run_linear_h<F16>(s, cw.pct_w + wsh, cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
+        run_bilstm<F16>(ctx, s, cw.pct[0], wsh, xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm<F16>(ctx, s, cw.pct[1], wsh, hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm<F16>(ctx, s, cw.pct[2], wsh, hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h<F16>(ctx, s, cw.pct_w + wsh, cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
 
         // ---- ResCRNN branch ----
         int Hc = CAT_ROWS;
@@ -507,12 +507,12 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
             // y = relu(bn1(conv1(x)))
             a.w = b.w1 + wsh; a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
             a.nk1 = 0; a.nk_img = a.nk0; a.out = Y; a.out_tile_stride = b.cc_out * TILE_F;
-            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
+            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), gemm_lds_ballast((long long)((unsigned)n_ptiles) * (rt) * (1), ctx->n_cu), s, L);
             // out = relu(bn2(conv2(y)) + shortcut(x))
             a.w = b.w2 + wsh; a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
             a.in1 = X; a.nk1 = b.cc_in; a.in1_tile_stride = b.cc_in * TILE_F; a.nk_img = a.nk0 + a.nk1;
             a.out = O; a.out_tile_stride = b.cc_out * TILE_F;
-            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, L);
+            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), gemm_lds_ballast((long long)((unsigned)n_ptiles) * (rt) * (1), ctx->n_cu), s, L);
             cur = (cur + 2) % 3;
             if (CAT_POOL[i]) {
                 const int kh = CAT_POOL[i], Ho = (Hc - kh) / kh + 1;
@@ -527,11 +527,11 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
         }
         if (Hc != 1) return NSNP_ESHAPE;                          // crnn.py:183 asserts the same
         // BidirectionalLSTM 0: all 11 columns, embedding on every column (crnn.py:12-20)
-        run_bilstm<F16>(s, cw.rnn[0], wsh, seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
-        run_linear_h<F16>(s, cw.emb_w[0] + wsh, cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
+        run_bilstm<F16>(ctx, s, cw.rnn[0], wsh, seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_linear_h<F16>(ctx, s, cw.emb_w[0] + wsh, cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
         // BidirectionalLSTM 1: only column 5 is used downstream
-        run_bilstm<F16>(s, cw.rnn[1], wsh, seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
-        run_linear_h<F16>(s, cw.emb_w[1] + wsh, cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
+        run_bilstm<F16>(ctx, s, cw.rnn[1], wsh, seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h<F16>(ctx, s, cw.emb_w[1] + wsh, cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
         hipLaunchKernelGGL(k_cat_head<F16>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, cat, n, cw.out_w, cw.out_b, gt_prob + n0 * CAT_CLASSES);
     }
     NSNP_HIP(ctx, hipGetLastError());

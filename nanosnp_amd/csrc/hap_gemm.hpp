@@ -49,6 +49,20 @@ struct StepLaunch { StepArgs z[4]; };
 
 enum { MODE_LSTM = 0, MODE_LINEAR = 1, MODE_LINEAR_TANH = 2, MODE_LINEAR_RELU = 3 };
 
+// Dynamic-LDS ballast for a launch of `wgs` workgroups of k_hap_gemm.  The kernel's 40 KB of static LDS let four workgroups share
+// a CU, and when the grid is smaller than that capacity the dispatcher fills the CUs unevenly (512 workgroups on 256 CUs: some hold
+// three or four, others one or none), so the launch lasts as long as its fullest CU: 138 instead of 153 TFLOP/s for the bare
+// MFMA loop (tools/probes/gemm_loop_rate.hip).  The ballast makes ceil(wgs / CUs) the most a CU can take, which spreads the grid.
+inline unsigned gemm_lds_ballast(long long wgs, int n_cu)
+{
+    constexpr unsigned kStatic = 2u * 2u * TR * LDK * sizeof(float), kCu = 160u * 1024u;
+    long long per = n_cu > 0 ? (wgs + n_cu - 1) / n_cu : 4;
+    if (per < 2) per = 2;
+    if (per >= 4) return 0u;
+    const unsigned b = kCu / (unsigned)(per + 1) - kStatic + 512u;          // per + 1 workgroups no longer fit ...
+    return (unsigned long long)per * (kStatic + b) <= kCu ? b : 0u;          // ... per still do
+}
+
 // F16 = false: operands are fp32, one element per 4 bytes, v_mfma_f32_32x32x2_f32 (exact fp32).
 // F16 = true : "f16x3" - every 4-byte element is a (hi, lo) fp16 pair (hi = fp16(v), lo = fp16(v - hi)); a row
 //              of a tile image holds its 16 hi halves followed by its 16 lo halves, so the two 16-byte LDS reads

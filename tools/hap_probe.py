@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development probe: HaplotypeModel forward alone (sites/s), fp32 and f16x3."""
+"""Development probe: HaplotypeModel forward alone (sites/s): hap_probe.py [N] [precisions, e.g. 0 or 0,1]."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,8 @@ ctx.hap_load_weights(seeded_hap_weights(12, H=256))
 rng = np.random.default_rng(0)
 xp = torch.from_numpy((rng.standard_normal((N, 105, 33)) * 30).astype(np.float32)).cuda()
 xh = torch.from_numpy((rng.standard_normal((N, 105, 11)) * 30).astype(np.float32)).cuda()
-for prec in (0, 1):
+precs = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1]
+for prec in precs:
     ctx.set_option("hap_precision", prec)
     ctx.hap_forward(xp, xh); torch.cuda.synchronize()
     t = time.time()
