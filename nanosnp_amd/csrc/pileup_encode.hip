@@ -233,7 +233,7 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
         else if (cls < 10) r.z = 1u << (8 * (cls - 8));
         else if (cls >= 11) r.w = 1u;
         if (is_fwd_char(tid)) r.z |= 1u << 24;
-        tab[tid] = r;
+        tab[tid ^ ((tid >> 2) & 8)] = r;        // row index = byte with its case bit (0x20) folded into bit 3: 'A' and 'a' in different banks
     }
     __syncthreads();
     const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
                         uint32_t w = cw[R];
                         w |= (R == 0) ? hm : 0u;
                         w |= R < trp ? 0u : (R == trp ? tm : 0xffffffffu);
+                        w ^= (w >> 2) & 0x08080808u;                       // the table's row permutation, four bytes at once
                         const uint4 r0 = tab[w & 0xffu], r1 = tab[(w >> 8) & 0xffu], r2 = tab[(w >> 16) & 0xffu], r3 = tab[w >> 24];
                         ax += r0.x + r1.x; ax += r2.x + r3.x;
                         ay += r0.y + r1.y; ay += r2.y + r3.y;
@@ -422,11 +423,13 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
                         const uint32_t al = __builtin_amdgcn_alignbyte(whi, wlo, L);                  // the first four skipped bytes
                         const uint32_t keep = nskip >= 4 ? 0xffffffffu : ((1u << (8 * (nskip & 3))) - 1u);
                         const uint32_t alm = al | ~keep;                                              // bytes beyond the allele: 0xff (a zero row)
-                        const uint4 r0 = tab[alm & 0xffu], r1 = tab[(alm >> 8) & 0xffu], r2 = tab[(alm >> 16) & 0xffu], r3 = tab[alm >> 24];
+                        const uint32_t alp = alm ^ ((alm >> 2) & 0x08080808u);
+                        const uint4 r0 = tab[alp & 0xffu], r1 = tab[(alp >> 8) & 0xffu], r2 = tab[(alp >> 16) & 0xffu], r3 = tab[alp >> 24];
                         uint32_t nx = r0.x + r1.x, ny = r0.y + r1.y, nz = r0.z + r1.z;
                         nx += r2.x + r3.x; ny += r2.y + r3.y; nz += r2.z + r3.z;
                         for (int k = q + 4; k < q + nskip; ++k) {                                     // longer alleles (rare)
-                            const uint4 rr = tab[st[k]];
+                            const uint32_t bk = st[k];
+                            const uint4 rr = tab[bk ^ ((bk >> 2) & 8u)];
                             nx += rr.x; ny += rr.y; nz += rr.z;
                         }
                         const bool counted = !caret && adv <= MAX_INDEL;
