@@ -208,7 +208,10 @@ __device__ __forceinline__ int wave_scan_incl(int v)
     return x;
 }
 
-__global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
+#ifndef NSNP_ENC_MINW
+#define NSNP_ENC_MINW 4
+#endif
+__global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
     int64_t M, AfThreshold af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
     uint8_t* __restrict__ flags)
@@ -218,10 +221,10 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
     // q | nskip << 13 | column << 20 | minus << 26 | counted << 27 | fwd << 28 (written by the lane that decoded it);
     // word 1: the first four allele bytes, zero beyond the allele's length
     __shared__ uint2 ents[ENC_WAVES][ENC_ECAP];
-    // per column: [0..2] skipped bytes by class (the table's three counter words), [3] indel reads by kind (8-bit fields),
+    // per column: [0..2] skipped bytes by class (the table's three counter words; bit 31 of [2]: hand the column to the exact path),
+    // [3] indel reads by kind (8-bit fields),
     // [4..7] largest multiplicity of one allele by kind
     __shared__ __attribute__((aligned(16))) uint32_t colacc[ENC_WAVES][64][8];
-    __shared__ unsigned long long badmask[ENC_WAVES];
     // byte -> x: A C G T, y: a c g t, z: * # (8-bit counters) | "ACGTN*" << 24, w: 1 for the construct openers + - ^
     __shared__ uint4 tab[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -313,7 +316,6 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
         }
         *reinterpret_cast<uint4*>(acc_mine) = uint4{0u, 0u, 0u, 0u};
         *reinterpret_cast<uint4*>(acc_mine + 4) = uint4{0u, 0u, 0u, 0u};
-        if (lane == 0) badmask[wave] = 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -440,12 +442,12 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
                         uint32_t* oa = colacc[wave][owner];
                         atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
                         if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
-                        if (mybad) atomicOr(&badmask[wave], 1ull << owner);
+                        if (mybad) atomicOr(oa + 2, 0x80000000u);                                     // (bit 31 of word 2: exact path)
                     }
                     // an opener inside the bytes an earlier construct of its column consumes is not an opener: exact path
                     int pe = __shfl_up(endpos, 1), po = __shfl_up(owner, 1);
                     if (lane == 0) { pe = carry_end; po = carry_owner; }
-                    if (valid && po == owner && p < pe) atomicOr(&badmask[wave], 1ull << owner);
+                    if (valid && po == owner && p < pe) atomicOr(colacc[wave][owner] + 2, 0x80000000u);
                     carry_end = __shfl(endpos, 63); carry_owner = __shfl(owner, 63);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(ENC_BLOCK, 4) void k_encode_columns(
                     tot = Quad{(int)(a0.w & 0xff), (int)((a0.w >> 8) & 0xff), (int)((a0.w >> 16) & 0xff), (int)(a0.w >> 24)};
                     mx = Quad{(int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
                 }
-                bad = bad || (act && ((badmask[wave] >> lane) & 1ull));
+                bad = bad || (act && (a0.z >> 31));
             }
             if (bad) {
                 // exact byte-at-a-time scan of this column out of LDS (tensor_maker.cpp:83-114 in structure): openers inside skipped
