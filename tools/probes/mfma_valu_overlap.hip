@@ -36,6 +36,26 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
             t1 = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += acc[u][0] + acc[u][3];
+        } else if (SHAPE == 1632) {
+            // v_mfma_f32_16x16x32_f16: the same 8 passes as 16x16x4_f32, on the fp16 matrix path
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 ha[4], hb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ha[i][e] = (_Float16)a[(i + e) & 7]; hb[i][e] = (_Float16)b[(i + e) & 7]; }
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            t0 = __builtin_amdgcn_s_memtime();
+            for (int it = 0; it < it_mfma; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[(r + u) & 3], hb[r & 3], acc[u], 0, 0, 0);
+            t1 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += acc[u][0] + acc[u][3];
         } else {
             f32x16 acc[4];
 #pragma unroll
@@ -117,7 +137,7 @@ void run(const char* name, double valu_cost_guess)
     once<OP, SHAPE, PRIO>(base, vbase * 4, m_b, d, ms);        // MFMA waves timed while the VALU waves are still busy
     once<OP, SHAPE, PRIO>(base * 4, vbase, d, v_b, ms);        // VALU waves timed while the MFMA waves are still busy
     printf("%s%s %-20s  per 16x16x4-equivalent MFMA: %5.1f cycles alone, %5.1f beside the op | per op: %5.2f cycles alone, %6.2f beside MFMAs\n",
-           SHAPE == 16 ? "16x16x4" : "32x32x2", PRIO ? " VALU-wave-prio3" : "                ", name, m_alone, m_b, v_alone, v_b);
+           SHAPE == 16 ? "16x16x4   " : (SHAPE == 1632 ? "16x16x32f16" : "32x32x2   "), PRIO ? " VALU-wave-prio3" : "                ", name, m_alone, m_b, v_alone, v_b);
 }
 int main()
 {
@@ -129,6 +149,10 @@ int main()
     run<OP_FMA, 16, 1>("v_fma_f32", 4.0);
     run<OP_EXP, 16, 1>("v_exp_f32 + v_sub", 12.0);
     run<OP_MIX, 16, 1>("sigmoid (4 ops)", 24.0);
+    run<OP_FMA, 1632, 0>("v_fma_f32", 4.0);
+    run<OP_EXP, 1632, 0>("v_exp_f32 + v_sub", 12.0);
+    run<OP_MIX, 1632, 0>("sigmoid (4 ops)", 24.0);
+    run<OP_MIX, 1632, 1>("sigmoid (4 ops)", 24.0);
     run<OP_FMA, 32, 0>("v_fma_f32", 4.0);
     run<OP_MIX, 32, 0>("sigmoid (4 ops)", 24.0);
     run<OP_FMA, 32, 1>("v_fma_f32", 4.0);
