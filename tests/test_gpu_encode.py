@@ -153,7 +153,8 @@ def test_full_size_invariants_1m_columns(gpu_ctx):
 
 def test_deep_and_indel_heavy_columns_take_the_sub_batch_and_rescan_paths(gpu_ctx):
     """waves whose 64 columns exceed the LDS stage (split into sub-batches), single columns longer than
-    the stage (global path), and columns with more indel reads than the per-lane list (exact rescan)"""
+    the stage (global path), columns beyond the fast path's 253 bytes (exact path out of LDS) and waves with more openers than one
+    segment of the entry list holds"""
     from oracle import oracle
     rng = np.random.default_rng(21)
     cols = []
