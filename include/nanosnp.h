@@ -90,8 +90,9 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "recurrence_waves"        0 auto | 1/2/4/8                 waves per workgroup of the LDS-image recurrence kernels
  *   "l0_register_stationary"  1 (default) | 0                 f16x3 layer 0: weights in VGPRs + LDS exchange of h, or LDS images
  *   "l0_site_groups"          0 auto | 1/2/4                   16-site groups per workgroup of that kernel
- *   "l1_register_stationary"  1 (default) | 0                 f16x3 fused layer 1: weights in VGPRs + LDS operands, or LDS images + ring
- *   "l1_site_groups"          0 auto | 2/4                     16-site groups per workgroup of that kernel
+ *   "l1_register_stationary"  1 (default) | 2 | 0             f16x3 fused layer 1: weights in VGPRs + LDS operands as four waves x four gate
+ *                                                              tiles and 16 sites per workgroup (1), as eight waves x two tiles (2), or LDS images + ring (0)
+ *   "l1_site_groups"          0 auto | 2/4                     16-site groups per workgroup of the eight-wave kernel (a non-zero value selects it)
  *   "fused_l1"                1 (default) | 0                 f16x3 layer 1: projection fused into the recurrence
  *   "fused_waves"             0 auto | 4/8/12                  waves per workgroup of the fused kernel
  *   "proj1_tiles"             1..64                            row tiles per wave of the unfused projection kernel

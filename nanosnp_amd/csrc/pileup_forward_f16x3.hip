@@ -893,6 +893,151 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K23r4: the same layer-1 step with FOUR gate tiles per wave and four waves per workgroup (the shape of the fp32 kernel
+// k_pileup_l1_rs4): wave w owns tiles 4w..4w+3, their W_ih1 and W_hh1 hi+lo fragments fill 192 VGPRs, a workgroup is one wave per
+// SIMD and 16 sites, and the second wave of a SIMD belongs to ANOTHER workgroup with its own barrier - in the eight-wave kernel above
+// both waves of a SIMD wait at the same barrier, and the matrix pipe idles 60 % of a step (39 % busy at N = 131072).  Every
+// fragment read from LDS feeds 12 MFMAs instead of 6.  Same weight images, same exchange-row layout (K position 8 (T >> 1) + 2 q +
+// (T & 1) <-> unit 4 T + q), same order of the six K blocks and three terms per accumulator: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+constexpr int r1_lds_bytes4() { return 2 * 16 * R1_H0ROW * 2 + 2 * 16 * R1_HROW * 2 + 16 * 4 * 16; }
+
+__global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4_h(
+    const _Float16* __restrict__ H0 /* padded to a multiple of 64 sites */, int64_t N,
+    const _Float16* __restrict__ wih0, const _Float16* __restrict__ wih1,
+    const _Float16* __restrict__ whh0, const _Float16* __restrict__ whh1,
+    const float* __restrict__ bias0, const float* __restrict__ bias1,
+    _Float16* __restrict__ H1c /* padded likewise */)
+{
+    extern __shared__ h8 ldsh[];
+    constexpr int NS = 16;
+    _Float16* const h0s = reinterpret_cast<_Float16*>(ldsh);                       // [2][16][R1_H0ROW]
+    _Float16* const h1x = h0s + 2 * NS * R1_H0ROW;                                 // [2][16][R1_HROW]
+    f32x4* const bls = reinterpret_cast<f32x4*>(h1x + 2 * NS * R1_HROW);           // [16 tiles][4 q] bias rows (registers are full)
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int64_t base_site = (int64_t)blockIdx.x * NS;
+
+    h8 Wih[4][4][2], Whh[4][2][2];
+    {
+        const h8* __restrict__ gih = reinterpret_cast<const h8*>(dir ? wih1 : wih0);        // [tile][kb 4][part][lane]
+        const h8* __restrict__ ghh = reinterpret_cast<const h8*>(dir ? whh1 : whh0);        // [tile][kb 2][part][lane]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) Wih[u][kb][part] = gih[(((4 * wave + u) * 4 + kb) * 2 + part) * 64 + lane];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) Whh[u][kb][part] = ghh[(((4 * wave + u) * 2 + kb) * 2 + part) * 64 + lane];
+        }
+        if (tid < 64) bls[tid] = reinterpret_cast<const f32x4*>(dir ? bias1 : bias0)[tid];
+    }
+    const f32x4* const myb = bls + 16 * wave + q;                                   // + 4 u
+
+    // h0 staging: 16 threads per site row, each moves 32 bytes of the 512-byte row
+    constexpr int TPR = 256 / NS, SPT = 32 / TPR;
+    const int srow = tid / TPR, spiece = tid % TPR;
+    const int64_t ssite = base_site + srow;                         // H0 is padded: rows beyond N hold garbage that only feeds dead sites
+    const h8* __restrict__ gsrc = reinterpret_cast<const h8*>(H0 + (ssite * PW) * (2 * 4 * 32)) + spiece * SPT;
+    h8 sreg[SPT];
+    auto load_h0 = [&](int t) {
+        const h8* p = gsrc + (int64_t)t * (2 * 4 * 32 / 8);
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) sreg[k] = p[k];
+    };
+    auto store_h0 = [&](int buf) {
+        h8* d = reinterpret_cast<h8*>(h0s + ((size_t)buf * NS + srow) * R1_H0ROW + spiece * SPT * 8);
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) d[k] = sreg[k];
+    };
+    for (int i = tid; i < NS * R1_HROW / 8; i += 256) reinterpret_cast<h8*>(h1x + (size_t)NS * R1_HROW)[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    load_h0(dir ? PW - 1 : 0);
+    store_h0(0);
+    __syncthreads();
+
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    h8 last_h = h8{0, 0, 0, 0, 0, 0, 0, 0};                            // hi(u0..u3) lo(u0..u3) of the final step
+
+    for (int s = 0; s < PSTEPS1; ++s) {
+        const int t = dir ? PW - 1 - s : s;
+        const int cur = s & 1;
+        if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
+        const _Float16* h0r = h0s + ((size_t)cur * NS + n) * R1_H0ROW + q * 32;
+        const _Float16* hrr = h1x + ((size_t)(cur ^ 1) * NS + n) * R1_HROW + q * 8;      // h1_{s-1}
+        _Float16* hwr = h1x + ((size_t)cur * NS + n) * R1_HROW + 16 * wave + 2 * q;      // h1_s
+
+        // piece k < 4: input K block k (dir = k >> 1, half = k & 1), k >= 4: recurrent K block k - 4; fetched one piece ahead
+        h8 fh[2], fl[2];
+        auto fetch = [&](int k, int slot) {
+            if (k < 4) {
+                const _Float16* r = h0r + (k >> 1) * 128 + (k & 1) * 8;
+                fh[slot] = *reinterpret_cast<const h8*>(r);
+                fl[slot] = *reinterpret_cast<const h8*>(r + 16);
+            } else {
+                const _Float16* r = hrr + (k - 4) * 32;
+                fh[slot] = *reinterpret_cast<const h8*>(r);
+                fl[slot] = *reinterpret_cast<const h8*>(r + 64);
+            }
+        };
+        fetch(0, 0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = myb[4 * u];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int slot = k & 1;
+            if (k + 1 < 6) fetch(k + 1, slot ^ 1);
+            if (k < 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Wih[u][k][0], fh[slot], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Wih[u][k][1], fh[slot], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Wih[u][k][0], fl[slot], acc[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][k - 4][0], fh[slot], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][k - 4][1], fh[slot], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = mfma_h(Whh[u][k - 4][0], fl[slot], acc[u]);
+            }
+        }
+        // cell: lane (n, q) holds units 4 (4 wave + u) + q, u = 0..3
+        _Float16 hi[4], lo[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][0]));
+            const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][1]));
+            const float gk = __builtin_fmaf(-2.0f * RS_K, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][2])), RS_K);
+            const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[u][3]));
+            const float cn = __builtin_fmaf(fg, c[u], ig * gk);
+            c[u] = cn;
+            const float h = og * __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn)), 1.0f);
+            split1(h, hi[u], lo[u]);
+        }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<h2*>(hwr) = h2{hi[0], hi[1]};                     // tiles 4w, 4w+1: positions 16 w + 2 q + {0, 1}
+        *reinterpret_cast<h2*>(hwr + 8) = h2{hi[2], hi[3]};                 // tiles 4w+2, 4w+3: positions 16 w + 8 + 2 q + {0, 1}
+        *reinterpret_cast<h2*>(hwr + 64) = h2{lo[0], lo[1]};
+        *reinterpret_cast<h2*>(hwr + 72) = h2{lo[2], lo[3]};
+        last_h = h8{hi[0], hi[1], hi[2], hi[3], lo[0], lo[1], lo[2], lo[3]};
+        if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
+        lds_barrier();
+    }
+    // H1c: [site][dir][q][16 hi | 16 lo], entries m = 4 wave + u of row q
+    {
+        _Float16* o = H1c + (((base_site + n) * 2 + dir) * 4 + q) * 32 + 4 * wave;
+        *reinterpret_cast<h4*>(o) = h4{last_h[0], last_h[1], last_h[2], last_h[3]};
+        *reinterpret_cast<h4*>(o + 16) = h4{last_h[4], last_h[5], last_h[6], last_h[7]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: heads, weights from L2 as fp16 hi/lo images.
 // ---------------------------------------------------------------------------------------------
 // HW waves of 16 sites per workgroup share every weight image through one 64 KB LDS stage (proj, dense rows 0-127,
@@ -1193,7 +1338,12 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
                                (const _Float16*)pw.l1_wih_rs[0], (const _Float16*)pw.l1_wih_rs[1], \
                                (const _Float16*)pw.l1_whh_rs[0], (const _Float16*)pw.l1_whh_rs[1], \
                                (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c, ctx->rs_prio)
-            if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2);
+            if (ctx->l1_rs == 1 && !ctx->l1_rs_groups) {      // default: four waves x four tiles, 16 sites per workgroup
+                hipLaunchKernelGGL(k_pileup_l1_rs4_h, dim3((unsigned)NSNP_CDIV(n, 16), 2), dim3(256), r1_lds_bytes4(), s, H0, n,
+                                   (const _Float16*)pw.l1_wih_rs[0], (const _Float16*)pw.l1_wih_rs[1],
+                                   (const _Float16*)pw.l1_whh_rs[0], (const _Float16*)pw.l1_whh_rs[1],
+                                   (const float*)pw.l1f_bias + 512, (const float*)pw.l1f_bias + 768, H1c);
+            } else if (g1 == 4) LAUNCH_R1(4); else LAUNCH_R1(2);
 #undef LAUNCH_R1
         } else if (ctx->fused_l1) {
             ScopedKernelTimer tm(ctx, NSNP_K_L1, s);

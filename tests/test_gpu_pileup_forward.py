@@ -347,10 +347,14 @@ def test_register_stationary_layer1_kernel(pileup_weights):
     assert np.abs(ref[0][:256].cpu().numpy() - og).max() < PROB_ATOL and np.abs(ref[1][:256].cpu().numpy() - oz).max() < PROB_ATOL
     again = c.pileup_forward(x)
     assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
-    for g in (2, 4, 0):                                         # 32 / 64 sites per workgroup / automatic
+    for g in (2, 4, 0):                                         # eight-wave kernel with 32 / 64 sites per workgroup / the default kernel
         c.set_option("l1_site_groups", g)
         got = c.pileup_forward(x)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), g
+    c.set_option("l1_register_stationary", 2)                 # the eight-wave x two-tile kernel against the default four x four
+    got = c.pileup_forward(x)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    c.set_option("l1_register_stationary", 1)
     with pytest.raises(_lib.NanoSNPError):
         c.set_option("l1_site_groups", 3)
     for n in (1, 31, 32, 33, 63, 64, 65, 200):
