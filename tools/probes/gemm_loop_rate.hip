@@ -4,6 +4,7 @@
 //   LDS   + the chunk's 8 ds_read_b128 fragment reads (16 KB LDS image per workgroup, rows 80 B apart)
 //   BAR   + 4 ds_write_b128 and one workgroup barrier per chunk (no global memory)
 //   GLD   + 4 global_load_dwordx4 per chunk (8 KB weight image + 8 KB input image per workgroup from a 64 MB L2/HBM-resident array)
+//   KRN   the same with the kernel's reuse: the weight chunk shared by the workgroups of a row tile, the input chunk by those of a site tile
 // Grid 512 = two workgroups per CU on average, 1024 = four (LDS would let four be resident: the placement is the dispatcher's).  Reports TFLOP/s from HIP events.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,12 +34,20 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ g, float* 
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) { af[rt][0] = f32x4{0.1f, 0.2f, -0.1f, 0.05f} * (float)(lane % 7); af[rt][1] = af[rt][0] * 0.5f; bf[rt][0] = af[rt][0] * 0.25f; bf[rt][1] = af[rt][0] * 0.125f; }
     f32x4 ga0 = af[0][0], ga1 = af[0][1], gb0 = bf[0][0], gb1 = bf[0][1];
+    f32x4 ha0 = ga0, ha1 = ga1, hb0 = gb0, hb1 = gb1;
     const size_t gbase = ((size_t)blockIdx.x * 4099) * 2048;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        if (MODE >= 3) {
+        if (MODE == 3) {
             const f32x4* pa = reinterpret_cast<const f32x4*>(g + ((gbase + (size_t)kc * 4096) & gmask)) + crow * 4 + cq;
             ga0 = pa[0]; ga1 = pa[1]; gb0 = pa[512]; gb1 = pa[513];
+        }
+        if (MODE == 4 || MODE == 5) {   // the kernel's sharing: weight chunk by row tile (y), input chunk by site tile (x), 48 chunks, 8 KB each
+            const int kk = kc % 48;
+            const f32x4* pa = reinterpret_cast<const f32x4*>(g + ((size_t)(blockIdx.z * 8 + blockIdx.y) * 48 + kk) * 2048) + crow * 4 + cq;
+            const f32x4* pb = reinterpret_cast<const f32x4*>(g + (size_t)(4 << 20) + ((size_t)(blockIdx.z * 32 + (blockIdx.x & 31)) * 48 + kk) * 2048) + crow * 4 + cq;
+            if (MODE == 5) { ha0 = ga0; ha1 = ga1; hb0 = gb0; hb1 = gb1; }      // what arrives now is stored one iteration later
+            ga0 = pa[0]; ga1 = pa[1]; gb0 = pb[0]; gb1 = pb[1];
         }
         if (MODE >= 1) {
 #pragma unroll
@@ -60,10 +69,10 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ g, float* 
                 for (int ct = 0; ct < 2; ++ct)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3], acc[rt][ct], 0, 0, 0);
         if (MODE >= 2) {
-            *reinterpret_cast<f32x4*>(&As[cur ^ 1][crow][cq * 4]) = ga0;
-            *reinterpret_cast<f32x4*>(&As[cur ^ 1][crow][cq * 4 + 4]) = ga1;
-            *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][crow][cq * 4]) = gb0;
-            *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][crow][cq * 4 + 4]) = gb1;
+            *reinterpret_cast<f32x4*>(&As[cur ^ 1][crow][cq * 4]) = MODE == 5 ? ha0 : ga0;
+            *reinterpret_cast<f32x4*>(&As[cur ^ 1][crow][cq * 4 + 4]) = MODE == 5 ? ha1 : ga1;
+            *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][crow][cq * 4]) = MODE == 5 ? hb0 : gb0;
+            *reinterpret_cast<f32x4*>(&Bs[cur ^ 1][crow][cq * 4 + 4]) = MODE == 5 ? hb1 : gb1;
             __syncthreads();
         }
         if (MODE == 0) {   // keep the operands loop-carried so that nothing is hoisted
@@ -75,23 +84,24 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ g, float* 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][15];
-    out[blockIdx.x * 256 + tid] = s;
+    out[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + tid] = s;
 }
 
 template <int MODE, int PAD>
-void run(const char* name, const float* g, float* out, int grid)
+void run(const char* name, const float* g, float* out, int grid, dim3 g3 = dim3(0, 0, 0))
 {
+    const dim3 gd = g3.x ? g3 : dim3(grid);
     const int nk = 4000;
-    hipLaunchKernelGGL((k<MODE, PAD>), dim3(grid), dim3(256), 0, 0, g, out, 100, (size_t)(16u << 20) - 1); hipDeviceSynchronize();
+    hipLaunchKernelGGL((k<MODE, PAD>), gd, dim3(256), 0, 0, g, out, 100, (size_t)(16u << 20) - 1); hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0); hipLaunchKernelGGL((k<MODE, PAD>), dim3(grid), dim3(256), 0, 0, g, out, nk, (size_t)(16u << 20) - 1); hipEventRecord(e1); hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL((k<MODE, PAD>), gd, dim3(256), 0, 0, g, out, nk, (size_t)(16u << 20) - 1); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)grid * 4 * nk * 32 * 4096.0;
     printf("%-48s grid %4d: %8.2f ms  %6.1f TFLOP/s\n", name, grid, ms, flop / (ms * 1e-3) / 1e12);
 }
 int main()
 {
-    float *g, *out; hipMalloc(&g, ((size_t)64 << 20) + 65536); hipMemset(g, 0, ((size_t)64 << 20) + 65536); hipMalloc(&out, 2048 * 256 * 4);
+    float *g, *out; hipMalloc(&g, ((size_t)128 << 20)); hipMemset(g, 0, ((size_t)128 << 20)); hipMalloc(&out, 2048 * 256 * 4);
     for (int grid : {512, 1024}) {
         run<0, 0>("REG  operands in registers", g, out, grid);
         run<1, 0>("LDS  + 8 ds_read_b128 per chunk", g, out, grid);
@@ -100,5 +110,12 @@ int main()
         run<0, 9216>("REG, at most 2 workgroups per CU (LDS ballast)", g, out, grid);
         run<3, 9216>("GLD, at most 2 workgroups per CU (LDS ballast)", g, out, grid);
     }
+    run<4, 0>("KRN  loads shared as in the kernel, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
+    run<4, 0>("KRN  loads shared as in the kernel, grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
+    run<4, 0>("KRN  loads shared as in the kernel, grid (128, 8, 2)", g, out, 2048, dim3(128, 8, 2));
+    run<5, 0>("KRN2 the same, global loads two chunks ahead, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
+    run<5, 0>("KRN2 the same, global loads two chunks ahead, grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
+    run<5, 13824>("KRN2 + at most 2 workgroups per CU, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
+    run<4, 13824>("KRN  + at most 2 workgroups per CU, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
     return 0;
 }
