@@ -106,6 +106,9 @@ def launch_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # torch.distributed.run force-sets OMP_NUM_THREADS=1 for nproc > 1 unless the variable is already in its environment; the
+    # ranks generate their synthetic pools with OpenMP, so the cores of the box are shared between them explicitly
+    env["OMP_NUM_THREADS"] = str(max(1, usable_cores() // max(1, args.gpus)))
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     for l in p.stdout.splitlines():
@@ -157,6 +160,7 @@ def selftest_launcher(args, rank, world):
         print(json.dumps({"metric": METRIC, "value": None, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / max(args.steps, 1) * 1e3, "selftest": True, "gather_ok": ok,
                           "world_size_observed": dist.get_world_size() if world > 1 else 1,
+                          "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "usable_cores": usable_cores(),
                           "slowest_rank_bound_ok": dt >= 0.002 * args.steps * world}))
     if world > 1:
         dist.barrier()
@@ -229,7 +233,10 @@ def main():
 
     if args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)      # must be set before HIP initialises
-    # the host-side generator / CPU baseline use OpenMP: share the cores between the ranks of a node
+    # the host-side generator / CPU baseline use OpenMP: share the cores between the ranks of a node (launch_ranks passes the
+    # same value to its children explicitly; an external torchrun that force-set 1 for nproc > 1 is overridden here)
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        os.environ["OMP_NUM_THREADS"] = str(max(1, usable_cores() // world))
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, world))))
     import numpy as np
     import torch
@@ -244,7 +251,7 @@ def main():
         sys.exit(3)
     from nanosnp_amd import _lib, host
     from nanosnp_amd.dist import gather_results, gather_results_abi
-    from tests.helpers import load_pileup_weights
+    from nanosnp_amd.fixtures import load_pileup_weights
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -87,6 +87,9 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "pileup_precision"        0 fp32 (default) | 1 f16x3      PileupModel forward
  *   "hap_precision"           0 fp32 (default) | 1 f16x3      HaplotypeModel forward
  *   "cat_precision"           0 fp32 (default) | 1 f16x3      legacy CatModel forward
+ *   "hap_pass_sites"          128..131072, multiple of 128     sites per internal pass of the HaplotypeModel forward (default 16384;
+ *                                                              workspace ~195 KB per site, (re)allocated synchronously by this call
+ *                                                              and by nsnp_hap_load_weights, never by nsnp_hap_forward)
  *   "recurrence_waves"        0 auto | 1/2/4/8                 waves per workgroup of the LDS-image recurrence kernels
  *   "l0_register_stationary"  1 (default) | 0                 f16x3 layer 0: weights in VGPRs + LDS exchange of h, or LDS images
  *   "l0_site_groups"          0 auto | 1/2/4                   16-site groups per workgroup of that kernel
@@ -100,7 +103,11 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   tiles (default) | 2 eight waves x two tiles | 0 LDS-image kernels with the Xp1 round trip, "l1_site_groups" 0 | 1 | 2 | 4,
  *   "l1_stagger" 0 (default) | 1 (eight-wave kernel: waves 4-7 issue a group's next input part ahead of its cell),
  *   "head_split" 1 (default) | 0 heads with the output tiles split over eight waves, "static_priority" 0..3 (f16x3
- *   register-stationary kernels: s_setprio 1 for waves 4-7 of layer 1 / odd workgroups of layer 0; measured without effect).
+ *   register-stationary kernels: s_setprio 1 for waves 4-7 of layer 1 / odd workgroups of layer 0; measured without effect),
+ *   "l0_input_weights_in_lds" 0 (default) | 1 (fp32 layer 0, 16-site workgroups: input-part weight fragments in LDS, 128
+ *   VGPRs; measured without gain).  Combinations without effect are accepted and ignored: "l1_site_groups" under
+ *   "l1_register_stationary" 1 (its workgroups are always one 16-site group), "l1_stagger" outside the eight-wave kernel,
+ *   "static_priority" and "fused_*" / "proj1_tiles" on the fp32 path.
  *   Every fp32 combination returns bit-identical probabilities. */
 int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
 
@@ -216,10 +223,19 @@ int nsnp_cat_groups(nsnp_ctx* ctx, const int32_t* read1, const int32_t* bq1, con
  * communicator to its context (collective call).  NSNP_ENOTSUP when no RCCL library can be resolved. */
 int nsnp_comm_unique_id(uint8_t* id128);
 int nsnp_comm_init(nsnp_ctx* ctx, const uint8_t* id128, int rank, int world);
+/* A host that already owns a communicator (nsnp_gather_results(ctx, rccl_comm, ...)) binds it instead:
+ * rccl_comm is its ncclComm_t, rank / world as it was created.  The context borrows it: nsnp_comm_destroy and
+ * nsnp_ctx_destroy only forget it.  The communicator must come from the RCCL image this library resolves (the one already
+ * loaded in the process). */
+int nsnp_comm_attach(nsnp_ctx* ctx, void* rccl_comm, int rank, int world);
 int nsnp_comm_destroy(nsnp_ctx* ctx);
-/* Rooted gather of per-rank byte blocks (device memory) into root_buf (device, root only) at byte_off[r] .. byte_off[r+1]
- * (HOST array of world + 1 offsets, read on the root only; local_bytes of the root must equal its own slot).  Grouped
- * ncclSend / ncclRecv on `stream`, asynchronous; rank order = site order, so the merge is a concatenation. */
+/* Rooted gather of per-rank byte blocks (device memory) into root_buf (device, root only) at byte_off[r] .. byte_off[r+1].
+ * byte_off is a HOST array of world + 1 offsets and is required on EVERY rank (byte_off[0] == 0, non-decreasing,
+ * byte_off[rank + 1] - byte_off[rank] == local_bytes): all ranks validate the same table before anything is posted, so a bad
+ * plan fails everywhere with NSNP_EINVAL instead of leaving peers in an unmatched send.  Grouped ncclSend / ncclRecv on
+ * `stream`, asynchronous; rank order = site order, so the merge is a concatenation.  nsnp_gather_check is the device-free
+ * part of that validation (usable to pre-check a plan). */
+int nsnp_gather_check(int rank, int world, int64_t local_bytes, const int64_t* byte_off, int root);
 int nsnp_gather_results(nsnp_ctx* ctx, const void* local, int64_t local_bytes, void* root_buf,
                         const int64_t* byte_off, int root, void* stream);
 

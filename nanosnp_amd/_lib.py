@@ -52,7 +52,9 @@ _SIGNATURES = {
     "nsnp_cat_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsnp_comm_unique_id": (C.c_int, [C.c_void_p]),
     "nsnp_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "nsnp_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "nsnp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "nsnp_gather_check": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int]),
     "nsnp_gather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nsnp_cat_groups": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] +
                         [C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void k_hap_heads(const float* __restrict__ inn
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
+struct HapWeightsDev;
+int nsnp_hap_reserve(nsnp_ctx* ctx);
+
 struct HapWeightsDev {
     int F, H, n_layers, n_gt, n_zy, nk_in0;           // nk_in0 = ceil(F/16)
     // [encoder][layer][dir]: weight images + bias
@@ -104,6 +107,38 @@ struct HapWeightsDev {
     float* arena; size_t arena_floats;
     float* arena16;                                    // the same images with every weight as an fp16 (hi, lo) pair
 };
+
+// workspace of one pass of `chunk` sites (floats): packed inputs of both encoders, h of all steps / both directions for two
+// layers per encoder (ping-pong), c for up to 4 z-slices, the concatenated projections, the dense output.  ~195 KB per site.
+struct HapWsLayout { size_t xT_f, hbuf_f, c_f, cat_f, inner_f, bytes; };
+static HapWsLayout hap_ws_layout(int64_t chunk, int nk_in0)
+{
+    const size_t max_tiles = (size_t)(chunk / TS);
+    HapWsLayout w;
+    w.xT_f = (size_t)33 * max_tiles * nk_in0 * TILE_F;
+    w.hbuf_f = (size_t)33 * max_tiles * 2 * 16 * TILE_F;
+    w.c_f = (size_t)4 * max_tiles * 16 * TILE_F;
+    w.cat_f = max_tiles * 32 * TILE_F;
+    w.inner_f = max_tiles * 16 * TILE_F;
+    w.bytes = (2 * w.xT_f + 4 * w.hbuf_f + w.c_f + w.cat_f + w.inner_f) * sizeof(float);
+    return w;
+}
+
+// (Re)allocates the workspace for the context's pass size.  Synchronous; called where the caller already expects a
+// synchronous call (nsnp_hap_load_weights, nsnp_ctx_set_option("hap_pass_sites")), never from nsnp_hap_forward.
+int nsnp_hap_reserve(nsnp_ctx* ctx)
+{
+    if (!ctx->hw) return NSNP_OK;                       // sized when the weights arrive
+    const HapWsLayout w = hap_ws_layout(ctx->hap_chunk, ctx->hw->nk_in0);
+    if (ctx->hap_ws && ctx->hap_ws_bytes == w.bytes) return NSNP_OK;
+    NSNP_HIP(ctx, hipSetDevice(ctx->device));
+    NSNP_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->hap_ws) (void)hipFree(ctx->hap_ws);
+    ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0;
+    if (hipMalloc(&ctx->hap_ws, w.bytes) != hipSuccess) { ctx->hap_ws = nullptr; ctx->last_err = hipErrorOutOfMemory; return NSNP_ENOMEM; }
+    ctx->hap_ws_bytes = w.bytes;
+    return NSNP_OK;
+}
 
 void nsnp_hap_free(nsnp_ctx* ctx)
 {
@@ -245,7 +280,7 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
         hw.proj_w[e] = hw.arena + off_pw[e]; hw.proj_b[e] = hw.arena + off_pb[e];
     }
     hw.dense_w = hw.arena + off_dw; hw.dense_b = hw.arena + off_db; hw.head_w = hw.arena + off_hw; hw.head_b = hw.arena + off_hb;
-    return NSNP_OK;
+    return nsnp_hap_reserve(ctx);                      // the forward itself never allocates (graph capture, no stream stalls)
 }
 
 extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N,
@@ -260,22 +295,13 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
     const bool f16 = ctx->hap_precision == 1;
     const ptrdiff_t wsh = f16 ? hw.arena16 - hw.arena : 0;     // weight images live at the same offsets in both arenas
     const int Lp = 33, Lh = 11;                       // ont_haplotype.yaml:10-11
-    const int64_t chunk = 4096;                        // sites per pass (workspace ~0.8 GB)
-    const int max_tiles = (int)(chunk / TS);
-    // workspace layout (floats)
-    const size_t xT_f = (size_t)Lp * max_tiles * hw.nk_in0 * TILE_F;       // packed input of the longer encoder
-    const size_t hbuf_f = (size_t)Lp * max_tiles * 2 * 16 * TILE_F;        // h of all steps, both directions, one layer
-    const size_t c_f = (size_t)4 * max_tiles * 16 * TILE_F;                // c for up to 4 z-slices
-    const size_t cat_f = (size_t)max_tiles * 32 * TILE_F;                  // [proj_p ; proj_h] (2 x 256 features)
-    const size_t inner_f = (size_t)max_tiles * 16 * TILE_F;
-    const size_t need = (2 * xT_f + 4 * hbuf_f + c_f + cat_f + inner_f) * sizeof(float);
-    if (ctx->hap_ws_bytes < need) {
-        NSNP_HIP(ctx, hipStreamSynchronize(s));
-        if (ctx->hap_ws) (void)hipFree(ctx->hap_ws);
-        ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0;
-        NSNP_HIP(ctx, hipMalloc(&ctx->hap_ws, need));
-        ctx->hap_ws_bytes = need;
-    }
+    // sites per pass: every time step of a layer is one launch over all sites of the pass, so the pass size sets how long
+    // each of the 83 dependent launches is (16384 sites: 2048-4096 workgroups, 2-4 rounds of the chip; ramp + tail of a launch
+    // ~5 % instead of ~18 % at 4096).  Option "hap_pass_sites"; workspace ~195 KB per site, allocated at load time.
+    const int64_t chunk = ctx->hap_chunk;
+    const HapWsLayout wl = hap_ws_layout(chunk, hw.nk_in0);
+    if (!ctx->hap_ws || ctx->hap_ws_bytes < wl.bytes) return NSNP_ENOMEM;      // nsnp_hap_load_weights reserves it
+    const size_t xT_f = wl.xT_f, hbuf_f = wl.hbuf_f, c_f = wl.c_f, cat_f = wl.cat_f;
     float* base = (float*)ctx->hap_ws;
     float* xT[2] = {base, base + xT_f};
     float* hb[2][2] = {{base + 2 * xT_f, base + 2 * xT_f + hbuf_f}, {base + 2 * xT_f + 2 * hbuf_f, base + 2 * xT_f + 3 * hbuf_f}};

@@ -40,6 +40,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->device = device;
     ctx->last_err = hipSuccess;
     ctx->chunk_sites = 32768;
+    ctx->hap_chunk = 16384;
     ctx->precision = 0;          // exact fp32 MFMA is the default of all three model forwards (the reference computes in
     ctx->hap_precision = 0;      // fp32); 1 opts into the f16x3 split (3 fp16 MFMAs per product, ~1e-6 from fp32)
     ctx->cat_precision = 0;
@@ -61,6 +62,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
 }
 
 void nsnp_hap_free(nsnp_ctx* ctx);   // hap_forward.hip
+int  nsnp_hap_reserve(nsnp_ctx* ctx);
 void nsnp_cat_free(nsnp_ctx* ctx);   // cat_forward.hip
 
 // ---- per-kernel timing ----------------------------------------------------------------------------
@@ -96,6 +98,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->hap_precision = (int)value;
         return NSNP_OK;
+    }
+    if (strcmp(name, "hap_pass_sites") == 0) {
+        if (value < 128 || value > 131072 || value % 128) return NSNP_EINVAL;
+        ctx->hap_chunk = value;
+        return nsnp_hap_reserve(ctx);                   // synchronous re-allocation when the weights are already loaded
     }
     if (strcmp(name, "pileup_precision") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;

@@ -90,7 +90,7 @@ struct nsnp_ctx {
     int l0_wx_lds;      // fp32 layer 0 (16-site workgroups): input-part weight fragments in LDS, 128 VGPRs, four workgroups per SIMD set
     int rs_prio;        // f16x3 register-stationary kernels: bit 0 = static s_setprio 1 for waves 4-7 of the layer-1 kernel, bit 1 = for odd layer-0 workgroups
     int head_rs;        // fp32 heads: 1 = output tiles split over the 8 waves of a workgroup, weights in VGPRs (default); 0 = one wave per 16 sites
-    int l1_stagger;     // fp32 register-stationary layer 1: waves 4-7 run a group's next-step input part ahead of its cell (default 1)
+    int l1_stagger;     // fp32 register-stationary layer 1: waves 4-7 run a group's next-step input part ahead of its cell (default 0)
     // workspace (sized by nsnp_ctx_reserve)
     int64_t chunk_sites;
     float*  ws_h0;      // [chunk][33][128]
@@ -100,11 +100,13 @@ struct nsnp_ctx {
     PileupWeightsF16 pw16;
     HapWeightsDev* hw;
     void*  hap_ws; size_t hap_ws_bytes;
+    int64_t hap_chunk;  // sites per pass of the HaplotypeModel forward (option "hap_pass_sites", default 16384)
     CatWeightsDev* cw;
     void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     KernelTimer* timer;
-    void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init (nsnp_comm.hip)
+    void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init / nsnp_comm_attach (nsnp_comm.hip)
+    bool comm_borrowed;                        // attached by the caller: never destroyed here
 };
 
 // records an event pair around one kernel launch when timing is enabled

@@ -18,7 +18,12 @@
  *       score_mode 0 = NumPy >= 2 (NEP 50, what this repository's container runs): Python scalars are weak,
  *         everything stays float32, the guards vanish and p == 1 raises "math domain error" -> the site is
  *         skipped by the bare except (haplotype.csv: the loop has no except, the batch fails).
- *     Both are pinned by goldens produced by the reference's predict() (tests/golden/make_golden.py vcf).
+ *     Both are pinned by goldens of the reference's predict() (tests/golden/make_golden.py vcf).  The score_mode 0
+ *     goldens are a plain run under this container's NumPy 2.2.  The score_mode 1 goldens are an EMULATION of NumPy 1.x
+ *     under NumPy 2: make_golden.py widens the float32 arrays to float64 where Tensor.numpy() hands them to the loop, which
+ *     reproduces NumPy 1.x value-based promotion for every scalar expression of predict.py (float32 scalar op Python
+ *     scalar -> float64) - equivalent for those expressions, but not a run inside the reference's py38 environment, which
+ *     this container cannot provide (no NumPy 1.x wheel, no network).
  */
 #include "nsnp_host.h"
 

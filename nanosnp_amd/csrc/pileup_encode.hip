@@ -325,7 +325,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
             // ---- pass 1: every byte counted through the table; the opener flags land in one bit mask per 32-byte block ----
             const int wb = lbeg & ~3;                                              // the column's first word
             const int tr = act ? ((lend - 1 - wb) >> 2) : -1;                      // its last word (relative); -1: none
-            bool bad = tr >= 8 * ENC_NBLK;                                          // longer than the fast path covers: exact path
+            bool bad = tr >= 8 * ENC_NBLK || lend - lbeg > 253;                     // beyond the fast path (word span, or a class count an 8-bit field cannot hold): exact path
             const int trp = bad ? -1 : tr;
             const uint32_t hm = (1u << (8 * (lbeg & 3))) - 1u;                     // bytes of word 0 in front of the column
             const int rem = lend - (wb + 4 * tr);                                  // bytes of the column in its last word, 1..4

@@ -33,57 +33,68 @@ def shard_columns(n_cols, rank, world, halo=16):
     return max(0, lo - halo), min(n_cols, hi + halo), lo, hi
 
 
-def gather_results(local, n_total, root=0, group=None):
-    """Gathers per-site result rows (a 2-D tensor [n_local, k]) to `root` in rank order.
-    Returns the [n_total, k] tensor on root, None elsewhere.  One collective, no ring all-reduce."""
+def _rooted_gather(local, counts, root, group):
+    """Rooted gather of contiguous row blocks straight into place: the root posts one receive per peer into ITS slice of one
+    preallocated [sum(counts), ...] buffer, every other rank posts one send; the operations go out as one batch (a grouped
+    ncclSend / ncclRecv on RCCL, so every peer uses its own xGMI link to the root; plain point-to-point on gloo).  No
+    padding to the longest shard, no list of world-many staging buffers, no concatenation."""
     import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    assert local.shape[0] == counts[rank], (tuple(local.shape), counts[rank])
+    local = local.contiguous()
+    ops, out = [], None
+    if rank == root:
+        out = torch.empty((sum(counts),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        off = 0
+        for r, c in enumerate(counts):
+            if r == root:
+                out[off:off + c].copy_(local)
+            elif c > 0:
+                ops.append(dist.P2POp(dist.irecv, out[off:off + c], peer(r), group))
+            off += c
+    elif counts[rank] > 0:
+        ops.append(dist.P2POp(dist.isend, local, peer(root), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def gather_results(local, n_total, root=0, group=None):
+    """Gathers per-site result rows (a tensor [n_local, ...]) of the shard_range partition of `n_total` sites to `root` in rank
+    order.  Returns the [n_total, ...] tensor on root, None elsewhere.  One batch of point-to-point transfers into the
+    root's preallocated buffer, no ring all-reduce."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [shard_range(n_total, r, world) for r in range(world)]
-    counts = [hi - lo for lo, hi in sizes]
-    assert local.shape[0] == counts[rank], (local.shape, counts[rank])
-    maxn = max(counts)
-    # equal-size all_gather of padded shards (a single grouped send/recv per peer pair on RCCL)
-    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
-    dist.gather(pad, bufs, dst=root, group=group)
-    if rank != root:
-        return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    world = dist.get_world_size(group)
+    counts = [hi - lo for lo, hi in (shard_range(n_total, r, world) for r in range(world))]
+    return _rooted_gather(local, counts, root, group)
 
 
 def gather_varlen(local, root=0, group=None):
     """Rooted gather of per-rank row blocks of DIFFERENT lengths ([n_r, k] tensors, e.g. the candidate sites a rank found in
-    its column shard) in rank order: sizes travel first (one small all_gather), then one gather of blocks padded to the longest.
+    its column shard) in rank order: the sizes travel first (one small all_gather), then the blocks as in gather_results.
     Returns the concatenation on root, None elsewhere; the input itself without an initialised process group."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    world = dist.get_world_size(group)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
-    counts = [int(s.item()) for s in sizes]
-    maxn = max(max(counts), 1)
-    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
-    dist.gather(pad, bufs, dst=root, group=group)
-    if rank != root:
-        return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return _rooted_gather(local, [int(s.item()) for s in sizes], root, group)
 
 
 def gather_results_abi(ctx, local, n_total, root=0, stream=None):
     """The same rooted gather through the library's own RCCL entry (nsnp_comm_init + nsnp_gather_results, include/nanosnp.h) instead of
     a torch.distributed collective: grouped ncclSend / ncclRecv straight into place on the root, no padded copies.  The 128-byte
-    communicator id travels over the existing process group once per context.  Validated on hardware at world size 1 only (the
-    development pool has one-GPU boxes); bench.py uses it with --gather rccl-abi."""
-    import torch
+    communicator id travels over the existing process group once per context.  EXPERIMENTAL: validated on hardware at world size 1
+    only (the development pool has one-GPU boxes); bench.py uses it with --gather rccl-abi."""
+    import math
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -92,7 +103,7 @@ def gather_results_abi(ctx, local, n_total, root=0, stream=None):
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], rank, world)
-    row_bytes = local.element_size() * (local.numel() // max(local.shape[0], 1)) if local.shape[0] else local.element_size() * int(torch.tensor(local.shape[1:]).prod())
+    row_bytes = local.element_size() * math.prod(local.shape[1:])
     counts = [(hi - lo) * row_bytes for lo, hi in (shard_range(n_total, r, world) for r in range(world))]
     out = ctx.gather_bytes(local.contiguous(), counts, root=root, stream=stream)
     if rank != root:

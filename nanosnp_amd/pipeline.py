@@ -40,7 +40,7 @@ def call_contig(model, mpileup_text: bytes, contig: str, chr_seq: np.ndarray, mi
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
     M = int(pos.size)
     c_lo, c_hi, own_lo, own_hi = shard_columns(M, rank, world, halo=16)
-    dev = "cuda"
+    dev = torch.device("cuda", ctx.device)          # the context's device, not torch's current one (one GPU per rank under torchrun)
     b0, b1 = int(col_off[c_lo]), int(col_off[c_hi])
     d_bases = torch.from_numpy(bases[b0:b1] if b1 > b0 else np.zeros(1, np.uint8)).to(dev)
     d_off = torch.from_numpy(col_off[c_lo:c_hi + 1] - b0).to(dev)
@@ -64,7 +64,7 @@ def call_contig(model, mpileup_text: bytes, contig: str, chr_seq: np.ndarray, mi
     else:
         rows = torch.zeros((0, 13), dtype=torch.float64, device=dev)
     if sharded:
-        backend_dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+        backend_dev = dev if tdist.get_backend() == "nccl" else "cpu"
         rows = gather_varlen(rows.to(backend_dev))
         if rank != 0:
             n_tot = torch.zeros(1, dtype=torch.int64, device=backend_dev)

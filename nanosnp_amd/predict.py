@@ -25,7 +25,7 @@ def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text,
     ctx = model.ctx
     table = host.ContigTable(list(contig_names))
     xt = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32))
-    xt = xt.to("cuda", torch.int32).contiguous()
+    xt = xt.to(torch.device("cuda", ctx.device), torch.int32).contiguous()          # the context's device, not torch's current one
     pos = np.asarray(positions, np.int64)
     refb = np.asarray(reference_bases, np.uint8)
     n = xt.shape[0]
@@ -66,11 +66,12 @@ def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions,
         narrow = all(a.dtype == np.int8 for a in planes[:4])
         return [np.dtype(np.int8 if narrow else np.int32)] * 4 + [np.dtype(np.int32)]
     tp, th = dtypes(planes_pileup), dtypes(planes_haplotype)
+    dev = torch.device("cuda", ctx.device)
     with open(output_file, "wb") as f:
         for b0 in range(0, n, batch_size):
             sl = slice(b0, b0 + batch_size)
-            dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).cuda() for a, t in zip(planes_pileup, tp)]
-            dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).cuda() for a, t in zip(planes_haplotype, th)]
+            dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_pileup, tp)]
+            dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_haplotype, th)]
             xp = ctx.hap_features(*dp)
             xh = ctx.hap_features(*dh)
             gt, _ = ctx.hap_forward(xp, xh)

@@ -124,7 +124,7 @@ def group_planes(ctx, rm, max_haplotype_depth, max_pileup_depth, pileup_flanking
     write_to_bins.py stores and nanosnp_amd.predict.predict_haplotype consumes (plus reference rows)."""
     import torch
     sl = group_slices(rm, pileup_flanking_size)
-    dev = "cuda"
+    dev = torch.device("cuda", ctx.device)
     full = [torch.from_numpy(a).to(dev) for a in (rm.seq, rm.baseq, rm.mapq, rm.hap)]
     outs = []
     for key, D in (("hap_cols", max_haplotype_depth), ("pile_cols", max_pileup_depth)):

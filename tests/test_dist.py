@@ -142,6 +142,8 @@ def test_bench_gpus2_spawns_two_ranks_and_relays_one_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["steps"] == 5 and d["selftest"] is True
     assert d["gather_ok"] is True and d["slowest_rank_bound_ok"] is True      # the time is the slowest rank's
+    # the ranks share the box's cores explicitly (torch.distributed.run would force OMP_NUM_THREADS=1 for nproc > 1)
+    assert d["omp_num_threads"] == str(max(1, d["usable_cores"] // 2))
 
 
 def test_bench_never_reports_fewer_ranks_than_asked_for():

@@ -104,6 +104,21 @@ def test_opener_dense_columns(gpu_ctx):
     assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
 
 
+def test_single_class_columns_at_the_8bit_counter_limit(gpu_ctx):
+    """columns of ONE symbol class starting on a 4-byte boundary: 256 equal bytes span exactly 64 words (the fast path's
+    word limit) but wrap an 8-bit class counter into its neighbour - they must take the exact path"""
+    from oracle import oracle
+    cols = [b"A" * 256, b"a" * 256, b"A" * 255 + b"C", b"*" * 256, b"#" * 252, b"T" * 254 + b"^]", b"g" * 253, b"G" * 256]
+    cols = [c + b"C" * ((-len(c)) % 4) if i < 4 else c for i, c in enumerate(cols)]          # the first four stay word-aligned
+    bases = np.frombuffer(b"".join(cols), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    ref = np.frombuffer(b"ACGTNacg", np.uint8).copy()
+    c, d, f = _enc(gpu_ctx, bases, off, ref)
+    oc, od, of = oracle.encode_columns(bases, off, ref)
+    assert np.array_equal(c.cpu().numpy(), oc), (c.cpu().numpy(), oc)
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
+
+
 def test_empty_call(gpu_ctx):
     import torch
     e8 = torch.zeros(1, dtype=torch.uint8, device="cuda")

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib
-from tests.helpers import seeded_cat_weights, synth_cat_groups
+from nanosnp_amd.fixtures import seeded_cat_weights, synth_cat_groups
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = _lib.Context(0)

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib
-from tests.helpers import load_pileup_weights
+from nanosnp_amd.fixtures import load_pileup_weights
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 prec = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5

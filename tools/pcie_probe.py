@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import ctypes as C
 import numpy as np, torch
 from nanosnp_amd import _lib, host
-from tests.helpers import load_pileup_weights
+from nanosnp_amd.fixtures import load_pileup_weights
 
 batch = 4096; S = 32; K = int(sys.argv[1]) if len(sys.argv) > 1 else 256; W = 16
 dev = torch.device("cuda", 0)

@@ -4,7 +4,8 @@ with every product evaluated as f16x3 (what the kernels do), with the two correc
 the h_lo term dropped, and in plain fp16.  DESIGN.md section 9."""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.helpers import load_pileup_weights, golden
+from nanosnp_amd.fixtures import load_pileup_weights
+from tests.helpers import golden
 w = load_pileup_weights()
 z = np.load(golden("pileup_fwd.npz"))
 x = z["x"].astype(np.float32)[:256]

@@ -40,7 +40,7 @@ def run(args, rank, world, local_rank):
         return 3
     from nanosnp_amd import _lib, host
     from nanosnp_amd.dist import gather_results, shard_range
-    from tests.helpers import load_pileup_weights, seeded_hap_weights
+    from nanosnp_amd.fixtures import load_pileup_weights, seeded_hap_weights
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":

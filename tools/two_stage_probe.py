@@ -15,7 +15,7 @@ import numpy as np, torch
 from nanosnp_amd import _lib, host, merge
 from nanosnp_amd.pileup_model import LSTMNetwork
 from nanosnp_amd.predict import predict_haplotype, COV_CHANNELS
-from tests.helpers import load_pileup_weights, seeded_hap_weights
+from nanosnp_amd.fixtures import load_pileup_weights, seeded_hap_weights
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 frac5 = float(sys.argv[2]) if len(sys.argv) > 2 else 0.15          # share of candidates sent to stage 5 at most
