@@ -36,25 +36,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "candidate SNP sites/sec (pileup encode + model fwd), 30x windows"
-
-# algorithmic work per site of the reference schedule
-ALG_FLOP_PER_SITE = {
-    "pileup_l0": 2 * 1_385_472,      # layer-0 BiLSTM, 33 steps x 2 directions (model.py:34-35)
-    "pileup_proj1": 2 * 2_162_688,   # layer-1 input GEMMs, 33 steps x 2 directions
-    "pileup_l1": 2 * 1_081_344,      # layer-1 recurrent GEMMs
-    "pileup_head": 2 * 1_645_056,    # output_proj + dense on 33 positions + 4 heads (model.py:37,67-72)
-}
-ALG_FLOP_PER_SITE["pileup_l1f"] = ALG_FLOP_PER_SITE["pileup_proj1"] + ALG_FLOP_PER_SITE["pileup_l1"]   # fused kernel
-ALG_FLOP_FORWARD = 2 * 6_274_560                                                                        # 12.55 MFLOP/site
-assert sum(v for k, v in ALG_FLOP_PER_SITE.items() if k != "pileup_l1f") == ALG_FLOP_FORWARD
-# what the kernels execute (exact reduced schedule: layer 1 only on the 17 steps per direction that reach position 16,
-# output_proj / dense / heads only at position 16 -- model.py:68; layer-0 K padded 18 -> 20 incl. the bias column)
-EXEC_FLOP_PER_SITE = {"pileup_l0": 2 * 33 * 256 * (20 + 64) * 2, "pileup_l1f": 2 * 17 * 256 * (128 + 64) * 2,
-                      "pileup_proj1": 2 * 17 * 256 * 128 * 2, "pileup_l1": 2 * 17 * 256 * 64 * 2,
-                      "pileup_head": (128 * 128 + 256 * 128 + 32 * 256) * 2}
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (the f16x3 path issues 3 fp16 MFMAs per fp32 product)
-PEAK_HBM_GBS = 8000.0
 N_POOL = 1 << 20
 
 
@@ -67,9 +48,15 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--windows", type=int, default=N_POOL, help="windows resident per GPU (BASELINE configs[1]: 1M)")
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workload", default="pileup", choices=["pileup", "two-stage"],
-                    help="pileup = BASELINE configs[1] (the metric's configuration); two-stage = configs[3]: stage 2 + stage 5 on a "
-                         "chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0")
+    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60"],
+                    help="pileup = BASELINE configs[1] (the metric's configuration); haplotype = configs[2]: haplotype features + "
+                         "HaplotypeModel fwd (+ the legacy crnn.py CatModel fwd) on 150 k G3 sites; two-stage = configs[3]: stage 2 + stage 5 "
+                         "on a chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0; deep60 = configs[4]: "
+                         "60x columns + D = 180 read planes + fp16-split conv weights")
+    ap.add_argument("--encode-group", type=int, default=8, help="batches encoded per column-encode launch (on the encode stream, into a "
+                    "ring of count buffers; the kernel is twice as efficient per byte at >= 1 M columns)")
+    ap.add_argument("--hap-sites", type=int, default=0, help="haplotype / deep60 workloads: sites resident per job (0 = the workload's default)")
+    ap.add_argument("--hap-batch", type=int, default=16384, help="haplotype / deep60 workloads: sites per step")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = runtime default of 4)")
     ap.add_argument("--precision", type=int, default=0, help="headline arithmetic of the PileupModel forward: 0 exact fp32 MFMA "
                     "(library default), 1 f16x3 split")
@@ -121,16 +108,7 @@ def launch_ranks(args):
     return 0
 
 
-def usable_cores():
-    """cores this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = max(1, min(n, int(math.ceil(int(q) / int(per)))))
-    except Exception:
-        pass
-    return n
+from tools.bench_common import usable_cores  # noqa: E402
 
 
 def selftest_launcher(args, rank, world):
@@ -172,6 +150,7 @@ def cpu_baseline(cols, batch, weights, target_s):
     """The oracle's cache-blocked arrangement of the reference algorithm (full reference schedule, AVX2) on this box's
     host cores, on a bounded sample of the same windows: column encode + forward."""
     from oracle import oracle
+    from tools.bench_common import host_cpu_name, reference_cpu
     cores = usable_cores()
 
     def run(n):
@@ -189,22 +168,14 @@ def cpu_baseline(cols, batch, weights, target_s):
     n = int(min(max(n0, n0 * target_s / max(t, 1e-6)), 1 << 19, cols.n_cols // 33))
     n = max(n0, (n // 64) * 64)
     t, t_enc = run(n)
-    cpu = ""
-    try:
-        for l in open("/proc/cpuinfo"):
-            if l.startswith("model name"):
-                cpu = l.split(":", 1)[1].strip(); break
-    except Exception:
-        pass
     out = {"value": n / t, "unit": "sites/s", "cores": cores, "kind": "port",
            "sample": f"{n} of the same synthetic windows: column encode (single thread, {t_enc:.1f} s) + full-schedule fp32 forward "
                      f"blocked for L1 with AVX2 FMA, OpenMP over {cores} threads ({t - t_enc:.1f} s); oracle/liboracle.so",
-           "host_cpu": cpu, "logical_cpus": os.cpu_count()}
-    ref = os.path.join(ROOT, "profiles", "r02_reference_cpu.json")
-    if os.path.exists(ref):                       # the reference itself, timed in the development container (cannot travel)
+           "host_cpu": host_cpu_name(), "logical_cpus": os.cpu_count()}
+    rj, fwd = reference_cpu("forward")               # the reference itself, timed in the development container (cannot travel)
+    if rj and fwd:
         try:
-            rj = json.load(open(ref))
-            f64 = next(r for r in rj["forward"] if r["batch"] == 64 and r["threads"] == rj["host"]["logical_cpus"])
+            f64 = next(r for r in fwd if r["batch"] == 64 and r["threads"] == rj["host"]["logical_cpus"])
             out["reference_in_dev_container"] = {
                 "value": f64["sites_per_s"], "unit": "sites/s", "cores": f64["threads"], "cpu": rj["host"]["cpu"],
                 "what": "the reference's own LSTMNetwork.predict on CPU torch, batch 64, 1,000 windows (BASELINE configs[0]); forward only; "
@@ -227,10 +198,6 @@ def main():
         sys.exit(2)
     if args.selftest_launcher:
         sys.exit(selftest_launcher(args, rank, world))
-    if args.workload == "two-stage":
-        from tools.two_stage_bench import run as run_two_stage
-        sys.exit(run_two_stage(args, rank, world, local_rank))
-
     if args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)      # must be set before HIP initialises
     # the host-side generator / CPU baseline use OpenMP: share the cores between the ranks of a node (launch_ranks passes the
@@ -238,7 +205,13 @@ def main():
     if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
         os.environ["OMP_NUM_THREADS"] = str(max(1, usable_cores() // world))
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, world))))
-    import numpy as np
+    if args.workload == "two-stage":
+        from tools.two_stage_bench import run as run_two_stage
+        sys.exit(run_two_stage(args, rank, world, local_rank))
+    if args.workload in ("haplotype", "deep60"):
+        from tools.hap_bench import run as run_hap
+        sys.exit(run_hap(args, rank, world, local_rank, deep60=args.workload == "deep60"))
+
     import torch
     import torch.distributed as dist
     if args.share_gpu:
@@ -249,9 +222,8 @@ def main():
     elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
         sys.exit(3)
-    from nanosnp_amd import _lib, host
     from nanosnp_amd.dist import gather_results, gather_results_abi
-    from nanosnp_amd.fixtures import load_pileup_weights
+    from tools.pileup_stage import PileupStage, pileup_rooflines
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -263,78 +235,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")       # where collective payloads live
 
-    batch, S = args.batch, max(1, args.streams)
-    n_windows = max(batch, (args.windows // batch) * batch)
-    n_batches = n_windows // batch
+    stage = PileupStage(local_rank, args.windows, batch=args.batch, streams=args.streams, coverage=args.coverage, seed=20260000 + rank,
+                        precision=args.precision, opts=args.opt, timing_streams=0 if args.no_kernel_timing else args.timing_streams,
+                        enc_group=args.encode_group)
+    batch, n_windows, n_batches = stage.batch, stage.n_windows, stage.n_batches
     W, K = max(0, args.warmup), max(1, args.steps)
     bps = max(1, -(-n_batches // K))                    # batches per step: K steps sweep the whole pool at least once
-    weights = load_pileup_weights()                      # the shipped ont_pileup weights (fixture)
-
-    # ---- synthetic pool, resident in HBM before the clock starts ---------------------------------
-    cols = host.synth_columns(20260000 + rank, n_windows * 33, coverage=args.coverage, window=33)
-    d_bases = torch.from_numpy(cols.bases).to(dev)
-    d_off = torch.from_numpy(cols.col_off).to(dev)
-    d_ref = torch.from_numpy(cols.ref).to(dev)
-    centers = (torch.arange(batch, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
-    mcols = batch * 33
-
-    lib = _lib.load()
-    ctxs, streams, bufs = [], [], []
-    timed_streams = 0 if args.no_kernel_timing else min(S, max(1, args.timing_streams))
-    for s in range(S):
-        ctx = _lib.Context(local_rank, chunk_sites=batch)
-        ctx.pileup_load_weights(weights)
-        ctx.enable_timing(s < timed_streams)
-        ctx.set_option("pileup_precision", args.precision)
-        for o in args.opt:
-            name, val = o.split("=")
-            ctx.set_option(name, int(val))
-        ctxs.append(ctx)
-        streams.append(torch.cuda.Stream(device=dev))
-        bufs.append(dict(
-            counts=torch.empty((mcols, 18), dtype=torch.int32, device=dev),
-            depth=torch.empty(mcols, dtype=torch.int32, device=dev),
-            flags=torch.empty(mcols, dtype=torch.uint8, device=dev)))
-    # results of every batch of the pool stay resident (24 fp32 + compact calls per site)
-    gt_all = torch.empty((n_windows, 21), dtype=torch.float32, device=dev)
-    zy_all = torch.empty((n_windows, 3), dtype=torch.float32, device=dev)
-    res = dict(ga=torch.empty(n_windows, dtype=torch.uint8, device=dev), za=torch.empty(n_windows, dtype=torch.uint8, device=dev),
-               gm=torch.empty(n_windows, dtype=torch.float32, device=dev), zm=torch.empty(n_windows, dtype=torch.float32, device=dev))
-
-    P = C.c_void_p
-
-    def make_launch(i, s=None):
-        """pre-built argument lists: one batch is three C-ABI calls"""
-        b = i % n_batches
-        s = i % S if s is None else s
-        c0 = b * mcols
-        st = P(streams[s].cuda_stream)
-        h = ctxs[s].handle
-        bf = bufs[s]
-        enc = (h, P(d_bases.data_ptr()), P(d_off.data_ptr() + 8 * c0), P(d_ref.data_ptr() + c0), mcols,
-               C.c_double(0.12), 6, P(bf["counts"].data_ptr()), P(bf["depth"].data_ptr()), P(bf["flags"].data_ptr()), st)
-        n0 = b * batch
-        gt_p, zy_p = P(gt_all.data_ptr() + 4 * 21 * n0), P(zy_all.data_ptr() + 4 * 3 * n0)
-        fwd = (h, P(bf["counts"].data_ptr()), P(centers.data_ptr()), batch, gt_p, zy_p, st)
-        post = (h, gt_p, zy_p, None, batch, P(res["ga"].data_ptr() + n0), P(res["za"].data_ptr() + n0),
-                P(res["gm"].data_ptr() + 4 * n0), P(res["zm"].data_ptr() + 4 * n0), None, st)
-        return enc, fwd, post
-
-    def run_batches(first, count, table):
-        for i in range(first, first + count):
-            enc, fwd, post = table[i]
-            rc = lib.nsnp_pileup_encode_columns(*enc)
-            rc = rc or lib.nsnp_pileup_forward_windows(*fwd)
-            rc = rc or lib.nsnp_pileup_postprocess(*post)
-            if rc:
-                _lib.check(rc, None, "bench step")
-
-    def sync_all():
-        for st in streams:
-            st.synchronize()
-        torch.cuda.synchronize(dev)
-
-    launches = [make_launch(i) for i in range((W + K) * bps)]
 
     def barrier():
         if world > 1:
@@ -344,37 +250,31 @@ def main():
 
     def merge_results():
         """final merge: compact per-site calls of this rank -> rank 0 (RCCL gather over xGMI)"""
-        compact = torch.stack([res["ga"][:n_done].float(), res["za"][:n_done].float(),
-                               res["gm"][:n_done], res["zm"][:n_done]], dim=1)
+        compact = stage.compact_calls(n_done)
         if args.gather == "rccl-abi":
-            return gather_results_abi(ctxs[0], compact, n_done * world)
+            return gather_results_abi(stage.ctxs[0], compact, n_done * world)
         return gather_results(compact.to(cdev), n_done * world) if world > 1 else compact
 
     def timed_pass():
         """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over ranks"""
-        run_batches(0, W * bps, launches)
-        sync_all()
+        stage.run(0, W * bps)
+        stage.sync()
         merge_results()                      # warm the merge path (first-use module loads) outside the clock
-        sync_all()
-        for ctx in ctxs:
-            ctx.read_timing()               # drop warm-up launches
-        barrier(); sync_all()
+        stage.sync()
+        stage.read_timing()                  # drop warm-up launches
+        barrier(); stage.sync()
         t0 = time.perf_counter()
-        run_batches(W * bps, K * bps, launches)
+        stage.run(W * bps, K * bps)
         t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (informational)
-        sync_all()
+        stage.sync()
         merged = merge_results()
-        sync_all(); barrier()
+        stage.sync(); barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        tot = {}
-        for ctx in ctxs:
-            for k, (ms, n) in ctx.read_timing().items():
-                a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
-        return dt, t_issue, merged, {k: v for k, v in tot.items() if v[1]}
+        return dt, t_issue, merged, stage.read_timing()
 
     extra = []
     for rep in range(max(0, args.repeat - 1)):      # informational repeats BEFORE the reported region
@@ -382,35 +282,24 @@ def main():
         extra.append(world * K * bps * batch / dt_r)
     dt, t_issue, merged, tot = timed_pass()
     sites_timed = world * K * bps * batch
-    fused = lambda prec: {"pileup_l1": "pileup_l1f"} if "pileup_proj1" not in tot else {}
 
     # the same kernels with the chip to themselves (one stream, after the timed region)
-    excl = {}
-    if timed_streams:
-        solo = [make_launch(i, 0) for i in range(36)]
-        run_batches(0, 4, solo); sync_all(); ctxs[0].read_timing()
-        run_batches(4, 32, solo); sync_all()
-        excl = {k: ms / n for k, (ms, n) in ctxs[0].read_timing().items() if n}
+    excl, excl_n = stage.exclusive_pass()
 
     # ---- second, labelled value: the opt-in f16x3 arithmetic on the same pool ----------------------
     second = None
     if not args.no_second_precision and args.precision == 0:
-        ref_gt = gt_all[:n_done].clone(); ref_zy = zy_all[:n_done].clone()
-        for ctx in ctxs:
-            ctx.set_option("pileup_precision", 1)
+        ref_gt = stage.gt_all[:n_done].clone(); ref_zy = stage.zy_all[:n_done].clone()
+        stage.set_precision(1)
         dt2, _, _, tot2 = timed_pass()
-        d = max((gt_all[:n_done] - ref_gt).abs().max().item(), (zy_all[:n_done] - ref_zy).abs().max().item())
+        d = max((stage.gt_all[:n_done] - ref_gt).abs().max().item(), (stage.zy_all[:n_done] - ref_zy).abs().max().item())
         second = {"value": sites_timed / dt2, "unit": "sites/s", "ms_per_step": dt2 / K * 1e3,
                   "dtype": "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)",
                   "max_abs_dp_vs_fp32_on_the_pool": d, "tolerance": 1e-4,
-                  "kernel_avg_ms": {("pileup_l1f" if k == "pileup_l1" else k): round(v[0] / v[1], 5) for k, v in sorted(tot2.items())}}
+                  "kernel_avg_ms_in_region": {k: round(v[0] / v[1], 5) for k, v in sorted(tot2.items())}}
         del ref_gt, ref_zy
 
     if rank == 0:
-        names = fused(args.precision)
-        tot = {names.get(k, k): v for k, v in tot.items()}
-        excl = {names.get(k, k): v for k, v in excl.items()}
-        avg_ms = {k: v[0] / v[1] for k, v in tot.items()}
         out = {
             "metric": METRIC, "value": sites_timed / dt, "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
@@ -419,67 +308,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: pileup encode + PileupModel fwd, 1M synthetic 30x windows (G2) resident in HBM, batch=4096",
                        "batch": batch, "windows_resident_per_gpu": n_windows, "batches_per_step": bps, "sites_per_step": bps * batch,
-                       "streams": S, "coverage": args.coverage, "precision": "fp32" if args.precision == 0 else "f16x3",
+                       "streams": stage.S, "encode_batches_per_launch": stage.G, "coverage": args.coverage,
+                       "precision": "fp32" if args.precision == 0 else "f16x3",
                        "weights": "ont_pileup.chkpt values (tests/golden fixture)",
                        "parallelism": f"site-sharded x{world}, rooted gather of calls",
                        "world_size_observed": dist.get_world_size() if world > 1 else 1, "gather": args.gather,
                        **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: not a scaling number"} if args.share_gpu else {})},
             "host_issue_ms_per_step": t_issue / K * 1e3,
         }
-        if avg_ms:
-            fwd_keys = [k for k in avg_ms if k in ALG_FLOP_PER_SITE]
-            dom = max(fwd_keys or list(avg_ms), key=lambda k: tot[k][0])               # dominant = most total time in the timed region
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else PEAK_F16_MFMA_TFLOPS
-            achieved = ALG_FLOP_PER_SITE[dom] * batch / (avg_ms[dom] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "avg_launch_ms": avg_ms[dom], "launches_timed": tot[dom][1],
-                    "algorithmic_flop_per_launch": ALG_FLOP_PER_SITE[dom] * batch,
-                    "executed": {"flop_per_launch": EXEC_FLOP_PER_SITE[dom] * batch * (3 if args.precision == 1 else 1),
-                                 "tflops": EXEC_FLOP_PER_SITE[dom] * batch * (3 if args.precision == 1 else 1) / (avg_ms[dom] * 1e-3) / 1e12,
-                                 "frac": EXEC_FLOP_PER_SITE[dom] * batch * (3 if args.precision == 1 else 1) / (avg_ms[dom] * 1e-3) / 1e12 / peak,
-                                 "note": "MFMA flops the kernel issues (reduced exact schedule: only position 16 is consumed, model.py:68); "
-                                         "achieved/frac above price the reference schedule's flops as SURVEY 8(d) prescribes, so frac can exceed "
-                                         "the executed fraction by the schedule reduction"},
-                    "concurrency": "avg_launch_ms is per launch inside the timed region, where launches of up to %d hardware queues (%d streams) "
-                                   "share the chip; `exclusive` = same kernel, one stream" % (args.hw_queues or 4, S),
-                    "traffic": None}
-            if dom in excl:
-                w_alg = ALG_FLOP_PER_SITE[dom] * batch / 1e12
-                roof["exclusive"] = {"avg_launch_ms": excl[dom], "achieved": w_alg / (excl[dom] * 1e-3), "frac": w_alg / (excl[dom] * 1e-3) / peak}
-            # chip-level view of the whole timed region: every forward flop of every site over the wall time
-            roof["chip"] = {"algorithmic_tflops": ALG_FLOP_FORWARD * (sites_timed / world) / dt / 1e12,
-                            "frac": ALG_FLOP_FORWARD * (sites_timed / world) / dt / 1e12 / peak,
-                            "executed_tflops": sum(EXEC_FLOP_PER_SITE[k] for k in fwd_keys) * (3 if args.precision == 1 else 1) * (sites_timed / world) / dt / 1e12,
-                            "note": "per GPU: forward flops of all timed sites / wall time of the timed region (encode, post-processing and the gather included in the time)"}
-            tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tp):                       # HBM bytes per launch from the committed PMC passes
-                try:
-                    tj = json.load(open(tp))
-                    if tj.get("batch") == batch and tj.get("precision", 1) == args.precision and dom in tj.get("kernels", {}):
-                        roof["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
-                except Exception:
-                    pass
-            out["roofline"] = roof
-            if "encode_columns" in avg_ms:               # the HBM-bound kernel of the path, priced the same way
-                nbytes = int(cols.col_off[mcols]) + mcols * (1 + 72)        # column bytes + ref + 18 int32 out
-                e = {"bound": "hbm", "kernel": "encode_columns", "achieved": nbytes / (avg_ms["encode_columns"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                     "unit": "GB/s", "avg_launch_ms": avg_ms["encode_columns"], "launches_timed": tot["encode_columns"][1],
-                     "algorithmic_bytes_per_launch": nbytes}
-                e["frac"] = e["achieved"] / PEAK_HBM_GBS
-                if "encode_columns" in excl:
-                    e["exclusive"] = {"avg_launch_ms": excl["encode_columns"], "achieved": nbytes / (excl["encode_columns"] * 1e-3) / 1e9,
-                                      "frac": nbytes / (excl["encode_columns"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
-                out["roofline_encode"] = e
-            out["kernel_avg_ms"] = {k: round(v, 5) for k, v in sorted(avg_ms.items())}
+        if tot:
+            out.update(pileup_rooflines(stage, tot, excl, excl_n, sites_timed / world, dt, args.precision, stage.G))
+            out.setdefault("roofline", None)
+            out["kernel_avg_ms_in_region"] = {k: round(v[0] / v[1], 5) for k, v in sorted(tot.items())}
             out["kernel_exclusive_ms"] = {k: round(v, 5) for k, v in sorted(excl.items())}
-            out["kernel_timing"] = {"streams_with_events": timed_streams, "launches_timed": {k: v[1] for k, v in sorted(tot.items())}}
+            out["kernel_timing"] = {"streams_with_events": stage.timed_streams, "launches_timed_in_region": {k: v[1] for k, v in sorted(tot.items())}}
         else:
             out["roofline"] = None
         if second:
             out["f16x3"] = second
         if extra:
             out["repeats_before"] = [round(v) for v in extra]
-        out["cpu_baseline"] = cpu_baseline(cols, batch, weights, args.cpu_seconds) if (not args.no_cpu_baseline and world == 1) else None
+        out["cpu_baseline"] = cpu_baseline(stage.cols, batch, stage.weights, args.cpu_seconds) if (not args.no_cpu_baseline and world == 1) else None
         assert merged is not None and merged.shape[0] == n_done * world
         print(json.dumps(out))
     if world > 1:

@@ -115,7 +115,10 @@ int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
  * HIP event pair recorded on the launch stream (up to 8192 launches per kernel between reads).
  * nsnp_ctx_read_timing waits for the recorded events, returns their summed duration and count
  * for kernel id (0 layer-0 recurrence, 1 layer-1 projection, 2 layer-1 recurrence, 3 heads,
- * 4 column encode, 5 haplotype features) and resets the counter.  Synchronous. */
+ * 4 column encode, 5 haplotype features) and resets the counter.  Ids 6-8 bracket a whole CHAIN of launches of one
+ * internal pass with one event pair each: 6 the fused LSTM step launches of a HaplotypeModel pass (83 launches of
+ * k_hap_gemm), 7 the convolution GEMM + pooling launches of a CatModel pass (12 + 4), 8 a whole CatModel pass;
+ * `launches` then counts passes.  Synchronous. */
 int nsnp_ctx_enable_timing(nsnp_ctx* ctx, int enable);
 int nsnp_ctx_read_timing(nsnp_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
 

@@ -131,7 +131,9 @@ class Context:
     def set_option(self, name, value):
         check(self.lib.nsnp_ctx_set_option(self.handle, name.encode(), int(value)), self.handle, f"nsnp_ctx_set_option({name})")
 
-    KERNELS = ("pileup_l0", "pileup_proj1", "pileup_l1", "pileup_head", "encode_columns", "hap_features")
+    # ids of nsnp_ctx_read_timing; the last three are ONE event pair around a chain of launches of a pass (include/nanosnp.h)
+    KERNELS = ("pileup_l0", "pileup_proj1", "pileup_l1", "pileup_head", "encode_columns", "hap_features",
+               "hap_lstm_chain", "cat_conv_chain", "cat_forward_pass")
 
     def enable_timing(self, enable=True):
         check(self.lib.nsnp_ctx_enable_timing(self.handle, int(bool(enable))), self.handle, "nsnp_ctx_enable_timing")

@@ -273,6 +273,39 @@ void pack_linear_h(float* img, const float* W)
 
 }  // namespace
 
+namespace {
+constexpr int64_t CAT_PASS = 4096;
+// workspace (floats): three rotating feature-map images, LSTM inputs / states / outputs
+struct CatWsLayout { size_t map_f, xp_f, seq_f, hb_f, c_f, cat_f, bytes; };
+CatWsLayout cat_ws_layout()
+{
+    const int64_t chunk = CAT_PASS; const size_t max_tiles = (size_t)(chunk / TS);
+    CatWsLayout w;
+    w.map_f = ((size_t)NSNP_CDIV(chunk * CAT_ROWS * CAT_L, TS) * 2 + 16) * TILE_F;   // 32 channels at full resolution = the largest map
+    w.xp_f = (size_t)CAT_L * max_tiles * 2 * TILE_F;
+    w.seq_f = (size_t)CAT_L * max_tiles * 16 * TILE_F;
+    w.hb_f = (size_t)CAT_L * max_tiles * 32 * TILE_F;
+    w.c_f = (size_t)2 * max_tiles * 16 * TILE_F;
+    w.cat_f = max_tiles * 32 * TILE_F;
+    w.bytes = (3 * w.map_f + w.xp_f + 2 * w.seq_f + 2 * w.hb_f + w.c_f + w.cat_f) * sizeof(float);
+    return w;
+}
+
+
+// (Re)allocates the workspace of one pass; synchronous, called from nsnp_cat_load_weights only
+int nsnp_cat_reserve(nsnp_ctx* ctx)
+{
+    const CatWsLayout w = cat_ws_layout();
+    if (ctx->cat_ws && ctx->cat_ws_bytes == w.bytes) return NSNP_OK;
+    NSNP_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->cat_ws) (void)hipFree(ctx->cat_ws);
+    ctx->cat_ws = nullptr; ctx->cat_ws_bytes = 0;
+    if (hipMalloc(&ctx->cat_ws, w.bytes) != hipSuccess) { ctx->cat_ws = nullptr; ctx->last_err = hipErrorOutOfMemory; return NSNP_ENOMEM; }
+    ctx->cat_ws_bytes = w.bytes;
+    return NSNP_OK;
+}
+}  // namespace
+
 extern "C" int nsnp_cat_load_weights(nsnp_ctx* ctx, const float* const* t, int n_tensors)
 {
     if (!ctx || !t) return NSNP_EINVAL;
@@ -394,7 +427,7 @@ extern "C" int nsnp_cat_load_weights(nsnp_ctx* ctx, const float* const* t, int n
     }
     for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) cw.pct[l][d] = LstmDir{cw.arena + o_pw[l][d], cw.arena + o_pb[l][d]};
     cw.pct_w = cw.arena + o_pcw; cw.pct_b = cw.arena + o_pcb; cw.out_w = cw.arena + o_ow; cw.out_b = cw.arena + o_ob;
-    return NSNP_OK;
+    return nsnp_cat_reserve(ctx);                        // the forward itself never allocates
 }
 
 namespace {
@@ -452,23 +485,12 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
     const CatWeightsDev& cw = *ctx->cw;
     hipStream_t s = (hipStream_t)stream;
     const ptrdiff_t wsh = F16 ? cw.arena16 - cw.arena : 0;      // weight images live at the same offsets in both arenas
-    const int64_t chunk = 4096;                                   // sites per pass
+    const int64_t chunk = CAT_PASS;                               // sites per pass
     const int max_tiles = (int)(chunk / TS);
-    // workspace (floats): three rotating feature-map images, LSTM inputs / states / outputs
-    const size_t map_f = ((size_t)NSNP_CDIV(chunk * CAT_ROWS * CAT_L, TS) * 2 + 16) * TILE_F;   // 32 channels at full resolution = the largest map
-    const size_t xp_f = (size_t)CAT_L * max_tiles * 2 * TILE_F;
-    const size_t seq_f = (size_t)CAT_L * max_tiles * 16 * TILE_F;
-    const size_t hb_f = (size_t)CAT_L * max_tiles * 32 * TILE_F;
-    const size_t c_f = (size_t)2 * max_tiles * 16 * TILE_F;
-    const size_t cat_f = (size_t)max_tiles * 32 * TILE_F;
-    const size_t need = (3 * map_f + xp_f + 2 * seq_f + 2 * hb_f + c_f + cat_f) * sizeof(float);
-    if (ctx->cat_ws_bytes < need) {
-        NSNP_HIP(ctx, hipStreamSynchronize(s));
-        if (ctx->cat_ws) (void)hipFree(ctx->cat_ws);
-        ctx->cat_ws = nullptr; ctx->cat_ws_bytes = 0;
-        NSNP_HIP(ctx, hipMalloc(&ctx->cat_ws, need));
-        ctx->cat_ws_bytes = need;
-    }
+    const CatWsLayout wl = cat_ws_layout();
+    if (!ctx->cat_ws || ctx->cat_ws_bytes < wl.bytes) return NSNP_ENOMEM;        // nsnp_cat_load_weights reserves it
+    const size_t map_f = wl.map_f, xp_f = wl.xp_f, seq_f = wl.seq_f, hb_f = wl.hb_f, c_f = wl.c_f;
+    (void)max_tiles;
     float* base = (float*)ctx->cat_ws;
     float* map[3] = {base, base + map_f, base + 2 * map_f};
     float* xp = base + 3 * map_f;
@@ -483,6 +505,7 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
         const float* a0 = g0 + n0 * CAT_ROWS * CAT_L * CAT_PLANES;
         const float* a1 = g1 + n0 * CAT_ROWS * CAT_L * CAT_PLANES;
         const size_t step_h = (size_t)n_tiles * 32 * TILE_F;
+        ScopedKernelTimer tm_all(ctx, NSNP_K_CAT, s);
 
         // ---- percentage branch: 3-layer BiLSTM on [11][n][20], Linear at column 5 -> cat chunks 0..15 ----
         hipLaunchKernelGGL(k_cat_percentage<F16>, dim3(grid_for((int64_t)CAT_L * n_tiles * TS * 4)), dim3(256), 0, s, a0, a1, n, n_tiles, xp);
@@ -497,6 +520,7 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
         int64_t n_ptiles = NSNP_CDIV(n_pix, (int64_t)TS);
         hipLaunchKernelGGL(k_cat_pack_pixels<F16>, dim3(grid_for(n_ptiles * TS * 16)), dim3(256), 0, s, a0, a1, n_pix, n_ptiles * TS, map[0]);
         int cur = 0;                                              // map[cur] holds the block input
+        ScopedKernelTimer tm_conv(ctx, NSNP_K_CATCONV, s);         // the 12 conv GEMM launches (+ 4 pools) of this pass
         for (int i = 0; i < 6; ++i) {
             const CatBlock& b = cw.blk[i];
             const int rt = NSNP_CDIV(b.cout, TR);
@@ -525,6 +549,7 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
                 cur = (cur + 1) % 3;
             }
         }
+        tm_conv.stop();
         if (Hc != 1) return NSNP_ESHAPE;                          // crnn.py:183 asserts the same
         // BidirectionalLSTM 0: all 11 columns, embedding on every column (crnn.py:12-20)
         run_bilstm<F16>(ctx, s, cw.rnn[0], wsh, seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);

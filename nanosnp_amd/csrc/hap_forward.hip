@@ -324,6 +324,7 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
         // tile at time t are contiguous (what the next layer and output_proj consume)
         const size_t tile_h = (size_t)16 * TILE_F;                 // one direction of one site tile at one step
         const size_t step_h = (size_t)n_tiles * 2 * tile_h;
+        ScopedKernelTimer tm_lstm(ctx, NSNP_K_HAPLSTM, s);         // one event pair around the 83 fused step launches of this pass
         for (int l = 0; l < 3; ++l) {
             // encoder e reads its layer input from (l == 0 ? xT[e] : hb[e][(l-1)&1]) and writes hb[e][l&1]
             const int steps[2] = {l == 2 ? Lp / 2 + 1 : Lp, l == 2 ? Lh / 2 + 1 : Lh};
@@ -359,6 +360,7 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                 else     hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, false>), dim3(n_tiles, 4 * H / TR, nz), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (4 * H / TR) * (nz), ctx->n_cu), s, L);
             }
         }
+        tm_lstm.stop();
         // output_proj at the centre step of the last layer (which wrote hb[e][0]), both encoders in one
         // launch -> cat image: 32 chunks per site tile = [proj_pileup(256) ; proj_haplotype(256)]
         {

@@ -84,7 +84,8 @@ ScopedKernelTimer::ScopedKernelTimer(nsnp_ctx* c, int kernel, hipStream_t stream
     stop_ev = t->stop[k][i];
     on = true;
 }
-ScopedKernelTimer::~ScopedKernelTimer() { if (on) (void)hipEventRecord(stop_ev, s); }
+void ScopedKernelTimer::stop() { if (on) { (void)hipEventRecord(stop_ev, s); on = false; } }
+ScopedKernelTimer::~ScopedKernelTimer() { stop(); }
 
 extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value)
 {

@@ -63,7 +63,10 @@ struct HapWeightsDev;   // hap_forward.hip
 struct CatWeightsDev;   // cat_forward.hip
 
 // optional per-kernel timing with HIP events on the launch stream (nsnp_ctx_enable_timing)
-enum { NSNP_K_L0 = 0, NSNP_K_PROJ1, NSNP_K_L1, NSNP_K_HEAD, NSNP_K_ENCODE, NSNP_K_HAPFEAT, NSNP_K_COUNT };
+// NSNP_K_HAPLSTM / NSNP_K_CATCONV / NSNP_K_CAT bracket a whole chain of launches of one pass with ONE event pair (the fused
+// LSTM step launches of a HaplotypeModel pass; the conv GEMM + pool launches of a CatModel pass; a whole CatModel pass)
+enum { NSNP_K_L0 = 0, NSNP_K_PROJ1, NSNP_K_L1, NSNP_K_HEAD, NSNP_K_ENCODE, NSNP_K_HAPFEAT, NSNP_K_HAPLSTM, NSNP_K_CATCONV, NSNP_K_CAT,
+       NSNP_K_COUNT };
 struct KernelTimer {
     std::vector<hipEvent_t> start[NSNP_K_COUNT], stop[NSNP_K_COUNT];
     size_t used[NSNP_K_COUNT];
@@ -113,6 +116,7 @@ struct nsnp_ctx {
 struct ScopedKernelTimer {
     nsnp_ctx* ctx; int k; hipStream_t s; hipEvent_t stop_ev; bool on;
     ScopedKernelTimer(nsnp_ctx* c, int kernel, hipStream_t stream);
+    void stop();                      // records the stop event now (the destructor does nothing afterwards)
     ~ScopedKernelTimer();
 };
 

@@ -10,7 +10,11 @@ Development container only (needs /root/reference; nothing here travels to the G
   * the reference's compiled DNA_CreateCanSnpTensor (oracle/_ref, -num_threads 1) on a G1 contig of
     200,000 columns: columns/s and candidate sites/s.
 
-Writes profiles/r02_reference_cpu.json (read by bench.py for the note beside `cpu_baseline`).
+  * (own interpreter: the two packages' module names collide) HaplotypeModel/model_dev.py LSTMNetwork.predict
+    (predict_dev.py:39) with seeded weights on 256 G3 sites, batch 64 and 256; dataset_dev.get_frequency_feature
+    per call at D = 90 / 180, L = 33; legacy model.CatModel.predict on 256 sites (BASELINE configs[2] / [4]).
+
+Writes profiles/r03_reference_cpu.json (read by bench.py for the note beside `cpu_baseline`).
 
     python tests/manual/time_reference_cpu.py
 """
@@ -121,9 +125,82 @@ def time_encode():
     return r
 
 
+def time_haplotype():
+    """runs in its own interpreter (python time_reference_cpu.py --haplotype): prints one JSON object"""
+    import torch
+    from nanosnp_amd import host
+    from nanosnp_amd.fixtures import (cat_weight_names, hap_weight_names, seeded_cat_weights, seeded_hap_weights,
+                                      synth_cat_groups)
+    from oracle import oracle
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    import dataset_dev                      # noqa: E402  (reference modules)
+    from model import CatModel              # noqa: E402
+    from model_dev import LSTMNetwork       # noqa: E402
+    from utils import AttrDict              # noqa: E402
+    ncpu = os.cpu_count() or 1
+    out = {"forward": [], "features": [], "cat": []}
+    cfg = AttrDict({"model": {"pileup_dim": 105, "haplotype_dim": 105, "pileup_length": 33, "haplotype_length": 11,
+                              "hidden_size": 256, "lstm_layers": 3, "gt_num_class": 10, "zy_num_class": 3, "dropout": 0.1}})
+    m = LSTMNetwork(cfg)
+    m.load_state_dict({k: torch.from_numpy(w) for k, w in zip(hap_weight_names(), seeded_hap_weights(12))}, strict=False)
+    m.eval()
+    n = 256
+    pp = host.synth_hap_planes(20260400, n, 30, 90, 33); ph = host.synth_hap_planes(20260500, n, 30, 90, 11)
+    xp = torch.from_numpy(oracle.hap_features_batch(*pp)); xh = torch.from_numpy(oracle.hap_features_batch(*ph))
+    for threads in (ncpu, 1):
+        torch.set_num_threads(threads)
+        for batch in (64, 256):
+            def run():
+                t0 = time.perf_counter()
+                for b0 in range(0, n, batch):
+                    with torch.no_grad():
+                        gt, zy = m.predict(xp[b0:b0 + batch].type(torch.FloatTensor), xh[b0:b0 + batch].type(torch.FloatTensor))   # predict_dev.py:35-39
+                    gt.detach().cpu().numpy()
+                return time.perf_counter() - t0
+            run()
+            med = statistics.median([run() for _ in range(3)])
+            out["forward"].append({"what": "model_dev.LSTMNetwork.predict (reference module, seeded weights, CPU torch %s)" % torch.__version__,
+                                   "sites": n, "batch": batch, "threads": threads, "median_s": med, "sites_per_s": n / med})
+            print(out["forward"][-1], file=sys.stderr)
+    for D in (90, 180):
+        pl = host.synth_hap_planes(7, 64, D / 3, D, 33)
+        def runf():
+            t0 = time.perf_counter()
+            for i in range(64):
+                dataset_dev.get_frequency_feature(pl[0][i], pl[1][i], pl[2][i], pl[3][i])      # dataset_dev.py:342
+            return (time.perf_counter() - t0) / 64
+        runf()
+        med = statistics.median([runf() for _ in range(3)])
+        out["features"].append({"what": "dataset_dev.get_frequency_feature (numpy, one call; two calls per site)", "D": D, "L": 33,
+                                "ms_per_call": med * 1e3, "sites_per_s_one_worker": 1.0 / (med * (1 + 11 / 33))})
+        print(out["features"][-1], file=sys.stderr)
+    cm = CatModel(nc0=5, nc1=5, nc2=2, nclass=10, nh=256)
+    cm.load_state_dict({k: torch.from_numpy(w) for k, w in zip(cat_weight_names(), seeded_cat_weights(21))}, strict=False)
+    cm.eval()
+    g0, g1 = synth_cat_groups(321, n)
+    g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
+    for threads in (ncpu, 1):
+        torch.set_num_threads(threads)
+        def runc():
+            t0 = time.perf_counter()
+            for b0 in range(0, n, 64):
+                with torch.no_grad():
+                    cm.predict(g0[b0:b0 + 64], g1[b0:b0 + 64], None, None).numpy()
+            return time.perf_counter() - t0
+        runc()
+        med = statistics.median([runc() for _ in range(3)])
+        out["cat"].append({"what": "model.CatModel.predict (reference module, seeded weights)", "sites": n, "batch": 64, "threads": threads,
+                           "median_s": med, "sites_per_s": n / med})
+        print(out["cat"][-1], file=sys.stderr)
+    print(json.dumps(out))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f"{REF} is not mounted: the reference can only be timed in the development container")
+    if "--haplotype" in sys.argv:
+        return time_haplotype()
     cpu = ""
     for l in open("/proc/cpuinfo"):
         if l.startswith("model name"):
@@ -133,7 +210,12 @@ def main():
         res["encode"] = time_encode()
     except Exception as e:                                        # the encode timing is secondary
         res["encode"] = {"error": repr(e)}
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json"), "w"), indent=1)
+    hp = subprocess.run([sys.executable, os.path.abspath(__file__), "--haplotype"], capture_output=True, text=True)
+    if hp.returncode == 0:
+        res["haplotype"] = json.loads(hp.stdout.strip().splitlines()[-1])
+    else:
+        res["haplotype"] = {"error": hp.stderr[-2000:]}
+    json.dump(res, open(os.path.join(ROOT, "profiles", "r03_reference_cpu.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

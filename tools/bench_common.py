@@ -1,0 +1,165 @@
+"""Shared pieces of the bench workloads (bench.py, tools/hap_bench.py, tools/two_stage_bench.py): chip peaks, roofline objects,
+the work-per-unit tables of DESIGN.md section 4, CPU-baseline helpers.
+
+Every fraction printed by a bench line is PHYSICAL: executed flops (or algorithmic bytes, which the HBM kernels move one to
+one) divided by a measured time and the chip peak, so it can never exceed 1.  The flop count of the reference's own schedule
+(12.55 MFLOP/site for the PileupModel, 353.7 MFLOP/site for the HaplotypeModel), which the kernels
+legitimately shorten (only the centre position is consumed: PileupModel/model.py:68, HaplotypeModel/model_dev.py:139-140),
+rides along as the labelled `achieved_algorithmic` and is never divided by the peak."""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak at 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (the f16x3 paths issue 3 fp16 MFMAs per fp32 product)
+PEAK_HBM_GBS = 8000.0
+
+# ---- PileupModel: work per site -----------------------------------------------------------------------------------
+# reference schedule
+PILEUP_ALG_FLOP = {
+    "pileup_l0": 2 * 1_385_472,      # layer-0 BiLSTM, 33 steps x 2 directions (model.py:34-35)
+    "pileup_proj1": 2 * 2_162_688,   # layer-1 input GEMMs, 33 steps x 2 directions
+    "pileup_l1": 2 * 1_081_344,      # layer-1 recurrent GEMMs
+    "pileup_head": 2 * 1_645_056,    # output_proj + dense on 33 positions + 4 heads (model.py:37,67-72)
+}
+PILEUP_ALG_FLOP["pileup_l1f"] = PILEUP_ALG_FLOP["pileup_proj1"] + PILEUP_ALG_FLOP["pileup_l1"]   # fused kernel
+PILEUP_ALG_FLOP_FORWARD = 2 * 6_274_560                                                           # 12.55 MFLOP/site
+assert sum(v for k, v in PILEUP_ALG_FLOP.items() if k != "pileup_l1f") == PILEUP_ALG_FLOP_FORWARD
+# what the kernels execute (exact reduced schedule: layer 1 only on the 17 steps per direction that reach position 16,
+# output_proj / dense / heads only at position 16 -- model.py:68; layer-0 K padded 18 -> 20 incl. the bias column)
+PILEUP_EXEC_FLOP = {"pileup_l0": 2 * 33 * 256 * (20 + 64) * 2, "pileup_l1f": 2 * 17 * 256 * (128 + 64) * 2,
+                    "pileup_proj1": 2 * 17 * 256 * 128 * 2, "pileup_l1": 2 * 17 * 256 * 64 * 2,
+                    "pileup_head": (128 * 128 + 256 * 128 + 32 * 256) * 2}
+PILEUP_EXEC_FLOP_FORWARD = PILEUP_EXEC_FLOP["pileup_l0"] + PILEUP_EXEC_FLOP["pileup_l1f"] + PILEUP_EXEC_FLOP["pileup_head"]
+
+# ---- HaplotypeModel (model_dev.LSTMNetwork, H = 256, F = 105, 3 layers, L = 33 / 11) ---------------------------------
+HAP_ALG_FLOP = 353.7e6             # 176.8 M MAC per site as the reference computes it
+
+
+def hap_exec_flop(F=105, H=256, Lp=33, Lh=11):
+    """MFMA flops the fused step launches execute per site: K padded to 16-wide chunks (F = 105 -> 112), all steps in
+    layers 0 / 1, only the steps that reach the centre position in layer 2 (17 of 33, 6 of 11), two directions."""
+    kin0 = 16 * math.ceil(F / 16)
+    per_step = lambda kin: 2 * (4 * H) * (kin + H) * 2          # two directions, flop = 2 MAC
+    chain = lambda L: L * per_step(kin0) + L * per_step(2 * H) + (L // 2 + 1) * per_step(2 * H)
+    return chain(Lp) + chain(Lh)
+
+
+def hap_lstm_launches(Lp=33, Lh=11):
+    """fused step launches per pass (both encoders share a launch while the short one is still running)"""
+    return Lp + Lp + (Lp // 2 + 1)
+
+
+# ---- legacy CatModel (model.CatModel: ResCRNN + percentage RNN) ----------------------------------------------------
+CAT_CH = (10, 32, 64, 128, 128, 256, 256)
+CAT_POOL = (2, 2, 0, 3, 0, 2)          # max-pool height after block i (crnn.py:118-190), 0 = none
+
+
+def cat_conv_exec_flop(rows=40, L=11):
+    """flops of the 12 implicit-GEMM convolution launches per site as executed: K = 9 x C_in padded to 16-channel chunks
+    (+ the 1x1 shortcut as extra K chunks of the second conv), output rows padded to the 32-row MFMA tile."""
+    pad16 = lambda c: 16 * math.ceil(c / 16)
+    pad32 = lambda c: 32 * math.ceil(c / 32)
+    total, h = 0, rows
+    for i in range(6):
+        cin, cout = CAT_CH[i], CAT_CH[i + 1]
+        pix = h * L
+        total += 2 * pix * pad32(cout) * 9 * pad16(cin)                       # conv1
+        total += 2 * pix * pad32(cout) * (9 * pad16(cout) + pad16(cin))       # conv2 + shortcut
+        if CAT_POOL[i]:
+            h = (h - CAT_POOL[i]) // CAT_POOL[i] + 1
+    return total
+
+
+def cat_conv_alg_flop(rows=40, L=11):
+    """the same convolutions as the reference computes them (no padding of K or rows): crnn.py:92-117"""
+    total, h = 0, rows
+    for i in range(6):
+        cin, cout = CAT_CH[i], CAT_CH[i + 1]
+        pix = h * L
+        total += 2 * pix * cout * (9 * cin + 9 * cout + cin)
+        if CAT_POOL[i]:
+            h = (h - CAT_POOL[i]) // CAT_POOL[i] + 1
+    return total
+
+
+def usable_cores():
+    """cores this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(math.ceil(int(q) / int(per)))))
+    except Exception:
+        pass
+    return n
+
+
+def host_cpu_name():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return ""
+
+
+def roofline_mfma(kernel, exec_flop_per_launch, avg_launch_ms, launches, *, alg_flop_per_launch=None, peak=PEAK_F32_MFMA_TFLOPS,
+                  traffic=None, how="", **extra):
+    """`achieved` = flops the kernel EXECUTES per launch / its average launch duration; frac = achieved / peak <= 1."""
+    ach = exec_flop_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+         "avg_launch_ms": avg_launch_ms, "launches_timed": launches, "executed_flop_per_launch": exec_flop_per_launch, "traffic": traffic}
+    if alg_flop_per_launch is not None:
+        r["achieved_algorithmic"] = {"tflops": alg_flop_per_launch / (avg_launch_ms * 1e-3) / 1e12, "flop_per_launch": alg_flop_per_launch,
+                                     "note": "flops of the reference's own schedule (SURVEY.md 8(d)) over the same time; the kernels execute the "
+                                             "exact reduced schedule (only the centre position is consumed), so this figure is NOT a fraction "
+                                             "of the chip peak and may exceed it"}
+    if how:
+        r["measured"] = how
+    r.update(extra)
+    return r
+
+
+def roofline_hbm(kernel, bytes_per_launch, avg_launch_ms, launches, *, traffic=None, how="", **extra):
+    ach = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+         "avg_launch_ms": avg_launch_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": traffic}
+    if how:
+        r["measured"] = how
+    r.update(extra)
+    return r
+
+
+def committed_traffic(workload, kernel, **match):
+    """HBM bytes per launch from the committed PMC passes (profiles/roofline_traffic.json: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, KiB units, FETCH x2 gfx950 correction), or None when no pass matches this configuration."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
+        w = tj.get("workloads", {}).get(workload)
+        if w is None and workload == "pileup" and "kernels" in tj:          # round-2 layout
+            w = tj
+        if not w or any(w.get(k) != v for k, v in match.items()) or kernel not in w.get("kernels", {}):
+            return None
+        return w["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def reference_cpu(section):
+    """the reference ITSELF timed on CPU in the development container (tests/manual/time_reference_cpu.py; it cannot travel
+    to the GPU box): profiles/r03_reference_cpu.json, falling back to the round-2 file"""
+    for name in ("r03_reference_cpu.json", "r02_reference_cpu.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                j = json.load(open(p))
+                return j, j.get(section) if section in j else (j.get("haplotype", {}) or {}).get(section)
+            except Exception:
+                pass
+    return None, None

@@ -1,0 +1,196 @@
+"""The pileup stage of the bench workloads: a pool of stand-alone 33-column windows (generator G2) resident in HBM,
+processed in batches through the hot path of PileupModel/predict.py:44-65 --
+
+    column encode (mpileup bytes -> int32 [M,18] counts)  ->  PileupModel forward reading the windows in place  ->  argmax / max
+
+Used by bench.py (BASELINE configs[1]), tools/two_stage_bench.py (configs[3], stage 2) and tools/hap_bench.py (configs[4], the 60x
+stage).  Scheduling: the column encode is twice as efficient per byte at >= 1 M columns than at the 135 k columns of one 4096-window
+batch (launch ramp + tail), and the forward only needs `counts`, so the encode runs on ITS OWN stream, `enc_group` consecutive
+batches per launch, into a ring of count buffers; the forward + post-processing of each batch follow on one of `streams` streams
+(one nsnp_ctx each) behind the group's encode event.  Every batch issued by run() is encoded by a launch issued by the same run()
+call (no encode work is carried into or out of a timed region).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+
+class PileupStage:
+    def __init__(self, local_rank, n_windows, batch=4096, streams=32, coverage=30.0, seed=20260000, precision=0, opts=(),
+                 timing_streams=16, enc_group=8, ring=3, weights=None):
+        import torch
+        from nanosnp_amd import _lib, host
+        from nanosnp_amd.fixtures import load_pileup_weights
+        self.torch, self._lib = torch, _lib
+        self.lib = _lib.load()
+        self.dev = torch.device("cuda", local_rank)
+        self.batch, self.S = int(batch), max(1, int(streams))
+        self.n_windows = max(self.batch, (int(n_windows) // self.batch) * self.batch)
+        self.n_batches = self.n_windows // self.batch
+        self.G = max(1, math.gcd(self.n_batches, max(1, int(enc_group))))       # groups never straddle the pool's wrap-around
+        self.R = max(2, int(ring))
+        self.coverage = coverage
+        self.weights = weights if weights is not None else load_pileup_weights()   # the shipped ont_pileup weights (fixture)
+        self.mcols = self.batch * 33
+        dev = self.dev
+        # ---- synthetic pool, resident in HBM ----
+        self.cols = host.synth_columns(seed, self.n_windows * 33, coverage=coverage, window=33)
+        self.d_bases = torch.from_numpy(self.cols.bases).to(dev)
+        self.d_off = torch.from_numpy(self.cols.col_off).to(dev)
+        self.d_ref = torch.from_numpy(self.cols.ref).to(dev)
+        self.centers = (torch.arange(self.batch, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
+        # ---- contexts: one per forward stream + one for the encode stream ----
+        self.timed_streams = min(self.S, max(0, int(timing_streams)))
+        self.ctxs, self.streams = [], []
+        for s in range(self.S):
+            ctx = _lib.Context(local_rank, chunk_sites=self.batch)
+            ctx.pileup_load_weights(self.weights)
+            ctx.enable_timing(s < self.timed_streams)
+            ctx.set_option("pileup_precision", precision)
+            for o in opts:
+                name, val = o.split("=")
+                ctx.set_option(name, int(val))
+            self.ctxs.append(ctx)
+            self.streams.append(torch.cuda.Stream(device=dev))
+        self.enc_ctx = _lib.Context(local_rank)
+        self.enc_ctx.enable_timing(self.timed_streams > 0)
+        self.enc_stream = torch.cuda.Stream(device=dev)
+        gm = self.G * self.mcols
+        self.ring = [dict(counts=torch.empty((gm, 18), dtype=torch.int32, device=dev),
+                          depth=torch.empty(gm, dtype=torch.int32, device=dev),
+                          flags=torch.empty(gm, dtype=torch.uint8, device=dev),
+                          enc_done=torch.cuda.Event(), users=[]) for _ in range(self.R)]
+        self.gseq = 0
+        # results of every batch of the pool stay resident (24 fp32 + compact calls per site)
+        n = self.n_windows
+        self.gt_all = torch.empty((n, 21), dtype=torch.float32, device=dev)
+        self.zy_all = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        self.res = dict(ga=torch.empty(n, dtype=torch.uint8, device=dev), za=torch.empty(n, dtype=torch.uint8, device=dev),
+                        gm=torch.empty(n, dtype=torch.float32, device=dev), zm=torch.empty(n, dtype=torch.float32, device=dev))
+        self._ev_pool = []
+
+    # ---- scheduling -----------------------------------------------------------------------------------------------
+    def set_precision(self, precision):
+        for ctx in self.ctxs:
+            ctx.set_option("pileup_precision", precision)
+
+    def _event(self):
+        return self._ev_pool.pop() if self._ev_pool else self.torch.cuda.Event()
+
+    def run(self, first, count, single_stream=False):
+        """issues batches first .. first + count - 1 of the endless batch sequence (batch i = pool batch i mod n_batches)"""
+        P, lib, check = C.c_void_p, self.lib, self._lib.check
+        i, end = first, first + count
+        while i < end:
+            b = i % self.n_batches
+            g = min(self.G - (b % self.G), end - i)                          # up to G consecutive pool batches, cut at a group boundary
+            slot = self.ring[self.gseq % self.R]; self.gseq += 1
+            es = self.enc_stream
+            for ev in slot["users"]:                                         # the forwards that last read this ring slot
+                es.wait_event(ev)
+                self._ev_pool.append(ev)
+            slot["users"] = []
+            c0 = b * self.mcols
+            rc = lib.nsnp_pileup_encode_columns(self.enc_ctx.handle, P(self.d_bases.data_ptr()), P(self.d_off.data_ptr() + 8 * c0),
+                                                P(self.d_ref.data_ptr() + c0), g * self.mcols, C.c_double(0.12), 6,
+                                                P(slot["counts"].data_ptr()), P(slot["depth"].data_ptr()), P(slot["flags"].data_ptr()),
+                                                P(es.cuda_stream))
+            if rc:
+                check(rc, self.enc_ctx.handle, "encode")
+            slot["enc_done"].record(es)
+            for j in range(g):
+                s = 0 if single_stream else (i + j) % self.S
+                st = self.streams[s]
+                st.wait_event(slot["enc_done"])
+                h, sp = self.ctxs[s].handle, P(st.cuda_stream)
+                n0 = (b + j) * self.batch
+                gt_p, zy_p = P(self.gt_all.data_ptr() + 84 * n0), P(self.zy_all.data_ptr() + 12 * n0)
+                rc = lib.nsnp_pileup_forward_windows(h, P(slot["counts"].data_ptr() + 72 * j * self.mcols), P(self.centers.data_ptr()),
+                                                     self.batch, gt_p, zy_p, sp)
+                rc = rc or lib.nsnp_pileup_postprocess(h, gt_p, zy_p, None, self.batch, P(self.res["ga"].data_ptr() + n0),
+                                                       P(self.res["za"].data_ptr() + n0), P(self.res["gm"].data_ptr() + 4 * n0),
+                                                       P(self.res["zm"].data_ptr() + 4 * n0), None, sp)
+                if rc:
+                    check(rc, h, "forward / postprocess")
+                ev = self._event(); ev.record(st); slot["users"].append(ev)
+            i += g
+
+    def sync(self):
+        self.enc_stream.synchronize()
+        for st in self.streams:
+            st.synchronize()
+        self.torch.cuda.synchronize(self.dev)
+
+    # ---- timing ---------------------------------------------------------------------------------------------------
+    def read_timing(self):
+        """{kernel: [total_ms, launches]} of the launches recorded since the last read (forward kernels: the timed streams; encode:
+        every launch).  The fused layer-1 kernel is reported as pileup_l1f."""
+        tot = {}
+        for ctx in self.ctxs[:self.timed_streams] + [self.enc_ctx]:
+            for k, (ms, n) in ctx.read_timing().items():
+                if n:
+                    a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+        if "pileup_proj1" not in tot and "pileup_l1" in tot:
+            tot["pileup_l1f"] = tot.pop("pileup_l1")
+        return tot
+
+    def exclusive_pass(self, groups=4):
+        """the same launches with the chip to themselves: everything on one forward stream behind the encode stream, `groups`
+        encode launches of enc_group batches each after one untimed group -> {kernel: avg ms per launch}, launches"""
+        if not self.timed_streams:
+            return {}, {}
+        self.sync(); self.read_timing()
+        self.run(0, self.G, single_stream=True); self.sync(); self.read_timing()
+        for k in range(groups):                      # one group at a time: no encode runs beside a forward
+            self.run(k * self.G, self.G, single_stream=True); self.sync()
+        tot = self.read_timing()
+        return {k: v[0] / v[1] for k, v in tot.items()}, {k: v[1] for k, v in tot.items()}
+
+    def encode_bytes(self, n_batches_in_launch):
+        """algorithmic bytes of one encode launch over the first batches of the pool: column bytes + ref + 18 int32 out"""
+        m = n_batches_in_launch * self.mcols
+        return int(self.cols.col_off[m]) + m * (1 + 72)
+
+    def compact_calls(self, n_done):
+        t = self.torch
+        return t.stack([self.res["ga"][:n_done].float(), self.res["za"][:n_done].float(), self.res["gm"][:n_done], self.res["zm"][:n_done]], dim=1)
+
+
+def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc_group):
+    """roofline objects of the pileup stage.  Headline = the dominant forward kernel (most total time in the timed region) priced
+    on its EXCLUSIVE launches (one stream, nothing else on the chip; the duration a rocprofv3 kernel trace shows for the same
+    launches): executed flops per launch / average launch duration / peak.  `chip` = executed forward flops of all timed sites
+    over the wall time of the timed region (encode, post-processing and the gather included in the time)."""
+    from tools import bench_common as bc
+    batch = stage.batch
+    mult = 3 if precision == 1 else 1                  # f16x3: three fp16 MFMAs per fp32 product
+    peak = bc.PEAK_F32_MFMA_TFLOPS if precision == 0 else bc.PEAK_F16_MFMA_TFLOPS
+    fwd_keys = [k for k in tot if k in bc.PILEUP_EXEC_FLOP]
+    out = {}
+    if fwd_keys:
+        dom = max(fwd_keys, key=lambda k: tot[k][0])
+        if dom in excl:
+            how = ("HIP events around every launch of the kernel, one stream, nothing else running (after the timed region; %d launches)"
+                   % excl_n[dom])
+            roof = bc.roofline_mfma(dom, bc.PILEUP_EXEC_FLOP[dom] * batch * mult, excl[dom], excl_n[dom],
+                                    alg_flop_per_launch=bc.PILEUP_ALG_FLOP[dom] * batch, peak=peak, how=how,
+                                    traffic=bc.committed_traffic("pileup", dom, batch=batch, precision=precision))
+            fwd_exec = sum(bc.PILEUP_EXEC_FLOP[k] for k in fwd_keys) * mult
+            chip = fwd_exec * sites_per_gpu / dt / 1e12
+            roof["chip"] = {"achieved": chip, "frac": chip / peak, "unit": "TFLOP/s",
+                            "achieved_algorithmic_tflops": bc.PILEUP_ALG_FLOP_FORWARD * sites_per_gpu / dt / 1e12,
+                            "note": "per GPU: executed forward flops of all timed sites / wall time of the timed region (encode, post-processing "
+                                    "and the gather included in the time); the algorithmic figure prices the reference's 12.55 MFLOP/site and is not a fraction"}
+            roof["in_region_avg_launch_ms"] = tot[dom][0] / tot[dom][1]
+            roof["in_region_note"] = ("in the timed region launches of several streams share the chip, so their durations overlap and are not "
+                                      "additive; no fraction is derived from them")
+            out["roofline"] = roof
+    if "encode_columns" in excl:
+        nbytes = stage.encode_bytes(enc_group)
+        e = bc.roofline_hbm("encode_columns", nbytes, excl["encode_columns"], excl_n["encode_columns"],
+                            traffic=bc.committed_traffic("pileup", "encode_columns", batch=batch, enc_group=enc_group),
+                            how="HIP events around every launch, nothing else running; one launch encodes %d batches = %d columns"
+                                % (enc_group, enc_group * stage.mcols), batches_per_launch=enc_group, columns_per_launch=enc_group * stage.mcols)
+        out["roofline_encode"] = e
+    return out

@@ -3,14 +3,17 @@
 sites sharded across the GPUs, RCCL gather" (run_caller.sh:109-136).
 
     stage 2  1,500,000 candidate windows (chr20: 64.4 Mbp x 2.36 % candidates): column encode + PileupModel
-             forward (exact fp32) + argmax/max, batches of 4096 windows
-    stage 5    150,000 low-confidence sites (10 % of stage 2; the reference gives no ratio): read planes (generator G3, int8,
-             resident in HBM) -> haplotype features -> HaplotypeModel forward (exact fp32) -> argmax/max, batches of 4096 sites
-    merge    compact per-site calls of both stages gathered to rank 0 in site order (one rooted collective each)
+             forward (exact fp32) + argmax/max, batches of 4096 windows (tools/pileup_stage.py: encode of 8 batches per launch on its
+             own stream, forwards on 32 streams)
+    stage 5    150,000 low-confidence sites (10 % of stage 2; the reference gives no ratio): the reference's int32 read planes
+             (generator G3) resident in HBM -> haplotype features -> HaplotypeModel forward (exact fp32) -> argmax/max, passes of
+             16384 sites (tools/hap_bench.py HapStage)
+    merge    compact per-site calls of both stages gathered to rank 0 in site order (one rooted transfer batch each)
 
-The TOTAL work is fixed and statically sharded by nanosnp_amd.dist.shard_range (strong scaling); a *step* is one sweep of a
-rank's shard of both stages.  Text output (pileup.vcf / haplotype.csv / merged VCF) is host work outside the metric
-(SURVEY.md 8(d)): tests/test_gpu_two_stage.py covers it against the reference, tools/two_stage_probe.py times it.
+The TOTAL work is fixed and statically sharded by nanosnp_amd.dist.shard_range (strong scaling; a rank's stage-2 shard is cut to
+whole batches of 4096 windows, the line reports the windows actually processed); a *step* is one sweep of a rank's shard of
+both stages.  Text output (pileup.vcf / haplotype.csv / merged VCF) is host work outside the metric:
+tests/test_gpu_two_stage.py covers it against the reference, tools/two_stage_probe.py times it.
 HaplotypeModel weights are seeded (the trained ones are absent upstream)."""
 from __future__ import annotations
 
@@ -27,7 +30,6 @@ N_STAGE5 = 150_000
 
 
 def run(args, rank, world, local_rank):
-    import numpy as np
     import torch
     import torch.distributed as dist
     if args.share_gpu:
@@ -38,9 +40,10 @@ def run(args, rank, world, local_rank):
     elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
         return 3
-    from nanosnp_amd import _lib, host
-    from nanosnp_amd.dist import gather_results, shard_range
-    from nanosnp_amd.fixtures import load_pileup_weights, seeded_hap_weights
+    from nanosnp_amd.dist import gather_results, gather_varlen, shard_range
+    from tools import bench_common as bc
+    from tools.hap_bench import HapStage, cpu_baseline_hap, hap_rooflines
+    from tools.pileup_stage import PileupStage, pileup_rooflines
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -52,63 +55,31 @@ def run(args, rank, world, local_rank):
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     batch = args.batch
     n2_tot = int(os.environ.get("NSNP_TWO_STAGE_N2", N_STAGE2)); n5_tot = int(os.environ.get("NSNP_TWO_STAGE_N5", N_STAGE5))
-    lo2, hi2 = shard_range(n2_tot, rank, world); n2 = hi2 - lo2
+    lo2, hi2 = shard_range(n2_tot, rank, world)
     lo5, hi5 = shard_range(n5_tot, rank, world); n5 = hi5 - lo5
 
     # ---- inputs of this rank's shard, resident in HBM before the clock starts ----
-    cols = host.synth_columns(20260300 + rank, max(n2, 1) * 33, coverage=args.coverage, window=33)
-    d_bases = torch.from_numpy(cols.bases).to(dev); d_off = torch.from_numpy(cols.col_off).to(dev); d_ref = torch.from_numpy(cols.ref).to(dev)
-    planes = []
-    for L, seed in ((33, 20260400), (11, 20260500)):
-        ps = [[], [], [], [], []]
-        for c0 in range(0, max(n5, 1), 16384):                      # generated in chunks: the int32 planes of 150k sites would be 2 x 9.5 GB of host memory
-            pl = host.synth_hap_planes(seed + 97 * rank + c0, min(16384, max(n5, 1) - c0), 30, 90, L)
-            for k in range(4):
-                ps[k].append(torch.from_numpy(pl[k].astype(np.int8)).to(dev))
-            ps[4].append(torch.from_numpy(pl[4]).to(dev))
-        planes.append([torch.cat(p) for p in ps])
-    S = max(1, min(args.streams, 8))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    w_pile = load_pileup_weights(); w_hap = seeded_hap_weights(12, H=256)
-    ctxs = []
-    for s in range(S):
-        c = _lib.Context(local_rank, chunk_sites=batch)
-        c.pileup_load_weights(w_pile); c.hap_load_weights(w_hap)
-        ctxs.append(c)
-    centers = (torch.arange(batch, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
-    res2 = torch.empty((max(n2, 1), 4), dtype=torch.float32, device=dev)
-    res5 = torch.empty((max(n5, 1), 2), dtype=torch.float32, device=dev)
+    ps = PileupStage(local_rank, max(hi2 - lo2, batch), batch=batch, streams=args.streams, coverage=args.coverage, seed=20260300 + rank,
+                     enc_group=args.encode_group)
+    n2 = ps.n_windows                                       # whole batches
+    hs = HapStage(local_rank, max(n5, 1), min(args.hap_batch, max(n5, 1)), 30.0, 90, 20260400 + 1000 * rank)
 
     def stage2():
-        for i, b0 in enumerate(range(0, n2, batch)):
-            b1 = min(n2, b0 + batch); s = i % S
-            with torch.cuda.stream(streams[s]):
-                c0, c1 = b0 * 33, b1 * 33
-                base0 = int(cols.col_off[c0])
-                counts, depth, flags = ctxs[s].pileup_encode_columns(d_bases[base0:], d_off[c0:c1 + 1] - base0, d_ref[c0:c1], stream=streams[s])
-                gt, zy = ctxs[s].pileup_forward_windows(counts, centers[:b1 - b0], stream=streams[s])
-                ga, za, gm, zm, _ = ctxs[s].pileup_postprocess(gt, zy, stream=streams[s])
-                res2[b0:b1] = torch.stack([ga.float(), za.float(), gm, zm], 1)
+        ps.run(0, ps.n_batches)
 
     def stage5():
-        for i, b0 in enumerate(range(0, n5, batch)):
-            b1 = min(n5, b0 + batch); s = i % S
-            with torch.cuda.stream(streams[s]):
-                xp = ctxs[s].hap_features(*[p[b0:b1] for p in planes[0]], stream=streams[s])
-                xh = ctxs[s].hap_features(*[p[b0:b1] for p in planes[1]], stream=streams[s])
-                gt, _ = ctxs[s].hap_forward(xp, xh, stream=streams[s])
-                gm, ga = gt.max(dim=1)
-                res5[b0:b1] = torch.stack([ga.float(), gm], 1)
+        for i in range(hs.n_batches):
+            hs.run_batch(i)
 
     def sync_all():
-        for st in streams:
-            st.synchronize()
+        ps.sync(); hs.sync()
         torch.cuda.synchronize(dev)
 
     def merge():
-        a = gather_results(res2[:n2].to(cdev), n2_tot) if world > 1 else res2[:n2]
-        b = gather_results(res5[:n5].to(cdev), n5_tot) if world > 1 else res5[:n5]
-        return a, b
+        a = ps.compact_calls(n2)
+        if world == 1:
+            return a, hs.res
+        return gather_varlen(a.to(cdev)), gather_results(hs.res[:n5].to(cdev), n5_tot)
 
     def barrier():
         if world > 1:
@@ -116,37 +87,102 @@ def run(args, rank, world, local_rank):
 
     W, K = max(1, args.warmup), max(1, args.steps)
     for _ in range(W):
-        stage2(); stage5(); sync_all(); merge(); sync_all()
+        stage2(); sync_all(); stage5(); sync_all(); merge(); sync_all()
+    ps.read_timing(); hs.ctx.read_timing()
     barrier(); sync_all()
     t0 = time.perf_counter()
     t2 = t5 = 0.0
+    hs.sites_in_chain = 0
     for _ in range(K):
         ta = time.perf_counter(); stage2(); sync_all()
         tb = time.perf_counter(); stage5(); sync_all()
         tc = time.perf_counter(); merged = merge(); sync_all()
         t2 += tb - ta; t5 += tc - tb
+        hs.sites_in_chain += n5
     barrier()
     dt = time.perf_counter() - t0
+    n2_all = n2
     if world > 1:
         tm = torch.tensor([dt, t2, t5], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt, t2, t5 = (float(v) for v in tm.tolist())
+        cnt = torch.tensor([n2], dtype=torch.int64, device=cdev)
+        dist.all_reduce(cnt)
+        n2_all = int(cnt.item())
+    ptot = ps.read_timing()
+    tim = hs.ctx.read_timing()
     if rank == 0:
-        assert merged[0].shape[0] == n2_tot and merged[1].shape[0] == n5_tot
-        print(json.dumps({
+        assert merged[0].shape[0] == n2_all and merged[1].shape[0] == (n5_tot if world > 1 else hs.n)
+        # rooflines: the dominant kernel of the whole job is the HaplotypeModel's fused step launch (80 % of the time)
+        chain_ms, chain_n = tim["hap_lstm_chain"]
+        b0, b1 = hs.batch_range(0)
+        for _ in range(4):
+            hs.features(b0, b1, which=(0,))
+        hs.sync()
+        feat_ms, feat_n = hs.ctx.read_timing()["hap_features"]
+        roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, b1 - b0)
+        excl, excl_n = ps.exclusive_pass(groups=2)
+        pr = pileup_rooflines(ps, ptot, excl, excl_n, n2 * K, t2, 0, ps.G)
+        roofs["roofline_stage2"] = pr.get("roofline")
+        roofs["roofline_encode"] = pr.get("roofline_encode")
+        out = {
             "metric": "candidate SNP sites/sec, two-stage (s2 pileup + s5 haplotype) on a chr20-sized synthetic candidate set",
-            "value": n2_tot * K / dt, "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "value": n2_all * K / dt, "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: 1.5 M stage-2 windows (encode + PileupModel fwd) + 150 k stage-5 sites (haplotype "
-                                   "features + HaplotypeModel fwd, seeded weights), sites sharded over the ranks, calls gathered to rank 0",
-                       "stage2_sites": n2_tot, "stage5_sites": n5_tot, "batch": batch, "streams": S,
-                       "parallelism": f"site-sharded x{world}, rooted gathers of calls", "world_size_observed": dist.get_world_size() if world > 1 else 1},
-            "stage2": {"ms_per_step": t2 / K * 1e3, "sites_per_s": n2_tot * K / t2},
+                                   "features on int32 read planes + HaplotypeModel fwd, seeded weights), sites sharded over the ranks, calls gathered to rank 0",
+                       "stage2_sites": n2_all, "stage2_sites_nominal": n2_tot, "stage5_sites": n5_tot, "batch": batch, "streams": ps.S,
+                       "encode_batches_per_launch": ps.G, "hap_sites_per_pass": hs.batch,
+                       "parallelism": f"site-sharded x{world}, rooted gathers of calls", "world_size_observed": dist.get_world_size() if world > 1 else 1,
+                       **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: not a scaling number"} if args.share_gpu else {})},
+            "stage2": {"ms_per_step": t2 / K * 1e3, "sites_per_s": n2_all * K / t2,
+                       "executed_tflops_per_gpu": bc.PILEUP_EXEC_FLOP_FORWARD * n2 * K / t2 / 1e12,
+                       "frac_of_fp32_mfma_peak": bc.PILEUP_EXEC_FLOP_FORWARD * n2 * K / t2 / 1e12 / bc.PEAK_F32_MFMA_TFLOPS},
             "stage5": {"ms_per_step": t5 / K * 1e3, "sites_per_s": n5_tot * K / t5,
-                       "algorithmic_tflops": 353.7e6 * n5_tot * K / t5 / 1e12 / world, "peak_tflops_f32_mfma": 157.3,
-                       "note": "per GPU; includes the feature reduction and the int8 -> fp32 feature write (HBM-bound part)"},
-            "roofline": None, "cpu_baseline": None}))
+                       "executed_tflops_per_gpu": bc.hap_exec_flop() * n5 * K / t5 / 1e12,
+                       "frac_of_fp32_mfma_peak": bc.hap_exec_flop() * n5 * K / t5 / 1e12 / bc.PEAK_F32_MFMA_TFLOPS,
+                       "algorithmic_tflops_per_gpu": bc.HAP_ALG_FLOP * n5 * K / t5 / 1e12,
+                       "note": "per GPU; the time includes the feature reduction (HBM-bound) and the argmax; the algorithmic figure prices the "
+                               "reference's 353.7 MFLOP/site and is not a fraction of the peak"},
+        }
+        out.update(roofs)
+        out.setdefault("roofline", None)
+        out["cpu_baseline"] = None
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_two_stage(ps, hs, args.cpu_seconds)
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def cpu_baseline_two_stage(ps, hs, target_s):
+    """both stages through the oracle on a bounded sample in the workload's 10 : 1 proportion"""
+    from oracle import oracle
+    from tools import bench_common as bc
+    cores = bc.usable_cores()
+
+    def run(nb):
+        na = 10 * nb
+        m = na * 33; b1 = int(ps.cols.col_off[m])
+        t0 = time.perf_counter()
+        counts, _, _ = oracle.encode_columns(ps.cols.bases[:b1], ps.cols.col_off[:m + 1], ps.cols.ref[:m])
+        oracle.pileup_forward(ps.weights, counts.reshape(na, 33, 18), nthreads=cores, blocked=True)
+        t1 = time.perf_counter()
+        pp = [p[:nb].cpu().numpy() for p in hs.planes[0]]; ph = [p[:nb].cpu().numpy() for p in hs.planes[1]]
+        xp = oracle.hap_features_batch(*pp, nthreads=cores); xh = oracle.hap_features_batch(*ph, nthreads=cores)
+        oracle.hap_forward(hs.weights, xp, xh, nthreads=cores)
+        return na, (t1 - t0, time.perf_counter() - t1)
+
+    nb0 = max(cores, 32)
+    if hs.n < nb0 or ps.n_windows < 10 * nb0:
+        return None
+    _, ts = run(nb0)
+    nb = int(min(max(nb0, nb0 * target_s / max(sum(ts), 1e-6)), 4096, hs.n, ps.n_windows // 10))
+    na, ts = run(nb)
+    out = {"value": na / sum(ts), "unit": "sites/s", "cores": cores, "kind": "port",
+           "sample": f"{na} stage-2 windows (encode + full-schedule forward, {ts[0]:.1f} s) + {nb} stage-5 sites (features + HaplotypeModel forward, "
+                     f"{ts[1]:.1f} s), the workload's 10 : 1 proportion, OpenMP over {cores} threads; oracle/liboracle.so",
+           "host_cpu": bc.host_cpu_name(), "logical_cpus": os.cpu_count()}
+    return out
