@@ -645,8 +645,90 @@ def group_haparrange():
 
 
 
+def _edge_planes(planes, base):
+    """overwrites sites base .. base+31 of G3 planes with the edge cases: all padding, depth 1, saturated, all deletions"""
+    seq, bq, mq, hap, ref_row = planes
+    for i in range(base, base + 8):                                   # all-padding planes: every statistic is zero
+        seq[i], bq[i], mq[i], hap[i] = -2, -2, -2, -2
+    for i in range(base + 8, base + 16):                              # depth-1 sites
+        seq[i, 1:], bq[i, 1:], mq[i, 1:], hap[i, 1:] = -2, -2, -2, -2
+    for k, i in enumerate(range(base + 16, base + 24)):               # saturated features: every read the same base, top qualities
+        seq[i] = 1 + k % 4; hap[i] = 1 + k % 3; bq[i] = 93; mq[i] = 60
+    for i in range(base + 24, base + 32):                             # deletions only
+        live = seq[i] != -2
+        seq[i][live] = -1; bq[i][live] = 0
+
+
+def group_hapfwd_large():
+    """hap_fwd_large.npz: 256 sites through the reference's OWN chain dataset_dev.get_frequency_feature (+ reference row, as
+    TestDataset.__getitem__ :337-349) -> model_dev.LSTMNetwork.predict (:133-143) with the scaled seeded weights (genotypes differ
+    from site to site); the fixture holds the int8 read planes and the probabilities, so a test runs features AND forward"""
+    import torch
+    from nanosnp_amd import host
+    from tests.helpers import hap_weight_names, seeded_hap_weights
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    import dataset_dev                      # noqa: E402  (reference modules)
+    from model_dev import LSTMNetwork       # noqa: E402
+    from utils import AttrDict              # noqa: E402
+    N, seed = 256, 14
+    cfg = AttrDict({"model": {"pileup_dim": 105, "haplotype_dim": 105, "pileup_length": 33, "haplotype_length": 11, "hidden_size": 256,
+                              "lstm_layers": 3, "gt_num_class": 10, "zy_num_class": 3, "dropout": 0.1}})
+    m = LSTMNetwork(cfg)
+    ws = seeded_hap_weights(seed, H=256, ih_scale=0.03, head_scale=120.0)
+    res = m.load_state_dict({k: torch.from_numpy(w) for k, w in zip(hap_weight_names(), ws)}, strict=False)
+    assert not res.unexpected_keys and all("crit" in k for k in res.missing_keys), res
+    m.eval()
+    fx = {"seed": seed}
+    xs = []
+    for tag, L, sd in (("p", 33, 300), ("h", 11, 400)):
+        planes = [a.copy() for a in host.synth_hap_planes(sd + seed, N, 30, 90, L)]
+        _edge_planes(planes, 0)
+        seq, bq, mq, hap, ref_row = planes
+        feat = np.stack([np.concatenate([dataset_dev.get_frequency_feature(seq[i], bq[i], mq[i], hap[i]),
+                                         ref_row[i][None].astype(np.float64)], 0) for i in range(N)])      # [N,105,L] float64
+        xs.append(torch.from_numpy(feat).type(torch.FloatTensor))                                            # predict_dev.py:35-36
+        for k, a in zip(("seq", "bq", "mq", "hap", "ref"), planes):
+            assert a.min() >= -128 and a.max() <= 127
+            fx[f"{tag}_{k}"] = a.astype(np.int8)
+    with torch.no_grad():
+        gt, zy = m.predict(xs[0], xs[1])
+    fx["gt"] = gt.numpy(); fx["zy"] = zy.numpy()
+    np.savez_compressed(os.path.join(GOLD, "hap_fwd_large.npz"), **fx)
+    g = gt.numpy()
+    print("hap_fwd_large: argmax histogram", np.bincount(g.argmax(1), minlength=10), "max p %.2f .. %.2f" % (g.max(1).min(), g.max(1).max()),
+          "finite", np.isfinite(g).all())
+
+
+def group_cat_large():
+    """cat_fwd_large.npz: 256 sites through the reference's CatModel.predict (seeded weights), incl. empty tags, one-read tags and
+    saturated group tensors"""
+    import torch
+    from tests.helpers import cat_weight_names, seeded_cat_weights, synth_cat_groups
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    from model import CatModel              # noqa: E402  (reference module)
+    seed, N = 22, 256
+    m = CatModel(nc0=5, nc1=5, nc2=2, nclass=10, nh=256)
+    res = m.load_state_dict({k: torch.from_numpy(w) for k, w in zip(cat_weight_names(), seeded_cat_weights(seed))}, strict=False)
+    assert not res.unexpected_keys and all("num_batches_tracked" in k or "crit" in k for k in res.missing_keys), res
+    m.eval()
+    g0, g1 = synth_cat_groups(400 + seed, N)
+    for g in (g0, g1):
+        g[0:4] = 0; g[0:4, :, :, 0] = -2; g[0:4, :20, :, 4] = 1; g[0:4, 20:, :, 4] = 2               # all padding
+        for i in range(4, 8):                                                                        # one read per tag
+            g[i, 1:20] = 0; g[i, 1:20, :, 0] = -2; g[i, 1:20, :, 4] = 1
+            g[i, 21:40] = 0; g[i, 21:40, :, 0] = -2; g[i, 21:40, :, 4] = 2
+        for k, i in enumerate(range(8, 12)):                                                         # saturated: one base, top qualities
+            g[i, :, :, 0] = 1 + k; g[i, :, :, 1] = 60; g[i, :, :, 2] = 60; g[i, :, :, 3] = 1
+    with torch.no_grad():
+        gt = m.predict(torch.from_numpy(g0), torch.from_numpy(g1), None, None).numpy()
+    np.savez_compressed(os.path.join(GOLD, "cat_fwd_large.npz"), g0=g0.astype(np.int8), g1=g1.astype(np.int8), gt=gt, seed=seed)
+    print("cat_fwd_large: argmax histogram", np.bincount(gt.argmax(1), minlength=10), "max p %.3f .. %.3f" % (gt.max(1).min(), gt.max(1).max()))
+
+
 GROUPS = {"haparrange": group_haparrange, "twostage": group_twostage, "twostage_s2": group_twostage_s2, "next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
-          "hapfwd": group_hapfwd, "cat": group_cat}
+          "hapfwd": group_hapfwd, "cat": group_cat, "hapfwd_large": group_hapfwd_large, "cat_large": group_cat_large}
 
 if __name__ == "__main__":
     if not os.path.isdir(REF):

@@ -37,6 +37,22 @@ def test_cat_forward_golden(cat_model):
     assert np.array_equal(got.argmax(1), z["gt"].argmax(1))
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "f16x3"])
+def test_cat_forward_large_golden_incl_edge_sites(prec):
+    """cat_fwd_large.npz: 256 sites of the reference's CatModel.predict, incl. empty tags, one-read tags and saturated tensors"""
+    from nanosnp_amd import _lib
+    from tests.helpers import seeded_cat_weights
+    z = np.load(golden("cat_fwd_large.npz"))
+    c = _lib.Context(0)
+    c.cat_load_weights(seeded_cat_weights(int(z["seed"])))
+    c.set_option("cat_precision", prec)
+    got = _fwd(c, z["g0"], z["g1"])
+    assert np.isfinite(got).all() and np.abs(got - z["gt"]).max() < PROB_ATOL
+    top2 = np.sort(z["gt"], 1)[:, -2:]
+    assert np.all((got.argmax(1) == z["gt"].argmax(1)) | (top2[:, 1] - top2[:, 0] < 1e-3))
+    c.close()
+
+
 @pytest.mark.parametrize("N", [1, 127, 129, 300])
 def test_cat_forward_vs_oracle(cat_model, N):
     from oracle import oracle

@@ -108,6 +108,65 @@ def test_hap_forward_golden_with_site_dependent_outputs(prec):
     c.close()
 
 
+@pytest.mark.parametrize("prec,narrow", [(0, False), (0, True), (1, False)], ids=["fp32-int32planes", "fp32-int8planes", "f16x3"])
+def test_features_and_forward_large_golden_incl_edge_sites(prec, narrow):
+    """hap_fwd_large.npz: 256 sites through the reference's own get_frequency_feature + ref row + LSTMNetwork.predict, incl. all-padding
+    planes, depth-1 sites, saturated features and deletion-only sites; here read planes -> nsnp_hap_features -> nsnp_hap_forward"""
+    import torch
+    from nanosnp_amd import _lib
+    from tests.helpers import PROB_ATOL, seeded_hap_weights
+    z = np.load(golden("hap_fwd_large.npz"))
+    c = _lib.Context(0)
+    c.hap_load_weights(seeded_hap_weights(int(z["seed"]), H=256, ih_scale=0.03, head_scale=120.0))
+    c.set_option("hap_precision", prec)
+    xs = []
+    for t in ("p", "h"):
+        pl = [torch.from_numpy(z[f"{t}_{k}"].astype(np.int8 if narrow else np.int32)).cuda() for k in ("seq", "bq", "mq", "hap")]
+        xs.append(c.hap_features(*pl, torch.from_numpy(z[f"{t}_ref"].astype(np.int32)).cuda()))
+    gt, zy = c.hap_forward(xs[0], xs[1])
+    torch.cuda.synchronize()
+    gt, zy = gt.cpu().numpy(), zy.cpu().numpy()
+    assert np.isfinite(gt).all() and np.abs(gt - z["gt"]).max() < PROB_ATOL and np.abs(zy - z["zy"]).max() < PROB_ATOL
+    top2 = np.sort(z["gt"], 1)[:, -2:]
+    assert np.all((gt.argmax(1) == z["gt"].argmax(1)) | (top2[:, 1] - top2[:, 0] < 1e-3))
+    c.close()
+
+
+def test_full_stage5_pool_properties():
+    """the whole 150,000-site stage-5 pool of the bench (generator G3, int8 read planes) through features + forward in both arithmetic
+    modes: probabilities finite, rows sum to 1, fp32 and f16x3 agree within the port's tolerance and on the argmax wherever the top
+    two classes are further apart than that tolerance"""
+    import torch
+    from nanosnp_amd import _lib
+    from tests.helpers import seeded_hap_weights
+    n, chunk = 150_000, 16384
+    c = _lib.Context(0)
+    c.hap_load_weights(seeded_hap_weights(12, H=256))
+    out = {0: [], 1: []}
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        xs = []
+        for L, sd in ((33, 20260400), (11, 20260500)):
+            pl = host.synth_hap_planes(sd + c0, m, 30, 90, L)
+            xs.append(c.hap_features(*[torch.from_numpy(a.astype(np.int8)).cuda() for a in pl[:4]], torch.from_numpy(pl[4]).cuda()))
+        for prec in (0, 1):
+            c.set_option("hap_precision", prec)
+            gt, zy = c.hap_forward(xs[0], xs[1])
+            out[prec].append(torch.cat([gt, zy], 1))
+    p32, p16 = torch.cat(out[0]), torch.cat(out[1])
+    assert p32.shape == (n, 13) and bool(torch.isfinite(p32).all()) and bool(torch.isfinite(p16).all())
+    for p in (p32, p16):
+        assert float((p[:, :10].sum(1) - 1).abs().max()) < 1e-5 and float((p[:, 10:].sum(1) - 1).abs().max()) < 1e-5
+        assert float(p.min()) >= 0.0
+    d = float((p32 - p16).abs().max())
+    print("stage-5 pool: max |p_fp32 - p_f16x3| =", d)
+    assert d < 1e-4
+    top2 = p32[:, :10].topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-4
+    assert bool((p32[:, :10].argmax(1) == p16[:, :10].argmax(1))[clear].all()) and int(clear.sum()) > n // 2
+    c.close()
+
+
 @pytest.mark.parametrize("n", [1, 127, 128, 129, 300])
 def test_hap_forward_vs_oracle_ragged(hap_model, n):
     from oracle import oracle

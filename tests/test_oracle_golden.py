@@ -88,6 +88,29 @@ def test_hap_forward_golden_with_site_dependent_outputs():
     assert np.array_equal(gt.argmax(1), z["gt"].argmax(1)) and len(set(z["gt"].argmax(1).tolist())) >= 3
 
 
+def test_hap_features_and_forward_large_golden_incl_edge_sites():
+    """hap_fwd_large.npz: 256 sites through the reference's own get_frequency_feature + ref row + LSTMNetwork.predict (all-padding
+    planes, depth-1 sites, saturated features, deletion-only sites among them); the oracle runs features AND forward"""
+    z = np.load(golden("hap_fwd_large.npz"))
+    ws = seeded_hap_weights(int(z["seed"]), H=256, ih_scale=0.03, head_scale=120.0)
+    xs = [oracle.hap_features_batch(*[z[f"{t}_{k}"].astype(np.int32) for k in ("seq", "bq", "mq", "hap", "ref")], nthreads=8) for t in ("p", "h")]
+    assert np.all(xs[0][:8, :104] == 0) and np.isfinite(xs[0]).all()              # all-padding planes: zero statistics
+    gt, zy = oracle.hap_forward(ws, xs[0], xs[1], H=256, nthreads=8)
+    assert np.abs(gt - z["gt"]).max() < 2e-5 and np.abs(zy - z["zy"]).max() < 2e-5
+    agree = gt.argmax(1) == z["gt"].argmax(1)
+    top2 = np.sort(z["gt"], 1)[:, -2:]
+    assert np.all(agree | (top2[:, 1] - top2[:, 0] < 1e-4)) and len(set(z["gt"].argmax(1).tolist())) >= 4
+
+
+def test_cat_forward_large_golden_incl_edge_sites():
+    """cat_fwd_large.npz: 256 sites of CatModel.predict (empty tags, one-read tags, saturated tensors among them)"""
+    from tests.helpers import seeded_cat_weights
+    z = np.load(golden("cat_fwd_large.npz"))
+    gt = oracle.cat_forward(seeded_cat_weights(int(z["seed"])), z["g0"], z["g1"], nthreads=8)
+    assert np.abs(gt - z["gt"]).max() < 2e-5 and np.isfinite(gt).all()
+    assert len(set(z["gt"].argmax(1).tolist())) >= 5
+
+
 def test_cat_forward_matches_reference_module_with_seeded_weights():
     """legacy CatModel.predict (HaplotypeModel/model.py:332-358): golden from the reference module (tests/golden/make_golden.py cat)"""
     from tests.helpers import seeded_cat_weights
