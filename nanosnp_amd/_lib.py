@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnanosnp_hip.so")
+# NANOSNP_HIP_LIB: development only (A/B builds of the same library from tools/ probes); the product always loads the in-tree build
+LIB_PATH = os.environ.get("NANOSNP_HIP_LIB") or os.path.join(_HERE, "libnanosnp_hip.so")
 
 
 class NanoSNPError(RuntimeError):

@@ -455,7 +455,7 @@ void run_bilstm(nsnp_ctx* ctx, hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh
             a.cstate = cst + (size_t)d * n_tiles * tile_h; a.c_tile_stride = (int)tile_h;
             a.first = st == 0;
         }
-        hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, F16>), dim3(n_tiles, 4 * CAT_NH / TR, 2), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (4 * CAT_NH / TR) * (2), ctx->n_cu), s, L);
+        launch_hap_gemm<MODE_LSTM, F16>(ctx, s, L, (int)(n_tiles), 4 * CAT_NH / TR, 2);
     }
 }
 
@@ -467,7 +467,7 @@ void run_linear_h(nsnp_ctx* ctx, hipStream_t s, const float* w, const float* b, 
     memset(&a, 0, sizeof(a));
     a.w = w; a.bias = b; a.in0 = in; a.nk0 = 32; a.in0_tile_stride = 32 * TILE_F; a.nk_img = 32;
     a.out = out; a.out_tile_stride = out_tile_stride;
-    hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, F16>), dim3(n_in_tiles, CAT_NH / TR, 1), dim3(256), gemm_lds_ballast((long long)(n_in_tiles) * (CAT_NH / TR) * (1), ctx->n_cu), s, L);
+    launch_hap_gemm<MODE_LINEAR, F16>(ctx, s, L, (int)(n_in_tiles), CAT_NH / TR, 1);
 }
 
 int grid_for(int64_t total) { int64_t b = NSNP_CDIV(total, (int64_t)256); return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
@@ -531,12 +531,12 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
             // y = relu(bn1(conv1(x)))
             a.w = b.w1 + wsh; a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
             a.nk1 = 0; a.nk_img = a.nk0; a.out = Y; a.out_tile_stride = b.cc_out * TILE_F;
-            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), gemm_lds_ballast((long long)((unsigned)n_ptiles) * (rt) * (1), ctx->n_cu), s, L);
+            launch_hap_gemm<MODE_LINEAR_RELU, F16, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
             // out = relu(bn2(conv2(y)) + shortcut(x))
             a.w = b.w2 + wsh; a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
             a.in1 = X; a.nk1 = b.cc_in; a.in1_tile_stride = b.cc_in * TILE_F; a.nk_img = a.nk0 + a.nk1;
             a.out = O; a.out_tile_stride = b.cc_out * TILE_F;
-            hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_RELU, F16, true>), dim3((unsigned)n_ptiles, rt, 1), dim3(256), gemm_lds_ballast((long long)((unsigned)n_ptiles) * (rt) * (1), ctx->n_cu), s, L);
+            launch_hap_gemm<MODE_LINEAR_RELU, F16, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
             cur = (cur + 2) % 3;
             if (CAT_POOL[i]) {
                 const int kh = CAT_POOL[i], Ho = (Hc - kh) / kh + 1;

@@ -356,8 +356,8 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                         ++nz;
                     }
                 }
-                if (f16) hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, true>), dim3(n_tiles, 4 * H / TR, nz), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (4 * H / TR) * (nz), ctx->n_cu), s, L);
-                else     hipLaunchKernelGGL((k_hap_gemm<MODE_LSTM, false>), dim3(n_tiles, 4 * H / TR, nz), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (4 * H / TR) * (nz), ctx->n_cu), s, L);
+                if (f16) launch_hap_gemm<MODE_LSTM, true>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
+                else     launch_hap_gemm<MODE_LSTM, false>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
             }
         }
         tm_lstm.stop();
@@ -374,16 +374,16 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                 a.out = cat + (size_t)e * 16 * TILE_F; a.out_tile_stride = 32 * TILE_F;
                 a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
             }
-            if (f16) hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, true>), dim3(n_tiles, H / TR, 2), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (H / TR) * (2), ctx->n_cu), s, L);
-            else     hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR, false>), dim3(n_tiles, H / TR, 2), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (H / TR) * (2), ctx->n_cu), s, L);
+            if (f16) launch_hap_gemm<MODE_LINEAR, true>(ctx, s, L, (int)(n_tiles), H / TR, 2);
+            else     launch_hap_gemm<MODE_LINEAR, false>(ctx, s, L, (int)(n_tiles), H / TR, 2);
         }
         {
             StepLaunch L; StepArgs& a = L.z[0];
             a.w = hw.dense_w + wsh; a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
             a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0; a.out = inner; a.out_tile_stride = 16 * TILE_F;
             a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
-            if (f16) hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_TANH, true>), dim3(n_tiles, H / TR, 1), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (H / TR) * (1), ctx->n_cu), s, L);
-            else     hipLaunchKernelGGL((k_hap_gemm<MODE_LINEAR_TANH, false>), dim3(n_tiles, H / TR, 1), dim3(256), gemm_lds_ballast((long long)(n_tiles) * (H / TR) * (1), ctx->n_cu), s, L);
+            if (f16) launch_hap_gemm<MODE_LINEAR_TANH, true>(ctx, s, L, (int)(n_tiles), H / TR, 1);
+            else     launch_hap_gemm<MODE_LINEAR_TANH, false>(ctx, s, L, (int)(n_tiles), H / TR, 1);
         }
         if (f16) hipLaunchKernelGGL(k_hap_heads<true>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
                                     hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);

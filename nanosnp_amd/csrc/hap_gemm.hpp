@@ -6,6 +6,29 @@
 #pragma once
 #include "nsnp_common.hpp"
 
+// main-loop pipeline shape (see k_hap_gemm); overridable for A/B builds (tools/build_variant.sh)
+#ifndef NSNP_GEMM_PIPE
+#define NSNP_GEMM_PIPE 2
+#endif
+#ifndef NSNP_GEMM_LDPOS
+#define NSNP_GEMM_LDPOS 4
+#endif
+#ifndef NSNP_GEMM_WRPOS
+#define NSNP_GEMM_WRPOS 1
+#endif
+#ifndef NSNP_GEMM_BIASINIT
+#define NSNP_GEMM_BIASINIT 1     // accumulators start at the bias (0: the epilogue loads and adds it)
+#endif
+#ifndef NSNP_GEMM_CEARLY
+#define NSNP_GEMM_CEARLY 0       // 1: the cell state is loaded from inside the last bursts (measured: -1 %); 0: in the epilogue
+#endif
+#ifndef NSNP_GEMM_CELL
+#define NSNP_GEMM_CELL 1         // LSTM cell with shared reciprocals (0: sigmoid / tanh one by one)
+#endif
+#ifndef NSNP_GEMM_MINW
+#define NSNP_GEMM_MINW 2
+#endif
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -13,6 +36,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
 __device__ __forceinline__ float tanh_f(float x) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f); }
+
+// LSTM cell on the four gate pre-activations (bias included) of one hidden unit (torch.nn.LSTM equations, gate order i f g o):
+//   c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c')
+// with sigmoid(x) = 1 / (1 + e^-x), tanh(x) = (1 - e^-2x) / (1 + e^-2x): the two products share ONE reciprocal each,
+//   sigmoid(i) tanh(g) = (1 - e^-2g) / ((1 + e^-i)(1 + e^-2g)),
+// 5 v_exp_f32 + 3 v_rcp_f32 per unit and step instead of 5 + 5 (fp32 MFMAs and vector instructions share a SIMD's lanes: every
+// instruction of the cell is matrix-pipe time).  The exponent of the tanh terms is capped at 2^64 so that 1 - e stays finite; an
+// overflowing product of the denominators gives reciprocal 0, the correct limit.
+__device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float c_prev, float& c_new)
+{
+    const float ei = __builtin_amdgcn_exp2f(-LOG2E * zi);
+    const float ef = __builtin_amdgcn_exp2f(-LOG2E * zf);
+    const float eo = __builtin_amdgcn_exp2f(-LOG2E * zo);
+    const float eg = __builtin_amdgcn_exp2f(fminf((-2.0f * LOG2E) * zg, 64.0f));
+    const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+    const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
+    const float cn = __builtin_fmaf(fg, c_prev, ig);
+    const float ec = __builtin_amdgcn_exp2f(fminf((-2.0f * LOG2E) * cn, 64.0f));
+    c_new = cn;
+    return (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
+}
 
 constexpr int TS = 128;        // sites per workgroup tile
 constexpr int TR = 128;        // weight rows per workgroup tile
@@ -80,22 +124,24 @@ __device__ __forceinline__ void split_sat(float v, _Float16& hi, _Float16& lo)
 }
 
 template <int MODE, bool F16, bool CONV = false>
-__global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
+__global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaunch L)
 {
     __shared__ float As[2][TR][LDK];
     __shared__ float Bs[2][TS][LDK];
-    const StepArgs& a = L.z[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // grid: x = site tile, y = row tile, z = slice (direction / encoder).  (A persistent variant - workgroups looping over the
+    // tiles of the launch - was measured: it needs more registers than four waves per SIMD leave and gained nothing at equal
+    // occupancy; pass sizes from 8192 to 65536 sites give the same rate, so neither dispatch turnaround nor launch ramps cost.)
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const StepArgs& a = L.z[blockIdx.z];
     // Wave mapping: 2 x 2 waves of 64 rows x 64 sites; CONV launches with at most 64 output rows (C_out 32 / 64) use
     // 1 x 4 waves of 64 rows x 32 sites instead, so that no wave multiplies padding rows (and one row tile at C_out <= 32).
-    const bool small_rows = CONV && L.z[blockIdx.z].n_rows <= 64;
+    const bool small_rows = CONV && a.n_rows <= 64;
     const int wr = small_rows ? 0 : wave >> 1, wc = wave & 1;
     const int nct = small_rows ? 1 : 2;
-    const int nrt = (CONV && L.z[blockIdx.z].n_rows <= 32) ? 1 : 2;
+    const int nrt = (CONV && a.n_rows <= 32) ? 1 : 2;
     const int site0 = small_rows ? 32 * wave : 64 * wc;              // first site of the wave's tile(s)
-    const int li = lane & 31, lh = lane >> 5;
-    const int bx = blockIdx.x;          // site tile
-    const int by = blockIdx.y;          // row tile
     const int nk = a.nk0 + a.nk1;
 
     const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_F;
@@ -139,39 +185,80 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
         *reinterpret_cast<f32x4*>(&Bs[buf][crow][cq * 4 + 4]) = bb1;
     };
 
+    // accumulators start at the bias of their rows (register r = 4*r4 + g of tile rt: row 32*rt + 8*r4 + 4*lh + g of the wave's
+    // 64 rows), so the epilogue neither loads it nor adds it: the sum is b + w0 x0 + w1 x1 + ... in the k order of the images
     f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int f = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;
+            f32x4 bz = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (NSNP_GEMM_BIASINIT && (!CONV || f < a.n_rows)) bz = *reinterpret_cast<const f32x4*>(a.bias + f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int g = 0; g < 4; ++g) { acc[rt][0][4 * r4 + g] = bz[g]; acc[rt][1][4 * r4 + g] = bz[g]; }
+        }
 
+    // ---- main loop: a software pipeline over the K chunks --------------------------------------------------------------
+    // What a wave does between the barrier that releases chunk kc and its first MFMA is on the critical path of its SIMD (the
+    // co-resident waves run the same program and tend to wait at the same time), so only the LDS reads of the first four K-steps
+    // stand there.  Everything else is issued from inside the burst of 32 MFMAs (sched_barrier fences keep it there):
+    //   PIPE 1  global loads of chunk kc+1 behind MFMA group LDPOS, written to LDS after the burst (one chunk ahead)
+    //   PIPE 2  global loads of chunk kc+2 behind MFMA group LDPOS, written to LDS behind group WRPOS of the NEXT iteration
+    //           (two chunks ahead with ONE set of staging registers: the write at WRPOS frees them before the load at LDPOS
+    //           refills them; the buffer written during iteration kc+1 was last read at the start of iteration kc)
+    // Measured on the HaplotypeModel forward (N = 32768): loads ahead of the LDS reads (round 2) 76.8 ms, LDPOS 2 72.9, LDPOS 6 +
+    // fragment reads split 69.2.  The accumulation order is untouched: results are bit-identical.
+    constexpr int PIPE = NSNP_GEMM_PIPE, LDPOS = NSNP_GEMM_LDPOS, WRPOS = NSNP_GEMM_WRPOS;
+    static_assert(PIPE == 1 || (PIPE == 2 && WRPOS < LDPOS), "two-ahead needs the write in front of the load");
+    const int pfd = PIPE == 1 ? 1 : 2;
     f32x4 ga0, ga1, gb0, gb1;
     gload(0, ga0, ga1, gb0, gb1);
     lstore(0, ga0, ga1, gb0, gb1);
+    if (PIPE == 2 && nk > 1) gload(1, ga0, ga1, gb0, gb1);
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < nk) gload(kc + 1, ga0, ga1, gb0, gb1);
-        // fragments: lane (li, lh) takes floats [lh*8, lh*8+8) of its row = 8 k-steps of 32x32x2
+        // fragments: lane (li, lh) takes floats [lh*8, lh*8+8) of its row = 8 k-steps of 32x32x2; the four fragments of
+        // K-steps 0..3 first (the burst starts when they are there), the other four from inside the burst
         f32x4 af[2][2], bf[2][2];
+        auto read_frags = [&](int h) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const float* p = &As[cur][64 * wr + 32 * rt + li][F16 ? lh * 4 : lh * 8];
-            af[rt][0] = *reinterpret_cast<const f32x4*>(p);
-            af[rt][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
-        }
+            for (int rt = 0; rt < 2; ++rt)
+                af[rt][h] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][(F16 ? lh * 4 : lh * 8) + h * (F16 ? 8 : 4)]);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const float* p = &Bs[cur][site0 + 32 * ct + li][F16 ? lh * 4 : lh * 8];
-            bf[ct][0] = *reinterpret_cast<const f32x4*>(p);
-            bf[ct][1] = *reinterpret_cast<const f32x4*>(p + (F16 ? 8 : 4));
-        }
+            for (int ct = 0; ct < 2; ++ct)
+                bf[ct][h] = *reinterpret_cast<const f32x4*>(&Bs[cur][site0 + 32 * ct + li][(F16 ? lh * 4 : lh * 8) + h * (F16 ? 8 : 4)]);
+        };
+        read_frags(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+        auto side_work = [&](int pos) {
+            if (PIPE == 2 && pos == WRPOS && kc + 1 < nk) {
+                __builtin_amdgcn_sched_barrier(0);
+                lstore(cur ^ 1, ga0, ga1, gb0, gb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pos == LDPOS && kc + pfd < nk) {
+                __builtin_amdgcn_sched_barrier(0);
+                gload(kc + pfd, ga0, ga1, gb0, gb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (NSNP_GEMM_CEARLY && MODE == MODE_LSTM && pos == LDPOS && kc + pfd == nk && !a.first) {
+                // the staging registers are free from here on: the cell state of the lane's 2 x 8 units rides in on them
+                __builtin_amdgcn_sched_barrier(0);
+                const float* c0 = a.cstate + (size_t)bx * a.c_tile_stride + (size_t)(2 * by + wr) * TILE_F + (64 * wc + li) * BK + lh * 8;
+                ga0 = *reinterpret_cast<const f32x4*>(c0); ga1 = *reinterpret_cast<const f32x4*>(c0 + 4);
+                gb0 = *reinterpret_cast<const f32x4*>(c0 + 32 * BK); gb1 = *reinterpret_cast<const f32x4*>(c0 + 32 * BK + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         if (F16) {
             // af[rt][0] / [1] are the lane's 8 hi / 8 lo halves of row (rt), likewise bf for the site
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < 3; ++term) {
+                side_work(term == 0 ? -1 : (term == 1 ? WRPOS : LDPOS));
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -181,9 +268,11 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                         const h8 bv = __builtin_bit_cast(h8, bf[ct][term == 2 ? 1 : 0]);
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[rt][ct], 0, 0, 0);
                     }
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
+                side_work(j);
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -192,8 +281,10 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bf[ct][j >> 2][j & 3],
                                                                             acc[rt][ct], 0, 0, 0);
                     }
+            }
         }
-        if (kc + 1 < nk) lstore(cur ^ 1, ga0, ga1, gb0, gb1);
+        side_work(8);
+        if (PIPE == 1 && kc + 1 < nk) lstore(cur ^ 1, ga0, ga1, gb0, gb1);
         __syncthreads();
     }
 
@@ -204,28 +295,32 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
         // rows are [unit][gate]: unit8 = 2*r4 + lh, gate = g.  The wave's 16 units form chunk
         // kc = 2*by + wr of the output image; a lane writes positions p = lh*8 + 4*rt + r4.
         const size_t img = (size_t)(2 * by + wr) * TILE_F;
+        if (a.first) { ga0 = f32x4{0.f, 0.f, 0.f, 0.f}; ga1 = ga0; gb0 = ga0; gb1 = ga0; }
+        else if (!NSNP_GEMM_CEARLY) {
+            const float* c0 = a.cstate + (size_t)bx * a.c_tile_stride + img + (64 * wc + li) * BK + lh * 8;
+            ga0 = *reinterpret_cast<const f32x4*>(c0); ga1 = *reinterpret_cast<const f32x4*>(c0 + 4);
+            gb0 = *reinterpret_cast<const f32x4*>(c0 + 32 * BK); gb1 = *reinterpret_cast<const f32x4*>(c0 + 32 * BK + 4);
+        }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int site = 64 * wc + 32 * ct + li;
             float* cptr = a.cstate + (size_t)bx * a.c_tile_stride + img + site * BK + lh * 8;
             float* hptr = a.out + (size_t)bx * a.out_tile_stride + img + site * BK + lh * 8;
-            f32x4 cv[2];
-            if (a.first) { cv[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cv[1] = cv[0]; }
-            else { cv[0] = *reinterpret_cast<const f32x4*>(cptr); cv[1] = *reinterpret_cast<const f32x4*>(cptr + 4); }
+            f32x4 cv[2] = {ct ? gb0 : ga0, ct ? gb1 : ga1};
             f32x4 hv[2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const int row = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;   // image row of gate 0
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + row);
-                    const float ig = sigmoid_f(acc[rt][ct][4 * r4 + 0] + bz[0]);
-                    const float fg = sigmoid_f(acc[rt][ct][4 * r4 + 1] + bz[1]);
-                    const float gg = tanh_f(acc[rt][ct][4 * r4 + 2] + bz[2]);
-                    const float og = sigmoid_f(acc[rt][ct][4 * r4 + 3] + bz[3]);
-                    const float cn = __builtin_fmaf(fg, cv[rt][r4], ig * gg);
+                    f32x4 z = f32x4{acc[rt][ct][4 * r4 + 0], acc[rt][ct][4 * r4 + 1], acc[rt][ct][4 * r4 + 2], acc[rt][ct][4 * r4 + 3]};
+                    if (!NSNP_GEMM_BIASINIT) z += *reinterpret_cast<const f32x4*>(a.bias + 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh);
+                    float cn;
+                    if (NSNP_GEMM_CELL) hv[rt][r4] = lstm_cell(z[0], z[1], z[2], z[3], cv[rt][r4], cn);
+                    else {
+                        cn = __builtin_fmaf(sigmoid_f(z[1]), cv[rt][r4], sigmoid_f(z[0]) * tanh_f(z[2]));
+                        hv[rt][r4] = sigmoid_f(z[3]) * tanh_f(cn);
+                    }
                     cv[rt][r4] = cn;
-                    hv[rt][r4] = og * tanh_f(cn);
                 }
             *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
             if (F16) {
@@ -252,11 +347,10 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int f = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;
                     if (CONV && f >= a.n_rows) continue;
-                    const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + f);
                     f32x4 v;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float t = acc[rt][ct][4 * r4 + g] + bz[g];
+                        const float t = acc[rt][ct][4 * r4 + g] + (NSNP_GEMM_BIASINIT ? 0.f : a.bias[f + g]);
                         v[g] = MODE == MODE_LINEAR_TANH ? tanh_f(t) : MODE == MODE_LINEAR_RELU ? fmaxf(t, 0.f) : t;
                     }
                     float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK;
@@ -275,5 +369,13 @@ __global__ __launch_bounds__(256, 2) void k_hap_gemm(const StepLaunch L)
     }
 }
 
+
+// launch of the tile GEMM over n_tiles site tiles x n_rt row tiles x nz slices
+template <int MODE, bool F16, bool CONV = false>
+inline void launch_hap_gemm(nsnp_ctx* ctx, hipStream_t s, StepLaunch& L, int n_tiles, int n_rt, int nz)
+{
+    hipLaunchKernelGGL((k_hap_gemm<MODE, F16, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
+                       gemm_lds_ballast((long long)n_tiles * n_rt * nz, ctx->n_cu), s, L);
+}
 
 }  // namespace

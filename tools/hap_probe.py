@@ -14,6 +14,8 @@ xp = torch.from_numpy((rng.standard_normal((N, 105, 33)) * 30).astype(np.float32
 xh = torch.from_numpy((rng.standard_normal((N, 105, 11)) * 30).astype(np.float32)).cuda()
 precs = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1]
 passes = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [16384]
+for o in sys.argv[4:]:                       # further nsnp_ctx_set_option pairs: name=value
+    ctx.set_option(o.split('=')[0], int(o.split('=')[1]))
 EXEC = 276.0e6          # executed flop per site (last layer: 17 of 33 / 6 of 11 steps), DESIGN.md section 4
 ref = {}
 for prec in precs:
@@ -32,4 +34,4 @@ for prec in precs:
         dt = (time.time() - t) / reps
         print(f"hap_forward precision={prec} N={N} pass={ps}: {dt*1e3:.2f} ms  {N/dt/1e3:.1f} k sites/s  "
               f"executed {N*EXEC/dt/1e12:.1f} TFLOP/s = {N*EXEC/dt/1e12/157.3:.3f} of fp32 MFMA peak ({N*353.7e6/dt/1e12:.0f} algorithmic)  "
-              f"bit-identical to first pass size: {same}", flush=True)
+              f"bit-identical to first pass size: {same}  crc {__import__('zlib').crc32(gt.cpu().numpy().tobytes()) & 0xffffffff:08x}", flush=True)

@@ -12,9 +12,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LDK = 20;
 
-template <int MODE, int PAD>
+// VAR (KRN modes only): 1 = s_setprio(workgroup slot on the CU & 3) for the whole kernel, 2 = one-time start skew of a quarter
+// chunk-round per workgroup slot, 3 = both.  Hypothesis: the four workgroups of a CU share every SIMD's matrix pipe, run the same
+// program and reach their per-chunk barrier / LDS phase together, so the pipe idles while all of them synchronise.
+template <int MODE, int PAD, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ g, float* out, int nk, size_t gmask)
 {
+    if (VAR) {
+        const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 3u;     // HW_REG_HW_ID.tg_id: the workgroup's slot on its CU
+        if (VAR & 1) { if (tg == 1) __builtin_amdgcn_s_setprio(1); else if (tg == 2) __builtin_amdgcn_s_setprio(2); else if (tg == 3) __builtin_amdgcn_s_setprio(3); }
+        if (VAR & 2) { for (unsigned i = 0; i < tg; ++i) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); } }
+    }
     __shared__ float As[2][128][LDK];
     __shared__ float Bs[2][128][LDK];
     __shared__ float pad[PAD ? PAD : 1];       // PAD > 0: LDS ballast so that at most two workgroups fit a CU
@@ -87,14 +95,14 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ g, float* 
     out[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + tid] = s;
 }
 
-template <int MODE, int PAD>
+template <int MODE, int PAD, int VAR = 0>
 void run(const char* name, const float* g, float* out, int grid, dim3 g3 = dim3(0, 0, 0))
 {
     const dim3 gd = g3.x ? g3 : dim3(grid);
     const int nk = 4000;
-    hipLaunchKernelGGL((k<MODE, PAD>), gd, dim3(256), 0, 0, g, out, 100, (size_t)(16u << 20) - 1); hipDeviceSynchronize();
+    hipLaunchKernelGGL((k<MODE, PAD, VAR>), gd, dim3(256), 0, 0, g, out, 100, (size_t)(16u << 20) - 1); hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0); hipLaunchKernelGGL((k<MODE, PAD>), gd, dim3(256), 0, 0, g, out, nk, (size_t)(16u << 20) - 1); hipEventRecord(e1); hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL((k<MODE, PAD, VAR>), gd, dim3(256), 0, 0, g, out, nk, (size_t)(16u << 20) - 1); hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)grid * 4 * nk * 32 * 4096.0;
     printf("%-48s grid %4d: %8.2f ms  %6.1f TFLOP/s\n", name, grid, ms, flop / (ms * 1e-3) / 1e12);
@@ -113,6 +121,13 @@ int main()
     run<4, 0>("KRN  loads shared as in the kernel, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
     run<4, 0>("KRN  loads shared as in the kernel, grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
     run<4, 0>("KRN  loads shared as in the kernel, grid (128, 8, 2)", g, out, 2048, dim3(128, 8, 2));
+    run<4, 0, 1>("KRN  + s_setprio(workgroup slot), grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
+    run<4, 0, 2>("KRN  + start skew by workgroup slot, grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
+    run<4, 0, 3>("KRN  + both, grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
+    run<4, 0, 1>("KRN  + s_setprio(workgroup slot), grid (128, 8, 2)", g, out, 2048, dim3(128, 8, 2));
+    run<4, 0, 2>("KRN  + start skew by workgroup slot, grid (128, 8, 2)", g, out, 2048, dim3(128, 8, 2));
+    run<2, 0, 1>("BAR  + s_setprio(workgroup slot)", g, out, 1024);
+    run<2, 0, 2>("BAR  + start skew by workgroup slot", g, out, 1024);
     run<5, 0>("KRN2 the same, global loads two chunks ahead, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
     run<5, 0>("KRN2 the same, global loads two chunks ahead, grid (32, 8, 4)", g, out, 1024, dim3(32, 8, 4));
     run<5, 13824>("KRN2 + at most 2 workgroups per CU, grid (32, 8, 2)", g, out, 512, dim3(32, 8, 2));
