@@ -42,6 +42,27 @@ __device__ __forceinline__ float tanh_f(float x)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f);
 }
 
+// LSTM cell on the four gate pre-activations (bias included) of one hidden unit (torch.nn.LSTM equations, gate order i f g o):
+//   c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c')          (PileupModel/model.py:34 = nn.LSTM)
+// with sigmoid(x) = 1 / (1 + e^-x), tanh(x) = (1 - e^-2x) / (1 + e^-2x): the two products share ONE reciprocal each,
+//   sigmoid(i) tanh(g) = (1 - e^-2g) / ((1 + e^-i)(1 + e^-2g)),
+// 5 v_exp_f32 + 3 v_rcp_f32 per unit and step instead of 5 + 5: fp32 MFMAs and vector instructions share a SIMD's lanes, so
+// every instruction of the cell is matrix-pipe time.  The exponent of the tanh terms is capped at 2^64 so that 1 - e stays finite;
+// an overflowing product of the denominators gives reciprocal 0, the correct limit.  c is updated in place, h' returned.
+__device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float& c)
+{
+    const float ei = __builtin_amdgcn_exp2f(-LOG2E * zi);
+    const float ef = __builtin_amdgcn_exp2f(-LOG2E * zf);
+    const float eo = __builtin_amdgcn_exp2f(-LOG2E * zo);
+    const float eg = __builtin_amdgcn_exp2f(fminf((-2.0f * LOG2E) * zg, 64.0f));
+    const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+    const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
+    const float cn = __builtin_fmaf(fg, c, ig);
+    const float ec = __builtin_amdgcn_exp2f(fminf((-2.0f * LOG2E) * cn, 64.0f));
+    c = cn;
+    return (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
+}
+
 // acc[NT] += W(image rows, K-steps [4*J4B, 4*(J4B+J4N))) . b, with the weight image read 16 B per
 // lane per 4 K-steps.  w points at image element [tile 0][j4 0][lane 0]; NJ4 is the image's j4
 // extent and TB the first of the NT tiles to compute (acc is indexed from 0).
@@ -87,12 +108,7 @@ __device__ __forceinline__ void lstm_pointwise8(const f32x4* acc, float* c, floa
 {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float ig = sigmoid_f(acc[i][0]);
-        const float fg = sigmoid_f(acc[i][1]);
-        const float gg = tanh_f(acc[i][2]);
-        const float og = sigmoid_f(acc[i][3]);
-        c[i] = __builtin_fmaf(fg, c[i], ig * gg);
-        h[i] = og * tanh_f(c[i]);
+        h[i] = lstm_cell(acc[i][0], acc[i][1], acc[i][2], acc[i][3], c[i]);
     }
 }
 
@@ -426,7 +442,9 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG == 1 ? 3 : 2))) void k_pileup_
     for (int s = 0; s < PW; ++s) {
         const int t = dir ? PW - 1 - s : s;
         const int cur = s & 1;
-        // x_t of this step was staged during the previous one; x_{t+1} is in flight in registers and is stored behind the MFMAs
+        // x_t of this step was staged during the previous one; x_{t+1} is in flight in registers and is stored behind the MFMAs.
+        // (Issuing the flush of h_{t-1} and the staging of x_{t+1} from inside the burst of 84 MFMAs instead - what gave the tile GEMM
+        // 14 % - was measured here without effect: 3.078 vs 3.079-3.12 ms at 131072 sites.)
         if (s > 0) flush_h(cur ^ 1, dir ? t + 1 : t - 1);
         if constexpr (NSG >= 2) {
             // Software pipeline over the site groups: the 84 MFMAs of group g+1 are issued AMONG the sigmoid / tanh work of group g
@@ -465,12 +483,7 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG == 1 ? 3 : 2))) void k_pileup_
                 f32x4 hn;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float ig = sigmoid_f(acc[u][0]);
-                    const float fg = sigmoid_f(acc[u][1]);
-                    const float gg = tanh_f(acc[u][2]);
-                    const float og = sigmoid_f(acc[u][3]);
-                    c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
-                    hn[u] = og * tanh_f(c[sg][u]);
+                    hn[u] = lstm_cell(acc[u][0], acc[u][1], acc[u][2], acc[u][3], c[sg][u]);
                 }
                 *reinterpret_cast<f32x4*>(&hx[cur][16 * sg + n][16 * wave + 4 * q]) = hn;
             };
@@ -542,12 +555,7 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG == 1 ? 3 : 2))) void k_pileup_
             f32x4 hn;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float ig = sigmoid_f(acc[u][0]);
-                const float fg = sigmoid_f(acc[u][1]);
-                const float gg = tanh_f(acc[u][2]);
-                const float og = sigmoid_f(acc[u][3]);
-                c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
-                hn[u] = og * tanh_f(c[sg][u]);
+                hn[u] = lstm_cell(acc[u][0], acc[u][1], acc[u][2], acc[u][3], c[sg][u]);
             }
             *reinterpret_cast<f32x4*>(&hx[cur][16 * sg + n][16 * wave + 4 * q]) = hn;
         }
@@ -676,12 +684,7 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
             float2 w2;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float ig = sigmoid_f(acc[sg][u][0]);
-                const float fg = sigmoid_f(acc[sg][u][1]);
-                const float gg = tanh_f(acc[sg][u][2]);
-                const float og = sigmoid_f(acc[sg][u][3]);
-                c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
-                const float h = og * tanh_f(c[sg][u]);
+                const float h = lstm_cell(acc[sg][u][0], acc[sg][u][1], acc[sg][u][2], acc[sg][u][3], c[sg][u]);
                 if (u == 0) w2.x = h; else w2.y = h;
             }
             *reinterpret_cast<float2*>(hwb + (size_t)(16 * sg + n) * RS_XROW + 16 * (wave >> 1) + 4 * q + 2 * (wave & 1)) = w2;
@@ -766,6 +769,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
     };
     load_h0(dir ? PW - 1 : 0);
     store_h0(0);
+    if (PSTEPS1 > 1) load_h0(dir ? PW - 2 : 1);
     __syncthreads();
 
     float c[NSG][4];
@@ -774,10 +778,13 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
 #pragma unroll
         for (int u = 0; u < 4; ++u) c[sg][u] = 0.f;
 
+    // What a wave does between the step barrier and its first MFMA is on the critical path of its SIMD (its partner wave belongs to
+    // another workgroup but runs the same program), so only the fragment reads stand there; the h0 staging runs two steps ahead
+    // from INSIDE the burst of 192 MFMAs: the rows of step s+1 (loaded during step s-1) go to LDS behind K block 1, the loads of
+    // step s+2 go out behind K block 4 into the same registers.
     for (int s = 0; s < PSTEPS1; ++s) {
         const int t = dir ? PW - 1 - s : s;
         const int cur = s & 1;
-        if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
         const float* h0b = h0s + (size_t)cur * NS * RS_H0ROW;
         const float* hrb = h1x + (size_t)(cur ^ 1) * NS * RS_XROW;       // h1_{s-1}
         float* hwb = h1x + (size_t)cur * NS * RS_XROW;                   // h1_s
@@ -789,6 +796,16 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
             for (int u = 0; u < 4; ++u) acc[u] = lbias[(4 * wave + u) * 4 + q];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                                 // K-steps 4j .. 4j+3: direction j / 4, chunk j % 4
+                if (sg == 0 && j == 2 && s + 1 < PSTEPS1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_h0(cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (sg == 0 && j == 5 && s + 2 < PSTEPS1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_h0(dir ? t - 2 : t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(r0 + 64 * (j >> 2) + 16 * (j & 3));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -810,16 +827,10 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
             f32x4 hn;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float ig = sigmoid_f(acc[u][0]);
-                const float fg = sigmoid_f(acc[u][1]);
-                const float gg = tanh_f(acc[u][2]);
-                const float og = sigmoid_f(acc[u][3]);
-                c[sg][u] = __builtin_fmaf(fg, c[sg][u], ig * gg);
-                hn[u] = og * tanh_f(c[sg][u]);
+                hn[u] = lstm_cell(acc[u][0], acc[u][1], acc[u][2], acc[u][3], c[sg][u]);
             }
             *reinterpret_cast<f32x4*>(hwb + (size_t)(16 * sg + n) * RS_XROW + 16 * wave + 4 * q) = hn;
         }
-        if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
         lds_barrier();
     }
     // h1 at position 16 -> H1c[site][dir][q][16]: entries 4 wave .. 4 wave + 3 of row q (read back from the exchange rows)

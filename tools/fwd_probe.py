@@ -25,6 +25,7 @@ ctx.set_option("l1_stagger", int(os.environ.get("STAG", "0")))
 ctx.set_option("head_split", int(os.environ.get("HEADS", "1")))
 ctx.set_option("static_priority", int(os.environ.get("PRIO", "0")))
 ctx.set_option("l0_input_weights_in_lds", int(os.environ.get("WXL", "0")))
+torch.manual_seed(1)
 x = torch.randint(-20, 40, (N, 33, 18), dtype=torch.int32, device=dev)
 gt = torch.empty((N, 21), device=dev); zy = torch.empty((N, 3), device=dev)
 ctx.pileup_forward(x, gt, zy); torch.cuda.synchronize()
@@ -34,4 +35,6 @@ for _ in range(iters): ctx.pileup_forward(x, gt, zy)
 torch.cuda.synchronize()
 dt = (time.time() - t) / iters
 tm = ctx.read_timing()
-print(f"N={N} precision={prec} wpb={wpb} L0RS={os.environ.get('L0RS','1')} L1RS={os.environ.get('L1RS','1')} L0SG={os.environ.get('L0SG','0')} L1SG={os.environ.get('L1SG','0')} STAG={os.environ.get('STAG','0')} PRIO={os.environ.get('PRIO','0')} WXL={os.environ.get('WXL','0')}: {dt*1e3:.3f} ms  {N/dt/1e6:.2f} M sites/s ", {k: round(v[0]/max(v[1],1), 4) for k, v in tm.items() if v[1]})
+import zlib
+crc = zlib.crc32(gt.cpu().numpy().tobytes()) & 0xffffffff
+print(f"crc {crc:08x} N={N} precision={prec} wpb={wpb} L0RS={os.environ.get('L0RS','1')} L1RS={os.environ.get('L1RS','1')} L0SG={os.environ.get('L0SG','0')} L1SG={os.environ.get('L1SG','0')} STAG={os.environ.get('STAG','0')} PRIO={os.environ.get('PRIO','0')} WXL={os.environ.get('WXL','0')}: {dt*1e3:.3f} ms  {N/dt/1e6:.2f} M sites/s ", {k: round(v[0]/max(v[1],1), 4) for k, v in tm.items() if v[1]})
