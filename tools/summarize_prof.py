@@ -4,7 +4,10 @@ profiles/: the --stats kernel table, and per-kernel HBM traffic from the FETCH_S
 PMC passes with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): counters are in KiB,
 FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x, WRITE_SIZE is exact.
 
-    python tools/summarize_prof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>] [--batch 4096] [--precision 0] [--timed SKIP TAKE]
+    python tools/summarize_prof.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>] [--workload pileup] [--batch 4096] [--precision 0]
+                                   [--enc-group 8] [--D 90] [--timed SKIP TAKE]
+
+Traffic of every workload is kept in profiles/roofline_traffic.json under "workloads" (tools/bench_common.py committed_traffic reads it).
 
 --timed SKIP TAKE: bench.py launches every kernel W x batches_per_step times before the timed region, K x batches_per_step times
 inside it and 36 more times alone afterwards (the `exclusive` figures); the average over launches SKIP .. SKIP+TAKE of each
@@ -22,12 +25,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"k_pileup_l1_rs4": "pileup_l1f", "k_pileup_l1_rs": "pileup_l1f", "k_pileup_head_rs": "pileup_head", "k_pileup_l0_rs32": "pileup_l0", "k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
          "k_pileup_head": "pileup_head", "k_encode_columns": "encode_columns", "k_hap_features": "hap_features",
          "k_pileup_post": "pileup_post", "k_select": "select_sites", "k_gather_windows": "gather_windows",
-         "k_hap_": "hap_forward"}
+         "k_hap_gemm<0,false,false>": "hap_gemm_lstm", "k_hap_gemm<0,true,false>": "hap_gemm_lstm_f16x3",
+         "k_hap_gemm<3,false,true>": "cat_conv", "k_hap_gemm<3,true,true>": "cat_conv_f16x3", "k_hap_gemm<1": "hap_gemm_linear",
+         "k_hap_gemm<2": "hap_gemm_linear_tanh", "k_hap_pack_input": "hap_pack_input", "k_hap_heads": "hap_heads", "k_hap_": "hap_other"}
 
 
 def short(name):
-    m = re.search(r"(k_[a-z0-9_]+)", name)
-    return m.group(1) if m else name[:60].replace(",", ";")
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>(]*>)?", name)
+    if not m:
+        return name[:60].replace(",", ";")
+    t = (m.group(2) or "").replace(" ", "")
+    return m.group(1) + (t if m.group(1) == "k_hap_gemm" else "")
 
 
 def one(d, pat):
@@ -37,7 +45,13 @@ def one(d, pat):
 
 def main():
     argv = list(sys.argv[1:])
-    batch, precision, timed = 4096, 0, None
+    batch, precision, timed, workload, enc_group, Dd = 4096, 0, None, "pileup", 8, 90
+    if "--workload" in argv:
+        i = argv.index("--workload"); workload = argv[i + 1]; del argv[i:i + 2]
+    if "--enc-group" in argv:
+        i = argv.index("--enc-group"); enc_group = int(argv[i + 1]); del argv[i:i + 2]
+    if "--D" in argv:
+        i = argv.index("--D"); Dd = int(argv[i + 1]); del argv[i:i + 2]
     if "--batch" in argv:
         i = argv.index("--batch"); batch = int(argv[i + 1]); del argv[i:i + 2]
     if "--precision" in argv:
@@ -52,7 +66,7 @@ def main():
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
         for r in rows:
-            f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.1f},"
+            f.write(f"{short(r['Name']).replace(',', ';')},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.1f},"
                     f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
     if timed:
         tr = collections.defaultdict(list)
@@ -61,16 +75,21 @@ def main():
         with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "a") as f:
             f.write(f"# launches {timed[0]} .. {timed[0] + timed[1]} of each kernel by start time = bench.py's timed region (kernel,launches,avg_ns); "
                     f"the launches behind it run alone (bench.py `exclusive`)\n")
+            n_max = max((len(v) for k, v in tr.items() if k.startswith("k_")), default=1)
             for k, v in sorted(tr.items()):
                 if not k.startswith("k_"):
                     continue
                 v.sort()
-                w = v[timed[0]:timed[0] + timed[1]]
-                tail = v[timed[0] + timed[1]:]
+                # a kernel launched once per GROUP of batches (the column encode: 8 batches per launch) has proportionally fewer
+                # launches in every phase of the run: scale the window by its launch count
+                sc = len(v) / n_max if len(v) * 2 < n_max else 1.0
+                t0, t1 = int(round(timed[0] * sc)), int(round((timed[0] + timed[1]) * sc))
+                w = v[t0:t1]
+                tail = v[t1:]
                 if w:
-                    f.write(f"timed_region,{k},{len(w)},{sum(e - s for s, e in w) / len(w):.1f}\n")
+                    f.write(f"timed_region,{k.replace(',', ';')},{len(w)},{sum(e - s for s, e in w) / len(w):.1f}\n")
                 if tail:
-                    f.write(f"alone_after,{k},{len(tail)},{sum(e - s for s, e in tail) / len(tail):.1f}\n")
+                    f.write(f"alone_after,{k.replace(',', ';')},{len(tail)},{sum(e - s for s, e in tail) / len(tail):.1f}\n")
     print(open(os.path.join(out_dir, f"{tag}_kernel_stats.csv")).read())
     if len(args) >= 4:
         traffic = collections.defaultdict(dict)
@@ -83,7 +102,7 @@ def main():
                 if k.startswith("k_"):
                     traffic[k][cname] = sum(v) / len(v)
                     traffic[k]["launches"] = len(v)
-        summary = {"batch": batch, "precision": precision, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
+        summary = {"batch": batch, "precision": precision, "enc_group": enc_group, "D": Dd, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
                    "correction": "KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1",
                    "kernels": {}}
         for k, v in traffic.items():
@@ -94,7 +113,16 @@ def main():
                                         "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                         "hbm_bytes_per_launch": rd + wr, "launches": v.get("launches")}
         json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-        json.dump(summary, open(os.path.join(out_dir, "roofline_traffic.json"), "w"), indent=1)
+        rt = os.path.join(out_dir, "roofline_traffic.json")
+        allw = {"workloads": {}}
+        if os.path.exists(rt):
+            try:
+                old = json.load(open(rt))
+                allw = old if "workloads" in old else {"workloads": {}}
+            except Exception:
+                pass
+        allw["workloads"][workload] = summary
+        json.dump(allw, open(rt, "w"), indent=1)
         print(json.dumps(summary, indent=1))
 
 
