@@ -5,11 +5,12 @@
 // four int32 read planes [D][L] -> float [105][L] (26 statistics x {all reads, HP1, HP2,
 // unphased} + the reference row).
 //
-// One workgroup per site streams the planes exactly once with coalesced row-major loads:
-// thread (rp, l) owns column l and rows d = rp, rp + RP, ...; nothing but the 52 x L running sums
-// and a per-row HP mask lives in LDS, so the depth axis is tiled at any coverage (the 60x
-// "spill path": D only lengthens the loop).  Integer sums are exact (int64); the divisions are
-// float64 with the reference's epsilons, then cast to fp32 -> bit-identical to numpy + .float().
+// One workgroup per site streams the planes exactly once: wave w owns the rows d = w, w + 4, ..., lane l the column l, so a
+// row's membership in the read sets (np.any(hap == g, axis=1)) is a wave ballot - no second pass over the hap plane, no row
+// mask in LDS, no barrier before the sums - and the set tests are scalar branches.  The loads of four rows (16 per lane) are
+// in flight together.  Only the 52 x L running sums live in LDS, so the depth axis is tiled at any coverage (the 60x "spill
+// path": D only lengthens the loop).  Integer sums are exact (counts int32, quality sums int64); the divisions are float64 with
+// the reference's epsilons, then cast to fp32 -> bit-identical to numpy + .float().
 #include "nsnp_common.hpp"
 
 namespace {
@@ -27,53 +28,63 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hap_features(
 {
     extern __shared__ unsigned long long hf_lds[];
     unsigned long long* sums = hf_lds;                                   // [4][NSTAT][L] int64
-    unsigned int* rowmask = reinterpret_cast<unsigned int*>(sums + 4 * NSTAT * L);   // [D] bit g set: any(hap == g)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = blockIdx.x;
     const size_t plane = (size_t)n * D * L;
-    const int RP = HF_BLOCK / L;                  // rows handled in parallel
-    const int rp = tid / L, l = tid - rp * L;
-    const bool active = rp < RP;
+    const bool active = lane < L;
+    constexpr int NW = HF_BLOCK / 64, U = 4;      // waves per workgroup, rows of a wave in flight together
 
     for (int i = tid; i < 4 * NSTAT * L; i += HF_BLOCK) sums[i] = 0ull;
-    for (int i = tid; i < D; i += HF_BLOCK) rowmask[i] = 0u;
-    __syncthreads();
-    // pass A: which read sets does each row belong to (np.any(hap == g, axis=1), dataset_dev.py:57-59)
-    if (active)
-        for (int d = rp; d < D; d += RP) {
-            const int hv = hap[plane + (size_t)d * L + l];
-            if (hv >= 1 && hv <= 3) atomicOr(&rowmask[d], 1u << hv);
+
+    int cnt[4][5];                                // per read set: A C G T D
+    long long qs[4][8];                           // per read set: baseq sum A C G T, mapq sum A C G T
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cnt[g][k] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qs[g][k] = 0;
+    }
+    for (int d0 = wave; d0 < D; d0 += NW * U) {
+        int sv[U], bv[U], mv[U], hv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int d = d0 + NW * u;
+            const bool on = active && d < D;
+            const size_t o = plane + (size_t)(on ? d : 0) * L + (on ? lane : 0);
+            sv[u] = on ? (int)seq[o] : 0; hv[u] = on ? (int)hap[o] : 0;
+            bv[u] = on ? (int)bq[o] : 0; mv[u] = on ? (int)mq[o] : 0;
         }
-    __syncthreads();
-    // pass B: column sums for the four read sets
-    if (active) {
-        long long acc[4][NSTAT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int k = 0; k < NSTAT; ++k) acc[g][k] = 0;
-        for (int d = rp; d < D; d += RP) {
-            const size_t o = plane + (size_t)d * L + l;
-            const int s = seq[o];
-            if (!((s >= 1 && s <= 4) || s == -1)) continue;      // 0 (not covering) and -2 (padding) match nothing
-            const long long b = bq[o], m = mq[o];
-            const unsigned int msk = rowmask[d] | 1u;            // bit 0 = "all reads"
+        for (int u = 0; u < U; ++u) {
+            if (d0 + NW * u >= D) break;                          // (uniform)
+            // read sets of this row: bit 0 "all reads", bit g any(hap == g) over the row's columns (dataset_dev.py:57-59)
+            const unsigned msk = 1u | (__ballot(hv[u] == 1) ? 2u : 0u) | (__ballot(hv[u] == 2) ? 4u : 0u) | (__ballot(hv[u] == 3) ? 8u : 0u);
+            const int s = sv[u];                                  // 0 (not covering) and -2 (padding) match nothing
+            const long long b = bv[u], m = mv[u];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (!((msk >> g) & 1u)) continue;
+                if (!((msk >> g) & 1u)) continue;                 // (uniform)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool hit = (s == k + 1);
-                    acc[g][k] += hit; acc[g][5 + k] += hit ? b : 0; acc[g][9 + k] += hit ? m : 0;
+                    cnt[g][k] += hit; qs[g][k] += hit ? b : 0; qs[g][4 + k] += hit ? m : 0;
                 }
-                acc[g][4] += (s == -1);
+                cnt[g][4] += (s == -1);
             }
         }
+    }
+    __syncthreads();                                              // sums are zeroed
+    if (active) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int k = 0; k < NSTAT; ++k)
-                if (acc[g][k] != 0) atomicAdd(&sums[(g * NSTAT + k) * L + l], (unsigned long long)acc[g][k]);
+            for (int k = 0; k < 5; ++k)
+                if (cnt[g][k] != 0) atomicAdd(&sums[(g * NSTAT + k) * L + lane], (unsigned long long)cnt[g][k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (qs[g][k] != 0) atomicAdd(&sums[(g * NSTAT + 5 + k) * L + lane], (unsigned long long)qs[g][k]);
+        }
     }
     __syncthreads();
     // pass C: the 105 x L outputs (row order of get_seq_baseq_mapq_feat, dataset_dev.py:51)
@@ -112,7 +123,7 @@ int hap_features_impl(nsnp_ctx* ctx, const PT* seq, const PT* bq, const PT* mq, 
     if (!ctx || N < 0 || D <= 0 || L <= 0 || L > HF_MAX_L) return NSNP_EINVAL;
     if (N > 0 && (!seq || !bq || !mq || !hap || !ref_row || !out)) return NSNP_EINVAL;
     if (N == 0) return NSNP_OK;
-    const size_t lds = (size_t)4 * NSTAT * L * 8 + (size_t)D * 4;
+    const size_t lds = (size_t)4 * NSTAT * L * 8;
     if (lds > 64 * 1024) return NSNP_ESHAPE;
     ScopedKernelTimer tm(ctx, NSNP_K_HAPFEAT, (hipStream_t)stream);
     hipLaunchKernelGGL(k_hap_features<PT>, dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream,
