@@ -290,6 +290,7 @@ def main():
     second = None
     if not args.no_second_precision and args.precision == 0:
         ref_gt = stage.gt_all[:n_done].clone(); ref_zy = stage.zy_all[:n_done].clone()
+        torch.cuda.synchronize(dev)                     # (the copies run on torch's current stream, the forwards on the stage's)
         stage.set_precision(1)
         dt2, _, _, tot2 = timed_pass()
         d = max((stage.gt_all[:n_done] - ref_gt).abs().max().item(), (stage.zy_all[:n_done] - ref_zy).abs().max().item())

@@ -158,7 +158,7 @@ def _timed(fn, sync, reps):
     return n, time.perf_counter() - t0
 
 
-def hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, feat_sites):
+def hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, feat_sites, workload="haplotype"):
     """roofline of the fused LSTM step launches (MFMA) and of the feature reduction (HBM)"""
     from tools import bench_common as bc
     out = {}
@@ -169,14 +169,14 @@ def hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, feat_sites):
         out["roofline"] = bc.roofline_mfma(
             "k_hap_gemm<LSTM> (fused step: gates GEMM + cell)", bc.hap_exec_flop() * sites_per_pass / n_launch, avg, chain_n * n_launch,
             alg_flop_per_launch=bc.HAP_ALG_FLOP * sites_per_pass / n_launch,
-            traffic=bc.committed_traffic("haplotype", "hap_gemm_lstm", D=hs.D),
+            traffic=bc.committed_traffic(workload, "hap_gemm_lstm", D=hs.D),
             how="one HIP event pair around the %d dependent step launches of a pass (one stream, nothing else running), divided by %d; "
                 "launches differ in size (K = 368 / 768, 2 or 4 direction slices), so flops and time are both per AVERAGE launch"
                 % (n_launch, n_launch), launches_per_pass=n_launch, sites_per_pass=sites_per_pass)
     if feat_n:
         nbytes = hs.feature_bytes(feat_sites, 33)
         out["roofline_features"] = bc.roofline_hbm("k_hap_features (L = 33, int32 planes)", nbytes, feat_ms / feat_n, feat_n,
-                                                   traffic=bc.committed_traffic("haplotype", "hap_features", D=hs.D),
+                                                   traffic=bc.committed_traffic(workload, "hap_features", D=hs.D),
                                                    how="HIP events around every launch, one stream, nothing else running", sites_per_launch=feat_sites,
                                                    D=hs.D)
     return out
@@ -344,6 +344,7 @@ def run(args, rank, world, local_rank, deep60=False):
                                        "frac_of_fp32_mfma_peak": bc.hap_exec_flop() * nf / tf / 1e12 / bc.PEAK_F32_MFMA_TFLOPS}
         if not args.no_second_precision:
             ref = hs.gt[b0:b1].clone()
+            torch.cuda.synchronize(dev)                 # (the copy runs on torch's current stream, the forwards on the stage's)
             hs.ctx.set_option("hap_precision", 1)
             nf, tf = _timed(lambda: (hs.forward(b0, b1), nfe)[1], hs.sync, 3)
             d = (hs.gt[b0:b1] - ref).abs().max().item()
@@ -358,11 +359,11 @@ def run(args, rank, world, local_rank, deep60=False):
             second["legacy_CatModel_forward_fp32"] = cat_report(cs, nc, tc, ct, bc)
 
     if rank == 0:
-        roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, nfe)
+        roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, nfe, "deep60" if deep60 else "haplotype")
         if deep60:
             from tools.pileup_stage import pileup_rooflines
             excl, excl_n = ps.exclusive_pass()
-            pr = pileup_rooflines(ps, ptot, excl, excl_n, done[0], dt, 0, ps.G)
+            pr = pileup_rooflines(ps, ptot, excl, excl_n, done[0], dt, 0, ps.G, "deep60")
             roofs["roofline_pileup_60x"] = pr.get("roofline")
             if roofs["roofline_pileup_60x"]:
                 roofs["roofline_pileup_60x"].pop("chip", None)      # the step also holds the other two stages

@@ -13,7 +13,6 @@ call (no encode work is carried into or out of a timed region).
 from __future__ import annotations
 
 import ctypes as C
-import math
 
 
 class PileupStage:
@@ -28,7 +27,7 @@ class PileupStage:
         self.batch, self.S = int(batch), max(1, int(streams))
         self.n_windows = max(self.batch, (int(n_windows) // self.batch) * self.batch)
         self.n_batches = self.n_windows // self.batch
-        self.G = max(1, math.gcd(self.n_batches, max(1, int(enc_group))))       # groups never straddle the pool's wrap-around
+        self.G = max(1, min(int(enc_group), self.n_batches))                  # batches per encode launch (cut at the pool's wrap-around)
         self.R = max(2, int(ring))
         self.coverage = coverage
         self.weights = weights if weights is not None else load_pileup_weights()   # the shipped ont_pileup weights (fixture)
@@ -84,7 +83,7 @@ class PileupStage:
         i, end = first, first + count
         while i < end:
             b = i % self.n_batches
-            g = min(self.G - (b % self.G), end - i)                          # up to G consecutive pool batches, cut at a group boundary
+            g = min(self.G - (b % self.G), end - i, self.n_batches - b)      # up to G consecutive pool batches, cut at a group boundary / the pool's end
             slot = self.ring[self.gseq % self.R]; self.gseq += 1
             es = self.enc_stream
             for ev in slot["users"]:                                         # the forwards that last read this ring slot
@@ -157,7 +156,7 @@ class PileupStage:
         return t.stack([self.res["ga"][:n_done].float(), self.res["za"][:n_done].float(), self.res["gm"][:n_done], self.res["zm"][:n_done]], dim=1)
 
 
-def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc_group):
+def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc_group, workload="pileup"):
     """roofline objects of the pileup stage.  Headline = the dominant forward kernel (most total time in the timed region) priced
     on its EXCLUSIVE launches (one stream, nothing else on the chip; the duration a rocprofv3 kernel trace shows for the same
     launches): executed flops per launch / average launch duration / peak.  `chip` = executed forward flops of all timed sites
@@ -175,7 +174,7 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
                    % excl_n[dom])
             roof = bc.roofline_mfma(dom, bc.PILEUP_EXEC_FLOP[dom] * batch * mult, excl[dom], excl_n[dom],
                                     alg_flop_per_launch=bc.PILEUP_ALG_FLOP[dom] * batch, peak=peak, how=how,
-                                    traffic=bc.committed_traffic("pileup", dom, batch=batch, precision=precision))
+                                    traffic=bc.committed_traffic(workload, dom, batch=batch, precision=precision))
             fwd_exec = sum(bc.PILEUP_EXEC_FLOP[k] for k in fwd_keys) * mult
             chip = fwd_exec * sites_per_gpu / dt / 1e12
             roof["chip"] = {"achieved": chip, "frac": chip / peak, "unit": "TFLOP/s",
@@ -189,7 +188,7 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
     if "encode_columns" in excl:
         nbytes = stage.encode_bytes(enc_group)
         e = bc.roofline_hbm("encode_columns", nbytes, excl["encode_columns"], excl_n["encode_columns"],
-                            traffic=bc.committed_traffic("pileup", "encode_columns", batch=batch, enc_group=enc_group),
+                            traffic=bc.committed_traffic(workload, "encode_columns", batch=batch, enc_group=enc_group),
                             how="HIP events around every launch, nothing else running; one launch encodes %d batches = %d columns"
                                 % (enc_group, enc_group * stage.mcols), batches_per_launch=enc_group, columns_per_launch=enc_group * stage.mcols)
         out["roofline_encode"] = e

@@ -120,9 +120,9 @@ def run(args, rank, world, local_rank):
             hs.features(b0, b1, which=(0,))
         hs.sync()
         feat_ms, feat_n = hs.ctx.read_timing()["hap_features"]
-        roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, b1 - b0)
+        roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, b1 - b0, "two-stage")
         excl, excl_n = ps.exclusive_pass(groups=2)
-        pr = pileup_rooflines(ps, ptot, excl, excl_n, n2 * K, t2, 0, ps.G)
+        pr = pileup_rooflines(ps, ptot, excl, excl_n, n2 * K, t2, 0, ps.G, "two-stage")
         roofs["roofline_stage2"] = pr.get("roofline")
         roofs["roofline_encode"] = pr.get("roofline_encode")
         out = {
