@@ -168,6 +168,28 @@ static AfThreshold make_af_threshold(double a)
     return r;
 }
 
+// The same test as a table for the depths the fast path can produce (a column of at most 253 bytes holds at most 253 reads):
+// af_min[d] = the smallest count c >= 1 with (double)c / (double)d >= min_af, 0xffff when no count <= d passes.  Built on the host
+// with the exact 128-bit comparison above, once per call; a column then tests its six alleles with one LDS read and six compares
+// instead of six 128-bit shifts and compares (110 of the kernel's 1,350 vector instructions per wave).
+struct AfTable { uint32_t w[128]; };        // 256 x uint16, passed by value
+
+static AfTable make_af_table(const AfThreshold& af)
+{
+    AfTable t;
+    uint16_t m[256];
+    for (int d = 0; d < 256; ++d) {
+        m[d] = 0xffff;
+        if (af.mode == 1) { m[d] = 1; continue; }
+        if (af.mode == 2) continue;
+        const unsigned __int128 rhs = (unsigned __int128)af.t * (uint32_t)(d ? d : 1);
+        for (int c = 1; c <= (d ? d : 1); ++c)
+            if ((((unsigned __int128)(uint32_t)c) << af.k) >= rhs) { m[d] = (uint16_t)c; break; }
+    }
+    for (int i = 0; i < 128; ++i) t.w[i] = (uint32_t)m[2 * i] | ((uint32_t)m[2 * i + 1] << 16);
+    return t;
+}
+
 // ---- main kernel ----------------------------------------------------------------------------------------
 // One lane per column, 64 columns per wave, their bytes (one contiguous range) staged into LDS with 16-byte loads.  The kernel is
 // bound by vector-instruction issue (MFMA-free, four waves per SIMD keep the vector pipe busy), so it is built around the
@@ -213,9 +235,10 @@ __device__ __forceinline__ int wave_scan_incl(int v)
 #endif
 __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
-    int64_t M, AfThreshold af, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
+    int64_t M, AfThreshold af, const AfTable aft, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
     uint8_t* __restrict__ flags)
 {
+    __shared__ uint32_t af_min[128];          // 256 x uint16: smallest passing count by depth (make_af_table)
     __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
     // one record per construct opener of the segment.  word 0: position | column << 16 (written by the column), then
     // q | nskip << 13 | column << 20 | minus << 26 | counted << 27 | fwd << 28 (written by the lane that decoded it);
@@ -237,6 +260,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
         else if (cls >= 11) r.w = 1u;
         if (is_fwd_char(tid)) r.z |= 1u << 24;
         tab[tid ^ ((tid >> 2) & 8)] = r;        // row index = byte with its case bit (0x20) folded into bit 3: 'A' and 'a' in different banks
+        if (tid < 128) af_min[tid] = aft.w[tid];
     }
     __syncthreads();
     const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
@@ -542,14 +566,24 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     int top = -1, topc = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) if (lc[k] > topc) { topc = lc[k]; top = lk[k]; }
-    const uint32_t den = (uint32_t)(depth ? depth : 1);
-    const unsigned __int128 rhs = (unsigned __int128)af.t * den;
     bool pass_snp = false, pass_indel = false;
+    if (__ballot(depth > 255) == 0ull) {
+        // every column of the wave inside the table (always, unless a column went through the exact path with more than 255 reads)
+        const int thr = (int)((af_min[depth >> 1] >> (16 * (depth & 1))) & 0xffffu);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        if (lc[k] <= 0 || lk[k] == chr_idx) continue;
-        const bool ok = af.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << af.k) >= rhs) : af.mode == 1;
-        if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
+        for (int k = 0; k < 6; ++k) {
+            const bool ok = lc[k] > 0 && lk[k] != chr_idx && lc[k] >= thr;
+            if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
+        }
+    } else {
+        const uint32_t den = (uint32_t)(depth ? depth : 1);
+        const unsigned __int128 rhs = (unsigned __int128)af.t * den;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (lc[k] <= 0 || lk[k] == chr_idx) continue;
+            const bool ok = af.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << af.k) >= rhs) : af.mode == 1;
+            if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
+        }
     }
     const bool pass_af = (top >= 0 && top != chr_idx) || pass_snp || pass_indel;
     const int up_ch[4] = {CH_A, CH_C, CH_G, CH_T}, lo_ch[4] = {CH_a, CH_c, CH_g, CH_t};
@@ -669,8 +703,9 @@ extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, c
     if (M == 0) return NSNP_OK;
     const unsigned grid = (unsigned)NSNP_CDIV(M, ENC_BLOCK);
     ScopedKernelTimer tm(ctx, NSNP_K_ENCODE, (hipStream_t)stream);
+    const AfThreshold af = make_af_threshold(min_af);
     hipLaunchKernelGGL(k_encode_columns, dim3(grid), dim3(ENC_BLOCK), 0, (hipStream_t)stream,
-                       bases, col_off, ref, M, make_af_threshold(min_af), min_coverage, counts, depth, flags);
+                       bases, col_off, ref, M, af, make_af_table(af), min_coverage, counts, depth, flags);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }
