@@ -107,6 +107,8 @@ struct nsnp_ctx {
     CatWeightsDev* cw;
     void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
+    // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
+    bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
     KernelTimer* timer;
     void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init / nsnp_comm_attach (nsnp_comm.hip)
     bool comm_borrowed;                        // attached by the caller: never destroyed here

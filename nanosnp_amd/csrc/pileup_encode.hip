@@ -183,8 +183,12 @@ static AfTable make_af_table(const AfThreshold& af)
         if (af.mode == 1) { m[d] = 1; continue; }
         if (af.mode == 2) continue;
         const unsigned __int128 rhs = (unsigned __int128)af.t * (uint32_t)(d ? d : 1);
-        for (int c = 1; c <= (d ? d : 1); ++c)
-            if ((((unsigned __int128)(uint32_t)c) << af.k) >= rhs) { m[d] = (uint16_t)c; break; }
+        int lo = 1, hi = (d ? d : 1) + 1;                         // the test is monotone in c: smallest passing c by bisection, hi = none
+        while (lo < hi) {
+            const int c = (lo + hi) >> 1;
+            if ((((unsigned __int128)(uint32_t)c) << af.k) >= rhs) hi = c; else lo = c + 1;
+        }
+        if (lo <= (d ? d : 1)) m[d] = (uint16_t)lo;
     }
     for (int i = 0; i < 128; ++i) t.w[i] = (uint32_t)m[2 * i] | ((uint32_t)m[2 * i + 1] << 16);
     return t;
@@ -703,9 +707,20 @@ extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, c
     if (M == 0) return NSNP_OK;
     const unsigned grid = (unsigned)NSNP_CDIV(M, ENC_BLOCK);
     ScopedKernelTimer tm(ctx, NSNP_K_ENCODE, (hipStream_t)stream);
-    const AfThreshold af = make_af_threshold(min_af);
+    // threshold + table of the last min_af are kept in the context (a caller passes the same value call after call)
+    static_assert(sizeof(AfTable) == sizeof(ctx->af_table_words), "AfTable is 128 words");
+    uint64_t af_bits; memcpy(&af_bits, &min_af, 8);
+    if (!ctx->af_cached || ctx->af_bits != af_bits) {
+        const AfThreshold a0 = make_af_threshold(min_af);
+        const AfTable t0 = make_af_table(a0);
+        ctx->af_t = a0.t; ctx->af_k = a0.k; ctx->af_mode = a0.mode;
+        memcpy(ctx->af_table_words, t0.w, sizeof(t0.w));
+        ctx->af_bits = af_bits; ctx->af_cached = true;
+    }
+    AfThreshold af{ctx->af_t, ctx->af_k, ctx->af_mode};
+    AfTable aft; memcpy(aft.w, ctx->af_table_words, sizeof(aft.w));
     hipLaunchKernelGGL(k_encode_columns, dim3(grid), dim3(ENC_BLOCK), 0, (hipStream_t)stream,
-                       bases, col_off, ref, M, af, make_af_table(af), min_coverage, counts, depth, flags);
+                       bases, col_off, ref, M, af, aft, min_coverage, counts, depth, flags);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }
