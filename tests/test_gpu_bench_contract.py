@@ -105,23 +105,26 @@ def test_deep60_workload_line():
     assert d["value"] > 1e4 and d["cpu_baseline"]["value"] > 0
 
 
-@pytest.mark.parametrize("workload", ["pileup", "two-stage"])
+@pytest.mark.parametrize("workload", ["pileup", "two-stage", "haplotype"])
 def test_two_ranks_through_the_launcher_on_one_gpu(workload):
     """`bench.py --gpus 2` end to end on the one-GPU box: the parent starts the ranks, both run the real kernels on GPU 0, the
     barrier / max-over-ranks timing / rooted gather run over gloo (TEST configuration: everything of the N > 1 path except
     the RCCL transport itself)"""
-    env = dict(os.environ, NSNP_TWO_STAGE_N2="30000", NSNP_TWO_STAGE_N5="3001")
+    env = dict(os.environ, NSNP_TWO_STAGE_N2="30000", NSNP_TWO_STAGE_N5="3001", NSNP_HAP_N="3000", NSNP_CAT_N="2048")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "65536",
-                          "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--workload", workload],
+                          "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--hap-batch", "2048", "--workload", workload],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["value"] > 1e5
-    if workload == "pileup":
+    if workload == "haplotype":
+        assert d["scaling"] == "weak" and d["config"]["hap_sites_resident_per_gpu"] == 3000 and "TEST_CONFIGURATION" in d["config"]
+        assert abs(d["value"] - 2 * d["sites_timed"]["haplotype_sites"] / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6          # whole-job aggregate
+    elif workload == "pileup":
         assert d["scaling"] == "weak" and d["config"]["windows_resident_per_gpu"] == 65536 and "TEST_CONFIGURATION" in d["config"]
         assert abs(d["value"] - 2 * d["config"]["sites_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6      # whole-job aggregate
     else:
