@@ -53,7 +53,7 @@ def parse_args(argv=None):
                          "HaplotypeModel fwd (+ the legacy crnn.py CatModel fwd) on 150 k G3 sites; two-stage = configs[3]: stage 2 + stage 5 "
                          "on a chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0; deep60 = configs[4]: "
                          "60x columns + D = 180 read planes + fp16-split conv weights")
-    ap.add_argument("--encode-group", type=int, default=8, help="batches encoded per column-encode launch (on the encode stream, into a "
+    ap.add_argument("--encode-group", type=int, default=32, help="batches encoded per column-encode launch (on the encode stream, into a "
                     "ring of count buffers; the kernel is twice as efficient per byte at >= 1 M columns)")
     ap.add_argument("--hap-sites", type=int, default=0, help="haplotype / deep60 workloads: sites resident per job (0 = the workload's default)")
     ap.add_argument("--hap-batch", type=int, default=16384, help="haplotype / deep60 workloads: sites per step")

@@ -48,7 +48,7 @@ def test_bench_line_schema():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["kernel"] in d["kernel_exclusive_ms"] and "chip" in r and "achieved_algorithmic" in r
     assert r["launches_timed"] >= 16
-    assert d["roofline_encode"]["bound"] == "hbm" and d["roofline_encode"]["batches_per_launch"] == d["config"]["encode_batches_per_launch"] == 8
+    assert d["roofline_encode"]["bound"] == "hbm" and d["roofline_encode"]["batches_per_launch"] == d["config"]["encode_batches_per_launch"] == 32
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -323,3 +323,35 @@ def test_reference_style_haplotype_model_interface():
         LSTMNetwork({"model": dict(cfg["model"], hidden_size=100)})
     with pytest.raises(KeyError):
         LSTMNetwork(cfg).load_state_dict({})
+
+
+def test_features_and_forward_are_capturable_in_a_hip_graph(hap_model):
+    """nsnp_hap_load_weights reserves the forward's workspace, so nsnp_hap_features + nsnp_hap_forward neither allocate nor
+    synchronise: the pair can be captured once and replayed (round 2 allocated 0.8 GB inside the first forward)"""
+    import ctypes
+    import torch
+    from nanosnp_amd import _lib
+    ctx, _ = hap_model
+    n = 300
+    pp = host.synth_hap_planes(7001, n, 30, 90, 33); ph = host.synth_hap_planes(7002, n, 30, 90, 11)
+    dp = [torch.from_numpy(a).cuda() for a in pp]; dh = [torch.from_numpy(a).cuda() for a in ph]
+    xp = ctx.hap_features(*dp); xh = ctx.hap_features(*dh)
+    gt, zy = ctx.hap_forward(xp, xh)                             # eager reference
+    want = (gt.clone(), zy.clone())
+    torch.cuda.synchronize()
+    P, lib = ctypes.c_void_p, _lib.load()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            sp = P(torch.cuda.current_stream().cuda_stream)
+            rc = 0
+            for pl, out, L in ((dp, xp, 33), (dh, xh, 11)):
+                rc = rc or lib.nsnp_hap_features(ctx.handle, *[P(t.data_ptr()) for t in pl], n, 90, L, P(out.data_ptr()), sp)
+            rc = rc or lib.nsnp_hap_forward(ctx.handle, P(xp.data_ptr()), P(xh.data_ptr()), n, P(gt.data_ptr()), P(zy.data_ptr()), sp)
+            assert rc == 0
+    for _ in range(2):
+        gt.zero_(); zy.zero_(); xp.zero_(); xh.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gt, want[0]) and torch.equal(zy, want[1])
