@@ -144,8 +144,11 @@ def committed_traffic(workload, kernel, **match):
         w = tj.get("workloads", {}).get(workload)
         if w is None and workload == "pileup" and "kernels" in tj:          # round-2 layout
             w = tj
+        columns = match.pop("columns", None)
         if not w or any(w.get(k) != v for k, v in match.items()) or kernel not in w.get("kernels", {}):
             return None
+        if columns is not None and "hbm_bytes_per_column" in w["kernels"][kernel]:
+            return w["kernels"][kernel]["hbm_bytes_per_column"] * columns      # launches of the profiled run differ in size
         return w["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None

@@ -188,7 +188,7 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
     if "encode_columns" in excl:
         nbytes = stage.encode_bytes(enc_group)
         e = bc.roofline_hbm("encode_columns", nbytes, excl["encode_columns"], excl_n["encode_columns"],
-                            traffic=bc.committed_traffic(workload, "encode_columns", batch=batch, enc_group=enc_group),
+                            traffic=bc.committed_traffic(workload, "encode_columns", batch=batch, columns=enc_group * stage.mcols),
                             how="HIP events around every launch, nothing else running; one launch encodes %d batches = %d columns"
                                 % (enc_group, enc_group * stage.mcols), batches_per_launch=enc_group, columns_per_launch=enc_group * stage.mcols)
         out["roofline_encode"] = e

@@ -95,12 +95,15 @@ def main():
         traffic = collections.defaultdict(dict)
         for cname, d in (("FETCH_SIZE", args[2]), ("WRITE_SIZE", args[3])):
             acc = collections.defaultdict(list)
+            grid = collections.defaultdict(int)
             for r in csv.DictReader(open(one(d, "*counter_collection.csv"))):
                 if r["Counter_Name"] == cname:
                     acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+                    grid[short(r["Kernel_Name"])] += int(r["Grid_Size"])
             for k, v in acc.items():
                 if k.startswith("k_"):
                     traffic[k][cname] = sum(v) / len(v)
+                    traffic[k][cname + "_per_thread"] = sum(v) / max(grid[k], 1)      # (the column encode: one thread = one column)
                     traffic[k]["launches"] = len(v)
         summary = {"batch": batch, "precision": precision, "enc_group": enc_group, "D": Dd, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
                    "correction": "KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1",
@@ -112,6 +115,8 @@ def main():
             summary["kernels"][name] = {"fetch_kib_raw": v.get("FETCH_SIZE"), "write_kib_raw": v.get("WRITE_SIZE"),
                                         "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                         "hbm_bytes_per_launch": rd + wr, "launches": v.get("launches")}
+            if name == "encode_columns":      # launches of different sizes (groups of batches): bytes per column travel with it
+                summary["kernels"][name]["hbm_bytes_per_column"] = v.get("FETCH_SIZE_per_thread", 0.0) * 1024 * 2 + v.get("WRITE_SIZE_per_thread", 0.0) * 1024
         json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_traffic.json"), "w"), indent=1)
         rt = os.path.join(out_dir, "roofline_traffic.json")
         allw = {"workloads": {}}
