@@ -90,6 +90,21 @@ def main():
                     f.write(f"timed_region,{k.replace(',', ';')},{len(w)},{sum(e - s for s, e in w) / len(w):.1f}\n")
                 if tail:
                     f.write(f"alone_after,{k.replace(',', ';')},{len(tail)},{sum(e - s for s, e in tail) / len(tail):.1f}\n")
+    # the tile GEMM is launched with different grids by different callers (HaplotypeModel passes, the CatModel's LSTMs, ragged last
+    # batches): per-grid averages, so that a bench line's per-launch figure can be compared with launches of the same shape
+    tp = one(stats_dir, "*kernel_trace.csv")
+    if tp:
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(tp)):
+            k = short(r["Kernel_Name"])
+            if k.startswith("k_hap_gemm"):
+                g = (int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+                by[(k, g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if by:
+            with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "a") as f:
+                f.write("# tile GEMM launches by grid (site tiles x row tiles x slices): by_grid,kernel,grid,launches,avg_ns,total_ns\n")
+                for (k, g), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+                    f.write(f"by_grid,{k.replace(',', ';')},{g[0]}x{g[1]}x{g[2]},{len(v)},{sum(v) / len(v):.1f},{sum(v)}\n")
     print(open(os.path.join(out_dir, f"{tag}_kernel_stats.csv")).read())
     if len(args) >= 4:
         traffic = collections.defaultdict(dict)
