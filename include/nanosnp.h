@@ -144,6 +144,14 @@ int nsnp_pileup_forward(nsnp_ctx* ctx, const int32_t* x, int64_t N,
 int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,
                                 int64_t N, float* gt_prob, float* zy_prob, void* stream);
 
+/* nsnp_pileup_forward_windows and predict.py:54-57 (np.argmax / np.max of both heads) in one call: the fp32 heads kernel writes
+ * gt_arg / zy_arg (uint8) and gt_max / zy_max (fp32) from the registers that hold the probabilities, one launch less per batch than
+ * forward + nsnp_pileup_postprocess; every other arithmetic mode / kernel generation runs the two back to back on `stream`.
+ * Same values as the two-call sequence, bit for bit (first maximum wins, as np.argmax). */
+int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, int64_t N,
+                                      float* gt_prob, float* zy_prob, uint8_t* gt_arg, uint8_t* zy_arg,
+                                      float* gt_max, float* zy_max, void* stream);
+
 /* predict.py:54-65: gt_arg/zy_arg = argmax, gt_max/zy_max = max probability,
  * depth = -(sum of the negative entries of x[n,16,{0,1,2,3,9,10,11,12}]).  All device. */
 int nsnp_pileup_postprocess(nsnp_ctx* ctx, const float* gt_prob, const float* zy_prob,

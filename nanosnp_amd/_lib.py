@@ -33,6 +33,7 @@ _SIGNATURES = {
     "nsnp_pileup_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsnp_pileup_forward_windows_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7),
     "nsnp_pileup_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
@@ -216,6 +217,19 @@ class Context:
                                                    _dptr(zy), _stream_ptr(stream)),
               self.handle, "nsnp_pileup_forward_windows")
         return gt, zy
+
+    def pileup_forward_windows_calls(self, counts, center_idx, stream=None):
+        """forward + argmax / max of both heads in one call -> (gt, zy, gt_arg, zy_arg, gt_max, zy_max)"""
+        import torch
+        n = center_idx.shape[0]
+        dev = counts.device
+        gt = torch.empty((n, 21), dtype=torch.float32, device=dev); zy = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        ga = torch.empty(n, dtype=torch.uint8, device=dev); za = torch.empty(n, dtype=torch.uint8, device=dev)
+        gm = torch.empty(n, dtype=torch.float32, device=dev); zm = torch.empty(n, dtype=torch.float32, device=dev)
+        check(self.lib.nsnp_pileup_forward_windows_calls(self.handle, _dptr(counts), _dptr(center_idx), n, _dptr(gt), _dptr(zy), _dptr(ga),
+                                                         _dptr(za), _dptr(gm), _dptr(zm), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_forward_windows_calls")
+        return gt, zy, ga, za, gm, zm
 
     def pileup_postprocess(self, gt, zy, x=None, stream=None):
         import torch

@@ -280,3 +280,21 @@ extern "C" int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts,
     if (ctx->precision == 1) return nsnp_pileup_forward_f16x3(ctx, counts, center_idx, N, gt_prob, zy_prob, (hipStream_t)stream);
     return nsnp_pileup_forward_impl(ctx, counts, center_idx, N, gt_prob, zy_prob, (hipStream_t)stream);
 }
+
+extern "C" int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, int64_t N,
+                                                 float* gt_prob, float* zy_prob, uint8_t* gt_arg, uint8_t* zy_arg,
+                                                 float* gt_max, float* zy_max, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!counts || !center_idx || !gt_prob || !zy_prob || !gt_arg || !zy_arg || !gt_max || !zy_max))) return NSNP_EINVAL;
+    if (N == 0) return NSNP_OK;
+    // the fp32 heads kernel writes argmax / max from the registers that hold the probabilities; the other paths (f16x3, the
+    // one-wave heads kernel of round 1) run the forward and then nsnp_pileup_postprocess on the same stream
+    ctx->post_out = PostOut{gt_arg, zy_arg, gt_max, zy_max};
+    ctx->post_done = false;
+    const int rc = nsnp_pileup_forward_windows(ctx, counts, center_idx, N, gt_prob, zy_prob, stream);
+    const bool done = ctx->post_done;
+    ctx->post_out = PostOut{nullptr, nullptr, nullptr, nullptr};
+    ctx->post_done = false;
+    if (rc) return rc;
+    return done ? NSNP_OK : nsnp_pileup_postprocess(ctx, gt_prob, zy_prob, nullptr, N, gt_arg, zy_arg, gt_max, zy_max, nullptr, stream);
+}

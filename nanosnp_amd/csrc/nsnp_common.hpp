@@ -73,6 +73,9 @@ struct KernelTimer {
     bool enabled;
 };
 
+// argmax / max outputs of a fused forward + post-processing call (nsnp_pileup_forward_windows_calls); all null otherwise
+struct PostOut { uint8_t* gt_arg; uint8_t* zy_arg; float* gt_max; float* zy_max; };
+
 struct nsnp_ctx {
     int device;
     int n_cu;
@@ -109,6 +112,7 @@ struct nsnp_ctx {
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
     bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
+    PostOut post_out; bool post_done;         // set around a fused call; post_done: the head kernel wrote them
     KernelTimer* timer;
     void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init / nsnp_comm_attach (nsnp_comm.hip)
     bool comm_borrowed;                        // attached by the caller: never destroyed here

@@ -958,7 +958,8 @@ __global__ __launch_bounds__(512, 2) void k_pileup_head_rs(
     const float* __restrict__ proj_w, const float* __restrict__ proj_b,
     const float* __restrict__ dense_w, const float* __restrict__ dense_b,
     const float* __restrict__ head_w, const float* __restrict__ head_b,
-    float* __restrict__ gt_prob, float* __restrict__ zy_prob)
+    float* __restrict__ gt_prob, float* __restrict__ zy_prob,
+    uint8_t* __restrict__ gt_arg, uint8_t* __restrict__ zy_arg, float* __restrict__ gt_max, float* __restrict__ zy_max)
 {
     __shared__ float x1[32][64];          // output_proj results as dense K-steps
     __shared__ float x2[64][64];          // tanh(dense) as head K-steps
@@ -1056,18 +1057,47 @@ __global__ __launch_bounds__(512, 2) void k_pileup_head_rs(
             const float zm = fmaxf(z1, fmaxf(z2, z3));
             const float ez1 = __expf(z1 - zm), ez2 = __expf(z2 - zm), ez3 = __expf(z3 - zm);
             const float zs = ez1 + ez2 + ez3;
+            float p0[4], p1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { p0[g] = e0[g] / sum; p1[g] = e1[g] / sum; }
+            const float pz1 = ez1 / zs, pz2 = ez2 / zs, pz3 = ez3 / zs;
             if (live) {
                 float* gp = gt_prob + site * NSNP_GT_CLASSES;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gp[4 * q + g] = e0[g] / sum;
+                for (int g = 0; g < 4; ++g) gp[4 * q + g] = p0[g];
                 if (q == 0) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) gp[16 + g] = e1[g] / sum;
+                    for (int g = 0; g < 4; ++g) gp[16 + g] = p1[g];
                 }
                 if (q == 1) {
-                    gp[20] = e1[0] / sum;
+                    gp[20] = p1[0];
                     float* zp = zy_prob + site * NSNP_ZY_CLASSES;
-                    zp[0] = ez1 / zs; zp[1] = ez2 / zs; zp[2] = ez3 / zs;
+                    zp[0] = pz1; zp[1] = pz2; zp[2] = pz3;
+                }
+            }
+            if (gt_arg) {
+                // predict.py:54-57 in the same launch: np.argmax / np.max over the stored probabilities (first maximum wins).
+                // Lane (site, q) holds classes 4q .. 4q+3 (p0), q == 0 also 16..19, q == 1 also 20; the four q lanes of a site are
+                // 16 lanes apart.
+                float bv = p0[0]; int bi = 4 * q;
+#pragma unroll
+                for (int g = 1; g < 4; ++g) if (p0[g] > bv) { bv = p0[g]; bi = 4 * q + g; }
+                if (q == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) if (p1[g] > bv) { bv = p1[g]; bi = 16 + g; }
+                }
+                if (q == 1 && p1[0] > bv) { bv = p1[0]; bi = 20; }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (live && q == 0) { gt_arg[site] = (uint8_t)bi; gt_max[site] = bv; }
+                if (live && q == 1) {
+                    float zb = pz1; int zi = 0;
+                    if (pz2 > zb) { zb = pz2; zi = 1; }
+                    if (pz3 > zb) { zb = pz3; zi = 2; }
+                    zy_arg[site] = (uint8_t)zi; zy_max[site] = zb;
                 }
             }
         }
@@ -1326,9 +1356,13 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         if (ctx->head_rs) {
             int64_t gh = NSNP_CDIV(n, 16);
             if (gh > 2 * (int64_t)ctx->n_cu) gh = 2 * (int64_t)ctx->n_cu;          // persistent: two 8-wave workgroups per CU
+            const PostOut& po = ctx->post_out;
             hipLaunchKernelGGL(k_pileup_head_rs, dim3((unsigned)gh), dim3(512), 0, s, ctx->ws_h1c, n,
                                pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,
-                               gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES);
+                               gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES,
+                               po.gt_arg ? po.gt_arg + base : nullptr, po.gt_arg ? po.zy_arg + base : nullptr,
+                               po.gt_arg ? po.gt_max + base : nullptr, po.gt_arg ? po.zy_max + base : nullptr);
+            ctx->post_done = true;
         } else
         hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,
                            pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,

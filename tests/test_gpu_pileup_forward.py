@@ -396,3 +396,28 @@ def test_forward_is_capturable_in_a_hip_graph(pileup_weights):
         torch.cuda.synchronize()
         assert torch.equal(gt, want[0]) and torch.equal(zy, want[1])
     c.close()
+
+
+@pytest.mark.parametrize("opts", [{}, {"pileup_precision": 1}, {"head_split": 0}], ids=["fp32", "f16x3", "fp32-one-wave-heads"])
+def test_fused_forward_and_argmax_equals_the_two_calls(pileup_weights, opts):
+    """nsnp_pileup_forward_windows_calls = nsnp_pileup_forward_windows + nsnp_pileup_postprocess (predict.py:51-57), bit for bit:
+    the fp32 heads kernel writes argmax / max itself, the other paths run the two kernels back to back; ragged N, ties included"""
+    import torch
+    from nanosnp_amd import _lib, host
+    c = _lib.Context(0, chunk_sites=2048)
+    c.pileup_load_weights(pileup_weights)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    n = 4099
+    cols = host.synth_columns(77, 33 * n, coverage=30, window=33)
+    counts, _, _ = c.pileup_encode_columns(torch.from_numpy(cols.bases).cuda(), torch.from_numpy(cols.col_off).cuda(), torch.from_numpy(cols.ref).cuda())
+    counts[33 * 5:33 * 6] = 0                                       # an all-zero window: many equal probabilities
+    centers = torch.arange(n, dtype=torch.int64, device="cuda") * 33 + 16
+    gt, zy = c.pileup_forward_windows(counts, centers)
+    ga, za, gm, zm, _ = c.pileup_postprocess(gt, zy)
+    gt2, zy2, ga2, za2, gm2, zm2 = c.pileup_forward_windows_calls(counts, centers)
+    torch.cuda.synchronize()
+    assert torch.equal(gt, gt2) and torch.equal(zy, zy2)
+    assert torch.equal(ga, ga2) and torch.equal(za, za2) and torch.equal(gm, gm2) and torch.equal(zm, zm2)
+    assert torch.equal(ga2.long(), gt2.argmax(1)) and torch.equal(gm2, gt2.max(1).values)
+    c.close()

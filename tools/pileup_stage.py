@@ -105,11 +105,11 @@ class PileupStage:
                 h, sp = self.ctxs[s].handle, P(st.cuda_stream)
                 n0 = (b + j) * self.batch
                 gt_p, zy_p = P(self.gt_all.data_ptr() + 84 * n0), P(self.zy_all.data_ptr() + 12 * n0)
-                rc = lib.nsnp_pileup_forward_windows(h, P(slot["counts"].data_ptr() + 72 * j * self.mcols), P(self.centers.data_ptr()),
-                                                     self.batch, gt_p, zy_p, sp)
-                rc = rc or lib.nsnp_pileup_postprocess(h, gt_p, zy_p, None, self.batch, P(self.res["ga"].data_ptr() + n0),
-                                                       P(self.res["za"].data_ptr() + n0), P(self.res["gm"].data_ptr() + 4 * n0),
-                                                       P(self.res["zm"].data_ptr() + 4 * n0), None, sp)
+                # forward + argmax / max (predict.py:51-57) in one call: the fp32 heads kernel writes both
+                rc = lib.nsnp_pileup_forward_windows_calls(h, P(slot["counts"].data_ptr() + 72 * j * self.mcols), P(self.centers.data_ptr()),
+                                                           self.batch, gt_p, zy_p, P(self.res["ga"].data_ptr() + n0),
+                                                           P(self.res["za"].data_ptr() + n0), P(self.res["gm"].data_ptr() + 4 * n0),
+                                                           P(self.res["zm"].data_ptr() + 4 * n0), sp)
                 if rc:
                     check(rc, h, "forward / postprocess")
                 ev = self._event(); ev.record(st); slot["users"].append(ev)
