@@ -87,30 +87,33 @@ __global__ __launch_bounds__(HF_BLOCK) void k_hap_features(
         }
     }
     __syncthreads();
-    // pass C: the 105 x L outputs (row order of get_seq_baseq_mapq_feat, dataset_dev.py:51)
+    // pass C: the 105 x L outputs (row order of get_seq_baseq_mapq_feat, dataset_dev.py:51).  One thread per (read set, column) reads
+    // its 13 sums once, forms the column total once and writes the set's 26 rows (a wave's stores of one row are consecutive floats):
+    // 13 float64 divisions per thread instead of one output element at a time with up to six LDS reads each.
     float* __restrict__ o = out + (size_t)n * 105 * L;
-    for (int i = tid; i < 105 * L; i += HF_BLOCK) {
-        const int row = i / L, col = i - row * L;
-        float v;
-        if (row == 104) v = (float)ref_row[n * L + col];
-        else {
-            const int g = row / 26, r = row - g * 26;
-            const long long* S = reinterpret_cast<const long long*>(sums) + (size_t)g * NSTAT * L + col;
-#define SUM(k) S[(size_t)(k) * L]
-            double x;
-            if (r < 5) {            // frequency = cnt / (A+C+G+T+D + 1e-6)            dataset_dev.py:17-22
-                const double total = (double)(SUM(0) + SUM(1) + SUM(2) + SUM(3) + SUM(4)) + 1e-6;
-                x = (double)SUM(r) / total;
-            } else if (r < 10) x = (double)SUM(r - 5);                                  // counts
-            else if (r < 14) x = (double)SUM(5 + (r - 10));                             // baseq sums
-            else if (r < 18) x = (double)SUM(5 + (r - 14)) / ((double)SUM(r - 14) + 1e-9);   // baseq means
-            else if (r < 22) x = (double)SUM(9 + (r - 18));                             // mapq sums
-            else             x = (double)SUM(9 + (r - 22)) / ((double)SUM(r - 22) + 1e-9);   // mapq means
-#undef SUM
-            v = (float)x;
+    for (int i = tid; i < 4 * L; i += HF_BLOCK) {
+        const int g = i / L, col = i - g * L;
+        const long long* S = reinterpret_cast<const long long*>(sums) + (size_t)g * NSTAT * L + col;
+        long long v[NSTAT];
+#pragma unroll
+        for (int k = 0; k < NSTAT; ++k) v[k] = S[(size_t)k * L];
+        float* og = o + (size_t)g * 26 * L + col;
+        const double total = (double)(v[0] + v[1] + v[2] + v[3] + v[4]) + 1e-6;          // dataset_dev.py:17-22
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            og[(size_t)r * L] = (float)((double)v[r] / total);                             // frequencies
+            og[(size_t)(5 + r) * L] = (float)(double)v[r];                                 // counts
         }
-        o[i] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double c = (double)v[k] + 1e-9;
+            og[(size_t)(10 + k) * L] = (float)(double)v[5 + k];                            // baseq sums
+            og[(size_t)(14 + k) * L] = (float)((double)v[5 + k] / c);                      // baseq means
+            og[(size_t)(18 + k) * L] = (float)(double)v[9 + k];                            // mapq sums
+            og[(size_t)(22 + k) * L] = (float)((double)v[9 + k] / c);                      // mapq means
+        }
     }
+    for (int col = tid; col < L; col += HF_BLOCK) o[(size_t)104 * L + col] = (float)ref_row[n * L + col];
 }
 
 }  // namespace
