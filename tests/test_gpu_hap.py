@@ -355,3 +355,30 @@ def test_features_and_forward_are_capturable_in_a_hip_graph(hap_model):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(gt, want[0]) and torch.equal(zy, want[1])
+
+
+def test_pass_size_option_multi_pass_ragged():
+    """"hap_pass_sites": N larger than the internal pass and not a multiple of it or of the 128-site tile - the passes see the same
+    arithmetic, so the result does not depend on the pass size (bit for bit); bad values are refused; N = 0 is a no-op"""
+    import torch
+    from nanosnp_amd import _lib
+    from nanosnp_amd._lib import NanoSNPError
+    from tests.helpers import seeded_hap_weights
+    c = _lib.Context(0)
+    c.hap_load_weights(seeded_hap_weights(12, H=256))
+    n = 700
+    rng = np.random.default_rng(3)
+    xp = torch.from_numpy((rng.standard_normal((n, 105, 33)) * 20).astype(np.float32)).cuda()
+    xh = torch.from_numpy((rng.standard_normal((n, 105, 11)) * 20).astype(np.float32)).cuda()
+    ref = c.hap_forward(xp, xh)
+    for ps in (128, 256, 640, 1024):
+        c.set_option("hap_pass_sites", ps)
+        got = c.hap_forward(xp, xh)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), ps
+    for bad in (0, 100, 129, 1 << 20):
+        with pytest.raises(NanoSNPError):
+            c.set_option("hap_pass_sites", bad)
+    e = c.hap_forward(xp[:0], xh[:0])
+    assert e[0].shape == (0, 10) and e[1].shape == (0, 3)
+    c.close()

@@ -421,3 +421,18 @@ def test_fused_forward_and_argmax_equals_the_two_calls(pileup_weights, opts):
     assert torch.equal(ga, ga2) and torch.equal(za, za2) and torch.equal(gm, gm2) and torch.equal(zm, zm2)
     assert torch.equal(ga2.long(), gt2.argmax(1)) and torch.equal(gm2, gt2.max(1).values)
     c.close()
+
+
+def test_fused_call_with_no_sites_and_bad_arguments(pileup_weights):
+    import ctypes
+    import torch
+    from nanosnp_amd import _lib
+    c = _lib.Context(0)
+    c.pileup_load_weights(pileup_weights)
+    lib, P = _lib.load(), ctypes.c_void_p
+    z = torch.zeros(8, device="cuda")
+    assert lib.nsnp_pileup_forward_windows_calls(c.handle, None, None, 0, None, None, None, None, None, None, None) == 0
+    assert lib.nsnp_pileup_forward_windows_calls(c.handle, P(z.data_ptr()), P(z.data_ptr()), 1, P(z.data_ptr()), P(z.data_ptr()), None, None,
+                                                 None, None, None) == -1                # argmax / max outputs are required
+    assert lib.nsnp_pileup_forward_windows_calls(None, None, None, 0, None, None, None, None, None, None, None) == -1
+    c.close()
