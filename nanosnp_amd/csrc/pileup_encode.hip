@@ -217,6 +217,14 @@ constexpr int ENC_WAVES = ENC_BLOCK / 64;
 #endif
 constexpr int STAGE_BYTES = NSNP_ENC_STAGE;          // per wave; 64 columns at 60x average ~4.4 KB
 constexpr int ENC_ECAP = NSNP_ENC_ECAP;              // opener entries of one segment of a wave's columns (more: further segments)
+#ifndef NSNP_ENC_P3STEP
+#define NSNP_ENC_P3STEP 4
+#endif
+#ifndef NSNP_ENC_P2G
+#define NSNP_ENC_P2G 1
+#endif
+constexpr int P3_STEP = NSNP_ENC_P3STEP;             // records one trip of the multiplicity walk reads
+constexpr int P2_GROUPS = NSNP_ENC_P2G;              // openers a lane decodes together
 constexpr int ENC_NBLK = 8;                          // 32-byte blocks of a column the fast path covers (8-bit counters: at most 253 bytes)
 static_assert(STAGE_BYTES >= 64 * NCH * 4, "the stage buffer doubles as the 64 x 18 output transposition buffer");
 static_assert(STAGE_BYTES <= 8192, "staged positions are kept in 13 bits");
@@ -244,10 +252,11 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
 {
     __shared__ uint32_t af_min[128];          // 256 x uint16: smallest passing count by depth (make_af_table)
     __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
-    // one record per construct opener of the segment.  word 0: position | column << 16 (written by the column), then
-    // q | nskip << 13 | column << 20 | minus << 26 | counted << 27 | fwd << 28 (written by the lane that decoded it);
-    // word 1: the first four allele bytes, zero beyond the allele's length
-    __shared__ uint2 ents[ENC_WAVES][ENC_ECAP];
+    // opener j of the segment sits behind P3_STEP end records (bit 31: no column; the walk of an indel over the earlier ones of its
+    // column ends there): { position | column << 16, end of the column }, written by the column.  The lanes that decode the openers compact the
+    // counted indels to the front, in order: { q | length << 13 | minus << 19 | fwd << 20 | column << 25, the first four allele
+    // bytes (zero beyond the allele's length) }
+    __shared__ uint2 ents[ENC_WAVES][ENC_ECAP + P3_STEP];
     // per column: [0..2] skipped bytes by class (the table's three counter words; bit 31 of [2]: hand the column to the exact path),
     // [3] indel reads by kind (8-bit fields),
     // [4..7] largest multiplicity of one allele by kind
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
         if (is_fwd_char(tid)) r.z |= 1u << 24;
         tab[tid ^ ((tid >> 2) & 8)] = r;        // row index = byte with its case bit (0x20) folded into bit 3: 'A' and 'a' in different banks
         if (tid < 128) af_min[tid] = aft.w[tid];
+        if (tid < ENC_WAVES * P3_STEP) ents[tid / P3_STEP][tid % P3_STEP] = uint2{0x80000000u, 0u};
     }
     __syncthreads();
     const int64_t wave_col0 = ((int64_t)blockIdx.x * ENC_WAVES + wave) * 64;
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
 
     uint8_t* st = stage_b[wave];
     const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
-    uint2* ent = ents[wave];
+    uint2* ent = ents[wave] + P3_STEP;                // opener j at ent[j]; ent[-1 .. -P3_STEP]: end records
     uint32_t* acc_mine = colacc[wave][lane];
     int32_t cnt[10];
 #pragma unroll
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                         uint32_t cur = (sact && n_op > 0) ? sm[b] : 0u;      // (a column handed to the exact path reserved no entries)
                         while (__ballot(cur != 0u) != 0ull) {
                             if (cur != 0u) {
-                                ent[j].x = tag + (uint32_t)(32 * b + __builtin_ctz(cur));
+                                ent[j] = uint2{tag + (uint32_t)(32 * b + __builtin_ctz(cur)), (uint32_t)lend};
                                 cur &= cur - 1u; ++j;
                             }
                         }
@@ -424,93 +434,120 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // P2b: one opener per lane: digits, skipped bytes out of the counts again, the record of a counted indel
-                int carry_end = 0, carry_owner = -1;
-                for (int r0i = 0; r0i < T; r0i += 64) {
-                    const int j = r0i + lane;
-                    const bool valid = j < T;
-                    const uint32_t e0 = valid ? ent[j].x : 0u;
-                    const int p = e0 & 0xffff, owner = valid ? (int)(e0 >> 16) : 64 + lane;
-                    const int lend_o = __shfl(lend, owner & 63);
-                    int endpos = 0;
-                    if (valid) {
-                        const int b = st[p];
-                        const int w0 = (p + 1) >> 2;
-                        const uint32_t a0 = st32[w0], a1 = st32[w0 + 1], a2 = st32[w0 + 2];
-                        const int sh = (p + 1) & 3;
-                        const uint32_t wlo = __builtin_amdgcn_alignbyte(a1, a0, sh), whi = __builtin_amdgcn_alignbyte(a2, a1, sh);   // byte i = st[p + 1 + i]
-                        const int avail1 = lend_o - (p + 1);
-                        const bool caret = b == '^';
+                // P2b: one opener per lane and group, P2_GROUPS groups of 64 in flight together (the kernel waits on LDS round trips
+                // here, not on the vector pipe): digits, skipped bytes out of the counts again, the record of a counted indel
+                int n_cnt = 0;                                                     // counted indels of the segment so far (uniform)
+                for (int r0i = 0; r0i < T; r0i += 64 * P2_GROUPS) {
+                    bool valid[P2_GROUPS];
+                    uint2 e0[P2_GROUPS];
+#pragma unroll
+                    for (int u = 0; u < P2_GROUPS; ++u) {
+                        const int j = r0i + 64 * u + lane;
+                        valid[u] = j < T;
+                        e0[u] = ent[valid[u] ? j : 0];                              // (T >= 1: slot 0 is an opener)
+                    }
+                    int p[P2_GROUPS], owner[P2_GROUPS], lend_o[P2_GROUPS], b[P2_GROUPS];
+                    uint32_t a0[P2_GROUPS], a1[P2_GROUPS], a2[P2_GROUPS];
+#pragma unroll
+                    for (int u = 0; u < P2_GROUPS; ++u) {
+                        p[u] = e0[u].x & 0xffff; owner[u] = (int)(e0[u].x >> 16); lend_o[u] = (int)e0[u].y;
+                        b[u] = st[p[u]];
+                        const int w0 = (p[u] + 1) >> 2;
+                        a0[u] = st32[w0]; a1[u] = st32[w0 + 1]; a2[u] = st32[w0 + 2];
+                    }
+                    int q[P2_GROUPS], nskip[P2_GROUPS];
+                    uint32_t al[P2_GROUPS], keep[P2_GROUPS];
+                    bool mybad[P2_GROUPS], counted[P2_GROUPS];
+                    uint4 r0[P2_GROUPS], r1[P2_GROUPS], r2[P2_GROUPS], r3[P2_GROUPS];
+#pragma unroll
+                    for (int u = 0; u < P2_GROUPS; ++u) {
+                        const int sh = (p[u] + 1) & 3;
+                        const uint32_t wlo = __builtin_amdgcn_alignbyte(a1[u], a0[u], sh), whi = __builtin_amdgcn_alignbyte(a2[u], a1[u], sh);   // byte i = st[p + 1 + i]
+                        const int avail1 = lend_o[u] - (p[u] + 1);
+                        const bool caret = b[u] == '^';
                         const uint32_t d0 = (wlo & 0xffu) - '0', d1 = ((wlo >> 8) & 0xffu) - '0', d2 = ((wlo >> 16) & 0xffu) - '0', d3 = (wlo >> 24) - '0';
                         const bool k0 = !caret && avail1 > 0 && d0 < 10u, k1 = k0 && avail1 > 1 && d1 < 10u, k2 = k1 && avail1 > 2 && d2 < 10u;
-                        const bool mybad = k2 && avail1 > 3 && d3 < 10u;                              // four digits and more: exact path
+                        mybad[u] = k2 && avail1 > 3 && d3 < 10u;                                      // four digits and more: exact path
                         const int L = k2 ? 3 : (k1 ? 2 : (k0 ? 1 : 0));
                         const int adv = caret ? 1 : (k2 ? (int)(d0 * 100 + d1 * 10 + d2) : (k1 ? (int)(d0 * 10 + d1) : (k0 ? (int)d0 : 0)));
-                        const int q = p + 1 + L;
-                        const int avail = lend_o - q;
-                        const int nskip = adv < avail ? adv : (avail > 0 ? avail : 0);
-                        endpos = q + adv;
-                        const uint32_t al = __builtin_amdgcn_alignbyte(whi, wlo, L);                  // the first four skipped bytes
-                        const uint32_t keep = nskip >= 4 ? 0xffffffffu : ((1u << (8 * (nskip & 3))) - 1u);
-                        const uint32_t alm = al | ~keep;                                              // bytes beyond the allele: 0xff (a zero row)
+                        q[u] = p[u] + 1 + L;
+                        const int avail = lend_o[u] - q[u];
+                        nskip[u] = adv < avail ? adv : (avail > 0 ? avail : 0);
+                        al[u] = __builtin_amdgcn_alignbyte(whi, wlo, L);                              // the first four skipped bytes
+                        keep[u] = nskip[u] >= 4 ? 0xffffffffu : ((1u << (8 * (nskip[u] & 3))) - 1u);
+                        const uint32_t alm = al[u] | ~keep[u];                                        // bytes beyond the allele: 0xff (a zero row)
                         const uint32_t alp = alm ^ ((alm >> 2) & 0x08080808u);
-                        const uint4 r0 = tab[alp & 0xffu], r1 = tab[(alp >> 8) & 0xffu], r2 = tab[(alp >> 16) & 0xffu], r3 = tab[alp >> 24];
-                        uint32_t nx = r0.x + r1.x, ny = r0.y + r1.y, nz = r0.z + r1.z;
-                        nx += r2.x + r3.x; ny += r2.y + r3.y; nz += r2.z + r3.z;
-                        for (int k = q + 4; k < q + nskip; ++k) {                                     // longer alleles (rare)
-                            const uint32_t bk = st[k];
-                            const uint4 rr = tab[bk ^ ((bk >> 2) & 8u)];
-                            nx += rr.x; ny += rr.y; nz += rr.z;
-                        }
-                        const bool counted = !caret && adv <= MAX_INDEL;
-                        const uint32_t fwd = (r0.z >> 24) & 1u;                                       // first allele byte in "ACGTN*" (0 without allele)
-                        ent[j] = uint2{(uint32_t)q | ((uint32_t)(nskip > 127 ? 127 : nskip) << 13) | ((uint32_t)owner << 20) | ((uint32_t)(b == '-') << 26) |
-                                           ((uint32_t)counted << 27) | (fwd << 28),
-                                       al & keep};
-                        uint32_t* oa = colacc[wave][owner];
-                        atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
-                        if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
-                        if (mybad) atomicOr(oa + 2, 0x80000000u);                                     // (bit 31 of word 2: exact path)
+                        r0[u] = tab[alp & 0xffu]; r1[u] = tab[(alp >> 8) & 0xffu]; r2[u] = tab[(alp >> 16) & 0xffu]; r3[u] = tab[alp >> 24];
+                        counted[u] = valid[u] && !caret && adv <= MAX_INDEL;                          // (then nskip <= 60)
                     }
-                    // an opener inside the bytes an earlier construct of its column consumes is not an opener: exact path
-                    int pe = __shfl_up(endpos, 1), po = __shfl_up(owner, 1);
-                    if (lane == 0) { pe = carry_end; po = carry_owner; }
-                    if (valid && po == owner && p < pe) atomicOr(colacc[wave][owner] + 2, 0x80000000u);
-                    carry_end = __shfl(endpos, 63); carry_owner = __shfl(owner, 63);
+#pragma unroll
+                    for (int u = 0; u < P2_GROUPS; ++u) {
+                        uint32_t nx = r0[u].x + r1[u].x, ny = r0[u].y + r1[u].y, nz = r0[u].z + r1[u].z;
+                        nx += r2[u].x + r3[u].x; ny += r2[u].y + r3[u].y; nz += r2[u].z + r3[u].z;
+                        uint32_t inner = (r0[u].w | r1[u].w) | (r2[u].w | r3[u].w);                  // an opener among the skipped bytes
+                        if (valid[u]) {
+                            for (int k = q[u] + 4; k < q[u] + nskip[u]; ++k) {                        // longer alleles (rare)
+                                const uint32_t bk = st[k];
+                                const uint4 rr = tab[bk ^ ((bk >> 2) & 8u)];
+                                nx += rr.x; ny += rr.y; nz += rr.z; inner |= rr.w;
+                            }
+                            uint32_t* oa = colacc[wave][owner[u]];
+                            atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
+                            if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
+                            // a flagged byte inside the bytes a construct consumes is not an opener (pass 1 cannot know): exact path
+                            if (mybad[u] || inner) atomicOr(oa + 2, 0x80000000u);                     // (bit 31 of word 2)
+                        }
+                    }
+                    // the counted indels move to the front of the list, order kept (slot c <= j: every slot of this trip has been read)
+#pragma unroll
+                    for (int u = 0; u < P2_GROUPS; ++u) {
+                        const unsigned long long cm = __ballot(counted[u]);
+                        const uint32_t fwd = (r0[u].z >> 24) & 1u;                                    // first allele byte in "ACGTN*" (0 without allele)
+                        if (counted[u])
+                            ent[n_cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))] =
+                                uint2{(uint32_t)q[u] | ((uint32_t)nskip[u] << 13) | ((uint32_t)(b[u] == '-') << 19) | (fwd << 20) | ((uint32_t)owner[u] << 25), al[u] & keep[u]};
+                        n_cnt += __builtin_popcountll(cm);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // P3: multiplicity of every counted indel among the earlier ones of its column, m(e) = #{f <= e equal to e};
-                // the column's totals and maxima by kind through LDS atomics
-                for (int r0i = 0; r0i < T; r0i += 64) {
+                // P3: multiplicity of every counted indel among the earlier ones of its column, m(e) = #{f <= e equal to e}: every lane
+                // steps back through the list, P3_STEP records per trip (all in flight together).  A record of the same column with the
+                // same length, sign and first four bytes differs from mine in the position bits only (x ^ x' < 2^13), one of another
+                // column (or an end record) in bit 25 or above.  The column's totals and maxima by kind through LDS atomics
+                for (int r0i = 0; r0i < n_cnt; r0i += 64) {
                     const int j = r0i + lane;
-                    const uint2 me = j < T ? ent[j] : uint2{0u, 0u};
-                    const bool counted = (me.x >> 27) & 1u;
-                    const uint32_t own_bits = me.x & (63u << 20);
-                    const uint32_t cmp_mask = (127u << 13) | (1u << 26) | (63u << 20) | (1u << 27);   // length, sign, column, counted
-                    const int le = (me.x >> 13) & 127, qe = me.x & 0x1fff;
+                    bool go = j < n_cnt;
+                    const uint2* f = ent + (go ? j : 0);
+                    const uint2 me = *f;
+                    const int le = (me.x >> 13) & 63, qe = me.x & 0x1fff;
                     int same = 1;
-                    int f = j - 1;
-                    bool go = counted && f >= 0;
                     while (__ballot(go) != 0ull) {
                         if (go) {
-                            const uint2 o = ent[f];
-                            if ((o.x & (63u << 20)) != own_bits) go = false;
-                            else {
-                                if (((o.x ^ me.x) & cmp_mask) == 0u && o.y == me.y) {
-                                    bool eq = true;
-                                    const int qf = o.x & 0x1fff;
-                                    for (int k = 4; k < le; ++k) if (st[qe + k] != st[qf + k]) { eq = false; break; }
-                                    same += eq;
+                            f -= P3_STEP;
+                            uint2 o[P3_STEP];
+#pragma unroll
+                            for (int u = 0; u < P3_STEP; ++u) o[u] = f[P3_STEP - 1 - u];
+                            uint32_t hit = 0u;                                     // bit u: record u equals mine as far as the record tells
+#pragma unroll
+                            for (int u = 0; u < P3_STEP; ++u) {
+                                const uint32_t t = o[u].x ^ me.x;
+                                go = go && t < (1u << 25);
+                                hit |= (uint32_t)(go && t < (1u << 13) && o[u].y == me.y) << u;
+                            }
+                            same += __builtin_popcount(hit);
+                            if (le > 4) {
+                                // alleles of more than four bytes: the rest byte by byte
+                                for (; hit; hit &= hit - 1u) {
+                                    const int qf = f[P3_STEP - 1 - __builtin_ctz(hit)].x & 0x1fff;
+                                    for (int k = 4; k < le; ++k) if (st[qe + k] != st[qf + k]) { --same; break; }
                                 }
-                                --f;
-                                if (f < 0) go = false;
                             }
                         }
                     }
-                    if (counted) {
-                        const int kind = (int)((me.x >> 26) & 1u) * 2 + (int)(((me.x >> 28) & 1u) ^ 1u);
-                        uint32_t* oa = colacc[wave][(me.x >> 20) & 63u];
+                    if (j < n_cnt) {
+                        const int kind = (int)((me.x >> 19) & 1u) * 2 + (int)(((me.x >> 20) & 1u) ^ 1u);
+                        uint32_t* oa = colacc[wave][me.x >> 25];
                         atomicAdd(oa + 3, 1u << (8 * kind));
                         atomicMax(oa + 4 + kind, (uint32_t)same);
                     }
