@@ -213,10 +213,11 @@ constexpr int ENC_WAVES = ENC_BLOCK / 64;
 #define NSNP_ENC_STAGE 5120
 #endif
 #ifndef NSNP_ENC_ECAP
-#define NSNP_ENC_ECAP 128
+#define NSNP_ENC_ECAP 208
 #endif
 constexpr int STAGE_BYTES = NSNP_ENC_STAGE;          // per wave; 64 columns at 60x average ~4.4 KB
-constexpr int ENC_ECAP = NSNP_ENC_ECAP;              // opener entries of one segment of a wave's columns (more: further segments)
+constexpr int ENC_ECAP = NSNP_ENC_ECAP;              // opener entries of one segment of a wave's columns (more: further segments); 64 columns at 60x
+                                                     // hold 153 on average, 199 at most (generator G2): one segment; the kernel's LDS stays at four blocks per CU
 #ifndef NSNP_ENC_P3STEP
 #define NSNP_ENC_P3STEP 4
 #endif
@@ -228,6 +229,7 @@ constexpr int P2_GROUPS = NSNP_ENC_P2G;              // openers a lane decodes t
 constexpr int ENC_NBLK = 8;                          // 32-byte blocks of a column the fast path covers (8-bit counters: at most 253 bytes)
 static_assert(STAGE_BYTES >= 64 * NCH * 4, "the stage buffer doubles as the 64 x 18 output transposition buffer");
 static_assert(STAGE_BYTES <= 8192, "staged positions are kept in 13 bits");
+static_assert(4 * (ENC_WAVES * (STAGE_BYTES + (ENC_ECAP + P3_STEP) * 8 + 64 * 32) + 4096 + 512) <= 160 * 1024, "four blocks per CU (LDS)");
 
 // inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (no LDS)
 __device__ __forceinline__ int wave_scan_incl(int v)
