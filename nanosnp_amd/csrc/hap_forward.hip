@@ -412,3 +412,5 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }
+
+NSNP_DEVCLK_READER(nsnp_devclk_read_hap)

@@ -4,6 +4,7 @@
 // linear+tanh, linear+ReLU.  With CONV the B operand of the in0 block is gathered as an implicit 3x3 / 1x1
 // convolution window over a pixel image (sites = pixels, chunks = (tap, channel chunk)).
 #pragma once
+#include "nsnp_devclock.hpp"
 #include "nsnp_common.hpp"
 
 // main-loop pipeline shape (see k_hap_gemm); overridable for A/B builds (tools/build_variant.sh)
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
 {
     __shared__ float As[2][TR][LDK];
     __shared__ float Bs[2][TS][LDK];
+    NSNP_DEVCLK_START
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // grid: x = site tile, y = row tile, z = slice (direction / encoder).  (A persistent variant - workgroups looping over the
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
                 }
         }
     }
+    NSNP_DEVCLK_STOP(CONV ? 3 : 2)
 }
 
 

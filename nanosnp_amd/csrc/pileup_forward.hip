@@ -23,6 +23,7 @@
 // sigmoid/tanh use v_exp_f32 / v_rcp_f32 (1 ulp).  Reduced schedule: 6.29 MFLOP/site executed
 // vs 12.55 MFLOP/site in the reference schedule, results identical to fp32 rounding.
 #include "nsnp_common.hpp"
+#include "nsnp_devclock.hpp"
 
 namespace {
 
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG == 1 ? 3 : 2))) void k_pileup_
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
+    NSNP_DEVCLK_START
     const int64_t base_site = (int64_t)blockIdx.x * (16 * NSG);
 
     // ---- this wave's four gate tiles -> registers (the images K1 stages in LDS) ----
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(256, (WXL ? 4 : (NSG == 1 ? 3 : 2))) void k_pileup_
         lds_barrier();
     }
     flush_h((PW - 1) & 1, dir ? 0 : PW - 1);
+    NSNP_DEVCLK_STOP(0)
 }
 
 // K23r: layer 1, input projection FUSED into the recurrence (no Xp1 round trip: 70 KB/site less HBM traffic than K2 + K3).
@@ -734,6 +737,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
     const int dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
+    NSNP_DEVCLK_START
     const int64_t base_site = (int64_t)blockIdx.x * NS;
 
     f32x4 Wih[4][8], Whh[4][4];
@@ -842,6 +846,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l1_rs4(
             *reinterpret_cast<f32x4*>(H1c + site * 128 + dir * 64 + q * 16 + 4 * wave) =
                 *reinterpret_cast<const f32x4*>(hfin + (size_t)(16 * sg + n) * RS_XROW + 16 * wave + 4 * q);
     }
+    NSNP_DEVCLK_STOP(1)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1371,6 +1376,8 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }
+
+NSNP_DEVCLK_READER(nsnp_devclk_read_pileup)
 
 extern "C" int nsnp_pileup_postprocess(nsnp_ctx* ctx, const float* gt_prob, const float* zy_prob,
                                        const int32_t* x, int64_t N, uint8_t* gt_arg, uint8_t* zy_arg,
