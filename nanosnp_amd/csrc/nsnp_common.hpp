@@ -35,7 +35,8 @@ struct PileupWeightsDev {
     float* l0_wih[2];   // [16][1][64][4]  16 KB   input channels 0..15
     float* l0_wlast[2]; // [16][64]         4 KB   K-step 4: channels 16,17, bias, zero (register operand)
     float* l1_wih[2];   // [16][8][64][4] 128 KB   K = 128 in H0 storage order
-    float* l1_bias[2];  // [16][64][4]      4 KB   b_ih + b_hh in accumulator layout
+    float* l1_bias[2];  // [16][64][4]      4 KB   b_ih + b_hh in accumulator layout, gate rows scaled like the weights
+    float* l1_bias_raw[2];  // the same, unscaled (layer-1 projection kernel of the f16x3 two-kernel path)
     float* l1_whh[2];   // [16][4][64][4]  64 KB
     float* proj_w;      // [8][8][64][4]   64 KB   K = 128 in H1c storage order
     float* proj_b;      // [8][64][4]

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 #define NSNP_DEVCLK_SLOTS 8
 __device__ unsigned long long nsnp_devclk_acc[NSNP_DEVCLK_SLOTS][3];      // per slot: shader cycles, 100 MHz ticks, workgroups
-__device__ unsigned long long nsnp_devclk_ext[NSNP_DEVCLK_SLOTS][4];      // per slot: ~min start tick, max end tick, max and ~min cycles of one workgroup
+__device__ unsigned long long nsnp_devclk_ext[NSNP_DEVCLK_SLOTS][4];
+#define NSNP_DEVCLK_TRACE 4096
+__device__ unsigned long long nsnp_devclk_trace[NSNP_DEVCLK_SLOTS][NSNP_DEVCLK_TRACE][4];   // per workgroup (of the last launch): start tick, end tick, cycles, HW_ID | XCC_ID << 32      // per slot: ~min start tick, max end tick, max and ~min cycles of one workgroup
 struct DevClock {
     unsigned long long t0, r0;
     __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -18,6 +20,14 @@ struct DevClock {
             const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
             if (t1 - t0 >= (1ull << 40) || r1 - r0 >= (1ull << 40)) return;                  // (a counter that wrapped: not a sample)
             atomicAdd(&nsnp_devclk_acc[slot][0], t1 - t0); atomicAdd(&nsnp_devclk_acc[slot][1], r1 - r0); atomicAdd(&nsnp_devclk_acc[slot][2], 1ull);
+            {
+                const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+                if (wg < NSNP_DEVCLK_TRACE) {
+                    unsigned long long* tr = nsnp_devclk_trace[slot][wg];
+                    tr[0] = r0; tr[1] = r1; tr[2] = t1 - t0;
+                    tr[3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xf804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xf814) << 32);   // HW_ID, XCC_ID
+                }
+            }
             atomicMax(&nsnp_devclk_ext[slot][0], ~r0); atomicMax(&nsnp_devclk_ext[slot][1], r1);
             atomicMax(&nsnp_devclk_ext[slot][2], t1 - t0); atomicMax(&nsnp_devclk_ext[slot][3], ~(t1 - t0));
         }
@@ -27,6 +37,12 @@ struct DevClock {
 #define NSNP_DEVCLK_STOP(slot) devclk_.stop(slot);
 // each translation unit with stamped kernels exports its own reader (no relocatable device code): out[slot][3] then ext[slot][4] (56 words), then zeroes the tables
 #define NSNP_DEVCLK_READER(name)                                                                                      \
+    extern "C" int name##_trace(int slot, unsigned long long* out)                                                    \
+    {                                                                                                                  \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                           \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsnp_devclk_trace), sizeof(unsigned long long) * NSNP_DEVCLK_TRACE * 4, \
+                                   sizeof(unsigned long long) * NSNP_DEVCLK_TRACE * 4 * slot) == hipSuccess ? 0 : -1;       \
+    }                                                                                                                  \
     extern "C" int name(unsigned long long* out)                                                                      \
     {                                                                                                                  \
         unsigned long long z[NSNP_DEVCLK_SLOTS][3] = {};                                                               \

@@ -52,10 +52,11 @@ __device__ __forceinline__ float tanh_f(float x)
 // an overflowing product of the denominators gives reciprocal 0, the correct limit.  c is updated in place, h' returned.
 __device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float& c)
 {
-    const float ei = __builtin_amdgcn_exp2f(-LOG2E * zi);
-    const float ef = __builtin_amdgcn_exp2f(-LOG2E * zf);
-    const float eo = __builtin_amdgcn_exp2f(-LOG2E * zo);
-    const float eg = __builtin_amdgcn_exp2f(fminf((-2.0f * LOG2E) * zg, 64.0f));
+    // (zi, zf, zo arrive multiplied by -log2 e and zg by -2 log2 e: nsnp_pileup_pack_weights scales the gate rows)
+    const float ei = __builtin_amdgcn_exp2f(zi);
+    const float ef = __builtin_amdgcn_exp2f(zf);
+    const float eo = __builtin_amdgcn_exp2f(zo);
+    const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
     const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
     const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
     const float cn = __builtin_fmaf(fg, c, ig);
@@ -1187,21 +1188,36 @@ int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w)
     const size_t n_whh = 16 * 4 * 256, n_wih0 = 16 * 1 * 256, n_wlast = 16 * 64, n_wih1 = 16 * 8 * 256,
                  n_b1 = 16 * 256, n_proj = 8 * 8 * 256, n_pb = 8 * 256, n_dense = 16 * 8 * 256, n_db = 16 * 256,
                  n_head = 2 * 16 * 256, n_hb = 2 * 256;
-    const size_t total = 2 * (n_whh + n_wih0 + n_wlast + n_wih1 + n_b1 + n_whh) + n_proj + n_pb + n_dense + n_db + n_head + n_hb;
+    const size_t total = 2 * (n_whh + n_wih0 + n_wlast + n_wih1 + 2 * n_b1 + n_whh) + n_proj + n_pb + n_dense + n_db + n_head + n_hb;
     std::vector<float> host(total);
     size_t off = 0;
     auto take = [&](size_t n) { float* p = host.data() + off; off += n; return p; };
-    float* h_l0_whh[2]; float* h_l0_wih[2]; float* h_l0_wlast[2]; float* h_l1_wih[2]; float* h_l1_b[2]; float* h_l1_whh[2];
+    float* h_l0_whh[2]; float* h_l0_wih[2]; float* h_l0_wlast[2]; float* h_l1_wih[2]; float* h_l1_b[2]; float* h_l1_braw[2]; float* h_l1_whh[2];
     for (int d = 0; d < 2; ++d) {
         h_l0_whh[d] = take(n_whh); h_l0_wih[d] = take(n_wih0); h_l0_wlast[d] = take(n_wlast);
-        h_l1_wih[d] = take(n_wih1); h_l1_b[d] = take(n_b1); h_l1_whh[d] = take(n_whh);
+        h_l1_wih[d] = take(n_wih1); h_l1_b[d] = take(n_b1); h_l1_braw[d] = take(n_b1); h_l1_whh[d] = take(n_whh);
     }
     float* h_proj = take(n_proj); float* h_pb = take(n_pb); float* h_dense = take(n_dense); float* h_db = take(n_db);
     float* h_head = take(n_head); float* h_hb = take(n_hb);
 
+    // The cell wants exp2(-log2 e z) for the gates i, f, o and exp2(-2 log2 e z) for g: the factor is folded into the gate's rows
+    // of W_ih, W_hh and the biases here (PyTorch row order i f g o), so that lstm_cell() starts with the exponentials
+    // (4 of its ~26 vector instructions per unit-step; fp32 MFMA and the vector ALU share the SIMD's lanes, section 4 of DESIGN.md)
+    std::vector<float> scaled[16];
+    const float* ws[16];
+    for (int t = 0; t < 16; ++t) {
+        const int layer = t / 8, kind = t % 4;      // w_ih, w_hh, b_ih, b_hh
+        const size_t cols = kind == 0 ? (layer ? 2 * PH : PC) : (kind == 1 ? PH : 1);
+        scaled[t].resize((size_t)4 * PH * cols);
+        for (int r = 0; r < 4 * PH; ++r) {
+            const float f = (r / PH == 2) ? -2.0f * LOG2E : -LOG2E;
+            for (size_t k = 0; k < cols; ++k) scaled[t][r * cols + k] = f * w[t][r * cols + k];
+        }
+        ws[t] = scaled[t].data();
+    }
     for (int d = 0; d < 2; ++d) {
-        const float* const* l0 = w + d * 4;        // w_ih, w_hh, b_ih, b_hh
-        const float* const* l1 = w + 8 + d * 4;
+        const float* const* l0 = ws + d * 4;        // w_ih, w_hh, b_ih, b_hh
+        const float* const* l1 = ws + 8 + d * 4;
         MatRef m;
         m = MatRef{l0[1], PH, nullptr, nullptr};  nsnp_pack_image(h_l0_whh[d], 16, 4, f_whh, &m);
         m = MatRef{l0[0], PC, nullptr, nullptr};  nsnp_pack_image(h_l0_wih[d], 16, 1, f_wih0, &m);
@@ -1219,6 +1235,7 @@ int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w)
                 for (int g = 0; g < 4; ++g) {
                     const int tr = gate_row(16 * tile + 4 * (lane >> 4) + g);
                     h_l1_b[d][(tile * 64 + lane) * 4 + g] = l1[2][tr] + l1[3][tr];
+                    h_l1_braw[d][(tile * 64 + lane) * 4 + g] = w[8 + d * 4 + 2][tr] + w[8 + d * 4 + 3][tr];     // unscaled: the f16x3 two-kernel path
                 }
         m = MatRef{l1[1], PH, nullptr, nullptr};  nsnp_pack_image(h_l1_whh[d], 16, 4, f_whh, &m);
     }
@@ -1244,7 +1261,7 @@ int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w)
     auto dev = [&](const float* hp) { return pw.arena + (hp - host.data()); };
     for (int d = 0; d < 2; ++d) {
         pw.l0_whh[d] = dev(h_l0_whh[d]); pw.l0_wih[d] = dev(h_l0_wih[d]); pw.l0_wlast[d] = dev(h_l0_wlast[d]);
-        pw.l1_wih[d] = dev(h_l1_wih[d]); pw.l1_bias[d] = dev(h_l1_b[d]); pw.l1_whh[d] = dev(h_l1_whh[d]);
+        pw.l1_wih[d] = dev(h_l1_wih[d]); pw.l1_bias[d] = dev(h_l1_b[d]); pw.l1_bias_raw[d] = dev(h_l1_braw[d]); pw.l1_whh[d] = dev(h_l1_whh[d]);
     }
     pw.proj_w = dev(h_proj); pw.proj_b = dev(h_pb); pw.dense_w = dev(h_dense); pw.dense_b = dev(h_db);
     pw.head_w = dev(h_head); pw.head_b = dev(h_hb);

@@ -1369,7 +1369,7 @@ int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* ce
         if (gp < 1) gp = 1;
         { ScopedKernelTimer tm(ctx, NSNP_K_PROJ1, s);
         hipLaunchKernelGGL(k_pileup_proj1_h, dim3((unsigned)gp, 2), dim3(1024), P1H_LDS_BYTES, s, H0, n,
-                           (const _Float16*)pw.l1_wih[0], (const _Float16*)pw.l1_wih[1], p32.l1_bias[0], p32.l1_bias[1], ctx->ws_xp1); }
+                           (const _Float16*)pw.l1_wih[0], (const _Float16*)pw.l1_wih[1], p32.l1_bias_raw[0], p32.l1_bias_raw[1], ctx->ws_xp1); }
         { ScopedKernelTimer tm(ctx, NSNP_K_L1, s);
 #define LAUNCH_L1(W) hipLaunchKernelGGL(k_pileup_l1_h<W>, g_rec, dim3(64 * W), L1H_LDS_BYTES, s, ctx->ws_xp1, n, \
             (const _Float16*)pw.l1_whh[0], (const _Float16*)pw.l1_whh[1], H1c)
