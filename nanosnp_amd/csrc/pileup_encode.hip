@@ -195,18 +195,19 @@ static AfTable make_af_table(const AfThreshold& af)
 }
 
 // ---- main kernel ----------------------------------------------------------------------------------------
-// One lane per column, 64 columns per wave, their bytes (one contiguous range) staged into LDS with 16-byte loads.  The kernel is
-// bound by vector-instruction issue (MFMA-free, four waves per SIMD keep the vector pipe busy), so it is built around the
-// instruction count per column:
+// One lane per column, 64 columns per wave, their bytes (one contiguous range) staged into LDS with 16-byte loads.  With its inputs
+// and outputs served from cache the kernel still takes 82 % of its time: it is bound by vector-instruction
+// issue and the LDS round trips between its phases at four waves per SIMD, so it is built around the instruction count per column:
 //   pass 1   EVERY byte of the column is counted through a 16-byte table row (three words of 8-bit class counters and the flag
 //            of the construct openers + - ^), whole words at a time: 5 vector instructions per byte, no grammar state, no flushes
 //            (the fast path covers columns of up to 253 bytes), the opener flags gathered in one bit mask per 32 bytes;
 //   openers  compacted over the wave (DPP prefix sum) and decoded ONE PER LANE whatever column they belong to: digits, the bytes
 //            they skip taken out of the column's counts again (LDS atomics on the same packed counters), the record of a counted
-//            indel; an opener inside the bytes an earlier construct consumes, a four-digit length, a column beyond the fast
-//            path: that column is re-scanned by the exact path;
-//   indels   every counted indel finds its multiplicity among the earlier ones of its column (length, sign and the first four
-//            allele bytes in one compare, longer alleles byte by byte); totals and maxima by kind reach the column through LDS
+//            indel (the counted ones compacted to the front of the list); an opener among the bytes a construct consumes (the
+//            table rows of the skipped bytes tell), a four-digit length, a column beyond the fast path: that column is
+//            re-scanned by the exact path;
+//   indels   every counted indel finds its multiplicity among the earlier ones of its column, four records per trip (length, sign
+//            and the first four allele bytes in one compare, longer alleles byte by byte); totals and maxima by kind reach the column through LDS
 //            atomics.
 constexpr int ENC_WAVES = ENC_BLOCK / 64;
 #ifndef NSNP_ENC_STAGE
@@ -221,11 +222,7 @@ constexpr int ENC_ECAP = NSNP_ENC_ECAP;              // opener entries of one se
 #ifndef NSNP_ENC_P3STEP
 #define NSNP_ENC_P3STEP 4
 #endif
-#ifndef NSNP_ENC_P2G
-#define NSNP_ENC_P2G 1
-#endif
 constexpr int P3_STEP = NSNP_ENC_P3STEP;             // records one trip of the multiplicity walk reads
-constexpr int P2_GROUPS = NSNP_ENC_P2G;              // openers a lane decodes together
 constexpr int ENC_NBLK = 8;                          // 32-byte blocks of a column the fast path covers (8-bit counters: at most 253 bytes)
 static_assert(STAGE_BYTES >= 64 * NCH * 4, "the stage buffer doubles as the 64 x 18 output transposition buffer");
 static_assert(STAGE_BYTES <= 8192, "staged positions are kept in 13 bits");
@@ -436,80 +433,57 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // P2b: one opener per lane and group, P2_GROUPS groups of 64 in flight together (the kernel waits on LDS round trips
-                // here, not on the vector pipe): digits, skipped bytes out of the counts again, the record of a counted indel
+                // P2b: one opener per lane: digits, skipped bytes out of the counts again, the record of a counted indel.  (Two or three
+                // groups of 64 per lane in flight together were measured: the half-empty last group costs more than the overlap gains.)
                 int n_cnt = 0;                                                     // counted indels of the segment so far (uniform)
-                for (int r0i = 0; r0i < T; r0i += 64 * P2_GROUPS) {
-                    bool valid[P2_GROUPS];
-                    uint2 e0[P2_GROUPS];
-#pragma unroll
-                    for (int u = 0; u < P2_GROUPS; ++u) {
-                        const int j = r0i + 64 * u + lane;
-                        valid[u] = j < T;
-                        e0[u] = ent[valid[u] ? j : 0];                              // (T >= 1: slot 0 is an opener)
-                    }
-                    int p[P2_GROUPS], owner[P2_GROUPS], lend_o[P2_GROUPS], b[P2_GROUPS];
-                    uint32_t a0[P2_GROUPS], a1[P2_GROUPS], a2[P2_GROUPS];
-#pragma unroll
-                    for (int u = 0; u < P2_GROUPS; ++u) {
-                        p[u] = e0[u].x & 0xffff; owner[u] = (int)(e0[u].x >> 16); lend_o[u] = (int)e0[u].y;
-                        b[u] = st[p[u]];
-                        const int w0 = (p[u] + 1) >> 2;
-                        a0[u] = st32[w0]; a1[u] = st32[w0 + 1]; a2[u] = st32[w0 + 2];
-                    }
-                    int q[P2_GROUPS], nskip[P2_GROUPS];
-                    uint32_t al[P2_GROUPS], keep[P2_GROUPS];
-                    bool mybad[P2_GROUPS], counted[P2_GROUPS];
-                    uint4 r0[P2_GROUPS], r1[P2_GROUPS], r2[P2_GROUPS], r3[P2_GROUPS];
-#pragma unroll
-                    for (int u = 0; u < P2_GROUPS; ++u) {
-                        const int sh = (p[u] + 1) & 3;
-                        const uint32_t wlo = __builtin_amdgcn_alignbyte(a1[u], a0[u], sh), whi = __builtin_amdgcn_alignbyte(a2[u], a1[u], sh);   // byte i = st[p + 1 + i]
-                        const int avail1 = lend_o[u] - (p[u] + 1);
-                        const bool caret = b[u] == '^';
-                        const uint32_t d0 = (wlo & 0xffu) - '0', d1 = ((wlo >> 8) & 0xffu) - '0', d2 = ((wlo >> 16) & 0xffu) - '0', d3 = (wlo >> 24) - '0';
-                        const bool k0 = !caret && avail1 > 0 && d0 < 10u, k1 = k0 && avail1 > 1 && d1 < 10u, k2 = k1 && avail1 > 2 && d2 < 10u;
-                        mybad[u] = k2 && avail1 > 3 && d3 < 10u;                                      // four digits and more: exact path
-                        const int L = k2 ? 3 : (k1 ? 2 : (k0 ? 1 : 0));
-                        const int adv = caret ? 1 : (k2 ? (int)(d0 * 100 + d1 * 10 + d2) : (k1 ? (int)(d0 * 10 + d1) : (k0 ? (int)d0 : 0)));
-                        q[u] = p[u] + 1 + L;
-                        const int avail = lend_o[u] - q[u];
-                        nskip[u] = adv < avail ? adv : (avail > 0 ? avail : 0);
-                        al[u] = __builtin_amdgcn_alignbyte(whi, wlo, L);                              // the first four skipped bytes
-                        keep[u] = nskip[u] >= 4 ? 0xffffffffu : ((1u << (8 * (nskip[u] & 3))) - 1u);
-                        const uint32_t alm = al[u] | ~keep[u];                                        // bytes beyond the allele: 0xff (a zero row)
-                        const uint32_t alp = alm ^ ((alm >> 2) & 0x08080808u);
-                        r0[u] = tab[alp & 0xffu]; r1[u] = tab[(alp >> 8) & 0xffu]; r2[u] = tab[(alp >> 16) & 0xffu]; r3[u] = tab[alp >> 24];
-                        counted[u] = valid[u] && !caret && adv <= MAX_INDEL;                          // (then nskip <= 60)
-                    }
-#pragma unroll
-                    for (int u = 0; u < P2_GROUPS; ++u) {
-                        uint32_t nx = r0[u].x + r1[u].x, ny = r0[u].y + r1[u].y, nz = r0[u].z + r1[u].z;
-                        nx += r2[u].x + r3[u].x; ny += r2[u].y + r3[u].y; nz += r2[u].z + r3[u].z;
-                        uint32_t inner = (r0[u].w | r1[u].w) | (r2[u].w | r3[u].w);                  // an opener among the skipped bytes
-                        if (valid[u]) {
-                            for (int k = q[u] + 4; k < q[u] + nskip[u]; ++k) {                        // longer alleles (rare)
-                                const uint32_t bk = st[k];
-                                const uint4 rr = tab[bk ^ ((bk >> 2) & 8u)];
-                                nx += rr.x; ny += rr.y; nz += rr.z; inner |= rr.w;
-                            }
-                            uint32_t* oa = colacc[wave][owner[u]];
-                            atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
-                            if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
-                            // a flagged byte inside the bytes a construct consumes is not an opener (pass 1 cannot know): exact path
-                            if (mybad[u] || inner) atomicOr(oa + 2, 0x80000000u);                     // (bit 31 of word 2)
+                for (int r0i = 0; r0i < T; r0i += 64) {
+                    const int j = r0i + lane;
+                    const bool valid = j < T;
+                    const uint2 e0 = ent[valid ? j : 0];                           // (T >= 1: slot 0 is an opener)
+                    const int p = e0.x & 0xffff, owner = (int)(e0.x >> 16), lend_o = (int)e0.y;
+                    const int b = st[p];
+                    const int w0 = (p + 1) >> 2;
+                    const uint32_t a0 = st32[w0], a1 = st32[w0 + 1], a2 = st32[w0 + 2];
+                    const int sh = (p + 1) & 3;
+                    const uint32_t wlo = __builtin_amdgcn_alignbyte(a1, a0, sh), whi = __builtin_amdgcn_alignbyte(a2, a1, sh);   // byte i = st[p + 1 + i]
+                    const int avail1 = lend_o - (p + 1);
+                    const bool caret = b == '^';
+                    const uint32_t d0 = (wlo & 0xffu) - '0', d1 = ((wlo >> 8) & 0xffu) - '0', d2 = ((wlo >> 16) & 0xffu) - '0', d3 = (wlo >> 24) - '0';
+                    const bool k0 = !caret && avail1 > 0 && d0 < 10u, k1 = k0 && avail1 > 1 && d1 < 10u, k2 = k1 && avail1 > 2 && d2 < 10u;
+                    const bool mybad = k2 && avail1 > 3 && d3 < 10u;                                  // four digits and more: exact path
+                    const int L = k2 ? 3 : (k1 ? 2 : (k0 ? 1 : 0));
+                    const int adv = caret ? 1 : (k2 ? (int)(d0 * 100 + d1 * 10 + d2) : (k1 ? (int)(d0 * 10 + d1) : (k0 ? (int)d0 : 0)));
+                    const int q = p + 1 + L;
+                    const int avail = lend_o - q;
+                    const int nskip = adv < avail ? adv : (avail > 0 ? avail : 0);
+                    const uint32_t al = __builtin_amdgcn_alignbyte(whi, wlo, L);                      // the first four skipped bytes
+                    const uint32_t keep = nskip >= 4 ? 0xffffffffu : ((1u << (8 * (nskip & 3))) - 1u);
+                    const uint32_t alm = al | ~keep;                                                  // bytes beyond the allele: 0xff (a zero row)
+                    const uint32_t alp = alm ^ ((alm >> 2) & 0x08080808u);
+                    const uint4 r0 = tab[alp & 0xffu], r1 = tab[(alp >> 8) & 0xffu], r2 = tab[(alp >> 16) & 0xffu], r3 = tab[alp >> 24];
+                    const bool counted = valid && !caret && adv <= MAX_INDEL;                         // (then nskip <= 60)
+                    uint32_t nx = r0.x + r1.x, ny = r0.y + r1.y, nz = r0.z + r1.z;
+                    nx += r2.x + r3.x; ny += r2.y + r3.y; nz += r2.z + r3.z;
+                    uint32_t inner = (r0.w | r1.w) | (r2.w | r3.w);                                  // an opener among the skipped bytes
+                    if (valid) {
+                        for (int k = q + 4; k < q + nskip; ++k) {                                     // longer alleles (rare)
+                            const uint32_t bk = st[k];
+                            const uint4 rr = tab[bk ^ ((bk >> 2) & 8u)];
+                            nx += rr.x; ny += rr.y; nz += rr.z; inner |= rr.w;
                         }
+                        uint32_t* oa = colacc[wave][owner];
+                        atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
+                        if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
+                        // a flagged byte inside the bytes a construct consumes is not an opener (pass 1 cannot know): exact path
+                        if (mybad || inner) atomicOr(oa + 2, 0x80000000u);                            // (bit 31 of word 2)
                     }
                     // the counted indels move to the front of the list, order kept (slot c <= j: every slot of this trip has been read)
-#pragma unroll
-                    for (int u = 0; u < P2_GROUPS; ++u) {
-                        const unsigned long long cm = __ballot(counted[u]);
-                        const uint32_t fwd = (r0[u].z >> 24) & 1u;                                    // first allele byte in "ACGTN*" (0 without allele)
-                        if (counted[u])
-                            ent[n_cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))] =
-                                uint2{(uint32_t)q[u] | ((uint32_t)nskip[u] << 13) | ((uint32_t)(b[u] == '-') << 19) | (fwd << 20) | ((uint32_t)owner[u] << 25), al[u] & keep[u]};
-                        n_cnt += __builtin_popcountll(cm);
-                    }
+                    const unsigned long long cm = __ballot(counted);
+                    const uint32_t fwd = (r0.z >> 24) & 1u;                                           // first allele byte in "ACGTN*" (0 without allele)
+                    if (counted)
+                        ent[n_cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))] =
+                            uint2{(uint32_t)q | ((uint32_t)nskip << 13) | ((uint32_t)(b == '-') << 19) | (fwd << 20) | ((uint32_t)owner << 25), al & keep};
+                    n_cnt += __builtin_popcountll(cm);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
