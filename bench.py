@@ -64,7 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="nsnp_ctx_set_option on every context (tuning)")
     ap.add_argument("--repeat", type=int, default=1, help="repeat the timed region (extra values are informational)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--timing-streams", type=int, default=16, help="record per-kernel HIP events on this many of the streams "
+    ap.add_argument("--timing-streams", type=int, default=4, help="record per-kernel HIP events on this many of the streams "
                     "(every kernel launch of those streams inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")

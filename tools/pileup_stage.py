@@ -17,7 +17,7 @@ import ctypes as C
 
 class PileupStage:
     def __init__(self, local_rank, n_windows, batch=4096, streams=32, coverage=30.0, seed=20260000, precision=0, opts=(),
-                 timing_streams=16, enc_group=32, ring=3, weights=None):
+                 timing_streams=4, enc_group=32, ring=3, weights=None):
         import torch
         from nanosnp_amd import _lib, host
         from nanosnp_amd.fixtures import load_pileup_weights
@@ -41,11 +41,14 @@ class PileupStage:
         self.centers = (torch.arange(self.batch, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
         # ---- contexts: one per forward stream + one for the encode stream ----
         self.timed_streams = min(self.S, max(0, int(timing_streams)))
+        # the timed streams are spread over the stream indices (batch i runs on stream i mod S: a short region still meets one), stream 0
+        # among them (the exclusive pass runs there); every recorded event costs the stream an extra packet, hence few of them (-0.5 % at 16)
+        self.timed_idx = sorted({(k * self.S) // self.timed_streams for k in range(self.timed_streams)}) if self.timed_streams else []
         self.ctxs, self.streams = [], []
         for s in range(self.S):
             ctx = _lib.Context(local_rank, chunk_sites=self.batch)
             ctx.pileup_load_weights(self.weights)
-            ctx.enable_timing(s < self.timed_streams)
+            ctx.enable_timing(s in self.timed_idx)
             ctx.set_option("pileup_precision", precision)
             for o in opts:
                 name, val = o.split("=")
@@ -126,7 +129,7 @@ class PileupStage:
         """{kernel: [total_ms, launches]} of the launches recorded since the last read (forward kernels: the timed streams; encode:
         every launch).  The fused layer-1 kernel is reported as pileup_l1f."""
         tot = {}
-        for ctx in self.ctxs[:self.timed_streams] + [self.enc_ctx]:
+        for ctx in [self.ctxs[s] for s in self.timed_idx] + [self.enc_ctx]:
             for k, (ms, n) in ctx.read_timing().items():
                 if n:
                     a = tot.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
