@@ -64,6 +64,27 @@ def test_mixed_hp_rows_and_large_values(gpu_ctx):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("D,L", [(40, 11), (700, 11), (130, 33), (64, 64), (50, 7), (33, 32)])
+def test_packed_sums_boundaries_and_the_exact_path(gpu_ctx, D, L):
+    """the running sums are packed (8-bit counts, 16-bit quality sums, flushed every 28 rows of a lane); qualities outside [0, 2048)
+    bypass them: values around the boundary, negatives and int32 extremes mixed with ordinary ones, several rows per wave
+    (L <= 32), depths that need several flushes"""
+    from oracle import oracle
+    rng = np.random.default_rng(D * 100 + L)
+    N = 24
+    seq = rng.integers(-2, 5, (N, D, L)).astype(np.int32)
+    hap = rng.integers(-2, 4, (N, D, L)).astype(np.int32)
+    pool = np.array([0, 1, 40, 93, 2046, 2047, 2048, 2049, 65535, 65536, -1, -2048, 2**31 - 1, -2**31], np.int64)
+    pick = lambda: np.where(rng.random((N, D, L)) < 0.9, rng.integers(0, 94, (N, D, L)), pool[rng.integers(0, pool.size, (N, D, L))]).astype(np.int32)
+    bq, mq = pick(), pick()
+    seq[0] = 1; hap[0] = 1; bq[0] = 2047; mq[0] = 2047              # one column class at the largest packed value, every row in HP1
+    seq[1] = 2; bq[1] = 2048; mq[1] = -1                             # everything through the exact path
+    ref = rng.integers(0, 5, (N, L)).astype(np.int32)
+    got = _feat(gpu_ctx, (seq, bq, mq, hap, ref))
+    want = oracle.hap_features_batch(seq, bq, mq, hap, ref)
+    assert np.array_equal(got, want)
+
+
 # ---- HaplotypeModel forward -------------------------------------------------------------------------
 @pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
 def hap_model(request, gpu_ctx):
