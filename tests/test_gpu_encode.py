@@ -104,6 +104,30 @@ def test_opener_dense_columns(gpu_ctx):
     assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
 
 
+def test_entry_list_capacity_boundaries(gpu_ctx):
+    """the opener list of a wave's segment holds 208 entries: columns and whole waves (64 consecutive columns) with exactly 208 and
+    209 openers, a wave whose first column fills the list alone, read starts (dropped from the compacted list) between counted indels"""
+    from oracle import oracle
+    four = b"A+1CA-1GA+1CA-2GT"                                    # four openers, all counted
+    waves = [
+        [four] * 52 + [b"ACGTacgt"] * 12,                           # 208: one segment
+        [four] * 52 + [b"AC^]GT"] + [b"ACGT"] * 11,                  # 209: two segments
+        [b"+" * 208] + [four] * 63,                                 # the first column fills a segment alone
+        [b"+" * 209] + [b"A"] * 63,                                 # one column beyond the list: exact path
+        [b"^+" * 60 + b"A+2CC" * 20] + [b"^!A+3ACG^~c-3acg" * 3] * 63,   # read starts whose quality byte is an opener; mixed lists
+        [b"A+2AC" * 3 + b"^IA+2AC" * 2 + b"a-2ac^Ia-2ac"] * 64,       # equal alleles around read starts: multiplicities 5 and 2
+    ]
+    cols = [c for w in waves for c in w]
+    bases = np.frombuffer(b"".join(cols), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    ref = np.frombuffer((b"ACGTN" * len(cols))[:len(cols)], np.uint8).copy()
+    c, d, f = _enc(gpu_ctx, bases, off, ref)
+    oc, od, of = oracle.encode_columns(bases, off, ref)
+    bad = np.nonzero((c.cpu().numpy() != oc).any(1))[0]
+    assert bad.size == 0, (bad[:5], c.cpu().numpy()[bad[:2]], oc[bad[:2]])
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
+
+
 def test_single_class_columns_at_the_8bit_counter_limit(gpu_ctx):
     """columns of ONE symbol class starting on a 4-byte boundary: 256 equal bytes span exactly 64 words (the fast path's
     word limit) but wrap an 8-bit class counter into its neighbour - they must take the exact path"""
