@@ -44,8 +44,9 @@ def test_bench_line_schema():
     assert d["dtype"] == "f32" and d["config"]["windows_resident_per_gpu"] == 131072 and d["config"]["batches_per_step"] == 4
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert _fractions_are_physical(d) == 2                      # roofline (MFMA, dominant forward kernel) + roofline_encode (HBM)
+    assert _fractions_are_physical(d) == 3                      # roofline (MFMA, dominant forward kernel), the other recurrence layer, roofline_encode (HBM)
     r = d["roofline"]
+    assert {r["kernel"]} | {d[k]["kernel"] for k in d if k.startswith("roofline_pileup_l")} == {"pileup_l0", "pileup_l1f"}
     assert r["bound"] == "mfma" and r["kernel"] in d["kernel_exclusive_ms"] and "chip" in r and "achieved_algorithmic" in r
     assert r["launches_timed"] >= 16
     assert d["roofline_encode"]["bound"] == "hbm" and d["roofline_encode"]["batches_per_launch"] == d["config"]["encode_batches_per_launch"] == 32

@@ -160,7 +160,9 @@ class PileupStage:
 
 
 def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc_group, workload="pileup"):
-    """roofline objects of the pileup stage.  Headline = the dominant forward kernel (most total time in the timed region) priced
+    """roofline objects of the pileup stage.  Headline = the dominant forward kernel - the one whose launches take longest with
+    the chip to themselves (in-region durations depend on which launches happened to share the chip and let the choice flip between
+    two kernels of nearly equal weight; ties go to the one with more executed flops) - priced
     on its EXCLUSIVE launches (one stream, nothing else on the chip; the duration a rocprofv3 kernel trace shows for the same
     launches): executed flops per launch / average launch duration / peak.  `chip` = executed forward flops of all timed sites
     over the wall time of the timed region (encode, post-processing and the gather included in the time)."""
@@ -171,7 +173,7 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
     fwd_keys = [k for k in tot if k in bc.PILEUP_EXEC_FLOP]
     out = {}
     if fwd_keys:
-        dom = max(fwd_keys, key=lambda k: tot[k][0])
+        dom = max(fwd_keys, key=lambda k: (round(excl.get(k, 0.0), 5), bc.PILEUP_EXEC_FLOP[k]))
         if dom in excl:
             how = ("HIP events around every launch of the kernel, one stream, nothing else running (after the timed region; %d launches)"
                    % excl_n[dom])
@@ -188,6 +190,12 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
             roof["in_region_note"] = ("in the timed region launches of several streams share the chip, so their durations overlap and are not "
                                       "additive; no fraction is derived from them")
             out["roofline"] = roof
+            # the other recurrence layer beside it, the same way (layers 0 and 1 are within 5 % of each other in time)
+            for k in fwd_keys:
+                if k != dom and k in excl and k in ("pileup_l0", "pileup_l1f", "pileup_l1"):
+                    out["roofline_" + k] = bc.roofline_mfma(k, bc.PILEUP_EXEC_FLOP[k] * batch * mult, excl[k], excl_n[k],
+                                                            alg_flop_per_launch=bc.PILEUP_ALG_FLOP[k] * batch, peak=peak, how=how,
+                                                            traffic=bc.committed_traffic(workload, k, batch=batch, precision=precision))
     if "encode_columns" in excl:
         nbytes = stage.encode_bytes(enc_group)
         e = bc.roofline_hbm("encode_columns", nbytes, excl["encode_columns"], excl_n["encode_columns"],
