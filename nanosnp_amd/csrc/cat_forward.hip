@@ -254,9 +254,9 @@ void pack_lstm(float* img, float* bias, const float* const* q, int I, int nki, b
                     } else {
                         v = q[1][(size_t)tr * H + (kc - nki) * BK + unit_of_pos(p)];
                     }
-                    img[(((size_t)by * nk + kc) * TR + row) * BK + p] = v;
+                    img[(((size_t)by * nk + kc) * TR + row) * BK + p] = lstm_gate_scale(by * TR + row) * v;
                 }
-    for (int R = 0; R < G; ++R) bias[R] = q[2][lstm_row(R)] + q[3][lstm_row(R)];
+    for (int R = 0; R < G; ++R) bias[R] = lstm_gate_scale(R) * (q[2][lstm_row(R)] + q[3][lstm_row(R)]);
 }
 
 // Linear(512 -> 256) on [h_fwd ; h_bwd] in LSTM storage order: image [2 row tiles][32][128][16]

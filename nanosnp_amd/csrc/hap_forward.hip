@@ -242,10 +242,10 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
                                     const int col = (kc - nki) * BK + unit_of_pos(p);
                                     v = q[1][(size_t)tr * H + col];
                                 }
-                                img[(((size_t)by * nk + kc) * TR + row) * BK + p] = v;
+                                img[(((size_t)by * nk + kc) * TR + row) * BK + p] = lstm_gate_scale(by * TR + row) * v;
                             }
                 float* bz = host.data() + off_b[e][l][d];
-                for (int R = 0; R < G; ++R) bz[R] = q[2][lstm_row(R)] + q[3][lstm_row(R)];
+                for (int R = 0; R < G; ++R) bz[R] = lstm_gate_scale(R) * (q[2][lstm_row(R)] + q[3][lstm_row(R)]);
             }
         // output_proj: Linear(2H -> H) on [h_fwd ; h_bwd] of the last layer at the centre step
         const float* pw = t[e * per_enc + per_enc - 2]; const float* pb = t[e * per_enc + per_enc - 1];

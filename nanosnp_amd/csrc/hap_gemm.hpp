@@ -45,12 +45,17 @@ __device__ __forceinline__ float tanh_f(float x) { return __builtin_fmaf(-2.0f, 
 // 5 v_exp_f32 + 3 v_rcp_f32 per unit and step instead of 5 + 5 (fp32 MFMAs and vector instructions share a SIMD's lanes: every
 // instruction of the cell is matrix-pipe time).  The exponent of the tanh terms is capped at 2^64 so that 1 - e stays finite; an
 // overflowing product of the denominators gives reciprocal 0, the correct limit.
+// factor folded into row R of an LSTM weight image and its bias (image row R: unit R / 4, gate R % 4 in the order i f g o): the cell
+// wants exp2(-log2 e z) for i, f, o and exp2(-2 log2 e z) for g, and every multiply it does not do is matrix-pipe time
+static inline float lstm_gate_scale(int R) { return (R & 3) == 2 ? -2.0f * LOG2E : -LOG2E; }
+
 __device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float c_prev, float& c_new)
 {
-    const float ei = __builtin_amdgcn_exp2f(-LOG2E * zi);
-    const float ef = __builtin_amdgcn_exp2f(-LOG2E * zf);
-    const float eo = __builtin_amdgcn_exp2f(-LOG2E * zo);
-    const float eg = __builtin_amdgcn_exp2f(fminf((-2.0f * LOG2E) * zg, 64.0f));
+    // (zi, zf, zo arrive multiplied by -log2 e and zg by -2 log2 e: the weight packers scale the gate rows, lstm_gate_scale())
+    const float ei = __builtin_amdgcn_exp2f(zi);
+    const float ef = __builtin_amdgcn_exp2f(zf);
+    const float eo = __builtin_amdgcn_exp2f(zo);
+    const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
     const float ig = (1.0f - eg) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
     const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
     const float cn = __builtin_fmaf(fg, c_prev, ig);
@@ -319,8 +324,10 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
                     float cn;
                     if (NSNP_GEMM_CELL) hv[rt][r4] = lstm_cell(z[0], z[1], z[2], z[3], cv[rt][r4], cn);
                     else {
-                        cn = __builtin_fmaf(sigmoid_f(z[1]), cv[rt][r4], sigmoid_f(z[0]) * tanh_f(z[2]));
-                        hv[rt][r4] = sigmoid_f(z[3]) * tanh_f(cn);
+                        // (A/B build of the plain cell: the gate rows are scaled for lstm_cell, undo it)
+                        const float ui = z[0] * (-1.0f / LOG2E), uf = z[1] * (-1.0f / LOG2E), ug = z[2] * (-0.5f / LOG2E), uo = z[3] * (-1.0f / LOG2E);
+                        cn = __builtin_fmaf(sigmoid_f(uf), cv[rt][r4], sigmoid_f(ui) * tanh_f(ug));
+                        hv[rt][r4] = sigmoid_f(uo) * tanh_f(cn);
                     }
                     cv[rt][r4] = cn;
                 }
