@@ -58,12 +58,14 @@ __device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float z
     const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
     // the cell state is kept multiplied by -2 log2 e (it is only ever the argument of the next tanh): K c' = f (K c) + (K - K e_g) r
     constexpr float K = -2.0f * LOG2E;
-    const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+    const float tg = 1.0f + eg;                                    // (1 + e_i)(1 + e_g) = e_i t + t
+    const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf(__builtin_fmaf(ei, tg, tg));
     const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
     const float cn = __builtin_fmaf(fg, c_prev, ig);
     const float ec = __builtin_amdgcn_exp2f(fminf(cn, 64.0f));
     c_new = cn;
-    return (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
+    const float tc = 1.0f + ec;
+    return (1.0f - ec) * __builtin_amdgcn_rcpf(__builtin_fmaf(eo, tc, tc));
 }
 
 constexpr int TS = 128;        // sites per workgroup tile

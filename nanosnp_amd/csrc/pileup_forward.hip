@@ -59,12 +59,14 @@ __device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float z
     const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
     // the cell state is kept multiplied by -2 log2 e (it is only ever the argument of the next tanh): K c' = f (K c) + (K - K e_g) r
     constexpr float K = -2.0f * LOG2E;
-    const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf((1.0f + ei) * (1.0f + eg));
+    const float tg = 1.0f + eg;                                    // (1 + e_i)(1 + e_g) = e_i t + t
+    const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf(__builtin_fmaf(ei, tg, tg));
     const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
     const float cn = __builtin_fmaf(fg, c, ig);
     const float ec = __builtin_amdgcn_exp2f(fminf(cn, 64.0f));
     c = cn;
-    return (1.0f - ec) * __builtin_amdgcn_rcpf((1.0f + eo) * (1.0f + ec));
+    const float tc = 1.0f + ec;
+    return (1.0f - ec) * __builtin_amdgcn_rcpf(__builtin_fmaf(eo, tc, tc));
 }
 
 // acc[NT] += W(image rows, K-steps [4*J4B, 4*(J4B+J4N))) . b, with the weight image read 16 B per
@@ -661,6 +663,9 @@ __global__ __launch_bounds__(512, 2) void k_pileup_l1_rs32(
     const bool late = STAGGER && wave >= 4;
 #pragma unroll
     for (int sg = 0; sg < NSG; ++sg) input_part(sg, 0, acc[sg][0], acc[sg][1]);
+    // step 0 stores the rows of step 2 over those of step 0: every wave must have read them (two waves share a SIMD and the
+    // older one can be a whole input part ahead; seen as wrong results of the 64-site variant once the cell got shorter)
+    lds_barrier();
 
     float c[NSG][2];
 #pragma unroll
