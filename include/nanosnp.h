@@ -122,6 +122,11 @@ int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
 int nsnp_ctx_enable_timing(nsnp_ctx* ctx, int enable);
 int nsnp_ctx_read_timing(nsnp_ctx* ctx, int kernel, double* total_ms, int64_t* launches);
 
+/* Diagnostic: the shader clock (MHz) the device holds under a full-chip fp32 MFMA load of about 2 ms on `stream` (s_memtime
+ * against the 100 MHz s_memrealtime in every workgroup of a probe kernel).  Boxes differ by 10 % and every MFMA fraction of a
+ * bench line is priced at the 2.4 GHz peak, so the lines record it.  Synchronous; no product path depends on it. */
+int nsnp_ctx_shader_clock(nsnp_ctx* ctx, double* mhz, void* stream);
+
 /* ---- PileupModel ---------------------------------------------------------------------- */
 /* host_tensors: the 24 fp32 tensors LSTMNetwork.predict uses, HOST pointers, in the
  * state-dict order of ont_pileup.chkpt (PileupModel/predict.py:212-214):

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "nsnp_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "nsnp_ctx_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "nsnp_ctx_read_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "nsnp_ctx_shader_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "nsnp_pileup_load_weights": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "nsnp_pileup_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -149,6 +150,12 @@ class Context:
                   "nsnp_ctx_read_timing")
             out[name] = (ms.value, n.value)
         return out
+
+    def shader_clock_mhz(self, stream=None):
+        """shader clock under a ~2 ms full-chip fp32 MFMA load (diagnostic; bench lines record it)"""
+        mhz = C.c_double(0)
+        check(self.lib.nsnp_ctx_shader_clock(self.handle, C.byref(mhz), _stream_ptr(stream)), self.handle, "nsnp_ctx_shader_clock")
+        return mhz.value
 
     def close(self):
         if getattr(self, "handle", None):

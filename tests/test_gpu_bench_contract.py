@@ -36,12 +36,20 @@ def _run(*argv, env=None, timeout=900):
 
 
 def test_bench_line_schema():
-    d = _run("--gpus", "1", "--steps", "8", "--warmup", "1", "--windows", "131072", "--cpu-seconds", "1.5")
+    d = _run("--gpus", "1", "--steps", "4", "--warmup", "1", "--windows", "131072", "--cpu-seconds", "1.5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 1 and d["unit"] == "sites/s"
-    assert d["dtype"] == "f32" and d["config"]["windows_resident_per_gpu"] == 131072 and d["config"]["batches_per_step"] == 4
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "sites/s"
+    # one step = one sweep of the resident pool
+    assert d["dtype"] == "f32" and d["config"]["windows_resident_per_gpu"] == 131072 and d["config"]["batches_per_step"] == 32
+    # three timed passes, the median one reported; the clock the chip held; the run's own outputs against the oracle
+    assert len(d["repeats"]["values"]) == 3 and sorted(d["repeats"]["values"])[1] == round(d["value"]) and d["repeats"]["reported"] == "median"
+    assert 1500 < d["shader_clock_mhz"]["value"] < 2600
+    p = d["parity_sample"]
+    assert p["ok"] and p["encode_bit_exact"] and p["calls_equal_own_argmax"] and p["max_abs_dp"] < p["tolerance"] == 1e-4
+    assert p["sites"] == 32 * 2048 and p["ring_slots_checked"] == 3 and p["ring_columns_checked"] > 0 and p["batches_sampled"] == 32
+    assert all(r is None or r["traffic"] is None or "not from this run" in r["traffic_source"] for k, r in d.items() if k.startswith("roofline"))
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert _fractions_are_physical(d) == 3                      # roofline (MFMA, dominant forward kernel), the other recurrence layer, roofline_encode (HBM)
@@ -74,6 +82,8 @@ def test_two_stage_workload_line():
     assert d["roofline"]["bound"] == "mfma" and d["roofline_features"]["bound"] == "hbm"
     assert 0 < d["stage5"]["frac_of_fp32_mfma_peak"] <= 1 and 0 < d["stage2"]["frac_of_fp32_mfma_peak"] <= 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    p = d["parity_sample"]
+    assert p["ok"] and p["stage2"]["ok"] and p["stage2"]["encode_bit_exact"] and p["stage5"]["ok"] and p["stage5"]["max_abs_dp"] < 1e-4
 
 
 def test_haplotype_workload_line():
@@ -93,6 +103,7 @@ def test_haplotype_workload_line():
     assert 0 < s["legacy_CatModel_forward_fp32"]["roofline"]["frac"] <= 1 and s["legacy_CatModel_forward_fp32"]["sites_per_s"] > 1e4
     assert 0 < s["forward_only_fp32"]["frac_of_fp32_mfma_peak"] <= 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["parity_sample"]["ok"] and d["parity_sample"]["haplotype"]["sites"] >= 192 and d["parity_sample"]["haplotype"]["max_abs_dp"] < 1e-4
 
 
 def test_deep60_workload_line():
@@ -104,6 +115,8 @@ def test_deep60_workload_line():
     assert _fractions_are_physical(d) == 5                      # hap LSTM chain, features, 60x forward kernel, 60x encode, f16x3 conv chain
     assert d["roofline_cat_conv_f16x3"]["peak"] == 2500.0 and d["roofline_features"]["D"] == 180
     assert d["value"] > 1e4 and d["cpu_baseline"]["value"] > 0
+    p = d["parity_sample"]
+    assert p["ok"] and p["haplotype"]["ok"] and p["pileup_60x"]["ok"] and p["pileup_60x"]["encode_bit_exact"] and p["cat_f16x3"]["ok"]
 
 
 @pytest.mark.parametrize("workload", ["pileup", "two-stage", "haplotype"])

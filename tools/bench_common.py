@@ -109,6 +109,11 @@ def host_cpu_name():
     return ""
 
 
+# `traffic` of every roofline object is NOT measured by the run that prints the line: rocprofv3 cannot wrap a bench run from inside
+TRAFFIC_SOURCE = ("profiles/roofline_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of the "
+                  "same bench command (tools/prof_run.sh, committed), not from this run")
+
+
 def roofline_mfma(kernel, exec_flop_per_launch, avg_launch_ms, launches, *, alg_flop_per_launch=None, peak=PEAK_F32_MFMA_TFLOPS,
                   traffic=None, how="", **extra):
     """`achieved` = flops the kernel EXECUTES per launch / its average launch duration; frac = achieved / peak <= 1."""
@@ -120,6 +125,7 @@ def roofline_mfma(kernel, exec_flop_per_launch, avg_launch_ms, launches, *, alg_
                                      "note": "flops of the reference's own schedule (SURVEY.md 8(d)) over the same time; the kernels execute the "
                                              "exact reduced schedule (only the centre position is consumed), so this figure is NOT a fraction "
                                              "of the chip peak and may exceed it"}
+    r["traffic_source"] = TRAFFIC_SOURCE if traffic is not None else None
     if how:
         r["measured"] = how
     r.update(extra)
@@ -129,7 +135,8 @@ def roofline_mfma(kernel, exec_flop_per_launch, avg_launch_ms, launches, *, alg_
 def roofline_hbm(kernel, bytes_per_launch, avg_launch_ms, launches, *, traffic=None, how="", **extra):
     ach = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-         "avg_launch_ms": avg_launch_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": traffic}
+         "avg_launch_ms": avg_launch_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": traffic,
+         "traffic_source": TRAFFIC_SOURCE if traffic is not None else None}
     if how:
         r["measured"] = how
     r.update(extra)

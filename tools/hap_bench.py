@@ -105,6 +105,41 @@ class HapStage:
     def sync(self):
         self.stream.synchronize()
 
+    # ---- parity of what a run wrote (the lines' "parity_sample") ---------------------------------------------------------
+    def snapshot(self, batch_ids, per_batch=256):
+        """host copies of the probabilities / calls the last run_batch() of the given pool batches left behind (first per_batch sites each)"""
+        t = self.torch
+        self.sync(); t.cuda.synchronize(self.dev)
+        ranges = []
+        for i in sorted({b % self.n_batches for b in batch_ids}):
+            b0, b1 = self.batch_range(i)
+            ranges.append((b0, min(per_batch, b1 - b0)))
+        idx = t.cat([t.arange(a, a + c, device=self.dev) for a, c in ranges])
+        return {"ranges": ranges, "gt": self.gt[idx].cpu().numpy(), "zy": self.zy[idx].cpu().numpy(), "res": self.res[idx].cpu().numpy()}
+
+    def parity_check(self, snap, tolerance=1e-4, nthreads=None):
+        """the snapshot against the oracle's chain on the same sites: haplotype features (float64 sums, fp32 cast) + HaplotypeModel
+        forward (oracle/hap_features_oracle.c, hap_forward_oracle.c); calls = argmax / max of the run's own probabilities"""
+        import numpy as np
+        from oracle import oracle
+        from tools.bench_common import usable_cores
+        nt = nthreads or usable_cores()
+        ogt, ozy = [], []
+        for a, c in snap["ranges"]:
+            pp = [p[a:a + c].cpu().numpy() for p in self.planes[0]]; ph = [p[a:a + c].cpu().numpy() for p in self.planes[1]]
+            xp = oracle.hap_features_batch(*pp, nthreads=nt); xh = oracle.hap_features_batch(*ph, nthreads=nt)
+            g, z = oracle.hap_forward(self.weights, xp, xh, nthreads=nt)
+            ogt.append(g); ozy.append(z)
+        ogt, ozy = np.concatenate(ogt), np.concatenate(ozy)
+        gt, zy, res = snap["gt"], snap["zy"], snap["res"]
+        dp = float(max(np.abs(gt - ogt).max(), np.abs(zy - ozy).max()))
+        calls_self = bool(np.array_equal(res[:, 0], gt.argmax(1).astype(np.float32)) and np.array_equal(res[:, 1], gt.max(1)))
+        ok = bool(np.isfinite(gt).all() and np.isfinite(zy).all() and dp <= tolerance and calls_self)
+        return {"ok": ok, "sites": int(gt.shape[0]), "max_abs_dp": dp, "tolerance": tolerance, "calls_equal_own_argmax": calls_self,
+                "batches_sampled": len(snap["ranges"]),
+                "what": "probabilities and calls the timed region's own run left behind for `sites` sites (read planes -> haplotype features -> "
+                        "HaplotypeModel forward) against oracle/liboracle.so on the same read planes"}
+
     def feature_bytes(self, n, L, int8=False):
         """algorithmic bytes of one feature launch: four read planes + the reference row in, [105, L] fp32 out"""
         return n * (4 * (1 if int8 else 4) * self.D * L + 4 * L + 105 * L * 4)
@@ -146,6 +181,18 @@ class CatStage:
 
     def sync(self):
         self.stream.synchronize()
+
+    def parity_check(self, b0, n, tolerance=1e-4, nthreads=None):
+        """gt[b0 : b0 + n] as the last run_batch() left it against oracle/cat_forward_oracle.c on the same group tensors"""
+        import numpy as np
+        from oracle import oracle
+        from tools.bench_common import usable_cores
+        self.sync(); self.torch.cuda.synchronize(self.dev)
+        gt = self.gt[b0:b0 + n].cpu().numpy()
+        ogt = oracle.cat_forward(self.weights, self.g0[b0:b0 + n].cpu().numpy(), self.g1[b0:b0 + n].cpu().numpy(), nthreads=nthreads or usable_cores())
+        dp = float(np.abs(gt - ogt).max())
+        return {"ok": bool(np.isfinite(gt).all() and dp <= tolerance), "sites": int(n), "max_abs_dp": dp, "tolerance": tolerance,
+                "precision": "f16x3" if self.precision == 1 else ("bf16x3" if self.precision == 2 else "fp32")}
 
 
 def _timed(fn, sync, reps):
@@ -290,6 +337,7 @@ def run(args, rank, world, local_rank, deep60=False):
             return outs
         return [gather_results(o.to(cdev), o.shape[0] * world) for o in outs]
 
+    exit_code = 0
     for i in range(W):
         step(i)
     sync_all(); merge(); sync_all()
@@ -317,6 +365,15 @@ def run(args, rank, world, local_rank, deep60=False):
     feat_in_region = tim["hap_features"]
     ctim = cs.ctx.read_timing()
     ptot = ps.read_timing() if ps else {}
+    # what the timed steps left behind, for the parity sample (compared with the oracle after everything else, outside every clock)
+    parity = None
+    if rank == 0 and not args.no_parity_sample:
+        parity = {"hap_snap": hs.snapshot(range(W, W + K), per_batch=max(64, 1024 // min(K, hs.n_batches)))}
+        if ps:
+            parity["ps_snap"] = ps.snapshot(ps.parity_ranges(min(K * wb, ps.n_batches) * ps.batch, per_batch=512, n_ranges=16))
+        if deep60:
+            cb0 = ((W + K - 1) % cs.n_batches) * cs.batch
+            parity["cat"] = cs.parity_check(cb0, min(256, cs.n - cb0))
 
     # ---- after the timed region, alone on the chip: feature launches by window length, second / labelled values ----
     b0, b1 = hs.batch_range(0)
@@ -395,15 +452,31 @@ def run(args, rank, world, local_rank, deep60=False):
         out.update(roofs)
         out.setdefault("roofline", None)
         out["second_values"] = second
+        out["timed_region_s"] = dt
+        out["shader_clock_mhz"] = {"value": hs.ctx.shader_clock_mhz(hs.stream), "how": "s_memtime / s_memrealtime in every workgroup of a ~2 ms full-chip "
+                                   "fp32 MFMA probe after the timed region (nsnp_ctx_shader_clock); the MFMA peaks are priced at 2400"}
+        out["parity_sample"] = None
+        if parity is not None:
+            par = {"haplotype": hs.parity_check(parity["hap_snap"])}
+            if ps:
+                par["pileup_60x"] = ps.parity_check(parity["ps_snap"])
+            if "cat" in parity:
+                par["cat_f16x3"] = parity["cat"]
+            par["ok"] = all(v["ok"] for v in par.values())
+            par["tolerance"] = 1e-4
+            out["parity_sample"] = par
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_deep(ps, hs, cs, args.cpu_seconds) if deep60 else cpu_baseline_hap(hs, args.cpu_seconds)
         assert merged[0].shape[0] == n_hap * world
         print(json.dumps(out))
+        if out["parity_sample"] is not None and not out["parity_sample"]["ok"]:
+            print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
+            exit_code = 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return exit_code
 
 
 def cat_report(cs, n_sites, seconds, ctim, bc):

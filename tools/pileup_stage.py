@@ -94,6 +94,7 @@ class PileupStage:
                 self._ev_pool.append(ev)
             slot["users"] = []
             c0 = b * self.mcols
+            slot["c0"], slot["ncols"] = c0, g * self.mcols          # what the slot holds (parity_check compares it with the oracle)
             rc = lib.nsnp_pileup_encode_columns(self.enc_ctx.handle, P(self.d_bases.data_ptr()), P(self.d_off.data_ptr() + 8 * c0),
                                                 P(self.d_ref.data_ptr() + c0), g * self.mcols, C.c_double(0.12), 6,
                                                 P(slot["counts"].data_ptr()), P(slot["depth"].data_ptr()), P(slot["flags"].data_ptr()),
@@ -153,6 +154,81 @@ class PileupStage:
         """algorithmic bytes of one encode launch over the first batches of the pool: column bytes + ref + 18 int32 out"""
         m = n_batches_in_launch * self.mcols
         return int(self.cols.col_off[m]) + m * (1 + 72)
+
+    # ---- parity of what a run wrote (bench.py "parity_sample"; tests/test_gpu_stage_parity.py) --------------------------
+    def parity_ranges(self, n_done, per_batch=2048, n_ranges=32):
+        """site ranges a parity sample looks at: the first `per_batch` windows of n_ranges batches spread over the pool, so that
+        every forward stream (batch i runs on stream i mod S) and every encode group of a sweep is represented"""
+        nb = max(1, min(int(n_done) // self.batch, self.n_batches))
+        step = max(1, nb // n_ranges) | 1                                 # odd stride: walks through the residues mod 32
+        picks = sorted({(k * step) % nb for k in range(min(n_ranges, nb))})
+        return [(b * self.batch, min(per_batch, self.batch)) for b in picks]
+
+    def snapshot(self, ranges, ring_batches=4):
+        """host copies of what the last run() calls left behind: probabilities and calls of the windows in `ranges`
+        [(first site, count)], and the first `ring_batches` batches of every ring slot's count buffer together with the column
+        range the slot was encoded from"""
+        t = self.torch
+        self.sync()
+        idx = t.cat([t.arange(a, a + c, device=self.dev) for a, c in ranges])
+        snap = {"ranges": list(ranges), "gt": self.gt_all[idx].cpu().numpy(), "zy": self.zy_all[idx].cpu().numpy(),
+                "res": {k: v[idx].cpu().numpy() for k, v in self.res.items()}, "ring": []}
+        for slot in self.ring:
+            if "c0" not in slot:
+                continue
+            m = min(slot["ncols"], ring_batches * self.mcols)
+            snap["ring"].append({"c0": slot["c0"], "m": m, "counts": slot["counts"][:m].cpu().numpy(),
+                                 "depth": slot["depth"][:m].cpu().numpy(), "flags": slot["flags"][:m].cpu().numpy()})
+        return snap
+
+    def _oracle_encode(self, c0, m):
+        from oracle import oracle
+        off = self.cols.col_off[c0:c0 + m + 1]
+        return oracle.encode_columns(self.cols.bases[int(off[0]):int(off[-1])], off - off[0], self.cols.ref[c0:c0 + m])
+
+    def parity_check(self, snap, tolerance=1e-4, nthreads=None):
+        """compares a snapshot() with the oracle (the plain restatement - the pinned checker, not the blocked arrangement bench.py
+        times) on the same windows: probabilities within `tolerance` (BASELINE north_star: 1e-4 abs), calls = np.argmax / np.max
+        of the run's own probabilities (predict.py:54-57), calls vs the oracle's except where its two best classes are closer than
+        2 x tolerance, every ring slot's counts / depth / flags bit for bit -> the "parity_sample" object of a bench line"""
+        import numpy as np
+        from oracle import oracle
+        from tools.bench_common import usable_cores
+        xs = []
+        for a, c in snap["ranges"]:
+            counts, _, _ = self._oracle_encode(a * 33, c * 33)
+            xs.append(counts.reshape(c, 33, 18))
+        x = np.concatenate(xs)
+        n = x.shape[0]
+        ogt, ozy = oracle.pileup_forward(self.weights, x, nthreads=nthreads or usable_cores())
+        gt, zy = snap["gt"], snap["zy"]
+        dp = float(max(np.abs(gt - ogt).max(), np.abs(zy - ozy).max()))
+        finite = bool(np.isfinite(gt).all() and np.isfinite(zy).all())
+        r = snap["res"]
+        calls_self = bool(np.array_equal(r["ga"], gt.argmax(1).astype(np.uint8)) and np.array_equal(r["za"], zy.argmax(1).astype(np.uint8))
+                          and np.array_equal(r["gm"], gt.max(1)) and np.array_equal(r["zm"], zy.max(1)))
+        flips = 0
+        for mine, ref in ((r["ga"], ogt), (r["za"], ozy)):
+            diff = np.nonzero(mine != ref.argmax(1))[0]
+            if diff.size:
+                top2 = np.sort(ref[diff], axis=1)[:, -2:]
+                if bool(((top2[:, 1] - top2[:, 0]) > 2 * tolerance).any()):
+                    flips = -1                                          # a call differs where the oracle has a clear winner
+                    break
+                flips += int(diff.size)
+        enc_ok, ring_cols = True, 0
+        for s in snap["ring"]:
+            oc, od, of = self._oracle_encode(s["c0"], s["m"])
+            enc_ok &= bool(np.array_equal(s["counts"], oc) and np.array_equal(s["depth"], od) and np.array_equal(s["flags"], of))
+            ring_cols += s["m"]
+        ok = finite and dp <= tolerance and calls_self and flips >= 0 and enc_ok and n > 0
+        return {"ok": bool(ok), "sites": int(n), "max_abs_dp": dp, "tolerance": tolerance, "encode_bit_exact": enc_ok,
+                "ring_slots_checked": len(snap["ring"]), "ring_columns_checked": int(ring_cols), "calls_equal_own_argmax": calls_self,
+                "calls_differing_from_oracle_at_near_ties": int(max(flips, 0)), "call_differs_at_a_clear_winner": flips < 0,
+                "batches_sampled": len(snap["ranges"]),
+                "what": "what the timed region's own run left behind (all streams, ring of count buffers) against oracle/liboracle.so "
+                        "(plain restatement): softmax probabilities of `sites` pool windows spread over the batches, argmax / max calls, "
+                        "and the count buffers still in the ring"}
 
     def compact_calls(self, n_done):
         t = self.torch

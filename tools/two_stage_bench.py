@@ -111,6 +111,11 @@ def run(args, rank, world, local_rank):
         n2_all = int(cnt.item())
     ptot = ps.read_timing()
     tim = hs.ctx.read_timing()
+    exit_code = 0
+    parity = None
+    if rank == 0 and not args.no_parity_sample:          # what the last timed step left behind (compared with the oracle below, outside every clock)
+        parity = (ps.snapshot(ps.parity_ranges(n2, per_batch=1024, n_ranges=32)),
+                  hs.snapshot(range(hs.n_batches), per_batch=max(64, 1024 // hs.n_batches)))
     if rank == 0:
         assert merged[0].shape[0] == n2_all and merged[1].shape[0] == (n5_tot if world > 1 else hs.n)
         # rooflines: the dominant kernel of the whole job is the HaplotypeModel's fused step launch (80 % of the time)
@@ -147,14 +152,26 @@ def run(args, rank, world, local_rank):
         }
         out.update(roofs)
         out.setdefault("roofline", None)
+        out["timed_region_s"] = dt
+        out["shader_clock_mhz"] = {"value": hs.ctx.shader_clock_mhz(hs.stream), "how": "s_memtime / s_memrealtime in every workgroup of a ~2 ms full-chip "
+                                   "fp32 MFMA probe after the timed region (nsnp_ctx_shader_clock); the MFMA peaks are priced at 2400"}
+        out["parity_sample"] = None
+        if parity is not None:
+            par = {"stage2": ps.parity_check(parity[0]), "stage5": hs.parity_check(parity[1])}
+            par["ok"] = par["stage2"]["ok"] and par["stage5"]["ok"]
+            par["tolerance"] = 1e-4
+            out["parity_sample"] = par
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_two_stage(ps, hs, args.cpu_seconds)
         print(json.dumps(out))
+        if out["parity_sample"] is not None and not out["parity_sample"]["ok"]:
+            print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
+            exit_code = 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return exit_code
 
 
 def cpu_baseline_two_stage(ps, hs, target_s):
