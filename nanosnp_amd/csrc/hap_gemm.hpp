@@ -6,6 +6,7 @@
 #pragma once
 #include "nsnp_devclock.hpp"
 #include "nsnp_common.hpp"
+#include "nsnp_lstm_cell.hpp"
 
 // main-loop pipeline shape (see k_hap_gemm); overridable for A/B builds (tools/build_variant.sh)
 #ifndef NSNP_GEMM_PIPE
@@ -38,35 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
 __device__ __forceinline__ float tanh_f(float x) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f); }
 
-// LSTM cell on the four gate pre-activations (bias included) of one hidden unit (torch.nn.LSTM equations, gate order i f g o):
-//   c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c')
-// with sigmoid(x) = 1 / (1 + e^-x), tanh(x) = (1 - e^-2x) / (1 + e^-2x): the two products share ONE reciprocal each,
-//   sigmoid(i) tanh(g) = (1 - e^-2g) / ((1 + e^-i)(1 + e^-2g)),
-// 5 v_exp_f32 + 3 v_rcp_f32 per unit and step instead of 5 + 5 (fp32 MFMAs and vector instructions share a SIMD's lanes: every
-// instruction of the cell is matrix-pipe time).  The exponent of the tanh terms is capped at 2^64 so that 1 - e stays finite; an
-// overflowing product of the denominators gives reciprocal 0, the correct limit.
-// factor folded into row R of an LSTM weight image and its bias (image row R: unit R / 4, gate R % 4 in the order i f g o): the cell
-// wants exp2(-log2 e z) for i, f, o and exp2(-2 log2 e z) for g, and every multiply it does not do is matrix-pipe time
-static inline float lstm_gate_scale(int R) { return (R & 3) == 2 ? -2.0f * LOG2E : -LOG2E; }
-
-__device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float c_prev, float& c_new)
-{
-    // (zi, zf, zo arrive multiplied by -log2 e and zg by -2 log2 e: the weight packers scale the gate rows, lstm_gate_scale())
-    const float ei = __builtin_amdgcn_exp2f(zi);
-    const float ef = __builtin_amdgcn_exp2f(zf);
-    const float eo = __builtin_amdgcn_exp2f(zo);
-    const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
-    // the cell state is kept multiplied by -2 log2 e (it is only ever the argument of the next tanh): K c' = f (K c) + (K - K e_g) r
-    constexpr float K = -2.0f * LOG2E;
-    const float tg = 1.0f + eg;                                    // (1 + e_i)(1 + e_g) = e_i t + t
-    const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf(__builtin_fmaf(ei, tg, tg));
-    const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
-    const float cn = __builtin_fmaf(fg, c_prev, ig);
-    const float ec = __builtin_amdgcn_exp2f(fminf(cn, 64.0f));
-    c_new = cn;
-    const float tc = 1.0f + ec;
-    return (1.0f - ec) * __builtin_amdgcn_rcpf(__builtin_fmaf(eo, tc, tc));
-}
+// LSTM cell and the gate-scale contract of the packers: nsnp_lstm_cell.hpp (one definition for every recurrence kernel)
+using nsnp_cell::lstm_cell;
+using nsnp_cell::lstm_gate_scale;
 
 constexpr int TS = 128;        // sites per workgroup tile
 constexpr int TR = 128;        // weight rows per workgroup tile

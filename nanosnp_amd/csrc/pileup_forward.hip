@@ -23,6 +23,7 @@
 // sigmoid/tanh use v_exp_f32 / v_rcp_f32 (1 ulp).  Reduced schedule: 6.29 MFLOP/site executed
 // vs 12.55 MFLOP/site in the reference schedule, results identical to fp32 rounding.
 #include "nsnp_common.hpp"
+#include "nsnp_lstm_cell.hpp"
 #include "nsnp_devclock.hpp"
 
 namespace {
@@ -43,30 +44,14 @@ __device__ __forceinline__ float tanh_f(float x)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * x)), 1.0f);
 }
 
-// LSTM cell on the four gate pre-activations (bias included) of one hidden unit (torch.nn.LSTM equations, gate order i f g o):
-//   c' = sigmoid(f) c + sigmoid(i) tanh(g),   h' = sigmoid(o) tanh(c')          (PileupModel/model.py:34 = nn.LSTM)
-// with sigmoid(x) = 1 / (1 + e^-x), tanh(x) = (1 - e^-2x) / (1 + e^-2x): the two products share ONE reciprocal each,
-//   sigmoid(i) tanh(g) = (1 - e^-2g) / ((1 + e^-i)(1 + e^-2g)),
-// 5 v_exp_f32 + 3 v_rcp_f32 per unit and step instead of 5 + 5: fp32 MFMAs and vector instructions share a SIMD's lanes, so
-// every instruction of the cell is matrix-pipe time.  The exponent of the tanh terms is capped at 2^64 so that 1 - e stays finite;
-// an overflowing product of the denominators gives reciprocal 0, the correct limit.  c is updated in place, h' returned.
+// LSTM cell: nsnp_lstm_cell.hpp (shared with hap_gemm.hpp and the bf16x3 kernels; gate rows pre-scaled by nsnp_pileup_pack_weights).
+// c is updated in place, h' returned.
 __device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float& c)
 {
-    // (zi, zf, zo arrive multiplied by -log2 e and zg by -2 log2 e: nsnp_pileup_pack_weights scales the gate rows)
-    const float ei = __builtin_amdgcn_exp2f(zi);
-    const float ef = __builtin_amdgcn_exp2f(zf);
-    const float eo = __builtin_amdgcn_exp2f(zo);
-    const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
-    // the cell state is kept multiplied by -2 log2 e (it is only ever the argument of the next tanh): K c' = f (K c) + (K - K e_g) r
-    constexpr float K = -2.0f * LOG2E;
-    const float tg = 1.0f + eg;                                    // (1 + e_i)(1 + e_g) = e_i t + t
-    const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf(__builtin_fmaf(ei, tg, tg));
-    const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
-    const float cn = __builtin_fmaf(fg, c, ig);
-    const float ec = __builtin_amdgcn_exp2f(fminf(cn, 64.0f));
+    float cn;
+    const float h = nsnp_cell::lstm_cell(zi, zf, zg, zo, c, cn);
     c = cn;
-    const float tc = 1.0f + ec;
-    return (1.0f - ec) * __builtin_amdgcn_rcpf(__builtin_fmaf(eo, tc, tc));
+    return h;
 }
 
 // acc[NT] += W(image rows, K-steps [4*J4B, 4*(J4B+J4N))) . b, with the weight image read 16 B per
