@@ -20,8 +20,9 @@ with the children's status.  One process per GPU, every rank owns its own pool (
 data-path collective); the only exchange is the rooted gather of the compact per-site calls at the end,
 inside the timed region (RCCL over xGMI).  Rank 0 prints ONE JSON line.
 
-The headline `value` is the exact-fp32 path (the library default, the reference's arithmetic); the
-opt-in f16x3 mode is timed afterwards on the same pool and reported under "f16x3" in the same line.
+The headline `value` is the exact-fp32 path (the library default, the reference's arithmetic); the bf16x3
+mode (three bf16 terms per operand: the full fp32 significand on the bf16 matrix pipe) and the opt-in f16x3
+mode are timed afterwards on the same pool and reported under "bf16x3" / "f16x3" in the same line.
 """
 from __future__ import annotations
 
@@ -62,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--hap-batch", type=int, default=16384, help="haplotype / deep60 workloads: sites per step")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = runtime default of 4)")
     ap.add_argument("--precision", type=int, default=0, help="headline arithmetic of the PileupModel forward: 0 exact fp32 MFMA "
-                    "(library default), 1 f16x3 split")
+                    "(library default), 1 f16x3 split, 2 bf16x3")
     ap.add_argument("--no-second-precision", action="store_true", help="skip the labelled f16x3 pass after the fp32 headline")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="nsnp_ctx_set_option on every context (tuning)")
     ap.add_argument("--repeat", type=int, default=3, help="timed passes of the headline arithmetic; the line reports the median pass")
@@ -294,18 +295,32 @@ def main():
     # the same kernels with the chip to themselves (one stream, after the timed region)
     excl, excl_n = stage.exclusive_pass()
 
-    # ---- second, labelled value: the opt-in f16x3 arithmetic on the same pool ----------------------
-    second = None
+    # ---- labelled second values on the same pool: bf16x3 (full fp32 operand width on the bf16 pipe) and the opt-in f16x3 ----------
+    seconds = {}
     if not args.no_second_precision and args.precision == 0:
         ref_gt = stage.gt_all[:n_done].clone(); ref_zy = stage.zy_all[:n_done].clone()
         torch.cuda.synchronize(dev)                     # (the copies run on torch's current stream, the forwards on the stage's)
-        stage.set_precision(1)
-        dt2, _, _, tot2 = timed_pass()
-        d = max((stage.gt_all[:n_done] - ref_gt).abs().max().item(), (stage.zy_all[:n_done] - ref_zy).abs().max().item())
-        second = {"value": sites_timed / dt2, "unit": "sites/s", "ms_per_step": dt2 / K * 1e3,
-                  "dtype": "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)",
+        for prec, label, text in ((2, "bf16x3", "bf16x3 (every fp32 operand as three bf16 terms = its full 24-bit significand and exponent range, "
+                                                "six bf16 MFMAs per product, fp32 accumulate)"),
+                                  (1, "f16x3", "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)")):
+            stage.set_precision(prec)
+            dt2, _, _, tot2 = timed_pass()
+            d = max((stage.gt_all[:n_done] - ref_gt).abs().max().item(), (stage.zy_all[:n_done] - ref_zy).abs().max().item())
+            sv = {"value": sites_timed / dt2, "unit": "sites/s", "ms_per_step": dt2 / K * 1e3, "dtype": text,
                   "max_abs_dp_vs_fp32_on_the_pool": d, "tolerance": 1e-4,
                   "kernel_avg_ms_in_region": {k: round(v[0] / v[1], 5) for k, v in sorted(tot2.items())}}
+            if prec == 2:
+                # its own rooflines against the dense bf16 MFMA peak, the six MFMAs of a product priced as executed, and its own
+                # outputs against the oracle
+                snap2 = stage.snapshot(stage.parity_ranges(n_done, per_batch=512)) if (rank == 0 and not args.no_parity_sample) else None
+                excl2, excl2_n = stage.exclusive_pass()
+                if rank == 0:
+                    pr = pileup_rooflines(stage, tot2, excl2, excl2_n, sites_timed / world, dt2, 2, stage.G) if tot2 else {}
+                    sv["roofline"] = pr.get("roofline"); sv["roofline_other_layer"] = next((v for k, v in pr.items() if k.startswith("roofline_pileup_l")), None)
+                    sv["kernel_exclusive_ms"] = {k: round(v, 5) for k, v in sorted(excl2.items())}
+                    sv["parity_sample"] = stage.parity_check(snap2) if snap2 is not None else None
+            seconds[label] = sv
+        stage.set_precision(0)
         del ref_gt, ref_zy
 
     exit_code = 0
@@ -314,12 +329,13 @@ def main():
             "metric": METRIC, "value": sites_timed / dt, "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == 0 else "f16x3 (fp32 split into two fp16, 3 MFMAs per product, fp32 accumulate)",
+            "dtype": {0: "f32", 1: "f16x3 (fp32 split into two fp16, 3 MFMAs per product, fp32 accumulate)",
+                      2: "bf16x3 (fp32 split into three bf16 = 24 significand bits, 6 MFMAs per product, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: pileup encode + PileupModel fwd, 1M synthetic 30x windows (G2) resident in HBM, batch=4096",
                        "batch": batch, "windows_resident_per_gpu": n_windows, "batches_per_step": bps, "sites_per_step": bps * batch,
                        "streams": stage.S, "encode_batches_per_launch": stage.G, "coverage": args.coverage,
-                       "precision": "fp32" if args.precision == 0 else "f16x3",
+                       "precision": {0: "fp32", 1: "f16x3", 2: "bf16x3"}[args.precision],
                        "weights": "ont_pileup.chkpt values (tests/golden fixture)",
                        "parallelism": f"site-sharded x{world}, rooted gather of calls",
                        "world_size_observed": dist.get_world_size() if world > 1 else 1, "gather": args.gather,
@@ -334,8 +350,7 @@ def main():
             out["kernel_timing"] = {"streams_with_events": stage.timed_streams, "launches_timed_in_region": {k: v[1] for k, v in sorted(tot.items())}}
         else:
             out["roofline"] = None
-        if second:
-            out["f16x3"] = second
+        out.update(seconds)
         out["repeats"] = {"values": [round(v) for v in repeats], "reported": "median", "spread": (max(repeats) - min(repeats)) / out["value"]}
         out["timed_region_s"] = dt
         out["shader_clock_mhz"] = {"value": clock_mhz, "how": "s_memtime / s_memrealtime in every workgroup of a ~2 ms full-chip fp32 MFMA "
@@ -347,9 +362,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(stage.cols, batch, stage.weights, args.cpu_seconds) if (not args.no_cpu_baseline and world == 1) else None
         assert merged is not None and merged.shape[0] == n_done * world
         print(json.dumps(out))
-        if out["parity_sample"] is not None and not out["parity_sample"]["ok"]:
-            print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
-            exit_code = 1
+        for who in (out, out.get("bf16x3") or {}):
+            if who.get("parity_sample") is not None and not who["parity_sample"]["ok"]:
+                print("bench.py: parity_sample FAILED: " + json.dumps(who["parity_sample"]), file=sys.stderr)
+                exit_code = 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

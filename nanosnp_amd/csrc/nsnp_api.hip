@@ -106,7 +106,7 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         return nsnp_hap_reserve(ctx);                   // synchronous re-allocation when the weights are already loaded
     }
     if (strcmp(name, "pileup_precision") == 0) {
-        if (value != 0 && value != 1) return NSNP_EINVAL;
+        if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->precision = (int)value;
         return NSNP_OK;
     }
@@ -219,6 +219,7 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     if (ctx->pw.arena) (void)hipFree(ctx->pw.arena);
     if (ctx->pw16.arena) (void)hipFree(ctx->pw16.arena);
     if (ctx->pw16.l1f_bias) (void)hipFree(ctx->pw16.l1f_bias);
+    if (ctx->pwb3.arena) (void)hipFree(ctx->pwb3.arena);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
     (void)nsnp_comm_destroy(ctx);
     nsnp_hap_free(ctx);
@@ -243,7 +244,8 @@ extern "C" int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites)
     free_ws(ctx);
     ctx->chunk_sites = max_sites;
     const size_t n = (size_t)max_sites;
-    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, (n + 64) * PW * 128 * sizeof(float)));
+    // H0: 512 B per site and step on the fp32 / f16x3 paths, 768 B (three bf16 planes) on the bf16x3 path: sized for the larger
+    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, (n + 64) * PW * 192 * sizeof(float)));
     // ws_xp1 (34.8 KB per site) only exists for the legacy unfused layer-1 path: nsnp_ctx_need_xp1 allocates it on first use
     NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h1c, (n + 64) * 128 * sizeof(float)));
     return NSNP_OK;
@@ -261,24 +263,37 @@ extern "C" int nsnp_pileup_load_weights(nsnp_ctx* ctx, const float* const* host_
     if (!ctx || !host_tensors || n_tensors < 24) return NSNP_EINVAL;
     for (int i = 0; i < 24; ++i) if (!host_tensors[i]) return NSNP_EINVAL;
     NSNP_HIP(ctx, hipSetDevice(ctx->device));
-    const int rc = nsnp_pileup_pack_weights(ctx, host_tensors);
-    return rc ? rc : nsnp_pileup_pack_weights_f16(ctx, host_tensors);
+    int rc = nsnp_pileup_pack_weights(ctx, host_tensors);
+    if (!rc) rc = nsnp_pileup_pack_weights_f16(ctx, host_tensors);
+    return rc ? rc : nsnp_pileup_pack_weights_bf16(ctx, host_tensors);
+}
+
+// one dispatch for the three arithmetic modes; post / post_written as in nsnp_common.hpp
+static int pileup_forward_any(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx, int64_t N, float* gt, float* zy,
+                              const PostOut* post, bool* post_written, hipStream_t s)
+{
+    if (post_written) *post_written = false;
+    if (ctx->precision == 1) return nsnp_pileup_forward_f16x3(ctx, x, center_idx, N, gt, zy, s);
+    if (ctx->precision == 2) {
+        const int rc = nsnp_pileup_forward_bf16x3(ctx, x, center_idx, N, gt, zy, post, s);
+        if (!rc && post_written) *post_written = post && post->gt_arg;
+        return rc;
+    }
+    return nsnp_pileup_forward_impl(ctx, x, center_idx, N, gt, zy, post, post_written, s);
 }
 
 extern "C" int nsnp_pileup_forward(nsnp_ctx* ctx, const int32_t* x, int64_t N,
                                    float* gt_prob, float* zy_prob, void* stream)
 {
     if (!ctx || N < 0 || (N > 0 && (!x || !gt_prob || !zy_prob))) return NSNP_EINVAL;
-    if (ctx->precision == 1) return nsnp_pileup_forward_f16x3(ctx, x, nullptr, N, gt_prob, zy_prob, (hipStream_t)stream);
-    return nsnp_pileup_forward_impl(ctx, x, nullptr, N, gt_prob, zy_prob, (hipStream_t)stream);
+    return pileup_forward_any(ctx, x, nullptr, N, gt_prob, zy_prob, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,
                                            int64_t N, float* gt_prob, float* zy_prob, void* stream)
 {
     if (!ctx || N < 0 || (N > 0 && (!counts || !center_idx || !gt_prob || !zy_prob))) return NSNP_EINVAL;
-    if (ctx->precision == 1) return nsnp_pileup_forward_f16x3(ctx, counts, center_idx, N, gt_prob, zy_prob, (hipStream_t)stream);
-    return nsnp_pileup_forward_impl(ctx, counts, center_idx, N, gt_prob, zy_prob, (hipStream_t)stream);
+    return pileup_forward_any(ctx, counts, center_idx, N, gt_prob, zy_prob, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, int64_t N,
@@ -287,14 +302,11 @@ extern "C" int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* c
 {
     if (!ctx || N < 0 || (N > 0 && (!counts || !center_idx || !gt_prob || !zy_prob || !gt_arg || !zy_arg || !gt_max || !zy_max))) return NSNP_EINVAL;
     if (N == 0) return NSNP_OK;
-    // the fp32 heads kernel writes argmax / max from the registers that hold the probabilities; the other paths (f16x3, the
-    // one-wave heads kernel of round 1) run the forward and then nsnp_pileup_postprocess on the same stream
-    ctx->post_out = PostOut{gt_arg, zy_arg, gt_max, zy_max};
-    ctx->post_done = false;
-    const int rc = nsnp_pileup_forward_windows(ctx, counts, center_idx, N, gt_prob, zy_prob, stream);
-    const bool done = ctx->post_done;
-    ctx->post_out = PostOut{nullptr, nullptr, nullptr, nullptr};
-    ctx->post_done = false;
+    // the fp32 and bf16x3 heads kernels write argmax / max from the registers that hold the probabilities; the other paths (f16x3,
+    // the one-wave heads kernel of round 1) run the forward and then nsnp_pileup_postprocess on the same stream
+    const PostOut post{gt_arg, zy_arg, gt_max, zy_max};
+    bool written = false;
+    const int rc = pileup_forward_any(ctx, counts, center_idx, N, gt_prob, zy_prob, &post, &written, (hipStream_t)stream);
     if (rc) return rc;
-    return done ? NSNP_OK : nsnp_pileup_postprocess(ctx, gt_prob, zy_prob, nullptr, N, gt_arg, zy_arg, gt_max, zy_max, nullptr, stream);
+    return written ? NSNP_OK : nsnp_pileup_postprocess(ctx, gt_prob, zy_prob, nullptr, N, gt_arg, zy_arg, gt_max, zy_max, nullptr, stream);
 }

@@ -60,6 +60,14 @@ struct PileupWeightsF16 {
     void* arena; size_t arena_bytes; bool loaded;
 };
 
+// bf16 three-plane images of the same weights for the bf16x3 path (pileup_forward_bf16x3.hip): [tile][K block][plane][lane] of 8 bf16
+struct PileupWeightsB3 {
+    void* l0_whh[2]; void* l0_wih[2]; void* l1_wih[2]; void* l1_whh[2];
+    void* proj_w; void* dense_w; void* head_w;
+    float* proj_b; float* dense_b; float* head_b;             // fp32, natural row order
+    void* arena; size_t arena_bytes; bool loaded;
+};
+
 struct HapWeightsDev;   // hap_forward.hip
 struct CatWeightsDev;   // cat_forward.hip
 
@@ -83,9 +91,10 @@ struct nsnp_ctx {
     hipError_t last_err;
     bool attr_set;
     bool attr_set_f16;
+    bool attr_set_b3;
     int cat_precision;  // legacy CatModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
     int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
-    int precision;      // PileupModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
+    int precision;      // PileupModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in), 2 = bf16x3 (three bf16 terms per operand, six bf16 MFMAs per product)
     int fused_waves;    // 0 = automatic, else 4 / 8 / 12 waves per workgroup of the fused kernel
     int l0_rs;          // f16x3: 1 = register-stationary layer-0 kernel (default), 0 = LDS-image kernel
     int l1_rs_groups;   // 0 = automatic, else 2 / 4 groups of 16 sites per workgroup of that kernel
@@ -105,6 +114,7 @@ struct nsnp_ctx {
     float*  ws_h1c;     // [chunk][128]
     PileupWeightsDev pw;
     PileupWeightsF16 pw16;
+    PileupWeightsB3 pwb3;
     HapWeightsDev* hw;
     void*  hap_ws; size_t hap_ws_bytes;
     int64_t hap_chunk;  // sites per pass of the HaplotypeModel forward (option "hap_pass_sites", default 16384)
@@ -113,7 +123,6 @@ struct nsnp_ctx {
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
     bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
-    PostOut post_out; bool post_done;         // set around a fused call; post_done: the head kernel wrote them
     KernelTimer* timer;
     void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init / nsnp_comm_attach (nsnp_comm.hip)
     bool comm_borrowed;                        // attached by the caller: never destroyed here
@@ -139,10 +148,15 @@ void nsnp_pack_image(float* img, int n_tiles, int n_j4, nsnp_wfun f, const void*
 
 int nsnp_ctx_need_xp1(nsnp_ctx* ctx);   // legacy unfused layer-1 path only (synchronous allocation on first use)
 
-// kernels' launchers (pileup_forward.hip)
+// kernels' launchers (pileup_forward.hip, pileup_forward_f16x3.hip, pileup_forward_bf16x3.hip).  `post` (may be null): argmax / max
+// outputs of a fused forward + post-processing call; a launcher whose heads kernel writes them returns with *post_written = true,
+// otherwise the caller runs nsnp_pileup_postprocess behind it.
 int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
-                             int64_t N, float* gt, float* zy, hipStream_t s);
+                             int64_t N, float* gt, float* zy, const PostOut* post, bool* post_written, hipStream_t s);
 int nsnp_pileup_pack_weights(nsnp_ctx* ctx, const float* const* w);
 int nsnp_pileup_forward_f16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
                               int64_t N, float* gt, float* zy, hipStream_t s);
 int nsnp_pileup_pack_weights_f16(nsnp_ctx* ctx, const float* const* w);
+int nsnp_pileup_forward_bf16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx, int64_t N, float* gt, float* zy,
+                               const PostOut* post, hipStream_t s);
+int nsnp_pileup_pack_weights_bf16(nsnp_ctx* ctx, const float* const* w);

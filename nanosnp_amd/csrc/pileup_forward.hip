@@ -1287,7 +1287,7 @@ static int set_lds_attr_once(nsnp_ctx* ctx)
 }
 
 int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* center_idx,
-                             int64_t N, float* gt, float* zy, hipStream_t s)
+                             int64_t N, float* gt, float* zy, const PostOut* post, bool* post_written, hipStream_t s)
 {
     if (!ctx->pw.loaded) return NSNP_ENOWEIGHTS;
     if (N == 0) return NSNP_OK;
@@ -1370,13 +1370,13 @@ int nsnp_pileup_forward_impl(nsnp_ctx* ctx, const int32_t* x, const int64_t* cen
         if (ctx->head_rs) {
             int64_t gh = NSNP_CDIV(n, 16);
             if (gh > 2 * (int64_t)ctx->n_cu) gh = 2 * (int64_t)ctx->n_cu;          // persistent: two 8-wave workgroups per CU
-            const PostOut& po = ctx->post_out;
+            const PostOut po = post ? *post : PostOut{nullptr, nullptr, nullptr, nullptr};
             hipLaunchKernelGGL(k_pileup_head_rs, dim3((unsigned)gh), dim3(512), 0, s, ctx->ws_h1c, n,
                                pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,
                                gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES,
                                po.gt_arg ? po.gt_arg + base : nullptr, po.gt_arg ? po.zy_arg + base : nullptr,
                                po.gt_arg ? po.gt_max + base : nullptr, po.gt_arg ? po.zy_max + base : nullptr);
-            ctx->post_done = true;
+            if (post_written) *post_written = po.gt_arg != nullptr;
         } else
         hipLaunchKernelGGL(k_pileup_head, dim3((unsigned)NSNP_CDIV(n, 64)), dim3(256), 0, s, ctx->ws_h1c, n,
                            pw.proj_w, pw.proj_b, pw.dense_w, pw.dense_b, pw.head_w, pw.head_b,

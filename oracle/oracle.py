@@ -191,3 +191,37 @@ def hap_arrange(seq, bq, mq, hap, d_out, rows=None):
     lib().orc_hap_arrange(_p(seq), _p(bq), _p(mq), _p(hap), R if rows is None else int(rows), R, L, int(d_out),
                           *[_p(o) for o in outs], _p(depth))
     return outs[0], outs[1], outs[2], outs[3], int(depth[0])
+
+
+def pileup_forward_f64(weights, x):
+    """LSTMNetwork.predict of the PileupModel (PileupModel/model.py:31-39,66-73,114-119) evaluated in FLOAT64 with numpy: the same
+    published equations as orc_pileup_forward (lstm_oracle.c), every product and sum in double.  Test infrastructure: the yardstick
+    that separates arithmetic error from summation-order noise - |path - f64| of the fp32 MFMA kernels, of the bf16x3 / f16x3 modes
+    and of the fp32 oracle itself are all measured against it (tests/test_gpu_pileup_forward.py, bench.py "error_vs_float64")."""
+    w = [np.asarray(t, np.float64) for t in weights]
+    x = np.asarray(x, np.float64)
+    N, T, H = x.shape[0], 33, 64
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+
+    def layer(inp, base):
+        out = np.zeros((N, T, 2 * H))
+        for d in range(2):
+            wih, whh, b = w[base + 4 * d], w[base + 4 * d + 1], w[base + 4 * d + 2] + w[base + 4 * d + 3]
+            h = np.zeros((N, H)); c = np.zeros((N, H))
+            for s in range(T):
+                t = T - 1 - s if d else s
+                g = inp[:, t] @ wih.T + h @ whh.T + b
+                i, f, gg, o = sig(g[:, :H]), sig(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), sig(g[:, 3 * H:])
+                c = f * c + i * gg
+                h = o * np.tanh(c)
+                out[:, t, d * H:(d + 1) * H] = h
+        return out
+
+    h1 = layer(layer(x, 0), 8)
+    enc = h1[:, 16] @ w[16].T + w[17]
+    mid = np.tanh(enc @ w[18].T + w[19])
+
+    def softmax(z):
+        e = np.exp(z - z.max(1, keepdims=True))
+        return e / e.sum(1, keepdims=True)
+    return softmax(mid @ w[20].T + w[21]), softmax(mid @ w[22].T + w[23])

@@ -8,9 +8,10 @@ from tests.helpers import PROB_ATOL, golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
+@pytest.fixture(scope="module", params=[2, 1, 0], ids=["bf16x3", "f16x3", "fp32"])
 def model(request, gpu_ctx, pileup_weights):
-    """the tests of this module that take `model` run in both precision modes: exact fp32 (library default) and the opt-in f16x3"""
+    """the tests of this module that take `model` run in all three arithmetic modes: exact fp32 MFMA (library default), bf16x3
+    (three bf16 terms per operand = the full fp32 significand, six bf16 MFMAs per product) and the opt-in f16x3"""
     gpu_ctx.pileup_load_weights(pileup_weights)
     gpu_ctx.set_option("pileup_precision", request.param)
     gpu_ctx.test_precision = request.param
@@ -398,7 +399,7 @@ def test_forward_is_capturable_in_a_hip_graph(pileup_weights):
     c.close()
 
 
-@pytest.mark.parametrize("opts", [{}, {"pileup_precision": 1}, {"head_split": 0}], ids=["fp32", "f16x3", "fp32-one-wave-heads"])
+@pytest.mark.parametrize("opts", [{}, {"pileup_precision": 1}, {"pileup_precision": 2}, {"head_split": 0}], ids=["fp32", "f16x3", "bf16x3", "fp32-one-wave-heads"])
 def test_fused_forward_and_argmax_equals_the_two_calls(pileup_weights, opts):
     """nsnp_pileup_forward_windows_calls = nsnp_pileup_forward_windows + nsnp_pileup_postprocess (predict.py:51-57), bit for bit:
     the fp32 heads kernel writes argmax / max itself, the other paths run the two kernels back to back; ragged N, ties included"""
@@ -436,3 +437,54 @@ def test_fused_call_with_no_sites_and_bad_arguments(pileup_weights):
                                                  None, None, None) == -1                # argmax / max outputs are required
     assert lib.nsnp_pileup_forward_windows_calls(None, None, None, 0, None, None, None, None, None, None, None) == -1
     c.close()
+
+
+def test_bf16x3_mode_carries_the_full_fp32_operand_width(pileup_weights):
+    """pileup_precision 2: every operand as three bf16 terms (8 + 8 + 8 significand bits, fp32 exponent range), six bf16 MFMAs per
+    product, fp32 accumulation.  (a) its error against a FLOAT64 evaluation of the model (oracle.pileup_forward_f64) is the error of
+    the exact-fp32 MFMA path itself - the two paths differ from each other by fp32 summation-order noise (2-3e-6 on 1 M windows:
+    the fp32 kernels sit 1-2e-6 from float64 themselves), not by operand width; (b) every site-group shape of the two recurrence
+    kernels gives the same bits; (c) counts of every split level - one bf16 (|x| <= 256), two (<= 65536), three - against the
+    oracle at the 1e-4 contract, incl. magnitudes the f16x3 mode saturates at (> 131008)"""
+    import torch
+    from nanosnp_amd import _lib, host
+    from oracle import oracle
+    c2 = _lib.Context(0); c2.pileup_load_weights(pileup_weights); c2.set_option("pileup_precision", 2)
+    c0 = _lib.Context(0); c0.pileup_load_weights(pileup_weights)
+    n = 4096
+    cols = host.synth_columns(20260002, n * 33, coverage=30, window=33)
+    counts, _, _ = oracle.encode_columns(cols.bases, cols.col_off, cols.ref)
+    rng = np.random.default_rng(5)
+    xr = (rng.integers(0, 50, (1531, 33, 18)) - 10).astype(np.int32)
+    for x_np in (counts.reshape(n, 33, 18), xr):
+        x = torch.from_numpy(np.ascontiguousarray(x_np)).cuda()
+        g2, z2 = c2.pileup_forward(x); g0, z0 = c0.pileup_forward(x)
+        torch.cuda.synchronize()
+        assert torch.isfinite(g2).all() and torch.isfinite(z2).all()
+        # (a) against float64 on the first 1024 sites
+        m = 1024
+        g64, z64 = oracle.pileup_forward_f64(pileup_weights, x_np[:m])
+        e2 = max(np.abs(g2[:m].cpu().numpy() - g64).max(), np.abs(z2[:m].cpu().numpy() - z64).max())
+        e0 = max(np.abs(g0[:m].cpu().numpy() - g64).max(), np.abs(z0[:m].cpu().numpy() - z64).max())
+        assert e2 <= max(1.5 * e0, 1e-6) and e2 < 3e-6, (e2, e0)
+        assert max((g2 - g0).abs().max().item(), (z2 - z0).abs().max().item()) < 5e-6
+        # (b) launch shapes
+        for l0g, l1g in ((1, 1), (2, 2), (4, 4), (1, 4), (4, 1)):
+            c2.set_option("l0_site_groups", l0g); c2.set_option("l1_site_groups", l1g)
+            g, z = c2.pileup_forward(x)
+            assert torch.equal(g, g2) and torch.equal(z, z2), (l0g, l1g)
+        c2.set_option("l0_site_groups", 0); c2.set_option("l1_site_groups", 0)
+    # (c) split levels of the input counts
+    x = np.zeros((48, 33, 18), np.int32)
+    x[:16] = rng.integers(-256, 257, (16, 33, 18))                      # one bf16 term
+    x[16:32] = rng.integers(-300, 301, (16, 33, 18)); x[16:32, ::5, 3] = 65536; x[20, 7, 1] = -40000      # two terms
+    x[32:] = rng.integers(-100, 101, (16, 33, 18)); x[33, 16, :4] = (1 << 20) + 3; x[40, 3, 9] = -16777215; x[41, 30, 2] = 200001
+    xt = torch.from_numpy(x).cuda()
+    g2, z2 = c2.pileup_forward(xt)
+    torch.cuda.synchronize()
+    og, oz = oracle.pileup_forward(pileup_weights, x, nthreads=8)
+    assert np.abs(g2.cpu().numpy() - og).max() < PROB_ATOL and np.abs(z2.cpu().numpy() - oz).max() < PROB_ATOL
+    # a 16-site group with a large count must not disturb its neighbours: sites are independent bit for bit
+    sub, _ = c2.pileup_forward(xt[:16].contiguous())
+    assert torch.equal(sub, g2[:16])
+    c2.close(); c0.close()

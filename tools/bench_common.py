@@ -35,6 +35,18 @@ PILEUP_EXEC_FLOP = {"pileup_l0": 2 * 33 * 256 * (20 + 64) * 2, "pileup_l1f": 2 *
                     "pileup_proj1": 2 * 17 * 256 * 128 * 2, "pileup_l1": 2 * 17 * 256 * 64 * 2,
                     "pileup_head": (128 * 128 + 256 * 128 + 32 * 256) * 2}
 PILEUP_EXEC_FLOP_FORWARD = PILEUP_EXEC_FLOP["pileup_l0"] + PILEUP_EXEC_FLOP["pileup_l1f"] + PILEUP_EXEC_FLOP["pileup_head"]
+# bf16x3 (pileup_forward_bf16x3.hip): bf16 MFMA flops as EXECUTED - six v_mfma_f32_16x16x32_bf16 per 32-deep K block of a product of
+# two fp32 operands, three for the layer-0 input block (integer counts up to 256 are one bf16 term; K padded 18 + 1 -> 32)
+PILEUP_EXEC_FLOP_BF16X3 = {"pileup_l0": 2 * 33 * 256 * (32 * 3 + 64 * 6) * 2, "pileup_l1f": 2 * 17 * 256 * (128 + 64) * 6 * 2,
+                           "pileup_head": (128 * 128 + 256 * 128 + 32 * 256) * 6 * 2}
+
+
+def pileup_exec_flop(kernel, precision):
+    """MFMA flops a forward kernel executes per site in the given arithmetic (0 fp32, 1 f16x3: three fp16 MFMAs per product,
+    2 bf16x3: six bf16 MFMAs per product)"""
+    if precision == 2:
+        return PILEUP_EXEC_FLOP_BF16X3[kernel]
+    return PILEUP_EXEC_FLOP[kernel] * (3 if precision == 1 else 1)
 
 # ---- HaplotypeModel (model_dev.LSTMNetwork, H = 256, F = 105, 3 layers, L = 33 / 11) ---------------------------------
 HAP_ALG_FLOP = 353.7e6             # SURVEY.md 8(d): 176.8 M MAC per site as the reference computes it

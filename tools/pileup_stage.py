@@ -244,19 +244,19 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
     over the wall time of the timed region (encode, post-processing and the gather included in the time)."""
     from tools import bench_common as bc
     batch = stage.batch
-    mult = 3 if precision == 1 else 1                  # f16x3: three fp16 MFMAs per fp32 product
-    peak = bc.PEAK_F32_MFMA_TFLOPS if precision == 0 else bc.PEAK_F16_MFMA_TFLOPS
-    fwd_keys = [k for k in tot if k in bc.PILEUP_EXEC_FLOP]
+    peak = bc.PEAK_F32_MFMA_TFLOPS if precision == 0 else bc.PEAK_F16_MFMA_TFLOPS       # fp16 and bf16 MFMAs share one dense peak
+    fwd_keys = [k for k in tot if k in bc.PILEUP_EXEC_FLOP and (precision != 2 or k in bc.PILEUP_EXEC_FLOP_BF16X3)]
+    xf = lambda k: bc.pileup_exec_flop(k, precision)   # executed MFMA flops per site (f16x3: 3, bf16x3: 6 MFMAs per fp32 product)
     out = {}
     if fwd_keys:
         dom = max(fwd_keys, key=lambda k: (round(excl.get(k, 0.0), 5), bc.PILEUP_EXEC_FLOP[k]))
         if dom in excl:
             how = ("HIP events around every launch of the kernel, one stream, nothing else running (after the timed region; %d launches)"
                    % excl_n[dom])
-            roof = bc.roofline_mfma(dom, bc.PILEUP_EXEC_FLOP[dom] * batch * mult, excl[dom], excl_n[dom],
+            roof = bc.roofline_mfma(dom, xf(dom) * batch, excl[dom], excl_n[dom],
                                     alg_flop_per_launch=bc.PILEUP_ALG_FLOP[dom] * batch, peak=peak, how=how,
                                     traffic=bc.committed_traffic(workload, dom, batch=batch, precision=precision))
-            fwd_exec = sum(bc.PILEUP_EXEC_FLOP[k] for k in fwd_keys) * mult
+            fwd_exec = sum(xf(k) for k in fwd_keys)
             chip = fwd_exec * sites_per_gpu / dt / 1e12
             roof["chip"] = {"achieved": chip, "frac": chip / peak, "unit": "TFLOP/s",
                             "achieved_algorithmic_tflops": bc.PILEUP_ALG_FLOP_FORWARD * sites_per_gpu / dt / 1e12,
@@ -269,7 +269,7 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
             # the other recurrence layer beside it, the same way (layers 0 and 1 are within 5 % of each other in time)
             for k in fwd_keys:
                 if k != dom and k in excl and k in ("pileup_l0", "pileup_l1f", "pileup_l1"):
-                    out["roofline_" + k] = bc.roofline_mfma(k, bc.PILEUP_EXEC_FLOP[k] * batch * mult, excl[k], excl_n[k],
+                    out["roofline_" + k] = bc.roofline_mfma(k, xf(k) * batch, excl[k], excl_n[k],
                                                             alg_flop_per_launch=bc.PILEUP_ALG_FLOP[k] * batch, peak=peak, how=how,
                                                             traffic=bc.committed_traffic(workload, k, batch=batch, precision=precision))
     if "encode_columns" in excl:
