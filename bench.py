@@ -297,6 +297,7 @@ def main():
 
     # ---- labelled second values on the same pool: bf16x3 (full fp32 operand width on the bf16 pipe) and the opt-in f16x3 ----------
     seconds = {}
+    f64_err = {"fp32": stage.float64_error(snap)} if snap is not None else {}
     if not args.no_second_precision and args.precision == 0:
         ref_gt = stage.gt_all[:n_done].clone(); ref_zy = stage.zy_all[:n_done].clone()
         torch.cuda.synchronize(dev)                     # (the copies run on torch's current stream, the forwards on the stage's)
@@ -309,6 +310,8 @@ def main():
             sv = {"value": sites_timed / dt2, "unit": "sites/s", "ms_per_step": dt2 / K * 1e3, "dtype": text,
                   "max_abs_dp_vs_fp32_on_the_pool": d, "tolerance": 1e-4,
                   "kernel_avg_ms_in_region": {k: round(v[0] / v[1], 5) for k, v in sorted(tot2.items())}}
+            if rank == 0 and not args.no_parity_sample:
+                f64_err[label] = stage.float64_error(stage.snapshot(stage.parity_ranges(n_done, per_batch=64), ring_batches=0))
             if prec == 2:
                 # its own rooflines against the dense bf16 MFMA peak, the six MFMAs of a product priced as executed, and its own
                 # outputs against the oracle
@@ -351,6 +354,9 @@ def main():
         else:
             out["roofline"] = None
         out.update(seconds)
+        if f64_err:
+            out["error_vs_float64"] = {"modes": f64_err, "what": "max |p - p64| on the same windows, p64 = LSTMNetwork.predict evaluated in float64 (numpy, "
+                                       "oracle.pileup_forward_f64): the fp32 MFMA path's own distance from exact arithmetic is the yardstick for the split modes"}
         out["repeats"] = {"values": [round(v) for v in repeats], "reported": "median", "spread": (max(repeats) - min(repeats)) / out["value"]}
         out["timed_region_s"] = dt
         out["shader_clock_mhz"] = {"value": clock_mhz, "how": "s_memtime / s_memrealtime in every workgroup of a ~2 ms full-chip fp32 MFMA "

@@ -79,14 +79,22 @@ int nsnp_ctx_destroy(nsnp_ctx* ctx);
  * the hot loop (and out of hipGraph capture). */
 int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
 
-/* Options (name, value).  Unknown names / values return NSNP_EINVAL.  Precision options choose between the exact
- * fp32 MFMA path (the default: the reference computes in fp32) and the opt-in "f16x3" (every fp32 operand split into
- * two fp16 halves, three fp16 MFMAs per product, fp32 accumulation: 21-22 significand bits per operand, measured ~1e-6
- * from the fp32 path in the probabilities, tolerance of the port 1e-4; caller-supplied inputs beyond +-131008 saturate,
- * the fp32 mode has no such limit); the others only change launch shapes.
- *   "pileup_precision"        0 fp32 (default) | 1 f16x3      PileupModel forward
- *   "hap_precision"           0 fp32 (default) | 1 f16x3      HaplotypeModel forward
- *   "cat_precision"           0 fp32 (default) | 1 f16x3      legacy CatModel forward
+/* Options (name, value).  Unknown names / values return NSNP_EINVAL.  Precision options choose the arithmetic of the matrix
+ * products (sums are fp32 in every mode):
+ *   0  exact fp32 MFMA (the default: the reference computes in fp32)
+ *   2  "bf16x3": every fp32 operand as three bf16 terms (8 + 8 + 8 significand bits = the full fp32 significand, fp32 exponent
+ *      range: v = p0 + p1 + p2 exactly), six bf16 MFMAs per product, the three dropped cross terms below 2^-24 of the product -
+ *      nothing is narrower than fp32.  Measured against a float64 evaluation of the PileupModel its error equals the fp32 path's
+ *      (1-2e-6 in the probabilities); every reference golden holds the 1e-4 contract with no relaxed bound; no input range limit.
+ *   1  "f16x3" (opt-in): every operand as two fp16 halves, three fp16 MFMAs per product: 21-22 significand bits per operand.
+ *      DOCUMENTED BOUND: within 1e-4 of the reference on inputs whose magnitudes stay below 2048 (every pileup count, every
+ *      generator-G3 feature); up to 2e-4 (measured 1.5e-4) on HaplotypeModel sites whose count-valued features reach several
+ *      thousand (the saturated sites of tests/golden/hap_fwd_large.npz); caller-supplied inputs beyond +-131008 saturate.
+ *      Use mode 2 where the 1e-4 contract must hold on arbitrary inputs.
+ * The other options only change launch shapes.
+ *   "pileup_precision"        0 fp32 (default) | 2 bf16x3 | 1 f16x3      PileupModel forward
+ *   "hap_precision"           0 fp32 (default) | 2 bf16x3 | 1 f16x3      HaplotypeModel forward
+ *   "cat_precision"           0 fp32 (default) | 2 bf16x3 | 1 f16x3      legacy CatModel forward
  *   "hap_pass_sites"          128..131072, multiple of 128     sites per internal pass of the HaplotypeModel forward (default 16384;
  *                                                              workspace ~195 KB per site, (re)allocated synchronously by this call
  *                                                              and by nsnp_hap_load_weights, never by nsnp_hap_forward)
@@ -108,6 +116,8 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   VGPRs; measured without gain).  Combinations without effect are accepted and ignored: "l1_site_groups" under
  *   "l1_register_stationary" 1 (its workgroups are always one 16-site group), "l1_stagger" outside the eight-wave kernel,
  *   "static_priority" and "fused_*" / "proj1_tiles" on the fp32 path.
+ *   bf16x3 path (pileup_precision 2): "l0_site_groups" 0 auto | 1/2/4 and "l1_site_groups" 0 auto | 1/2/4 (16-site groups per
+ *   workgroup of its layer-0 / layer-1 kernel); every combination returns the same bits.
  *   Every fp32 combination returns bit-identical probabilities. */
 int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t value);
 

@@ -219,6 +219,7 @@ struct CatWeightsDev {
     float* out_w; float* out_b;        // out_layer [10][512], [10]
     float* arena; size_t arena_floats;
     float* arena16;                    // the same images with every weight as an fp16 (hi, lo) pair (cat_precision 1)
+    void* arena_b3;                    // ... as three bf16 planes, every image at 1.5 x its fp32 offset (cat_precision 2; hap_gemm.hpp WeightMap)
 };
 
 void nsnp_cat_free(nsnp_ctx* ctx)
@@ -226,6 +227,7 @@ void nsnp_cat_free(nsnp_ctx* ctx)
     if (ctx->cw) {
         if (ctx->cw->arena) (void)hipFree(ctx->cw->arena);
         if (ctx->cw->arena16) (void)hipFree(ctx->cw->arena16);
+        if (ctx->cw->arena_b3) (void)hipFree(ctx->cw->arena_b3);
         delete ctx->cw; ctx->cw = nullptr;
     }
     if (ctx->cat_ws) { (void)hipFree(ctx->cat_ws); ctx->cat_ws = nullptr; ctx->cat_ws_bytes = 0; }
@@ -417,6 +419,23 @@ extern "C" int nsnp_cat_load_weights(nsnp_ctx* ctx, const float* const* t, int n
         if (!cw.arena16) NSNP_HIP(ctx, hipMalloc((void**)&cw.arena16, total * sizeof(float)));
         NSNP_HIP(ctx, hipMemcpy(cw.arena16, h16.data(), total * sizeof(float), hipMemcpyHostToDevice));
     }
+    {
+        // bf16x3 images: every weight as three bf16 planes, image at 1.5 x its fp32 offset; biases and out_layer stay fp32
+        std::vector<uint16_t> h3(total * 3, 0);
+        auto conv3 = [&](size_t off, size_t n_floats) { pack_bf16x3_rows(host.data(), h3.data(), off, n_floats); };
+        for (int i = 0; i < 6; ++i) {
+            conv3(o_w1[i], (size_t)rt[i] * 9 * cc_in[i] * TILE_F);
+            conv3(o_w2[i], (size_t)rt[i] * (9 * cc_out[i] + cc_in[i]) * TILE_F);
+        }
+        for (int r = 0; r < 2; ++r) {
+            for (int d = 0; d < 2; ++d) conv3(o_rw[r][d], (size_t)(G / TR) * 32 * TILE_F);
+            conv3(o_ew[r], (size_t)(H / TR) * 32 * TILE_F);
+        }
+        for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) conv3(o_pw[l][d], (size_t)(G / TR) * ((l == 0 ? 2 : 32) + 16) * TILE_F);
+        conv3(o_pcw, (size_t)(H / TR) * 32 * TILE_F);
+        if (!cw.arena_b3) NSNP_HIP(ctx, hipMalloc(&cw.arena_b3, total * 6));
+        NSNP_HIP(ctx, hipMemcpy(cw.arena_b3, h3.data(), total * 6, hipMemcpyHostToDevice));
+    }
     for (int i = 0; i < 6; ++i) {
         cw.blk[i] = CatBlock{cw.arena + o_w1[i], cw.arena + o_b1[i], cw.arena + o_w2[i], cw.arena + o_b2[i],
                              CAT_CH[i], CAT_CH[i + 1], cc_in[i], cc_out[i]};
@@ -434,8 +453,8 @@ namespace {
 
 // one bidirectional LSTM layer: `steps` launches, both directions per launch.
 //   in : [t][site tile][nk_in chunks] tile images;  hout: [t][site tile][dir][16 chunks]
-template <bool F16>
-void run_bilstm(nsnp_ctx* ctx, hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh, const float* in, int nk_in, float* hout, float* cst,
+template <int AR>
+void run_bilstm(nsnp_ctx* ctx, hipStream_t s, const LstmDir* dirs, const WeightMap& wm, const float* in, int nk_in, float* hout, float* cst,
                 int n_tiles, int T, int steps)
 {
     const size_t tile_h = (size_t)16 * TILE_F, step_h = (size_t)n_tiles * 2 * tile_h;
@@ -446,7 +465,7 @@ void run_bilstm(nsnp_ctx* ctx, hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh
             const int t = d ? T - 1 - st : st, tprev = d ? t + 1 : t - 1;
             StepArgs& a = L.z[d];
             memset(&a, 0, sizeof(a));
-            a.w = dirs[d].w + wsh; a.bias = dirs[d].b;
+            a.w = wm(dirs[d].w); a.bias = dirs[d].b;
             a.in0 = in + (size_t)t * in_step; a.nk0 = nk_in; a.in0_tile_stride = (int)in_tile;
             a.in1 = st ? hout + (size_t)tprev * step_h + (size_t)d * tile_h : nullptr;
             a.nk1 = st ? 16 : 0; a.in1_tile_stride = (int)(2 * tile_h);
@@ -455,19 +474,19 @@ void run_bilstm(nsnp_ctx* ctx, hipStream_t s, const LstmDir* dirs, ptrdiff_t wsh
             a.cstate = cst + (size_t)d * n_tiles * tile_h; a.c_tile_stride = (int)tile_h;
             a.first = st == 0;
         }
-        launch_hap_gemm<MODE_LSTM, F16>(ctx, s, L, (int)(n_tiles), 4 * CAT_NH / TR, 2);
+        launch_hap_gemm<MODE_LSTM, AR>(ctx, s, L, (int)(n_tiles), 4 * CAT_NH / TR, 2);
     }
 }
 
 // Linear(512 -> 256) over `n_in_tiles` consecutive [dir][16 chunks] h tiles
-template <bool F16>
+template <int AR>
 void run_linear_h(nsnp_ctx* ctx, hipStream_t s, const float* w, const float* b, const float* in, int n_in_tiles, float* out, int out_tile_stride)
 {
     StepLaunch L; StepArgs& a = L.z[0];
     memset(&a, 0, sizeof(a));
     a.w = w; a.bias = b; a.in0 = in; a.nk0 = 32; a.in0_tile_stride = 32 * TILE_F; a.nk_img = 32;
     a.out = out; a.out_tile_stride = out_tile_stride;
-    launch_hap_gemm<MODE_LINEAR, F16>(ctx, s, L, (int)(n_in_tiles), CAT_NH / TR, 1);
+    launch_hap_gemm<MODE_LINEAR, AR>(ctx, s, L, (int)(n_in_tiles), CAT_NH / TR, 1);
 }
 
 int grid_for(int64_t total) { int64_t b = NSNP_CDIV(total, (int64_t)256); return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
@@ -476,7 +495,7 @@ int grid_for(int64_t total) { int64_t b = NSNP_CDIV(total, (int64_t)256); return
 
 namespace {
 
-template <bool F16>
+template <int AR>            // 0 exact fp32, 1 f16x3 (activation images hold fp16 pairs), 2 bf16x3 (activations stay fp32, weights as three bf16 planes)
 int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream)
 {
     if (!ctx || N < 0 || (N > 0 && (!g0 || !g1 || !gt_prob))) return NSNP_EINVAL;
@@ -484,7 +503,8 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
     if (N == 0) return NSNP_OK;
     const CatWeightsDev& cw = *ctx->cw;
     hipStream_t s = (hipStream_t)stream;
-    const ptrdiff_t wsh = F16 ? cw.arena16 - cw.arena : 0;      // weight images live at the same offsets in both arenas
+    constexpr bool F16 = AR == 1;                                 // element format of the activation images
+    const WeightMap wm{cw.arena, AR == 1 ? (const void*)cw.arena16 : (const void*)cw.arena_b3, AR};
     const int64_t chunk = CAT_PASS;                               // sites per pass
     const int max_tiles = (int)(chunk / TS);
     const CatWsLayout wl = cat_ws_layout();
@@ -509,10 +529,10 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
 
         // ---- percentage branch: 3-layer BiLSTM on [11][n][20], Linear at column 5 -> cat chunks 0..15 ----
         hipLaunchKernelGGL(k_cat_percentage<F16>, dim3(grid_for((int64_t)CAT_L * n_tiles * TS * 4)), dim3(256), 0, s, a0, a1, n, n_tiles, xp);
-        run_bilstm<F16>(ctx, s, cw.pct[0], wsh, xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
-        run_bilstm<F16>(ctx, s, cw.pct[1], wsh, hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
-        run_bilstm<F16>(ctx, s, cw.pct[2], wsh, hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
-        run_linear_h<F16>(ctx, s, cw.pct_w + wsh, cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
+        run_bilstm<AR>(ctx, s, cw.pct[0], wm, xp, 2, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm<AR>(ctx, s, cw.pct[1], wm, hb[0], 32, hb[1], cst, n_tiles, CAT_L, CAT_L);
+        run_bilstm<AR>(ctx, s, cw.pct[2], wm, hb[1], 32, hb[0], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h<AR>(ctx, s, wm(cw.pct_w), cw.pct_b, hb[0] + (size_t)CAT_CENTER * step_h, n_tiles, cat, 32 * TILE_F);
 
         // ---- ResCRNN branch ----
         int Hc = CAT_ROWS;
@@ -529,14 +549,14 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
             memset(&a, 0, sizeof(a));
             a.conv_h = Hc; a.conv_w = CAT_L; a.n_pix = n_pix; a.n_rows = b.cout;
             // y = relu(bn1(conv1(x)))
-            a.w = b.w1 + wsh; a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
+            a.w = wm(b.w1); a.bias = b.b1; a.in0 = X; a.nk0 = 9 * b.cc_in; a.cc0_shift = shift_of(b.cc_in);
             a.nk1 = 0; a.nk_img = a.nk0; a.out = Y; a.out_tile_stride = b.cc_out * TILE_F;
-            launch_hap_gemm<MODE_LINEAR_RELU, F16, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
+            launch_hap_gemm<MODE_LINEAR_RELU, AR, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
             // out = relu(bn2(conv2(y)) + shortcut(x))
-            a.w = b.w2 + wsh; a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
+            a.w = wm(b.w2); a.bias = b.b2; a.in0 = Y; a.nk0 = 9 * b.cc_out; a.cc0_shift = shift_of(b.cc_out);
             a.in1 = X; a.nk1 = b.cc_in; a.in1_tile_stride = b.cc_in * TILE_F; a.nk_img = a.nk0 + a.nk1;
             a.out = O; a.out_tile_stride = b.cc_out * TILE_F;
-            launch_hap_gemm<MODE_LINEAR_RELU, F16, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
+            launch_hap_gemm<MODE_LINEAR_RELU, AR, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
             cur = (cur + 2) % 3;
             if (CAT_POOL[i]) {
                 const int kh = CAT_POOL[i], Ho = (Hc - kh) / kh + 1;
@@ -552,11 +572,11 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
         tm_conv.stop();
         if (Hc != 1) return NSNP_ESHAPE;                          // crnn.py:183 asserts the same
         // BidirectionalLSTM 0: all 11 columns, embedding on every column (crnn.py:12-20)
-        run_bilstm<F16>(ctx, s, cw.rnn[0], wsh, seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
-        run_linear_h<F16>(ctx, s, cw.emb_w[0] + wsh, cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
+        run_bilstm<AR>(ctx, s, cw.rnn[0], wm, seq[0], 16, hb[0], cst, n_tiles, CAT_L, CAT_L);
+        run_linear_h<AR>(ctx, s, wm(cw.emb_w[0]), cw.emb_b[0], hb[0], CAT_L * n_tiles, seq[1], 16 * TILE_F);
         // BidirectionalLSTM 1: only column 5 is used downstream
-        run_bilstm<F16>(ctx, s, cw.rnn[1], wsh, seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
-        run_linear_h<F16>(ctx, s, cw.emb_w[1] + wsh, cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
+        run_bilstm<AR>(ctx, s, cw.rnn[1], wm, seq[1], 16, hb[1], cst, n_tiles, CAT_L, CAT_CENTER + 1);
+        run_linear_h<AR>(ctx, s, wm(cw.emb_w[1]), cw.emb_b[1], hb[1] + (size_t)CAT_CENTER * step_h, n_tiles, cat + 16 * TILE_F, 32 * TILE_F);
         hipLaunchKernelGGL(k_cat_head<F16>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, cat, n, cw.out_w, cw.out_b, gt_prob + n0 * CAT_CLASSES);
     }
     NSNP_HIP(ctx, hipGetLastError());
@@ -567,8 +587,9 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
 
 extern "C" int nsnp_cat_forward(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N, float* gt_prob, void* stream)
 {
-    if (ctx && ctx->cat_precision == 1) return cat_forward_impl<true>(ctx, g0, g1, N, gt_prob, stream);
-    return cat_forward_impl<false>(ctx, g0, g1, N, gt_prob, stream);
+    if (ctx && ctx->cat_precision == 1) return cat_forward_impl<1>(ctx, g0, g1, N, gt_prob, stream);
+    if (ctx && ctx->cat_precision == 2) return cat_forward_impl<2>(ctx, g0, g1, N, gt_prob, stream);
+    return cat_forward_impl<0>(ctx, g0, g1, N, gt_prob, stream);
 }
 
 extern "C" int nsnp_cat_groups(nsnp_ctx* ctx, const int32_t* read1, const int32_t* bq1, const int32_t* mq1, int depth1,

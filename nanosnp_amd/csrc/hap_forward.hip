@@ -126,6 +126,7 @@ struct HapWeightsDev {
     float* head_w; float* head_b;                      // [(n_gt+n_zy) x H] natural order
     float* arena; size_t arena_floats;
     float* arena16;                                    // the same images with every weight as an fp16 (hi, lo) pair
+    void* arena_b3;                                    // ... as three bf16 planes, every image at 1.5 x its fp32 offset (hap_gemm.hpp WeightMap)
 };
 
 // workspace of one pass of `chunk` sites (floats): packed inputs of both encoders, h of all steps / both directions for two
@@ -165,6 +166,7 @@ void nsnp_hap_free(nsnp_ctx* ctx)
     if (ctx->hw) {
         if (ctx->hw->arena) (void)hipFree(ctx->hw->arena);
         if (ctx->hw->arena16) (void)hipFree(ctx->hw->arena16);
+        if (ctx->hw->arena_b3) (void)hipFree(ctx->hw->arena_b3);
         delete ctx->hw; ctx->hw = nullptr;
     }
     if (ctx->hap_ws) { (void)hipFree(ctx->hap_ws); ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0; }
@@ -266,6 +268,7 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
     if (hw.arena_floats != total) {     // both arenas are sized by `total`: a reload with other dimensions re-allocates both
         if (hw.arena) { (void)hipFree(hw.arena); hw.arena = nullptr; }
         if (hw.arena16) { (void)hipFree(hw.arena16); hw.arena16 = nullptr; }
+        if (hw.arena_b3) { (void)hipFree(hw.arena_b3); hw.arena_b3 = nullptr; }
         hw.arena_floats = 0;
     }
     if (!hw.arena) NSNP_HIP(ctx, hipMalloc((void**)&hw.arena, total * sizeof(float)));
@@ -294,6 +297,18 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
         hw.arena_floats = total;
         NSNP_HIP(ctx, hipMemcpy(hw.arena16, h16.data(), total * sizeof(float), hipMemcpyHostToDevice));
     }
+    {
+        // bf16x3 images: every weight as three bf16 planes (rows of 16 weights -> 16 p0 | 16 p1 | 16 p2), image at 1.5 x its fp32 offset
+        std::vector<uint16_t> h3(total * 3, 0);
+        for (int e = 0; e < 2; ++e) {
+            for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d)
+                pack_bf16x3_rows(host.data(), h3.data(), off_w[e][l][d], (size_t)n_rt * ((l == 0 ? nk0 : 2 * H / BK) + H / BK) * TILE_F);
+            pack_bf16x3_rows(host.data(), h3.data(), off_pw[e], (size_t)(H / TR) * (2 * H / BK) * TILE_F);
+        }
+        pack_bf16x3_rows(host.data(), h3.data(), off_dw, (size_t)(H / TR) * (2 * H / BK) * TILE_F);
+        if (!hw.arena_b3) NSNP_HIP(ctx, hipMalloc(&hw.arena_b3, total * 6));
+        NSNP_HIP(ctx, hipMemcpy(hw.arena_b3, h3.data(), total * 6, hipMemcpyHostToDevice));
+    }
     hw.F = F; hw.H = H; hw.n_layers = n_layers; hw.n_gt = n_gt; hw.n_zy = n_zy; hw.nk_in0 = nk0;
     for (int e = 0; e < 2; ++e) {
         for (int l = 0; l < 3; ++l) for (int d = 0; d < 2; ++d) { hw.w[e][l][d] = hw.arena + off_w[e][l][d]; hw.b[e][l][d] = hw.arena + off_b[e][l][d]; }
@@ -303,17 +318,14 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
     return nsnp_hap_reserve(ctx);                      // the forward itself never allocates (graph capture, no stream stalls)
 }
 
-extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N,
-                                float* gt_prob, float* zy_prob, void* stream)
+// AR: 0 exact fp32, 1 f16x3 (activation images hold (hi, lo) fp16 pairs), 2 bf16x3 (activation images stay fp32, weights as three bf16 planes)
+template <int AR>
+static int hap_forward_t(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N, float* gt_prob, float* zy_prob, hipStream_t s)
 {
-    if (!ctx || N < 0 || (N > 0 && (!xp || !xh || !gt_prob || !zy_prob))) return NSNP_EINVAL;
-    if (!ctx->hw) return NSNP_ENOWEIGHTS;
-    if (N == 0) return NSNP_OK;
     const HapWeightsDev& hw = *ctx->hw;
-    hipStream_t s = (hipStream_t)stream;
     const int H = hw.H, F = hw.F;
-    const bool f16 = ctx->hap_precision == 1;
-    const ptrdiff_t wsh = f16 ? hw.arena16 - hw.arena : 0;     // weight images live at the same offsets in both arenas
+    constexpr bool F16 = AR == 1;                              // element format of the activation images
+    const WeightMap wm{hw.arena, AR == 1 ? (const void*)hw.arena16 : (const void*)hw.arena_b3, AR};
     const int Lp = 33, Lh = 11;                       // ont_haplotype.yaml:10-11
     // sites per pass: every time step of a layer is one launch over all sites of the pass, so the pass size sets how long
     // each of the 83 dependent launches is (16384 sites: 2048-4096 workgroups, 2-4 rounds of the chip; ramp + tail of a launch
@@ -336,8 +348,7 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
         const float* xin[2] = {xp + n0 * F * Lp, xh + n0 * F * Lh};
         for (int e = 0; e < 2; ++e) {
             const unsigned blocks = (unsigned)n_tiles * hw.nk_in0 * (TS / PK_SITES);
-            if (f16) hipLaunchKernelGGL(k_hap_pack_input<true>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
-            else     hipLaunchKernelGGL(k_hap_pack_input<false>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
+            hipLaunchKernelGGL(k_hap_pack_input<F16>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
         }
         // h of one layer: [t][site tile][dir][16 chunks][128][16] -> the 32 chunks [h_fwd ; h_bwd] of a site
         // tile at time t are contiguous (what the next layer and output_proj consume)
@@ -356,7 +367,7 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                         const int t = d ? Ls[e] - 1 - st : st;
                         const int tprev = d ? t + 1 : t - 1;
                         StepArgs& a = L.z[nz];
-                        a.w = hw.w[e][l][d] + wsh; a.bias = hw.b[e][l][d];
+                        a.w = wm(hw.w[e][l][d]); a.bias = hw.b[e][l][d];
                         if (l == 0) {
                             a.in0 = xT[e] + (size_t)t * n_tiles * hw.nk_in0 * TILE_F;
                             a.nk0 = hw.nk_in0; a.in0_tile_stride = hw.nk_in0 * TILE_F;
@@ -375,8 +386,7 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
                         ++nz;
                     }
                 }
-                if (f16) launch_hap_gemm<MODE_LSTM, true>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
-                else     launch_hap_gemm<MODE_LSTM, false>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
+                launch_hap_gemm<MODE_LSTM, AR>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
             }
         }
         tm_lstm.stop();
@@ -386,31 +396,39 @@ extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh,
             StepLaunch L;
             for (int e = 0; e < 2; ++e) {
                 StepArgs& a = L.z[e];
-                a.w = hw.proj_w[e] + wsh; a.bias = hw.proj_b[e];
+                a.w = wm(hw.proj_w[e]); a.bias = hw.proj_b[e];
                 a.in0 = hb[e][0] + (size_t)(Ls[e] / 2) * step_h;
                 a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(2 * tile_h);
                 a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0;
                 a.out = cat + (size_t)e * 16 * TILE_F; a.out_tile_stride = 32 * TILE_F;
                 a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
             }
-            if (f16) launch_hap_gemm<MODE_LINEAR, true>(ctx, s, L, (int)(n_tiles), H / TR, 2);
-            else     launch_hap_gemm<MODE_LINEAR, false>(ctx, s, L, (int)(n_tiles), H / TR, 2);
+            launch_hap_gemm<MODE_LINEAR, AR>(ctx, s, L, (int)(n_tiles), H / TR, 2);
         }
         {
             StepLaunch L; StepArgs& a = L.z[0];
-            a.w = hw.dense_w + wsh; a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
+            a.w = wm(hw.dense_w); a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
             a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0; a.out = inner; a.out_tile_stride = 16 * TILE_F;
             a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
-            if (f16) launch_hap_gemm<MODE_LINEAR_TANH, true>(ctx, s, L, (int)(n_tiles), H / TR, 1);
-            else     launch_hap_gemm<MODE_LINEAR_TANH, false>(ctx, s, L, (int)(n_tiles), H / TR, 1);
+            launch_hap_gemm<MODE_LINEAR_TANH, AR>(ctx, s, L, (int)(n_tiles), H / TR, 1);
         }
-        if (f16) hipLaunchKernelGGL(k_hap_heads<true>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
-                                    hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
-        else     hipLaunchKernelGGL(k_hap_heads<false>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
-                                    hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
+        hipLaunchKernelGGL(k_hap_heads<F16>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
+                           hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);
     }
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
+}
+
+extern "C" int nsnp_hap_forward(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N,
+                                float* gt_prob, float* zy_prob, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!xp || !xh || !gt_prob || !zy_prob))) return NSNP_EINVAL;
+    if (!ctx->hw) return NSNP_ENOWEIGHTS;
+    if (N == 0) return NSNP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (ctx->hap_precision == 1) return hap_forward_t<1>(ctx, xp, xh, N, gt_prob, zy_prob, s);
+    if (ctx->hap_precision == 2) return hap_forward_t<2>(ctx, xp, xh, N, gt_prob, zy_prob, s);
+    return hap_forward_t<0>(ctx, xp, xh, N, gt_prob, zy_prob, s);
 }
 
 NSNP_DEVCLK_READER(nsnp_devclk_read_hap)

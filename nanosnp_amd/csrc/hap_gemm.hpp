@@ -108,11 +108,34 @@ __device__ __forceinline__ void split_sat(float v, _Float16& hi, _Float16& lo)
     lo = (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -65504.0f, 65504.0f);
 }
 
-template <int MODE, bool F16, bool CONV = false>
+// AR = 2 : "bf16x3" - weights are stored as three bf16 planes per element (a row of a weight tile image = 16 p0 | 16 p1 | 16 p2 bf16 =
+//          96 bytes, v = p0 + p1 + p2 with p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1): the full 24-bit significand and the
+//          fp32 exponent range), ACTIVATIONS STAY fp32 in memory exactly as in the fp32 mode and are split the same way on their way
+//          into LDS; a product is the six v_mfma_f32_32x32x16_bf16 whose dropped terms are below 2^-24 of it, fp32 accumulation.
+//          Same launch sequence, activation images and epilogues as AR = 0; weight tile images are 12 KB instead of 8.
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+constexpr int LDB3 = 56;          // bf16 per LDS row in the bf16x3 mode: 3 x 16 + 8 pad (112 B = 7 slots of 16 B: an odd number of slots, so
+                                  // the 16 rows a ds_read_b128 lane group touches fall into 16 distinct bank slots)
+__device__ __forceinline__ void split3_b8(const f32x4& lo, const f32x4& hi, b8_t& p0, b8_t& p1, b8_t& p2)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? lo[j & 3] : hi[j & 3];
+        const __bf16 a = (__bf16)v;
+        const float r1 = v - (float)a;
+        const __bf16 b = (__bf16)r1;
+        p0[j] = a; p1[j] = b; p2[j] = (__bf16)(r1 - (float)b);
+    }
+}
+
+template <int MODE, int AR, bool CONV = false>
 __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaunch L)
 {
-    __shared__ float As[2][TR][LDK];
-    __shared__ float Bs[2][TS][LDK];
+    constexpr bool F16 = AR == 1, B3 = AR == 2;
+    constexpr int LDS_ROW_F = B3 ? LDB3 / 2 : LDK;            // floats per LDS row
+    constexpr int TILE_W = B3 ? TILE_F * 3 / 2 : TILE_F;      // floats per weight tile image
+    __shared__ float As[2][TR][LDS_ROW_F];
+    __shared__ float Bs[2][TS][LDS_ROW_F];
     NSNP_DEVCLK_START
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -130,7 +153,7 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
     const int site0 = small_rows ? 32 * wave : 64 * wc;              // first site of the wave's tile(s)
     const int nk = a.nk0 + a.nk1;
 
-    const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_F;
+    const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_W;
     const float* __restrict__ b0 = a.in0 ? a.in0 + (size_t)bx * a.in0_tile_stride : nullptr;
     const float* __restrict__ b1 = a.in1 ? a.in1 + (size_t)bx * a.in1_tile_stride : nullptr;
 
@@ -143,9 +166,15 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
         const int rem = (int)(pix % (a.conv_h * a.conv_w));
         py = rem / a.conv_w; px = rem - py * a.conv_w;
     }
+    f32x4 ga2;                                     // bf16x3: the third 16-byte piece of the thread's half of a 96-byte weight row
     auto gload = [&](int kc, f32x4& a0, f32x4& a1, f32x4& bb0, f32x4& bb1) {
-        const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_F) + crow * 4 + cq;
-        a0 = pa[0]; a1 = pa[1];
+        if (B3) {
+            const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_W) + crow * 6 + (tid & 1) * 3;
+            a0 = pa[0]; a1 = pa[1]; ga2 = pa[2];
+        } else {
+            const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_F) + crow * 4 + cq;
+            a0 = pa[0]; a1 = pa[1];
+        }
         if (CONV && kc < a.nk0) {
             const int tap = kc >> a.cc0_shift, cc = kc & ((1 << a.cc0_shift) - 1);
             const int ty = tap / 3, dy = ty - 1, dx = tap - 3 * ty - 1;
@@ -165,6 +194,16 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
         bb0 = pb[0]; bb1 = pb[1];
     };
     auto lstore = [&](int buf, const f32x4& a0, const f32x4& a1, const f32x4& bb0, const f32x4& bb1) {
+        if (B3) {
+            f32x4* ra = reinterpret_cast<f32x4*>(&As[buf][crow][0]) + (tid & 1) * 3;
+            ra[0] = a0; ra[1] = a1; ra[2] = ga2;
+            // the thread's 8 activations (K positions 8 (tid & 1) ..) -> its 16-byte piece of each of the three planes
+            b8_t p0, p1, p2;
+            split3_b8(bb0, bb1, p0, p1, p2);
+            b8_t* rb = reinterpret_cast<b8_t*>(&Bs[buf][crow][0]) + (tid & 1);
+            rb[0] = p0; rb[2] = p1; rb[4] = p2;
+            return;
+        }
         *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4]) = a0;
         *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4 + 4]) = a1;
         *reinterpret_cast<f32x4*>(&Bs[buf][crow][cq * 4]) = bb0;
@@ -207,7 +246,15 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
         const int cur = kc & 1;
         // fragments: lane (li, lh) takes floats [lh*8, lh*8+8) of its row = 8 k-steps of 32x32x2; the four fragments of
         // K-steps 0..3 first (the burst starts when they are there), the other four from inside the burst
-        f32x4 af[2][2], bf[2][2];
+        f32x4 af[2][B3 ? 3 : 2], bf[2][B3 ? 3 : 2];
+        auto read_frags3 = [&](int p) {             // bf16x3: plane p of the lane's rows / sites (8 bf16 at K positions 8 lh ..)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][p * 8 + lh * 4]);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                bf[ct][p] = *reinterpret_cast<const f32x4*>(&Bs[cur][site0 + 32 * ct + li][p * 8 + lh * 4]);
+        };
         auto read_frags = [&](int h) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -216,10 +263,17 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
             for (int ct = 0; ct < 2; ++ct)
                 bf[ct][h] = *reinterpret_cast<const f32x4*>(&Bs[cur][site0 + 32 * ct + li][(F16 ? lh * 4 : lh * 8) + h * (F16 ? 8 : 4)]);
         };
+        if (B3) {
+            read_frags3(0); read_frags3(2);          // the first product is w0 . x2
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags3(1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         read_frags(0);
         __builtin_amdgcn_sched_barrier(0);
         read_frags(1);
         __builtin_amdgcn_sched_barrier(0);
+        }
         auto side_work = [&](int pos) {
             if (PIPE == 2 && pos == WRPOS && kc + 1 < nk) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +294,22 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (F16) {
+        if (B3) {
+            // six products, smallest first: (w plane, x plane) = (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
+            constexpr int WP[6] = {0, 1, 2, 0, 1, 0}, XP[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                side_work(g == 0 ? -1 : (g == 1 ? WRPOS : (g == 3 ? LDPOS : -1)));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (CONV && (ct >= nct || rt >= nrt)) continue;
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, af[rt][WP[g]]), __builtin_bit_cast(b8_t, bf[ct][XP[g]]),
+                                                                               acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        } else if (F16) {
             // af[rt][0] / [1] are the lane's 8 hi / 8 lo halves of row (rt), likewise bf for the site
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -360,11 +429,42 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
 
 
 // launch of the tile GEMM over n_tiles site tiles x n_rt row tiles x nz slices
-template <int MODE, bool F16, bool CONV = false>
+// AR: 0 exact fp32, 1 f16x3, 2 bf16x3 (k_hap_gemm); `true` / `false` of the round-2 callers still mean f16x3 / fp32
+template <int MODE, int AR, bool CONV = false>
 inline void launch_hap_gemm(nsnp_ctx* ctx, hipStream_t s, StepLaunch& L, int n_tiles, int n_rt, int nz)
 {
-    hipLaunchKernelGGL((k_hap_gemm<MODE, F16, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
-                       gemm_lds_ballast((long long)n_tiles * n_rt * nz, ctx->n_cu), s, L);
+    // (the bf16x3 mode holds 56 KB of LDS per workgroup: two per CU as its launch bounds ask, no ballast)
+    hipLaunchKernelGGL((k_hap_gemm<MODE, AR, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
+                       AR == 2 ? 0u : gemm_lds_ballast((long long)n_tiles * n_rt * nz, ctx->n_cu), s, L);
+}
+
+// Weight images of the three arithmetic modes live at corresponding offsets of three arenas: fp32 at float offset o, the f16x3 copy
+// at the same offset of its arena (same size), the bf16x3 copy at BYTE offset 6 o of its arena (every image is 1.5 times as large).
+struct WeightMap {
+    const float* a32; const void* other; int ar;
+    const float* operator()(const float* w) const
+    {
+        if (ar == 0) return w;
+        if (ar == 1) return reinterpret_cast<const float*>(other) + (w - a32);
+        return reinterpret_cast<const float*>(reinterpret_cast<const char*>(other) + (size_t)(w - a32) * 6);
+    }
+};
+
+// host: fp32 weight images (rows of 16) -> bf16x3 images at 1.5 x the offset; n_floats a multiple of 16
+inline void pack_bf16x3_rows(const float* src, uint16_t* dst_arena, size_t off_floats, size_t n_floats)
+{
+    auto rne = [](float v) { uint32_t u; memcpy(&u, &v, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+                             return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+    auto f32 = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float v; memcpy(&v, &u, 4); return v; };
+    for (size_t r = 0; r + 16 <= n_floats; r += 16) {
+        uint16_t* d = dst_arena + (off_floats + r) * 3;               // 6 bytes per element
+        for (int k = 0; k < 16; ++k) {
+            const float v = src[off_floats + r + k];
+            const uint16_t p0 = rne(v); const float r1 = v - f32(p0);
+            const uint16_t p1 = rne(r1);
+            d[k] = p0; d[16 + k] = p1; d[32 + k] = rne(r1 - f32(p1));
+        }
+    }
 }
 
 }  // namespace

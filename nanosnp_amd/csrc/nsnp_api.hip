@@ -91,12 +91,12 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
 {
     if (!ctx || !name) return NSNP_EINVAL;
     if (strcmp(name, "cat_precision") == 0) {
-        if (value != 0 && value != 1) return NSNP_EINVAL;
+        if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->cat_precision = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "hap_precision") == 0) {
-        if (value != 0 && value != 1) return NSNP_EINVAL;
+        if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->hap_precision = (int)value;
         return NSNP_OK;
     }

@@ -70,10 +70,14 @@ def test_bench_line_schema():
     assert abs(r["chip"]["achieved"] - exec_flop_site * d["value"] / 1e12) / r["chip"]["achieved"] < 1e-6
     # the opt-in arithmetic is a second, labelled value measured on the same pool, within the port's tolerance of fp32
     assert d["f16x3"]["value"] > 1e6 and d["f16x3"]["max_abs_dp_vs_fp32_on_the_pool"] < 1e-4
-    # bf16x3: full fp32 operand width on the bf16 pipe - within 1e-6 of fp32 on the pool, its own roofline against the bf16 peak with the
+    # bf16x3: full fp32 operand width on the bf16 pipe - its error against a float64 evaluation of the model is the fp32 path's own (the
+    # two differ from each other by fp32 summation-order noise, a few 1e-6 on the pool), its own roofline against the bf16 peak with the
     # six MFMAs of a product priced as executed, its own outputs against the oracle
     b = d["bf16x3"]
-    assert b["value"] > 1e6 and b["max_abs_dp_vs_fp32_on_the_pool"] <= 1e-6 and b["parity_sample"]["ok"] and b["parity_sample"]["max_abs_dp"] < 1e-4
+    assert b["value"] > 1e6 and b["max_abs_dp_vs_fp32_on_the_pool"] < 5e-6 and b["parity_sample"]["ok"] and b["parity_sample"]["max_abs_dp"] < 1e-4
+    e = d["error_vs_float64"]["modes"]
+    assert e["fp32"]["sites"] == e["bf16x3"]["sites"] == e["f16x3"]["sites"] == 2048
+    assert e["bf16x3"]["max_abs_error"] <= max(1.5 * e["fp32"]["max_abs_error"], 1e-6) and e["bf16x3"]["max_abs_error"] < 3e-6
     assert b["roofline"]["peak"] == 2500.0 and 0 < b["roofline"]["frac"] <= 1 and 0 < b["roofline"]["chip"]["frac"] <= 1
     assert b["roofline"]["executed_flop_per_launch"] in (4096 * 2 * 33 * 256 * (32 * 3 + 64 * 6) * 2, 4096 * 2 * 17 * 256 * 192 * 6 * 2)
 

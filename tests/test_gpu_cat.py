@@ -9,9 +9,9 @@ pytestmark = pytest.mark.gpu
 PROB_ATOL = 1e-4        # BASELINE.json north_star tolerance on probabilities
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
+@pytest.fixture(scope="module", params=[2, 1, 0], ids=["bf16x3", "f16x3", "fp32"])
 def cat_model(request, gpu_ctx):
-    """the forward tests run in both modes: exact fp32 (library default) and the opt-in f16x3"""
+    """the forward tests run in all three modes: exact fp32 (library default), bf16x3 and the opt-in f16x3"""
     ws = seeded_cat_weights(21)
     gpu_ctx.cat_load_weights(ws)
     gpu_ctx.set_option("cat_precision", request.param)
@@ -37,7 +37,7 @@ def test_cat_forward_golden(cat_model):
     assert np.array_equal(got.argmax(1), z["gt"].argmax(1))
 
 
-@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "f16x3"])
+@pytest.mark.parametrize("prec", [0, 1, 2], ids=["fp32", "f16x3", "bf16x3"])
 def test_cat_forward_large_golden_incl_edge_sites(prec):
     """cat_fwd_large.npz: 256 sites of the reference's CatModel.predict, incl. empty tags, one-read tags and saturated tensors"""
     from nanosnp_amd import _lib
@@ -65,21 +65,23 @@ def test_cat_forward_vs_oracle(cat_model, N):
     assert np.allclose(got.sum(1), 1.0, atol=1e-5)
 
 
-def test_cat_forward_f16x3_mode(cat_model):
-    """cat_precision = 1: every product as three fp16 MFMAs with fp32 accumulation (as hap_precision = 1), same goldens"""
+@pytest.mark.parametrize("mode", [1, 2], ids=["f16x3", "bf16x3"])
+def test_cat_forward_split_modes(cat_model, mode):
+    """cat_precision = 1: every product as three fp16 MFMAs; 2: six bf16 MFMAs on three bf16 terms per operand (as hap_precision);
+    fp32 accumulation, same goldens"""
     from oracle import oracle
     ctx, ws = cat_model
     z = np.load(golden("cat_fwd.npz"))
     g0, g1 = synth_cat_groups(555, 200)
     ctx.set_option("cat_precision", 0)
     ref32 = _fwd(ctx, g0, g1)
-    ctx.set_option("cat_precision", 1)
+    ctx.set_option("cat_precision", mode)
     try:
         got = _fwd(ctx, z["g0"], z["g1"])
         assert np.abs(got - z["gt"]).max() < PROB_ATOL and np.array_equal(got.argmax(1), z["gt"].argmax(1))
         got = _fwd(ctx, g0, g1)
         d32 = np.abs(got - ref32).max()
-        print("cat f16x3 vs fp32 path", d32)
+        print("cat split mode", mode, "vs fp32 path", d32)
         assert d32 < 2e-5
         assert np.abs(got - oracle.cat_forward(ws, g0, g1, nthreads=8)).max() < PROB_ATOL
         assert np.array_equal(got, _fwd(ctx, g0, g1))            # run-to-run deterministic

@@ -57,7 +57,8 @@ class HapStage:
                 self.planes8.append([p.to(torch.int8) for p in self.planes[-1][:4]] + [self.planes[-1][4]])
         self.weights = seeded_hap_weights(12, H=256)
         self.ctx = _lib.Context(local_rank)
-        self.ctx.set_option("hap_pass_sites", min(max(128, -(-self.batch // 128) * 128), 131072))
+        self.ctx_pass_sites = min(max(128, -(-self.batch // 128) * 128), 131072)
+        self.ctx.set_option("hap_pass_sites", self.ctx_pass_sites)
         self.ctx.hap_load_weights(self.weights)
         self.ctx.enable_timing(timing)
         self.stream = torch.cuda.Stream(device=dev)
@@ -133,7 +134,7 @@ class HapStage:
         ogt, ozy = np.concatenate(ogt), np.concatenate(ozy)
         gt, zy, res = snap["gt"], snap["zy"], snap["res"]
         dp = float(max(np.abs(gt - ogt).max(), np.abs(zy - ozy).max()))
-        calls_self = bool(np.array_equal(res[:, 0], gt.argmax(1).astype(np.float32)) and np.array_equal(res[:, 1], gt.max(1)))
+        calls_self = res is None or bool(np.array_equal(res[:, 0], gt.argmax(1).astype(np.float32)) and np.array_equal(res[:, 1], gt.max(1)))
         ok = bool(np.isfinite(gt).all() and np.isfinite(zy).all() and dp <= tolerance and calls_self)
         return {"ok": ok, "sites": int(gt.shape[0]), "max_abs_dp": dp, "tolerance": tolerance, "calls_equal_own_argmax": calls_self,
                 "batches_sampled": len(snap["ranges"]),
@@ -402,18 +403,44 @@ def run(args, rank, world, local_rank, deep60=False):
         if not args.no_second_precision:
             ref = hs.gt[b0:b1].clone()
             torch.cuda.synchronize(dev)                 # (the copy runs on torch's current stream, the forwards on the stage's)
-            hs.ctx.set_option("hap_precision", 1)
-            nf, tf = _timed(lambda: (hs.forward(b0, b1), nfe)[1], hs.sync, 3)
-            d = (hs.gt[b0:b1] - ref).abs().max().item()
+            for prec, label, text in ((2, "bf16x3", "bf16x3 (weights as three bf16 planes, fp32 activations split on their way into LDS: 24 significand bits "
+                                                    "per operand, six bf16 MFMAs per product, fp32 accumulate)"),
+                                      (1, "f16x3", "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)")):
+                hs.ctx.set_option("hap_precision", prec)
+                hs.sync(); hs.ctx.read_timing()
+                nf, tf = _timed(lambda: (hs.forward(b0, b1), nfe)[1], hs.sync, 3)
+                ch_ms, ch_n = hs.ctx.read_timing()["hap_lstm_chain"]
+                d = (hs.gt[b0:b1] - ref).abs().max().item()
+                sv = {"sites_per_s": nf / tf, "max_abs_dp_vs_fp32": d, "tolerance": 1e-4, "dtype": text}
+                if prec == 2 and ch_n:
+                    # its own roofline against the dense bf16 MFMA peak, the six MFMAs of a product priced as executed
+                    n_launch = bc.hap_lstm_launches()
+                    spp = min(nfe, int(hs.ctx_pass_sites))
+                    sv["roofline"] = bc.roofline_mfma("k_hap_gemm<LSTM, bf16x3>", bc.hap_exec_flop() * 6 * spp / n_launch, ch_ms / ch_n / n_launch,
+                                                      ch_n * n_launch, peak=bc.PEAK_F16_MFMA_TFLOPS, launches_per_pass=n_launch, sites_per_pass=spp,
+                                                      how="one HIP event pair around the %d step launches of a pass, divided by %d" % (n_launch, n_launch))
+                    if rank == 0 and not args.no_parity_sample:
+                        t = torch
+                        m = min(256, nfe)
+                        sv["parity_sample"] = hs.parity_check({"ranges": [(b0, m)], "gt": hs.gt[b0:b0 + m].cpu().numpy(),
+                                                               "zy": hs.zy[b0:b0 + m].cpu().numpy(), "res": None})
+                second["forward_only_" + label] = sv
             hs.ctx.set_option("hap_precision", 0)
-            second["forward_only_f16x3"] = {"sites_per_s": nf / tf, "max_abs_dp_vs_fp32": d, "tolerance": 1e-4,
-                                            "dtype": "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)"}
         if not deep60:
             # config 2 names crnn.py: the legacy CatModel forward, exact fp32, on its own pool
             cs.ctx.read_timing()
             nc, tc = _timed(lambda: cs.run_batch(0), cs.sync, 3)
             ct = cs.ctx.read_timing()
             second["legacy_CatModel_forward_fp32"] = cat_report(cs, nc, tc, ct, bc)
+            if not args.no_second_precision:
+                cs.ctx.set_option("cat_precision", 2); cs.precision = 2
+                cs.ctx.read_timing()
+                nc, tc = _timed(lambda: cs.run_batch(0), cs.sync, 3)
+                ct = cs.ctx.read_timing()
+                second["legacy_CatModel_forward_bf16x3"] = cat_report(cs, nc, tc, ct, bc)
+                if rank == 0 and not args.no_parity_sample:
+                    second["legacy_CatModel_forward_bf16x3"]["parity_sample"] = cs.parity_check(0, min(256, cs.n))
+                cs.ctx.set_option("cat_precision", 0); cs.precision = 0
 
     if rank == 0:
         roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, nfe, "deep60" if deep60 else "haplotype")
@@ -488,8 +515,8 @@ def cat_report(cs, n_sites, seconds, ctim, bc):
         out["sites_per_s"] = n_sites / seconds
     if conv_n:
         sites_per_pass = min(4096, cs.batch)
-        mult = 3 if cs.precision == 1 else 1
-        peak = bc.PEAK_F16_MFMA_TFLOPS if mult == 3 else bc.PEAK_F32_MFMA_TFLOPS
+        mult = {0: 1, 1: 3, 2: 6}[cs.precision]         # fp16 / bf16 MFMAs executed per fp32 product
+        peak = bc.PEAK_F16_MFMA_TFLOPS if mult > 1 else bc.PEAK_F32_MFMA_TFLOPS
         out["roofline"] = bc.roofline_mfma(
             "k_hap_gemm<LINEAR_RELU, CONV> (implicit-GEMM 3x3 convolution)", bc.cat_conv_exec_flop() * mult * sites_per_pass / 12, conv_ms / conv_n / 12,
             conv_n * 12, alg_flop_per_launch=bc.cat_conv_alg_flop() * sites_per_pass / 12, peak=peak,

@@ -174,7 +174,7 @@ class PileupStage:
         snap = {"ranges": list(ranges), "gt": self.gt_all[idx].cpu().numpy(), "zy": self.zy_all[idx].cpu().numpy(),
                 "res": {k: v[idx].cpu().numpy() for k, v in self.res.items()}, "ring": []}
         for slot in self.ring:
-            if "c0" not in slot:
+            if "c0" not in slot or ring_batches <= 0:
                 continue
             m = min(slot["ncols"], ring_batches * self.mcols)
             snap["ring"].append({"c0": slot["c0"], "m": m, "counts": slot["counts"][:m].cpu().numpy(),
@@ -185,6 +185,22 @@ class PileupStage:
         from oracle import oracle
         off = self.cols.col_off[c0:c0 + m + 1]
         return oracle.encode_columns(self.cols.bases[int(off[0]):int(off[-1])], off - off[0], self.cols.ref[c0:c0 + m])
+
+    def float64_error(self, snap, per_range=64):
+        """max |p - p64| of a snapshot()'s probabilities on the first `per_range` windows of each of its ranges, p64 = the model evaluated
+        in float64 (oracle.pileup_forward_f64): separates the arithmetic error of a mode from fp32 summation-order noise"""
+        import numpy as np
+        from oracle import oracle
+        key = tuple((a, min(c, per_range)) for a, c in snap["ranges"])
+        if getattr(self, "_f64_key", None) != key:
+            xs = [self._oracle_encode(a * 33, c * 33)[0].reshape(c, 33, 18) for a, c in key]
+            self._f64 = oracle.pileup_forward_f64(self.weights, np.concatenate(xs))
+            self._f64_key = key
+        sel, off = [], 0
+        for (a, c), (_, ck) in zip(snap["ranges"], key):
+            sel.append(np.arange(off, off + ck)); off += c
+        sel = np.concatenate(sel)
+        return {"sites": int(sel.size), "max_abs_error": float(max(np.abs(snap["gt"][sel] - self._f64[0]).max(), np.abs(snap["zy"][sel] - self._f64[1]).max()))}
 
     def parity_check(self, snap, tolerance=1e-4, nthreads=None):
         """compares a snapshot() with the oracle (the plain restatement - the pinned checker, not the blocked arrangement bench.py

@@ -116,6 +116,37 @@ def run(args, rank, world, local_rank):
     if rank == 0 and not args.no_parity_sample:          # what the last timed step left behind (compared with the oracle below, outside every clock)
         parity = (ps.snapshot(ps.parity_ranges(n2, per_batch=1024, n_ranges=32)),
                   hs.snapshot(range(hs.n_batches), per_batch=max(64, 1024 // hs.n_batches)))
+    # ---- labelled second value: both stages in the bf16x3 arithmetic (full fp32 operand width on the bf16 matrix pipe) ----
+    second = None
+    if not args.no_second_precision:
+        ref2 = ps.gt_all[:n2].clone(); ref5 = hs.gt[:max(n5, 1)].clone()
+        torch.cuda.synchronize(dev)
+        ps.set_precision(2); hs.ctx.set_option("hap_precision", 2)
+        stage2(); sync_all(); stage5(); sync_all(); merge(); sync_all()
+        barrier(); sync_all()
+        tb0 = time.perf_counter(); tb2 = tb5 = 0.0
+        for _ in range(K):
+            ta = time.perf_counter(); stage2(); sync_all()
+            tb = time.perf_counter(); stage5(); sync_all()
+            tc = time.perf_counter(); merge(); sync_all()
+            tb2 += tb - ta; tb5 += tc - tb
+        barrier()
+        dtb = time.perf_counter() - tb0
+        if world > 1:
+            tm = torch.tensor([dtb, tb2, tb5], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dtb, tb2, tb5 = (float(v) for v in tm.tolist())
+        second = {"value": n2_all * K / dtb, "unit": "sites/s", "ms_per_step": dtb / K * 1e3,
+                  "dtype": "bf16x3 (every fp32 operand as three bf16 terms = 24 significand bits, six bf16 MFMAs per product, fp32 accumulate)",
+                  "stage2_ms_per_step": tb2 / K * 1e3, "stage5_ms_per_step": tb5 / K * 1e3,
+                  "max_abs_dp_vs_fp32": {"stage2": float((ps.gt_all[:n2] - ref2).abs().max().item()),
+                                         "stage5": float((hs.gt[:max(n5, 1)] - ref5).abs().max().item())}, "tolerance": 1e-4}
+        if rank == 0 and not args.no_parity_sample:
+            second["parity_sample"] = {"stage2": ps.parity_check(ps.snapshot(ps.parity_ranges(n2, per_batch=256, n_ranges=16))),
+                                       "stage5": hs.parity_check(hs.snapshot(range(hs.n_batches), per_batch=max(32, 256 // hs.n_batches)))}
+            second["parity_sample"]["ok"] = all(v["ok"] for v in second["parity_sample"].values())
+        ps.set_precision(0); hs.ctx.set_option("hap_precision", 0)
+        del ref2, ref5
     if rank == 0:
         assert merged[0].shape[0] == n2_all and merged[1].shape[0] == (n5_tot if world > 1 else hs.n)
         # rooflines: the dominant kernel of the whole job is the HaplotypeModel's fused step launch (80 % of the time)
@@ -152,6 +183,8 @@ def run(args, rank, world, local_rank):
         }
         out.update(roofs)
         out.setdefault("roofline", None)
+        if second:
+            out["bf16x3"] = second
         out["timed_region_s"] = dt
         out["shader_clock_mhz"] = {"value": hs.ctx.shader_clock_mhz(hs.stream), "how": "s_memtime / s_memrealtime in every workgroup of a ~2 ms full-chip "
                                    "fp32 MFMA probe after the timed region (nsnp_ctx_shader_clock); the MFMA peaks are priced at 2400"}
@@ -165,7 +198,7 @@ def run(args, rank, world, local_rank):
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_two_stage(ps, hs, args.cpu_seconds)
         print(json.dumps(out))
-        if out["parity_sample"] is not None and not out["parity_sample"]["ok"]:
+        if (out["parity_sample"] is not None and not out["parity_sample"]["ok"]) or (second and second.get("parity_sample") and not second["parity_sample"]["ok"]):
             print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
             exit_code = 1
     if world > 1:
