@@ -285,6 +285,182 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// layer 0, SKEWED over two site groups (the default at batch sizes that fill the chip with 32-site workgroups).  In k_pileup_l0_b3
+// the cell of a step's last site group, the exchange write and the barrier stand between the MFMAs of one step and the next: by
+// removal timing the matrix work is 1.4 ms of a 2.1 ms launch (N = 131072).  Here a workgroup owns two groups A and B and runs them
+// half a step apart, two barriers per step:
+//     phase 1 of step s:   MFMAs of B(s)     beside   cell of A(s)  (+ the input image of step s + 1)      barrier
+//     phase 2 of step s:   MFMAs of A(s + 1) beside   cell of B(s)                                          barrier
+// so every cell has 60 independent MFMAs of the other group in its scheduling region, and what a barrier waits for is the other
+// waves' cells, not a drained matrix pipe.  Same arithmetic in the same order per site: bit-identical to k_pileup_l0_b3.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_pileup_l0_b3p(
+    const int32_t* __restrict__ x, const int64_t* __restrict__ center_idx, int64_t N,
+    const __bf16* __restrict__ whh0, const __bf16* __restrict__ whh1,
+    const __bf16* __restrict__ wih0, const __bf16* __restrict__ wih1,
+    __bf16* __restrict__ H0)
+{
+    extern __shared__ b8 lds_b3[];
+    constexpr int NSG = 2;
+    __bf16* const hx = reinterpret_cast<__bf16*>(lds_b3);                 // [2][NSG][FR_H]
+    __bf16* const xx = hx + 2 * NSG * FR_H;                               // [2][NSG][FR_X]
+    int* const xflag = reinterpret_cast<int*>(xx + 2 * NSG * FR_X);       // [2][4]
+    const int dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+
+    b8 Whh[2][4][3], Wih[4][3];
+    {
+        const b8* __restrict__ ghh = reinterpret_cast<const b8*>(dir ? whh1 : whh0);
+        const b8* __restrict__ gih = reinterpret_cast<const b8*>(dir ? wih1 : wih0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) Whh[kb][u][p] = ghh[(((4 * wave + u) * 2 + kb) * 3 + p) * 64 + lane];
+                Wih[u][p] = gih[((4 * wave + u) * 3 + p) * 64 + lane];
+            }
+    }
+
+    const int64_t group0 = (int64_t)blockIdx.x * NSG;
+    const bool stager = wave < NSG;
+    const int64_t xsite = (group0 + wave) * 16 + n;
+    const int64_t xsc = (stager && xsite < N) ? xsite : N - 1;
+    const int32_t* __restrict__ xs = center_idx ? x + (center_idx[xsc] - PCENTER) * PC : x + xsc * (PW * PC);
+    int xa[8], xb_[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xa[j] = (q == 2 && j == 2) ? 1 : 0; xb_[j] = xa[j]; }
+    auto load_x = [&](int (&xi)[8], int t) __attribute__((always_inline)) {
+        if (!stager) return;
+        const int32_t* p = xs + t * PC;
+        if (q < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xi[j] = p[8 * q + j];
+        } else if (q == 2) {
+            xi[0] = p[16]; xi[1] = p[17];
+        }
+    };
+    auto stage_x = [&](const int (&xi)[8], int buf) __attribute__((always_inline)) {
+        if (!stager) return;
+        __bf16* row = xx + (size_t)(buf * NSG + wave) * FR_X + q * 128 + n * 8;
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) big |= (unsigned)(xi[j] + 256) > 512u;
+        int lvl = 0;
+        if (__builtin_expect(__ballot(big) == 0ull, 1)) {
+            b8 p0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p0[j] = (__bf16)(float)xi[j];
+            *reinterpret_cast<b8*>(row) = p0;
+        } else {
+            b8 p0, p1, p2;
+            bool nz1 = false, nz2 = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 a, b, c; split3((float)xi[j], a, b, c);
+                p0[j] = a; p1[j] = b; p2[j] = c;
+                nz1 |= (float)b != 0.f; nz2 |= (float)c != 0.f;
+            }
+            lvl = __ballot(nz2) != 0ull ? 2 : (__ballot(nz1) != 0ull ? 1 : 0);
+            *reinterpret_cast<b8*>(row) = p0;
+            *reinterpret_cast<b8*>(row + 512) = p1;
+            *reinterpret_cast<b8*>(row + 1024) = p2;
+        }
+        if (lane == 0) xflag[buf * 4 + wave] = lvl;
+    };
+    if (tid < 8) xflag[tid] = 0;
+    for (int i = tid; i < NSG * FR_H / 8; i += 256) reinterpret_cast<b8*>(hx + (size_t)NSG * FR_H)[i] = b8{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    auto t_of = [&](int s) { return dir ? PW - 1 - s : s; };
+    load_x(xa, t_of(0));
+    stage_x(xa, 0);
+    load_x(xb_, t_of(1));
+    __syncthreads();
+
+    float c[4 * NSG];
+#pragma unroll
+    for (int i = 0; i < 4 * NSG; ++i) c[i] = 0.f;
+    const int wofs = (wave >> 1) * 512 + (2 * (wave & 1) + (q >> 1)) * 128 + n * 8 + 4 * (q & 1);
+
+    // gate pre-activations of site group sg at step s: 60 MFMAs (+ 8 / 12 for counts beyond 256 / 65536)
+    auto gemm = [&](int sg, int s, f32x4* acc) __attribute__((always_inline)) {
+        const int xbuf = s & 1, hr = (s & 1) ^ 1;
+        const int lvl = max(max(xflag[xbuf * 4 + 0], xflag[xbuf * 4 + 1]), max(xflag[xbuf * 4 + 2], xflag[xbuf * 4 + 3]));
+        const __bf16* hrow = hx + (size_t)(hr * NSG + sg) * FR_H + q * 128 + n * 8;
+        const __bf16* xrow = xx + (size_t)(xbuf * NSG + sg) * FR_X + q * 128 + n * 8;
+        b8 bh[2][3], bx[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            bh[0][p] = *reinterpret_cast<const b8*>(hrow + p * 1024);
+            bh[1][p] = *reinterpret_cast<const b8*>(hrow + p * 1024 + 512);
+        }
+        bx[0] = *reinterpret_cast<const b8*>(xrow);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (__builtin_expect(lvl != 0, 0)) {                // rare: counts beyond one bf16 term - the extra products first (smallest terms first)
+            bx[1] = *reinterpret_cast<const b8*>(xrow + 512);
+            bx[2] = *reinterpret_cast<const b8*>(xrow + 1024);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][0], bx[2], acc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][1], bx[1], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][2], bx[0], acc[u]);
+        if (__builtin_expect(lvl != 0, 0)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][0], bx[1], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][1], bx[0], acc[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][0], bx[0], acc[u]);
+        six_products<4>(Whh[0], bh[0], acc);
+        six_products<4>(Whh[1], bh[1], acc);
+    };
+    auto cell = [&](int sg, int s, const f32x4* acc) __attribute__((always_inline)) {
+        b4 n0, n1, n2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float cn;
+            const float h = nsnp_cell::lstm_cell(acc[u][0], acc[u][1], acc[u][2], acc[u][3], c[4 * sg + u], cn);
+            c[4 * sg + u] = cn;
+            __bf16 a, b, d; split3(h, a, b, d);
+            n0[u] = a; n1[u] = b; n2[u] = d;
+        }
+        __bf16* w = hx + (size_t)((s & 1) * NSG + sg) * FR_H + wofs;
+        *reinterpret_cast<b4*>(w) = n0;
+        *reinterpret_cast<b4*>(w + 1024) = n1;
+        *reinterpret_cast<b4*>(w + 2048) = n2;
+        __bf16* g = H0 + (((group0 + sg) * PW + t_of(s)) * 2 + dir) * FR_H + wofs;
+        *reinterpret_cast<b4*>(g) = n0;
+        *reinterpret_cast<b4*>(g + 1024) = n1;
+        *reinterpret_cast<b4*>(g + 2048) = n2;
+    };
+
+    f32x4 accA[4], accB[4];
+    gemm(0, 0, accA);
+    auto one_step = [&](int s, int (&mine)[8], const int (&next)[8]) __attribute__((always_inline)) {
+        // phase 1: MFMAs of B(s) beside the cell of A(s); the input image of step s + 1
+        if (s + 2 < PW) load_x(mine, t_of(s + 2));
+        gemm(1, s, accB);
+        cell(0, s, accA);
+        if (s + 1 < PW) stage_x(next, (s & 1) ^ 1);
+        lds_barrier();
+        // phase 2: MFMAs of A(s + 1) beside the cell of B(s)
+        if (s + 1 < PW) gemm(0, s + 1, accA);
+        cell(1, s, accB);
+        lds_barrier();
+    };
+    for (int s = 0; s + 1 < PW; s += 2) {
+        one_step(s, xa, xb_);
+        one_step(s + 1, xb_, xa);
+    }
+    one_step(PW - 1, xa, xb_);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // layer 1: input projection (K = 128: h0_t of both directions) fused into the recurrence (K = 64), only the 17 steps per direction
 // that reach position 16 (model.py:68).  Workgroup = 8 waves x NSG groups of 16 sites; wave w owns gate tiles 2w, 2w+1 and keeps
 // their W_ih1 (4 K blocks) and W_hh1 (2 K blocks) planes in 144 VGPRs - one workgroup per CU (two waves per SIMD).  LDS holds
@@ -694,6 +870,7 @@ static int set_lds_attr_b3(nsnp_ctx* ctx)
 #define SET(K, B) NSNP_HIP(ctx, hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B))
     SET(k_pileup_l0_b3<1>, b3_l0_lds_bytes(1)); SET(k_pileup_l0_b3<2>, b3_l0_lds_bytes(2)); SET(k_pileup_l0_b3<4>, b3_l0_lds_bytes(4));
     SET(k_pileup_l1_b3<1>, b3_l1_lds_bytes(1)); SET(k_pileup_l1_b3<2>, b3_l1_lds_bytes(2)); SET(k_pileup_l1_b3<4>, b3_l1_lds_bytes(4));
+    SET(k_pileup_l0_b3p, b3_l0_lds_bytes(2));
     SET(k_pileup_head_b3, HB3_STAGE_B8 * 16);
 #undef SET
     ctx->attr_set_b3 = true;
@@ -717,13 +894,16 @@ int nsnp_pileup_forward_bf16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* c
         const int64_t* cc = center_idx ? center_idx + base : nullptr;
         {
             ScopedKernelTimer tm(ctx, NSNP_K_L0, s);
-            // 64 sites per workgroup when that still gives every CU two workgroups, else 32 or 16
-            int nsg = 4;
-            while (nsg > 1 && NSNP_CDIV(n, 16 * nsg) * 2 < 2 * (int64_t)ctx->n_cu) nsg >>= 1;
+            // 32 sites per workgroup (measured best: 64 lose to register pressure) when that gives every CU a workgroup, else 16
+            int nsg = NSNP_CDIV(n, 32) * 2 >= (int64_t)ctx->n_cu ? 2 : 1;
             if (ctx->l0_rs_groups) nsg = ctx->l0_rs_groups;
 #define LAUNCH_L0(G) hipLaunchKernelGGL(k_pileup_l0_b3<G>, dim3((unsigned)NSNP_CDIV(n, 16 * G), 2), dim3(256), b3_l0_lds_bytes(G), s, xc, cc, n, \
             (const __bf16*)pw.l0_whh[0], (const __bf16*)pw.l0_whh[1], (const __bf16*)pw.l0_wih[0], (const __bf16*)pw.l0_wih[1], H0)
-            if (nsg == 4) LAUNCH_L0(4); else if (nsg == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
+            // 32 sites per workgroup run the skewed two-group kernel ("l0_register_stationary" 0 selects the plain one: A/B, tests)
+            if (nsg == 2 && ctx->l0_rs)
+                hipLaunchKernelGGL(k_pileup_l0_b3p, dim3((unsigned)NSNP_CDIV(n, 32), 2), dim3(256), b3_l0_lds_bytes(2), s, xc, cc, n,
+                                   (const __bf16*)pw.l0_whh[0], (const __bf16*)pw.l0_whh[1], (const __bf16*)pw.l0_wih[0], (const __bf16*)pw.l0_wih[1], H0);
+            else if (nsg == 4) LAUNCH_L0(4); else if (nsg == 2) LAUNCH_L0(2); else LAUNCH_L0(1);
 #undef LAUNCH_L0
         }
         {
