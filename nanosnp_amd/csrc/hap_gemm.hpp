@@ -114,8 +114,10 @@ __device__ __forceinline__ void split_sat(float v, _Float16& hi, _Float16& lo)
 //          into LDS; a product is the six v_mfma_f32_32x32x16_bf16 whose dropped terms are below 2^-24 of it, fp32 accumulation.
 //          Same launch sequence, activation images and epilogues as AR = 0; weight tile images are 12 KB instead of 8.
 typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
-constexpr int LDB3 = 56;          // bf16 per LDS row in the bf16x3 mode: 3 x 16 + 8 pad (112 B = 7 slots of 16 B: an odd number of slots, so
-                                  // the 16 rows a ds_read_b128 lane group touches fall into 16 distinct bank slots)
+constexpr int LDB3 = 48;          // bf16 per LDS row in the bf16x3 mode: 3 planes x 16, NO padding (96 B = 6 slots of 16 B; 48 KB per workgroup, three
+                                  // per CU).  Slot s of row r is stored at s ^ ((r >> 3) & 1): the 16 rows a ds_read_b128 lane group touches
+                                  // (r mod 16 all different) then fall into 16 distinct bank slots (6 r + s mod 16 pairs r with r + 8; the flipped
+                                  // low bit separates the two, and 6 k is never +-1 mod 16)
 __device__ __forceinline__ void split3_b8(const f32x4& lo, const f32x4& hi, b8_t& p0, b8_t& p1, b8_t& p2)
 {
 #pragma unroll
@@ -195,13 +197,15 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
     };
     auto lstore = [&](int buf, const f32x4& a0, const f32x4& a1, const f32x4& bb0, const f32x4& bb1) {
         if (B3) {
-            f32x4* ra = reinterpret_cast<f32x4*>(&As[buf][crow][0]) + (tid & 1) * 3;
-            ra[0] = a0; ra[1] = a1; ra[2] = ga2;
+            const int sw = (crow >> 3) & 1, h3 = (tid & 1) * 3;
+            f32x4* ra = reinterpret_cast<f32x4*>(&As[buf][crow][0]);
+            ra[(h3 + 0) ^ sw] = a0; ra[(h3 + 1) ^ sw] = a1; ra[(h3 + 2) ^ sw] = ga2;
             // the thread's 8 activations (K positions 8 (tid & 1) ..) -> its 16-byte piece of each of the three planes
             b8_t p0, p1, p2;
             split3_b8(bb0, bb1, p0, p1, p2);
-            b8_t* rb = reinterpret_cast<b8_t*>(&Bs[buf][crow][0]) + (tid & 1);
-            rb[0] = p0; rb[2] = p1; rb[4] = p2;
+            b8_t* rb = reinterpret_cast<b8_t*>(&Bs[buf][crow][0]);
+            const int hb = (tid & 1) ^ sw;
+            rb[hb] = p0; rb[2 + hb] = p1; rb[4 + hb] = p2;
             return;
         }
         *reinterpret_cast<f32x4*>(&As[buf][crow][cq * 4]) = a0;
@@ -247,13 +251,14 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
         // fragments: lane (li, lh) takes floats [lh*8, lh*8+8) of its row = 8 k-steps of 32x32x2; the four fragments of
         // K-steps 0..3 first (the burst starts when they are there), the other four from inside the burst
         f32x4 af[2][B3 ? 3 : 2], bf[2][B3 ? 3 : 2];
-        auto read_frags3 = [&](int p) {             // bf16x3: plane p of the lane's rows / sites (8 bf16 at K positions 8 lh ..)
+        auto read_frags3 = [&](int p) {             // bf16x3: plane p of the lane's rows / sites (8 bf16 at K positions 8 lh ..), swizzled slot
+            const int sl = (2 * p + (lh ^ ((li >> 3) & 1))) * 4;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
-                af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][p * 8 + lh * 4]);
+                af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][sl]);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
-                bf[ct][p] = *reinterpret_cast<const f32x4*>(&Bs[cur][site0 + 32 * ct + li][p * 8 + lh * 4]);
+                bf[ct][p] = *reinterpret_cast<const f32x4*>(&Bs[cur][site0 + 32 * ct + li][sl]);
         };
         auto read_frags = [&](int h) {
 #pragma unroll
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
 template <int MODE, int AR, bool CONV = false>
 inline void launch_hap_gemm(nsnp_ctx* ctx, hipStream_t s, StepLaunch& L, int n_tiles, int n_rt, int nz)
 {
-    // (the bf16x3 mode holds 56 KB of LDS per workgroup: two per CU as its launch bounds ask, no ballast)
+    // (the bf16x3 mode holds 48 KB of LDS per workgroup: three per CU, no ballast)
     hipLaunchKernelGGL((k_hap_gemm<MODE, AR, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
                        AR == 2 ? 0u : gemm_lds_ballast((long long)n_tiles * n_rt * nz, ctx->n_cu), s, L);
 }
