@@ -259,7 +259,10 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     // per column: [0..2] skipped bytes by class (the table's three counter words; bit 31 of [2]: hand the column to the exact path),
     // [3] indel reads by kind (8-bit fields),
     // [4..7] largest multiplicity of one allele by kind
-    __shared__ __attribute__((aligned(16))) uint32_t colacc[ENC_WAVES][64][8];
+    // Stored WORD-MAJOR ([word][column]): the lanes that decode openers reach the accumulators of OTHER columns through LDS atomics,
+    // and with eight consecutive words per column (32 B) the word w of every column sat in one of four banks - an atomic instruction
+    // over 50 distinct owner columns took 8 to 16 LDS cycles.  Now distinct columns are distinct banks (two columns 32 apart share one).
+    __shared__ uint32_t colacc[ENC_WAVES][8][64];
     // byte -> x: A C G T, y: a c g t, z: * # (8-bit counters) | "ACGTN*" << 24, w: 1 for the construct openers + - ^
     __shared__ uint4 tab[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,7 +274,11 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
         else if (cls < 10) r.z = 1u << (8 * (cls - 8));
         else if (cls >= 11) r.w = 1u;
         if (is_fwd_char(tid)) r.z |= 1u << 24;
-        tab[tid ^ ((tid >> 2) & 8)] = r;        // row index = byte with its case bit (0x20) folded into bit 3: 'A' and 'a' in different banks
+        // row index = byte ^ ((byte >> 2) & 12): bits 4-5 of the byte folded into bits 2-3 of the row, so that the symbols a column
+        // is made of fall into different 16-byte bank slots of a ds_read_b128 lane group - the eight letters (A a C c G g T t: slots
+        // 1 9 3 11 7 15 0 8), '.' ',' of real pileups (6, 4), and the construct bytes + - ^ $ 1 2 3 mostly beside them: 1.41 LDS cycles
+        // per lane group on generator G2's bytes, 1.09 on '.'/','-dominated ones, against 1.57 / 1.24 with only the case bit folded
+        tab[tid ^ ((tid >> 2) & 12)] = r;
         if (tid < 128) af_min[tid] = aft.w[tid];
         if (tid < ENC_WAVES * P3_STEP) ents[tid / P3_STEP][tid % P3_STEP] = uint2{0x80000000u, 0u};
     }
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     uint8_t* st = stage_b[wave];
     const uint32_t* st32 = reinterpret_cast<const uint32_t*>(st);
     uint2* ent = ents[wave] + P3_STEP;                // opener j at ent[j]; ent[-1 .. -P3_STEP]: end records
-    uint32_t* acc_mine = colacc[wave][lane];
+    uint32_t (*const cacc)[64] = colacc[wave];           // cacc[word][column]
     int32_t cnt[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) cnt[k] = 0;
@@ -351,8 +358,8 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                 }
             }
         }
-        *reinterpret_cast<uint4*>(acc_mine) = uint4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<uint4*>(acc_mine + 4) = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cacc[k][lane] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                         uint32_t w = cw[R];
                         w |= (R == 0) ? hm : 0u;
                         w |= R < trp ? 0u : (R == trp ? tm : 0xffffffffu);
-                        w ^= (w >> 2) & 0x08080808u;                       // the table's row permutation, four bytes at once
+                        w ^= (w >> 2) & 0x0c0c0c0cu;                       // the table's row permutation, four bytes at once
                         const uint4 r0 = tab[w & 0xffu], r1 = tab[(w >> 8) & 0xffu], r2 = tab[(w >> 16) & 0xffu], r3 = tab[w >> 24];
                         ax += r0.x + r1.x; ax += r2.x + r3.x;
                         ay += r0.y + r1.y; ay += r2.y + r3.y;
@@ -439,7 +446,11 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                 for (int r0i = 0; r0i < T; r0i += 64) {
                     const int j = r0i + lane;
                     const bool valid = j < T;
-                    const uint2 e0 = ent[valid ? j : 0];                           // (T >= 1: slot 0 is an opener)
+                    uint2 e0 = ent[valid ? j : 0];
+                    // lanes beyond the last opener take a record of their own (staged position 0, no bytes: every read below stays inside
+                    // the stage buffer, every result is discarded behind `valid`); from the second trip on slot 0 holds a COMPACTED record
+                    // whose length bits would otherwise be read as position bits
+                    if (!valid) e0 = uint2{0u, 0u};
                     const int p = e0.x & 0xffff, owner = (int)(e0.x >> 16), lend_o = (int)e0.y;
                     const int b = st[p];
                     const int w0 = (p + 1) >> 2;
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                     const uint32_t al = __builtin_amdgcn_alignbyte(whi, wlo, L);                      // the first four skipped bytes
                     const uint32_t keep = nskip >= 4 ? 0xffffffffu : ((1u << (8 * (nskip & 3))) - 1u);
                     const uint32_t alm = al | ~keep;                                                  // bytes beyond the allele: 0xff (a zero row)
-                    const uint32_t alp = alm ^ ((alm >> 2) & 0x08080808u);
+                    const uint32_t alp = alm ^ ((alm >> 2) & 0x0c0c0c0cu);
                     const uint4 r0 = tab[alp & 0xffu], r1 = tab[(alp >> 8) & 0xffu], r2 = tab[(alp >> 16) & 0xffu], r3 = tab[alp >> 24];
                     const bool counted = valid && !caret && adv <= MAX_INDEL;                         // (then nskip <= 60)
                     uint32_t nx = r0.x + r1.x, ny = r0.y + r1.y, nz = r0.z + r1.z;
@@ -468,14 +479,13 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                     if (valid) {
                         for (int k = q + 4; k < q + nskip; ++k) {                                     // longer alleles (rare)
                             const uint32_t bk = st[k];
-                            const uint4 rr = tab[bk ^ ((bk >> 2) & 8u)];
+                            const uint4 rr = tab[bk ^ ((bk >> 2) & 12u)];
                             nx += rr.x; ny += rr.y; nz += rr.z; inner |= rr.w;
                         }
-                        uint32_t* oa = colacc[wave][owner];
-                        atomicAdd(oa + 0, nx); atomicAdd(oa + 1, ny);
-                        if (nz & 0xffffffu) atomicAdd(oa + 2, nz & 0xffffffu);
+                        atomicAdd(&cacc[0][owner], nx); atomicAdd(&cacc[1][owner], ny);
+                        if (nz & 0xffffffu) atomicAdd(&cacc[2][owner], nz & 0xffffffu);
                         // a flagged byte inside the bytes a construct consumes is not an opener (pass 1 cannot know): exact path
-                        if (mybad || inner) atomicOr(oa + 2, 0x80000000u);                            // (bit 31 of word 2)
+                        if (mybad || inner) atomicOr(&cacc[2][owner], 0x80000000u);                   // (bit 31 of word 2)
                     }
                     // the counted indels move to the front of the list, order kept (slot c <= j: every slot of this trip has been read)
                     const unsigned long long cm = __ballot(counted);
@@ -523,9 +533,9 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                     }
                     if (j < n_cnt) {
                         const int kind = (int)((me.x >> 19) & 1u) * 2 + (int)(((me.x >> 20) & 1u) ^ 1u);
-                        uint32_t* oa = colacc[wave][me.x >> 25];
-                        atomicAdd(oa + 3, 1u << (8 * kind));
-                        atomicMax(oa + 4 + kind, (uint32_t)same);
+                        const int col = (int)(me.x >> 25);
+                        atomicAdd(&cacc[3][col], 1u << (8 * kind));
+                        atomicMax(&cacc[4 + kind][col], (uint32_t)same);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -534,7 +544,8 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(acc_mine), a1 = *reinterpret_cast<const uint4*>(acc_mine + 4);
+                const uint4 a0 = uint4{cacc[0][lane], cacc[1][lane], cacc[2][lane], cacc[3][lane]};
+                const uint4 a1 = uint4{cacc[4][lane], cacc[5][lane], cacc[6][lane], cacc[7][lane]};
                 ax -= a0.x; ay -= a0.y; az -= a0.z;
                 if (act) {
                     cnt[0] = ax & 0xff; cnt[1] = (ax >> 8) & 0xff; cnt[2] = (ax >> 16) & 0xff; cnt[3] = ax >> 24;
