@@ -52,11 +52,12 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--windows", type=int, default=N_POOL, help="windows resident per GPU (BASELINE configs[1]: 1M)")
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60"],
+    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60", "e2e"],
                     help="pileup = BASELINE configs[1] (the metric's configuration); haplotype = configs[2]: haplotype features + "
                          "HaplotypeModel fwd (+ the legacy crnn.py CatModel fwd) on 150 k G3 sites; two-stage = configs[3]: stage 2 + stage 5 "
                          "on a chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0; deep60 = configs[4]: "
-                         "60x columns + D = 180 read planes + fp16-split conv weights")
+                         "60x columns + D = 180 read planes + fp16-split conv weights; e2e = a labelled text-to-VCF measurement: samtools-mpileup text of a synthetic contig "
+                         "on the page cache -> host parse beside H2D + encode + forward -> pileup.vcf (tools/e2e_bench.py)")
     ap.add_argument("--encode-group", type=int, default=32, help="batches encoded per column-encode launch (on the encode stream, into a "
                     "ring of count buffers; the kernel is twice as efficient per byte at >= 1 M columns)")
     ap.add_argument("--hap-sites", type=int, default=0, help="haplotype / deep60 workloads: sites resident per job (0 = the workload's default)")
@@ -213,6 +214,9 @@ def main():
     if args.workload == "two-stage":
         from tools.two_stage_bench import run as run_two_stage
         sys.exit(run_two_stage(args, rank, world, local_rank))
+    if args.workload == "e2e":
+        from tools.e2e_bench import run as run_e2e
+        sys.exit(run_e2e(args, rank, world, local_rank))
     if args.workload in ("haplotype", "deep60"):
         from tools.hap_bench import run as run_hap
         sys.exit(run_hap(args, rank, world, local_rank, deep60=args.workload == "deep60"))

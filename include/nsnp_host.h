@@ -42,6 +42,13 @@ int64_t nsnp_synth_columns(uint64_t seed, int64_t M, double coverage, int max_de
 int nsnp_synth_hap_planes(uint64_t seed, int64_t N, double coverage, int D, int L,
                           int32_t* seq, int32_t* bq, int32_t* mq, int32_t* hap, int32_t* ref_row);
 
+/* Columns -> samtools-mpileup text, one line per column: contig \t pos \t N \t depth \t bases \t 'I' x max(depth, 1) \n (the input
+ * format of the reference's stage 1: make_predict_data.sh:117 runs samtools mpileup without -f, so the reference column is N).
+ * Returns the bytes written, or -(needed + 16) when cap is too small / out NULL.  Used to put whole synthetic contigs on disk for
+ * the text-to-VCF measurement. */
+int64_t nsnp_columns_to_mpileup_text(const char* contig, int64_t M, const int64_t* pos, const uint8_t* bases, const int64_t* col_off,
+                                     char* out, int64_t cap);
+
 /* ---- mpileup text -> column arrays ---------------------------------------------------- */
 /* Parses samtools-mpileup text (columns 0,1,4 are used, as
  * make_candidate_snp_tensor/main.cpp:162-172 does; tokens are maximal runs of non-tab bytes,
@@ -50,6 +57,12 @@ int nsnp_synth_hap_planes(uint64_t seed, int64_t N, double coverage, int D, int 
  * belong to one contig (the per-chromosome files DNA_ExtractChrPileupData writes). */
 int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int64_t* n_bytes,
                        int64_t* pos, int64_t* col_off, uint8_t* bases);
+
+/* The same parse in ONE call for callers that bring their own (e.g. pinned) buffers: every line is tokenised once.  cap_cols /
+ * cap_bytes are the capacities of pos, col_off (cap_cols + 1 entries) and bases; text_len / 8 columns and text_len bytes always
+ * suffice.  NSNP_HOST_ERANGE when a capacity is too small (n_cols / n_bytes then hold what is needed). */
+int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
+                            int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases);
 
 /* ---- FASTA (+.fai) -------------------------------------------------------------------- */
 /* Loads one contig of a FASTA file into seq (capacity cap).  Uses the .fai when present

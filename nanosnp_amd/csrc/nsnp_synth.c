@@ -192,3 +192,54 @@ int nsnp_synth_hap_planes(uint64_t seed, int64_t N, double coverage, int D, int 
     }
     return 0;
 }
+
+/* ---- columns -> samtools-mpileup text (the input format of the reference's stage 1, make_predict_data.sh:117) ----------------------
+ * One line per column: contig \t pos \t N \t depth \t bases \t 'I' x max(depth, 1) \n, depth = the reads of the column (bytes of
+ * "ACGTNacgtn*#").  Two passes over 1024-column chunks (sizes, then text), OpenMP over the chunks.  Returns the bytes written, or
+ * -(needed + 16) when cap is too small / out NULL. */
+static int dec_len(int64_t v) { int n = 1; while (v >= 10) { v /= 10; ++n; } return n; }
+static char* put_dec(char* p, int64_t v) { char t[24]; int n = 0; do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v); while (n) *p++ = t[--n]; return p; }
+
+int64_t nsnp_columns_to_mpileup_text(const char* contig, int64_t M, const int64_t* pos, const uint8_t* bases, const int64_t* col_off,
+                                     char* out, int64_t cap)
+{
+    if (!contig || M < 0 || !pos || !bases || !col_off) return NSNP_HOST_EINVAL;
+    const int64_t n_chunk = (M + CHUNK - 1) / CHUNK;
+    int64_t* cb = (int64_t*)calloc((size_t)n_chunk + 1, sizeof(int64_t));
+    if (!cb) return NSNP_HOST_ENOMEM;
+    const size_t ln = strlen(contig);
+    uint8_t is_read[256];
+    memset(is_read, 0, sizeof is_read);
+    for (const char* s = "ACGTNacgtn*#"; *s; ++s) is_read[(unsigned char)*s] = 1;
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t ch = 0; ch < n_chunk; ++ch) {
+        const int64_t c0 = ch * CHUNK, c1 = (c0 + CHUNK < M) ? c0 + CHUNK : M;
+        int64_t n = 0;
+        for (int64_t c = c0; c < c1; ++c) {
+            int64_t d = 0;
+            for (int64_t i = col_off[c]; i < col_off[c + 1]; ++i) d += is_read[bases[i]];
+            n += (int64_t)ln + 1 + dec_len(pos[c]) + 3 + dec_len(d) + 1 + (col_off[c + 1] - col_off[c]) + 1 + (d > 1 ? d : 1) + 1;
+        }
+        cb[ch] = n;
+    }
+    int64_t total = 0;
+    for (int64_t ch = 0; ch < n_chunk; ++ch) { const int64_t n = cb[ch]; cb[ch] = total; total += n; }
+    if (!out || cap < total) { free(cb); return -(total + 16); }
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t ch = 0; ch < n_chunk; ++ch) {
+        const int64_t c0 = ch * CHUNK, c1 = (c0 + CHUNK < M) ? c0 + CHUNK : M;
+        char* p = out + cb[ch];
+        for (int64_t c = c0; c < c1; ++c) {
+            int64_t d = 0;
+            for (int64_t i = col_off[c]; i < col_off[c + 1]; ++i) d += is_read[bases[i]];
+            memcpy(p, contig, ln); p += ln; *p++ = '\t';
+            p = put_dec(p, pos[c]); *p++ = '\t'; *p++ = 'N'; *p++ = '\t';
+            p = put_dec(p, d); *p++ = '\t';
+            memcpy(p, bases + col_off[c], (size_t)(col_off[c + 1] - col_off[c])); p += col_off[c + 1] - col_off[c]; *p++ = '\t';
+            const int64_t nq = d > 1 ? d : 1;
+            memset(p, 'I', (size_t)nq); p += nq; *p++ = '\n';
+        }
+    }
+    free(cb);
+    return total;
+}

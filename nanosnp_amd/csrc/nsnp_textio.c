@@ -120,6 +120,94 @@ int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int6
     return 0;
 }
 
+/* Single-call form for callers that bring their own (e.g. pinned) buffers: every line is tokenised ONCE - each thread records
+ * (position, column-5 token) of the lines of its chunk in a growing list - then the lists are laid end to end and the tokens
+ * copied.  cap_cols / cap_bytes: capacities of pos / col_off (cap_cols + 1) / bases; text_len / 8 columns and text_len bytes
+ * always suffice.  NSNP_HOST_ERANGE when a capacity is too small (n_cols / n_bytes then hold what is needed). */
+typedef struct { int64_t pos; const char* tok; int64_t len; } col_rec;
+
+int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
+                            int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases)
+{
+    if (!text || text_len < 0 || !n_cols || !n_bytes || !pos || !col_off || !bases) return NSNP_HOST_EINVAL;
+    int T = 1;
+#ifdef _OPENMP
+    T = omp_get_max_threads();
+#endif
+    if ((int64_t)T > text_len / (1 << 20)) T = (int)(text_len / (1 << 20));
+    if (T < 1) T = 1;
+    if (T > 1024) T = 1024;
+    const char* cut[1025];
+    cut[0] = text; cut[T] = text + text_len;
+    for (int c = 1; c < T; ++c) {
+        const char* g = text + text_len / T * c;
+        if (g < cut[c - 1]) g = cut[c - 1];
+        const char* nl = memchr(g, '\n', (size_t)(text + text_len - g));
+        cut[c] = nl ? nl + 1 : text + text_len;
+    }
+    col_rec* recs[1024];
+    int64_t cm[1025], cb[1025];
+    int err = 0;
+    #pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int c = 0; c < T; ++c) {
+        int64_t cap = (cut[c + 1] - cut[c]) / 64 + 1024, m = 0, nb = 0;
+        col_rec* r = (col_rec*)malloc((size_t)cap * sizeof(col_rec));
+        const char* p = cut[c]; const char* end = cut[c + 1];
+        int bad = r == NULL;
+        while (!bad && p < end) {
+            const char* le = memchr(p, '\n', (size_t)(end - p));
+            const char* next = le ? le + 1 : end;
+            if (!le) le = end;
+            if (le > p && le[-1] == '\r') --le;
+            if (le > p) {
+                const char* q = p; const char* te;
+                const char* t0 = next_tok(&q, le, &te);
+                const char* t1 = t0 ? next_tok(&q, le, &te) : NULL;
+                const char* t1e = te;
+                const char* t2 = t1 ? next_tok(&q, le, &te) : NULL;
+                const char* t3 = t2 ? next_tok(&q, le, &te) : NULL;
+                const char* t4 = t3 ? next_tok(&q, le, &te) : NULL;
+                if (!t4) { bad = 2; break; }
+                if (m == cap) {
+                    cap *= 2;
+                    col_rec* r2 = (col_rec*)realloc(r, (size_t)cap * sizeof(col_rec));
+                    if (!r2) { bad = 1; break; }
+                    r = r2;
+                }
+                r[m].pos = parse_i64(t1, t1e); r[m].tok = t4; r[m].len = te - t4;
+                nb += te - t4; ++m;
+            }
+            p = next;
+        }
+        recs[c] = r; cm[c] = m; cb[c] = nb;
+        if (bad) {
+            #pragma omp atomic write
+            err = bad;
+        }
+    }
+    int64_t m = 0, nb = 0;
+    for (int c = 0; c < T; ++c) { const int64_t a = cm[c], b = cb[c]; cm[c] = m; cb[c] = nb; m += a; nb += b; }
+    *n_cols = m; *n_bytes = nb;
+    int rc = err == 2 ? NSNP_HOST_EFORMAT : (err ? NSNP_HOST_ENOMEM : 0);
+    if (!rc && (m > cap_cols || nb > cap_bytes)) rc = NSNP_HOST_ERANGE;
+    if (!rc) {
+        #pragma omp parallel for num_threads(T) schedule(static, 1)
+        for (int c = 0; c < T; ++c) {
+            const int64_t m1 = (c + 1 < T ? cm[c + 1] : m) - cm[c];
+            int64_t o = cb[c];
+            const col_rec* r = recs[c];
+            for (int64_t i = 0; i < m1; ++i) {
+                pos[cm[c] + i] = r[i].pos; col_off[cm[c] + i] = o;
+                memcpy(bases + o, r[i].tok, (size_t)r[i].len);
+                o += r[i].len;
+            }
+        }
+        col_off[m] = nb;
+    }
+    for (int c = 0; c < T; ++c) free(recs[c]);
+    return rc;
+}
+
 int64_t nsnp_fasta_load_contig(const char* fasta_path, const char* contig, uint8_t* seq, int64_t cap)
 {
     if (!fasta_path || !contig) return NSNP_HOST_EINVAL;

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libnanosnp_host.so")
 
 NSNP_EINVAL = -1
+NSNP_ERANGE = -5
 _ERR = {-1: "invalid argument", -2: "out of memory", -3: "I/O error", -4: "malformed input",
         -5: "buffer too small"}
 
@@ -37,7 +38,7 @@ def _load():
     lib.nsnp_synth_hap_planes.argtypes = [C.c_uint64, C.c_int64, C.c_double, C.c_int, C.c_int,
                                           p, p, p, p, p]
     lib.nsnp_mpileup_parse.restype = C.c_int
-    lib.nsnp_mpileup_parse.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_int64),
+    lib.nsnp_mpileup_parse.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64), p, p, p]
     lib.nsnp_fasta_load_contig.restype = C.c_int64
     lib.nsnp_fasta_load_contig.argtypes = [C.c_char_p, C.c_char_p, p, C.c_int64]
@@ -79,6 +80,19 @@ class Columns:
 
     def column(self, c):
         return self.bases[self.col_off[c]:self.col_off[c + 1]].tobytes()
+
+    def mpileup_text_native(self, contig="chrS"):
+        """the same text as mpileup_text(), written by libnanosnp_host.so (OpenMP; whole synthetic contigs for the text-to-VCF bench)"""
+        l = lib()
+        args = (contig.encode(), self.n_cols, _ptr(np.ascontiguousarray(self.pos, np.int64)), _ptr(self.bases), _ptr(self.col_off))
+        l.nsnp_columns_to_mpileup_text.restype = C.c_int64
+        l.nsnp_columns_to_mpileup_text.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        need = -int(l.nsnp_columns_to_mpileup_text(*args, None, 0)) - 16
+        if need < 0:
+            _check(NSNP_EINVAL, "nsnp_columns_to_mpileup_text")
+        buf = np.empty(max(need, 1), np.uint8)
+        n = _check(l.nsnp_columns_to_mpileup_text(*args, _ptr(buf), need), "nsnp_columns_to_mpileup_text")
+        return buf[:n]
 
     def mpileup_text(self, contig="chrS"):
         """samtools-mpileup text of these columns (no -f: the ref column is 'N',
@@ -134,15 +148,42 @@ def synth_hap_planes(seed, n_sites, coverage=30.0, depth=None, length=33):
 def mpileup_parse(text: bytes):
     """mpileup text of one contig -> (pos int64[M], col_off int64[M+1], bases uint8[...])."""
     n_cols, n_bytes = C.c_int64(0), C.c_int64(0)
-    _check(lib().nsnp_mpileup_parse(text, len(text), C.byref(n_cols), C.byref(n_bytes),
+    text = bytes(text)
+    tp = C.cast(C.c_char_p(text), C.c_void_p)
+    _check(lib().nsnp_mpileup_parse(tp, len(text), C.byref(n_cols), C.byref(n_bytes),
                                     None, None, None), "nsnp_mpileup_parse")
     M, B = n_cols.value, n_bytes.value
     pos = np.empty(M, np.int64)
     col_off = np.empty(M + 1, np.int64)
     bases = np.empty(max(B, 1), np.uint8)
-    _check(lib().nsnp_mpileup_parse(text, len(text), C.byref(n_cols), C.byref(n_bytes),
+    _check(lib().nsnp_mpileup_parse(tp, len(text), C.byref(n_cols), C.byref(n_bytes),
                                     _ptr(pos), _ptr(col_off), _ptr(bases)), "nsnp_mpileup_parse")
     return pos, col_off, bases[:B]
+
+
+def mpileup_parse_range(buf, lo, hi, out=None):
+    """The lines of buf[lo:hi] (any buffer: bytes, mmap, numpy uint8; lo / hi on line boundaries) -> (pos, col_off, bases) without
+    copying the text, every line tokenised once (nsnp_mpileup_parse_into).  out = (pos, col_off, bases) numpy arrays to fill (e.g.
+    views of pinned host tensors); the returned arrays are views of their first M / M + 1 / B elements.  Without `out` the arrays
+    are allocated at the always-sufficient bounds (hi - lo) / 8 columns and hi - lo bytes and trimmed."""
+    a = np.frombuffer(buf, np.uint8) if not isinstance(buf, np.ndarray) else buf
+    n = int(hi) - int(lo)
+    if n <= 0:
+        return np.empty(0, np.int64), np.zeros(1, np.int64), np.empty(0, np.uint8)
+    fn = lib().nsnp_mpileup_parse_into
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]
+    if out is None:
+        out = (np.empty(n // 8 + 2, np.int64), np.empty(n // 8 + 3, np.int64), np.empty(n, np.uint8))
+    pos, col_off, bases = out
+    n_cols, n_bytes = C.c_int64(0), C.c_int64(0)
+    rc = fn(C.c_void_p(a.ctypes.data + int(lo)), n, min(pos.size, col_off.size - 1), bases.size, C.byref(n_cols), C.byref(n_bytes),
+            _ptr(pos), _ptr(col_off), _ptr(bases))
+    if rc == NSNP_ERANGE:
+        raise HostError(f"mpileup_parse_range: output buffers too small ({n_cols.value} columns, {n_bytes.value} bytes needed)")
+    _check(rc, "nsnp_mpileup_parse_into")
+    M, B = n_cols.value, n_bytes.value
+    return pos[:M], col_off[:M + 1], bases[:B]
 
 
 def fasta_load_contig(path, contig):

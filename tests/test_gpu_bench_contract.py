@@ -129,6 +129,18 @@ def test_deep60_workload_line():
     assert p["ok"] and p["haplotype"]["ok"] and p["pileup_60x"]["ok"] and p["pileup_60x"]["encode_bit_exact"] and p["cat_f16x3"]["ok"]
 
 
+def test_e2e_text_to_vcf_line():
+    """bench.py --workload e2e (a labelled measurement, never the headline): mpileup text on the page cache -> chunked, double-buffered
+    parse / H2D / encode / forward -> VCF; per-stage busy times, the bounding stage, parity against the one-chunk run"""
+    env = dict(os.environ, NSNP_E2E_COLS="600000", NSNP_E2E_CHUNK_MB="8")
+    d = _run("--workload", "e2e", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1.5", env=env)
+    assert d["scaling"] == "strong" and d["unit"] == "sites/s" and d["config"]["columns"] == 600000 and "NOT the headline" in d["config"]["workload"]
+    assert d["parity_sample"]["ok"] and d["parity_sample"]["sites"] == d["config"]["candidate_sites"] > 5000
+    assert d["value"] > 1e4 and d["columns_per_s"] > 1e6 and abs(d["value"] - d["config"]["candidate_sites"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert len(d["stage_busy_s_per_step"]) == 4 and d["bound_by"] in d["stage_busy_s_per_step"] and d["cpu_baseline"]["value"] > 0
+    assert d["config"]["text_bytes"] // d["config"]["chunk_bytes"] >= 5          # several chunks in flight
+
+
 @pytest.mark.parametrize("workload", ["pileup", "two-stage", "haplotype"])
 def test_two_ranks_through_the_launcher_on_one_gpu(workload):
     """`bench.py --gpus 2` end to end on the one-GPU box: the parent starts the ranks, both run the real kernels on GPU 0, the

@@ -95,3 +95,31 @@ def test_mpileup_to_vcf_pipeline(tmp_path, pileup_weights):
             continue
         assert abs(float(gf[5]) - float(wf[5])) <= 0.0101
     assert diff <= 3
+
+
+def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_weights):
+    """pipeline.call_contig works the text off in chunks of whole lines (parse of chunk k + 1 on the host beside the device work of
+    chunk k, 16 lines of halo re-parsed): the VCF is byte-identical whatever the chunk size - one chunk, a few, or chunks shorter
+    than a window - on a contig with position gaps and lower-case / N reference bases (encode_g1) and on a 40 k-column G1 contig"""
+    import gzip
+    from nanosnp_amd import host
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_contig
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    text = gzip.open(golden("encode_g1.mpileup.gz")).read()
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(gzip.open(golden("encode_g1.fa.gz")).read())
+    seq = host.fasta_load_contig(str(fa), "chrS")
+    ref_rows, n_sites, n_rows = call_contig(m, text, "chrS", seq, chunk_bytes=1 << 30)
+    assert n_sites > 50 and n_rows > 0
+    for cb in (100_000, 20_000, 3_000, 700):
+        st = {}
+        rows, ns, nr = call_contig(m, text, "chrS", seq, chunk_bytes=cb, stats=st)
+        assert (ns, nr) == (n_sites, n_rows) and rows == ref_rows, cb
+        assert st["chunks"] >= len(text) // cb and st["columns"] == text.count(b"\n") and st["sites"] == n_sites
+    cols = host.synth_columns(20261111, 40_000, coverage=30, het_rate=0.03)
+    big = cols.mpileup_text_native("chrB")
+    seqb = cols.ref.copy()
+    want = call_contig(m, big, "chrB", seqb, chunk_bytes=1 << 30)
+    got = call_contig(m, big, "chrB", seqb, chunk_bytes=256 << 10)
+    assert got == want and want[1] > 500

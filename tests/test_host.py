@@ -103,3 +103,39 @@ def test_haplotype_ref_rows_follow_the_reference_quirks():
     groups = [[f"c1:{p}" for p in range(2, 24, 2)]]
     g = host.haplotype_ref_rows(refs, ["c1:12"], 11, position_lists=groups)
     assert g.shape == (1, 11) and g[0].tolist() == [base2int.get(seq.decode()[p - 1], 0) for p in range(2, 24, 2)]
+
+
+def test_line_cuts_and_halo_ranges_of_the_streamed_pipeline():
+    """nanosnp_amd.pipeline.line_cuts / halo_range: parts of whole lines that tile the text, halos of up to 16 whole lines that stop
+    at the ends of the text; the same on bytes and on a memory-mapped file"""
+    import mmap
+    import tempfile
+    from nanosnp_amd.pipeline import halo_range, line_cuts
+    cols = host.synth_columns(3, 500, coverage=12)
+    text = cols.mpileup_text_native("chr9").tobytes()
+    assert text == cols.mpileup_text("chr9")
+    starts = [0] + [i + 1 for i, ch in enumerate(text) if ch == 10]
+    with tempfile.TemporaryFile() as f:
+        f.write(text); f.flush()
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        for buf in (text, mm):
+            for parts in (1, 2, 3, 7, 64, 501):
+                cuts = line_cuts(buf, parts)
+                assert cuts[0] == 0 and cuts[-1] == len(text) and all(a <= b for a, b in zip(cuts, cuts[1:])) and all(c in starts for c in cuts)
+                for a, b in zip(cuts, cuts[1:]):
+                    if b <= a:
+                        continue
+                    a2, b2, n_lo, n_hi = halo_range(buf, a, b)
+                    ia, ib = starts.index(a), starts.index(b)
+                    assert n_lo == min(16, ia) and n_hi == min(16, len(starts) - 1 - ib)
+                    assert a2 == starts[ia - n_lo] and b2 == starts[ib + n_hi]
+                    pos, off, bases = host.mpileup_parse_range(buf, a2, b2)
+                    assert np.array_equal(pos, cols.pos[ia - n_lo:ib + n_hi])
+                    assert np.array_equal(bases, cols.bases[cols.col_off[ia - n_lo]:cols.col_off[ib + n_hi]])
+        mm.close()
+    # caller-supplied (pinned-style) buffers, and the too-small case
+    out = (np.empty(600, np.int64), np.empty(601, np.int64), np.empty(len(text), np.uint8))
+    pos, off, bases = host.mpileup_parse_range(text, 0, len(text), out=out)
+    assert np.array_equal(pos, cols.pos) and np.array_equal(off, cols.col_off) and np.array_equal(bases, cols.bases) and pos.base is out[0]
+    with pytest.raises(host.HostError):
+        host.mpileup_parse_range(text, 0, len(text), out=(np.empty(10, np.int64), np.empty(11, np.int64), np.empty(len(text), np.uint8)))

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py --workload e2e: mpileup TEXT to VCF, the path that replaces make_predict_data.sh:184-234 + PileupModel/predict.py:37-195
+(DNA_CreateCanSnpTensor -> DNA_CreatePredictData -> make_bin_predict_data.py -> predict.py and the four text / HDF5 files between
+them) - a labelled measurement, never the headline `value` of the repository (BASELINE's metric is quoted with inputs in HBM).
+
+    a synthetic contig of NSNP_E2E_COLS columns (default 6,000,000: generator G1, 30x) written as samtools-mpileup text to a file that
+    sits in the page cache -> memory-mapped -> nanosnp_amd.pipeline.call_contig: chunks of whole lines, parse of chunk k + 1
+    (libnanosnp_host.so, OpenMP, into pinned buffers) beside H2D + column encode + site selection + PileupModel forward + argmax of
+    chunk k -> call rows gathered -> nsnp_vcf_format_batches -> pileup.vcf written.  One *step* = the whole contig.
+
+Under N ranks the TEXT is sharded by byte range (every rank parses only its lines) and the calls are gathered to rank 0 (strong
+scaling).  The line carries the per-stage busy times and names the stage that bounds the pipeline; parity = the VCF of the chunked
+run is byte-identical to the one-chunk run of the same text."""
+from __future__ import annotations
+
+import json
+import mmap
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+N_COLS = 6_000_000
+
+
+def run(args, rank, world, local_rank):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if args.share_gpu:
+        if args.dist_backend != "gloo":
+            print("bench.py: --share-gpu needs --dist-backend gloo", file=sys.stderr)
+            return 2
+        local_rank = 0
+    elif torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
+        return 3
+    from nanosnp_amd import host
+    from nanosnp_amd.fixtures import load_pileup_weights
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_contig
+    from tools import bench_common as bc
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+    n_cols = int(os.environ.get("NSNP_E2E_COLS", N_COLS))
+    chunk = int(os.environ.get("NSNP_E2E_CHUNK_MB", 64)) << 20
+    weights = load_pileup_weights()
+    model = LSTMNetwork(device=local_rank).load_weight_list(weights)
+    # ---- the contig: G1 columns -> mpileup text on a file (page cache), memory-mapped by every rank ----
+    cols = host.synth_columns(20260900, n_cols, coverage=args.coverage, het_rate=0.03)
+    seq = cols.ref
+    path = os.path.join(tempfile.gettempdir(), f"nsnp_e2e_{n_cols}_{int(args.coverage)}.mpileup")
+    if rank == 0:
+        text_np = cols.mpileup_text_native("chr20s")
+        with open(path + ".tmp", "wb") as f:
+            f.write(memoryview(text_np))
+        os.replace(path + ".tmp", path)
+        del text_np
+    if world > 1:
+        dist.barrier()
+    f = open(path, "rb")
+    text = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    text_bytes = len(text)
+    W, K = max(1, args.warmup), max(1, args.steps)
+    out_path = os.path.join(tempfile.gettempdir(), f"nsnp_e2e_{rank}.vcf")
+
+    def one_pass(stats=None, cb=chunk):
+        rows_text, n_sites, n_rows = call_contig(model, text, "chr20s", seq, chunk_bytes=cb, stats=stats)
+        if rank == 0:
+            with open(out_path, "wb") as g:
+                g.write(host.vcf_header("chr20s\t%d\t8\t60\t61\n" % n_cols).encode())
+                g.write(rows_text)
+        return rows_text, n_sites, n_rows
+
+    for _ in range(W):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    stats = {}
+    t0 = time.perf_counter()
+    for _ in range(K):
+        rows_text, n_sites, n_rows = one_pass(stats)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+    exit_code = 0
+    if rank == 0:
+        # parity: the chunked run against the one-chunk run of the same text, byte for byte (outside the clock)
+        parity = None
+        if not args.no_parity_sample and world == 1:
+            whole, ns1, nr1 = call_contig(model, text, "chr20s", seq, chunk_bytes=1 << 40)
+            parity = {"ok": bool(whole == rows_text and ns1 == n_sites), "vcf_bytes": len(rows_text), "sites": n_sites,
+                      "what": "pileup.vcf rows of the chunked, double-buffered run byte-identical to the one-chunk run of the same text "
+                              "(nanosnp_amd.pipeline.call_contig; against the reference's own rows: tests/test_gpu_predict.py)"}
+        per = {k: stats.get(k, 0.0) / K for k in ("parse_s", "h2d_s", "gpu_s", "vcf_s")}
+        bound = max(per, key=per.get)
+        names = {"parse_s": "host parse (nsnp_mpileup_parse_into, OpenMP)", "h2d_s": "H2D copies", "gpu_s": "device: encode + select + forward + calls",
+                 "vcf_s": "D2H + VCF formatting (nsnp_vcf_format_batches)"}
+        cols_per_pass = stats.get("columns", 0) / K * (world if world > 1 else 1)
+        out = {
+            "metric": "candidate SNP sites/sec, mpileup text to VCF (text on the page cache, parse + H2D + encode + forward + VCF)",
+            "value": n_sites * K / dt, "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "text to VCF: a synthetic G1 contig of %d columns at %gx as samtools-mpileup text (%.0f MB, page cache) -> "
+                                   "chunks of %d MB: host parse beside H2D + column encode + site selection + PileupModel fwd (fp32) -> pileup.vcf; "
+                                   "NOT the headline configuration (BASELINE configs[1] has its inputs in HBM)" % (n_cols, args.coverage, text_bytes / 1e6, chunk >> 20),
+                       "columns": n_cols, "text_bytes": text_bytes, "chunk_bytes": chunk, "candidate_sites": n_sites, "vcf_rows": n_rows,
+                       "parallelism": f"text sharded by byte range x{world}, calls gathered to rank 0",
+                       "world_size_observed": dist.get_world_size() if world > 1 else 1,
+                       **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: not a scaling number"} if args.share_gpu else {})},
+            "columns_per_s": n_cols * K / dt, "text_MB_per_s": text_bytes * K / dt / 1e6,
+            "stage_busy_s_per_step": {names[k]: round(v, 4) for k, v in per.items()},
+            "stage_rates": {"parse_MB_per_s": text_bytes / world / max(per["parse_s"], 1e-9) / 1e6,
+                            "h2d_GB_per_s": (int(cols.col_off[-1]) + 16 * n_cols) / world / max(per["h2d_s"], 1e-9) / 1e9,
+                            "device_columns_per_s": n_cols / world / max(per["gpu_s"], 1e-9),
+                            "vcf_rows_per_s": n_rows / max(per["vcf_s"], 1e-9)},
+            "bound_by": names[bound],
+            "overlap": {"sum_of_stage_busy_s": round(sum(per.values()), 4), "wall_s_per_step": round(dt / K, 4),
+                        "note": "parse runs on a worker thread beside the device work of the previous chunk: wall < sum when they overlap"},
+            "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,
+            "cpu_baseline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cols, weights, args.cpu_seconds)
+        print(json.dumps(out))
+        if parity is not None and not parity["ok"]:
+            print("bench.py: parity_sample FAILED: " + json.dumps(parity), file=sys.stderr)
+            exit_code = 1
+    text.close(); f.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        for pth in (path, out_path):
+            try:
+                os.remove(pth)
+            except OSError:
+                pass
+    return exit_code
+
+
+def cpu_baseline(cols, weights, target_s):
+    """the oracle on a bounded prefix of the same contig: text parse is not part of it (the oracle starts from the column arrays): column
+    encode (one thread) + site selection + full-schedule forward of the selected windows (blocked, OpenMP)"""
+    import numpy as np
+    from oracle import oracle
+    from tools import bench_common as bc
+    cores = bc.usable_cores()
+
+    def run(m):
+        b1 = int(cols.col_off[m])
+        t0 = time.perf_counter()
+        counts, depth, flags = oracle.encode_columns(cols.bases[:b1], cols.col_off[:m + 1], cols.ref[:m])
+        centers = oracle.select_sites(cols.pos[:m], flags)
+        x = np.stack([counts[c - 16:c + 17] for c in centers]) if len(centers) else np.zeros((0, 33, 18), np.int32)
+        oracle.pileup_forward(weights, x, nthreads=cores, blocked=True)
+        return time.perf_counter() - t0, len(centers)
+
+    m0 = min(200_000, cols.n_cols)
+    t, n = run(m0)
+    m = int(min(cols.n_cols, max(m0, m0 * target_s / max(t, 1e-6))))
+    t, n = run(m)
+    return {"value": n / t, "unit": "sites/s", "cores": cores, "kind": "port",
+            "sample": f"the first {m} columns of the same contig as arrays (no text parse): column encode + site selection + full-schedule fp32 forward of "
+                      f"the {n} selected windows, OpenMP over {cores} threads ({t:.1f} s); oracle/liboracle.so",
+            "host_cpu": bc.host_cpu_name(), "logical_cpus": os.cpu_count()}
