@@ -33,6 +33,9 @@ class _MvFind:
     def __init__(self, mv):
         self.a = np.frombuffer(mv, np.uint8)
 
+    def __len__(self):
+        return int(self.a.size)
+
     def find(self, ch, lo, hi=None):
         hi = self.a.size if hi is None else hi
         step = 1 << 16
@@ -95,13 +98,14 @@ class _HostSet:
         self.h2d_done = None
 
 
-def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None):
+def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None, on_rows=None):
     """The device part of stages s1 + s2 over the lines of text[lo:hi], chunk by chunk: a worker thread parses chunk k + 1
     (libnanosnp_host.so, OpenMP, straight into pinned buffers) while this thread sends chunk k to the device and runs column encode
     -> site selection -> PileupModel forward + argmax / max on it.  Every chunk is parsed with 16 lines of halo on either side
     (re-parsed, not exchanged) and calls the sites centred in its own lines, so the result does not depend on where the cuts fall.
     Returns the call rows [n, 13] float64 (position, argmax / max of both heads, the eight coverage channels: all exact in float64)
-    as a device tensor in position order.  stats (a dict) receives per-stage busy times."""
+    as a device tensor in position order - or, with on_rows, hands every chunk's rows to that callback as soon as they are issued
+    (call_contig formats the VCF rows of complete batches meanwhile) and returns None.  stats (a dict) receives per-stage busy times."""
     import time
     from concurrent.futures import ThreadPoolExecutor
     import torch
@@ -169,13 +173,32 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
                     gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(counts, centers)
                     cov = counts[centers][:, COV_CHANNELS].to(torch.float64)              # predict.py:63
                     f64 = lambda t: t.to(torch.float64)[:, None]
-                    rows_all.append(torch.cat([f64(d_pos[centers]), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1))
-            ev[k][2].record(stream)
+                    rows_k = torch.cat([f64(d_pos[centers]), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1)
+                    ev[k][2].record(stream)
+                    if on_rows is not None:
+                        on_rows(rows_k)
+                    else:
+                        rows_all.append(rows_k)
+            if own <= 0 or not n_loc:
+                ev[k][2].record(stream)
     torch.cuda.synchronize(dev)
     for e0, e1, e2 in ev:
         st["h2d_s"] += e0.elapsed_time(e1) * 1e-3
         st["gpu_s"] += e1.elapsed_time(e2) * 1e-3
+    if on_rows is not None:
+        return None
     return torch.cat(rows_all) if rows_all else torch.zeros((0, 13), dtype=torch.float64, device=dev)
+
+
+def _format_rows(r, contig, chr_seq, batch_size, score_mode):
+    """call rows [n, 13] (host float64) -> (VCF text, rows written) of the reference's predict loop over consecutive batches"""
+    n = r.shape[0]
+    site_pos = r[:, 0].astype(np.int64)
+    site_ref = chr_seq[site_pos - 1] & 0xDF                                  # make_predict_data/main.cpp:91 upper-cases
+    # the VCF rows depend on the batch boundary: one native call formats every batch (OpenMP over the batches)
+    return host.vcf_format_batches(host.ContigTable([contig]), np.zeros(n, np.int32), site_pos, site_ref, r[:, 1].astype(np.uint8),
+                                   r[:, 2].astype(np.uint8), r[:, 3].astype(np.float32), r[:, 4].astype(np.float32),
+                                   r[:, 5:13].astype(np.float32), batch_size=batch_size, score_mode=score_mode)
 
 
 def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.12, min_coverage=6,
@@ -207,19 +230,14 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
             tdist.broadcast(n_tot, src=0)
             return b"", int(n_tot.item()), 0
         tdist.broadcast(torch.tensor([rows.shape[0]], dtype=torch.int64, device=backend_dev), src=0)
+    # (formatting the rows of finished chunks on a worker thread while later chunks are parsed was measured: parse and formatter are
+    # both OpenMP-parallel host work on the same cores - 24 + 34 ms per 6 M-column contig on 16 cores - and run slower side by side
+    # than one after the other: 162 against 75 ms per contig)
     n_sites = int(rows.shape[0])
     if n_sites == 0:
         return b"", 0, 0
     t0 = time.perf_counter()
-    r = rows.cpu().numpy()
-    site_pos = r[:, 0].astype(np.int64)
-    table = host.ContigTable([contig])
-    ids = np.zeros(n_sites, np.int32)
-    site_ref = chr_seq[site_pos - 1] & 0xDF                                  # make_predict_data/main.cpp:91 upper-cases
-    # the VCF rows depend on the batch boundary: one native call formats every batch (OpenMP over the batches)
-    text, n_rows = host.vcf_format_batches(table, ids, site_pos, site_ref, r[:, 1].astype(np.uint8), r[:, 2].astype(np.uint8),
-                                           r[:, 3].astype(np.float32), r[:, 4].astype(np.float32), r[:, 5:13].astype(np.float32),
-                                           batch_size=batch_size, score_mode=score_mode)
+    text, n_rows = _format_rows(rows.cpu().numpy(), contig, chr_seq, batch_size, score_mode)
     if stats is not None:
         stats["vcf_s"] = stats.get("vcf_s", 0.0) + time.perf_counter() - t0
         stats["sites"] = stats.get("sites", 0) + n_sites
