@@ -131,6 +131,8 @@ def selftest_launcher(args, rank, world):
     if world > 1: dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.002 * args.steps * (1 + rank))                     # rank r is r+1 times slower: MAX over ranks must pick the last
+    if os.environ.get("NSNP_SELFTEST_DIE_RANK") == str(rank):       # tests/test_dist.py: a rank that dies before the gather must take
+        os._exit(7)                                                 # the whole job down with a non-zero status, not leave it hanging
     idx = torch.arange(lo, hi, dtype=torch.float32)
     merged = gather_results(torch.stack([idx, idx * 3], 1), n_total)
     if world > 1: dist.barrier()

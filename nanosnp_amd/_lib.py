@@ -10,8 +10,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NANOSNP_HIP_LIB: development only (A/B builds of the same library from tools/ probes); the product always loads the in-tree build
-LIB_PATH = os.environ.get("NANOSNP_HIP_LIB") or os.path.join(_HERE, "libnanosnp_hip.so")
+# The product always loads the in-tree build.  A/B builds of the same library (tools/build_variant.sh) are loaded only when BOTH
+# NANOSNP_DEV_LIB_OVERRIDE=1 and NANOSNP_HIP_LIB=<path> are set: an environment variable alone cannot point the package at an
+# arbitrary shared object, and the override says so on stderr.
+_OVERRIDE = os.environ.get("NANOSNP_HIP_LIB") if os.environ.get("NANOSNP_DEV_LIB_OVERRIDE") == "1" else None
+LIB_PATH = _OVERRIDE or os.path.join(_HERE, "libnanosnp_hip.so")
 
 
 class NanoSNPError(RuntimeError):
@@ -82,6 +85,9 @@ def load():
     # resolves to it by soname.  Loading /opt/rocm's copy first would leave two HIP runtimes in one
     # process and every call from the second one fails.
     import torch  # noqa: F401
+    if _OVERRIDE:
+        import sys
+        print(f"nanosnp_amd: DEVELOPMENT OVERRIDE - loading {LIB_PATH} instead of the in-tree library", file=sys.stderr)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch

@@ -44,6 +44,12 @@ def _rooted_gather(local, counts, root, group):
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     assert local.shape[0] == counts[rank], (tuple(local.shape), counts[rank])
     local = local.contiguous()
+    # A rank with an empty block posts nothing below.  On the NCCL / RCCL backend batch_isend_irecv must not be the FIRST
+    # operation of a group on only a subset of its ranks (the communicator is created lazily by a call every rank makes), so
+    # when some rank sits out, every rank - they all hold the same `counts` - first meets in one tiny all_reduce.
+    if any(c == 0 for r, c in enumerate(counts) if r != root):
+        token = torch.zeros(1, dtype=torch.int32, device=local.device)
+        dist.all_reduce(token, group=group)
     ops, out = [], None
     if rank == root:
         out = torch.empty((sum(counts),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

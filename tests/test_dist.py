@@ -146,6 +146,53 @@ def test_bench_gpus2_spawns_two_ranks_and_relays_one_line():
     assert d["omp_num_threads"] == str(max(1, d["usable_cores"] // 2))
 
 
+def test_a_rank_that_dies_before_the_gather_fails_the_whole_job_closed():
+    """one rank exits before the rooted gather - the launcher's parent must come back NON-ZERO, without a
+    result line and without hanging on the surviving rank's receive (torch.distributed.run tears the survivors down)"""
+    import time
+    t0 = time.time()
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-launcher", env={"NSNP_SELFTEST_DIE_RANK": "1"})
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "failed" in out.stderr and time.time() - t0 < 240
+    # the root dying is no different
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-launcher", env={"NSNP_SELFTEST_DIE_RANK": "0"})
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _empty_shard_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from nanosnp_amd.dist import gather_results
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # n_total < world: rank 2 owns nothing, and gather_results is the FIRST operation on the group (ADVICE round 3)
+        from nanosnp_amd.dist import shard_range
+        lo, hi = shard_range(2, rank, world)
+        local = torch.arange(lo, hi, dtype=torch.float32)[:, None]
+        out = gather_results(local, 2)
+        q.put(out.numpy() if rank == 0 else None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_results_with_an_empty_shard_as_the_first_call_on_the_group():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_shard_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    merged = next(o for o in outs if o is not None)
+    assert merged.shape == (2, 1) and merged[:, 0].tolist() == [0.0, 1.0]
+
+
 def test_bench_never_reports_fewer_ranks_than_asked_for():
     # a torchrun environment that disagrees with --gpus is an error, not a silent n_gpus: 1
     out = _bench("--gpus", "4", "--selftest-launcher", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME [extra hipcc flags...] -> build_tmp/libs/libnanosnp_hip_NAME.so  (A/B builds; select with NANOSNP_HIP_LIB)
+# tools/build_variant.sh NAME [extra hipcc flags...] -> build_tmp/libs/libnanosnp_hip_NAME.so  (A/B builds; select with NANOSNP_DEV_LIB_OVERRIDE=1 NANOSNP_HIP_LIB)
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift

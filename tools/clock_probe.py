@@ -2,7 +2,7 @@
 """Shader clock the hot kernels actually run at (diagnostic build only):
 
     tools/build_variant.sh clock -DNSNP_DEV_CLOCK
-    NANOSNP_HIP_LIB=build_tmp/libs/libnanosnp_hip_clock.so python tools/clock_probe.py
+    NANOSNP_DEV_LIB_OVERRIDE=1 NANOSNP_HIP_LIB=build_tmp/libs/libnanosnp_hip_clock.so python tools/clock_probe.py
 
 Runs the bench's pileup stage (32 streams, batches of 4096 windows), the same kernels alone, and the HaplotypeModel stage, each for
 about two seconds, and prints clock = 0.1 GHz x shader cycles / 100 MHz ticks summed over the workgroups of each kernel, the cycles a workgroup lives
@@ -19,7 +19,7 @@ from tools.hap_bench import HapStage
 
 lib = _lib.load()
 if not hasattr(lib, "nsnp_devclk_read_pileup"):
-    sys.exit("clock_probe.py: the loaded library is not a -DNSNP_DEV_CLOCK build (set NANOSNP_HIP_LIB)")
+    sys.exit("clock_probe.py: the loaded library is not a -DNSNP_DEV_CLOCK build (set NANOSNP_DEV_LIB_OVERRIDE=1 NANOSNP_HIP_LIB=...)")
 NAMES = {("pileup", 0): "k_pileup_l0_rs32", ("pileup", 1): "k_pileup_l1_rs4", ("hap", 2): "k_hap_gemm"}
 
 
