@@ -96,8 +96,12 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "hap_precision"           0 fp32 (default) | 2 bf16x3 | 1 f16x3      HaplotypeModel forward
  *   "cat_precision"           0 fp32 (default) | 2 bf16x3 | 1 f16x3      legacy CatModel forward
  *   "hap_pass_sites"          128..131072, multiple of 128     sites per internal pass of the HaplotypeModel forward (default 16384;
- *                                                              workspace ~195 KB per site, (re)allocated synchronously by this call
- *                                                              and by nsnp_hap_load_weights, never by nsnp_hap_forward)
+ *                                                              workspace ~195 KB per site = 3.2 GB per context at the default,
+ *                                                              (re)allocated synchronously by this call and by nsnp_hap_load_weights,
+ *                                                              never by nsnp_hap_forward; callers with small batches or many contexts
+ *                                                              set a smaller pass BEFORE loading the weights.  When the new size cannot
+ *                                                              be allocated the call returns NSNP_ENOMEM and the previous pass size and
+ *                                                              workspace stay in force)
  *   "recurrence_waves"        0 auto | 1/2/4/8                 waves per workgroup of the LDS-image recurrence kernels
  *   "l0_register_stationary"  1 (default) | 0                 f16x3 layer 0: weights in VGPRs + LDS exchange of h, or LDS images
  *   "l0_site_groups"          0 auto | 1/2/4                   16-site groups per workgroup of that kernel

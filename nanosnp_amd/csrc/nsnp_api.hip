@@ -102,8 +102,13 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     }
     if (strcmp(name, "hap_pass_sites") == 0) {
         if (value < 128 || value > 131072 || value % 128) return NSNP_EINVAL;
+        // synchronous re-allocation when the weights are already loaded; when the new workspace cannot be had, the previous pass size and
+        // its workspace come back (the context keeps working at the old size instead of failing every later forward with ENOMEM)
+        const int64_t old = ctx->hap_chunk;
         ctx->hap_chunk = value;
-        return nsnp_hap_reserve(ctx);                   // synchronous re-allocation when the weights are already loaded
+        const int rc = nsnp_hap_reserve(ctx);
+        if (rc) { ctx->hap_chunk = old; (void)nsnp_hap_reserve(ctx); }
+        return rc;
     }
     if (strcmp(name, "pileup_precision") == 0) {
         if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;

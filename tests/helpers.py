@@ -89,3 +89,21 @@ def synth_groups(seed=78, centres=(260, 300, 455, 610), ctg="c"):
         right = sorted(rng.choice(np.arange(c + 2, c + 120), 5, replace=False).tolist())
         groups.append([(ctg, int(p)) for p in left] + [(ctg, int(c))] + [(ctg, int(p)) for p in right])
     return groups
+
+
+# ---- a QUAL / GQ that differs from the reference's row must be explained by a probability difference of at most dp ------------------
+def qual_reachable(q_ref, p_zy, p_gt=None, refcall=False, score_mode=1, dp=1e-6):
+    """PileupModel/predict.py:86-88: QUAL = calculate_score(zy_prob) on PASS rows, min(calculate_score(gt_prob), calculate_score(zy_prob)) on
+    RefCall rows; calculate_score is monotone in the probability.  True when the reference's QUAL q_ref lies between the QUALs of
+    probabilities dp below and dp above the GPU's own: the row differs only because the float32 probability differs by <= dp (the
+    two sides then sit on either side of a rounding boundary of the two-decimal QUAL)."""
+    from nanosnp_amd import host
+
+    def q(pz, pg):
+        s = host.calculate_score(np.float32(min(max(pz, 0.0), 1.0)), score_mode)[0]
+        if refcall and pg is not None:
+            s = min(s, host.calculate_score(np.float32(min(max(pg, 0.0), 1.0)), score_mode)[0])
+        return s
+    lo = q(float(p_zy) - dp, None if p_gt is None else float(p_gt) - dp)
+    hi = q(float(p_zy) + dp, None if p_gt is None else float(p_gt) + dp)
+    return lo - 1e-9 <= float(q_ref) <= hi + 1e-9

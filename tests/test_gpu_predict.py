@@ -23,17 +23,27 @@ def test_pileup_vcf_end_to_end(tmp_path, pileup_weights):
     got = out.read_bytes().decode().splitlines()
     want = bytes(z["vcf_np1_bs1000"]).decode().splitlines()
     assert len(got) == len(want) and rows == sum(1 for l in want if not l.startswith("#"))
+    # every row that differs is checked on its own (no budget of tolerated rows): only QUAL / GQ may differ, the GPU's probabilities
+    # of that site are within 1e-6 of the reference's (golden gt / zy), and the reference's QUAL is the QUAL of a probability at most
+    # 1e-6 away from the GPU's - the two sit on either side of a rounding boundary of the two-decimal score
+    import torch
+    from tests.helpers import qual_reachable
+    site = {(str(n), int(p)): j for j, (n, p) in enumerate(zip(z["names"], z["pos"]))}
+    gt_gpu, zy_gpu = m.predict(torch.from_numpy(z["x"].astype(np.int32)).cuda())
+    gt_gpu, zy_gpu = gt_gpu.cpu().numpy(), zy_gpu.cpu().numpy()
+    assert np.abs(gt_gpu - z["gt"]).max() < 1e-6 and np.abs(zy_gpu - z["zy"]).max() < 1e-6
     n_qual_diff = 0
     for g, w in zip(got, want):
         if g == w:
             continue
         gf, wf = g.split("\t"), w.split("\t")
         assert gf[:5] == wf[:5] and gf[6:9] == wf[6:9], (g, w)
-        assert abs(float(gf[5]) - float(wf[5])) <= 0.0101, (g, w)
         gs, ws = gf[9].split(":"), wf[9].split(":")
-        assert gs[0] == ws[0] and gs[2:] == ws[2:] and abs(int(gs[1]) - int(ws[1])) <= 1
+        assert gs[0] == ws[0] and gs[2:] == ws[2:] and int(gs[1]) == int(float(gf[5])) and int(ws[1]) == int(float(wf[5])), (g, w)
+        j = site[(gf[0], int(gf[1]))]
+        assert qual_reachable(float(wf[5]), zy_gpu[j].max(), gt_gpu[j].max(), refcall=gf[6] == "RefCall"), (g, w, zy_gpu[j].max(), gt_gpu[j].max())
         n_qual_diff += 1
-    assert n_qual_diff <= len(want) // 20
+    print("rows whose QUAL differs by a rounding boundary:", n_qual_diff, "of", len(want))
 
 
 def test_haplotype_csv_end_to_end(tmp_path, gpu_ctx):
@@ -82,19 +92,39 @@ def test_mpileup_to_vcf_pipeline(tmp_path, pileup_weights):
     out = tmp_path / "pileup.vcf"
     rows = call_variants(m, [("chrS", str(mp))], str(fa), "chrS\t6100\t6\t60\t61\n", str(out))
     got = [l for l in out.read_text().splitlines() if not l.startswith("#")]
-    want = [l for l in bytes(z["vcf_bs1000"]).decode().splitlines() if l.startswith("chrS\t")]
-    # the golden batch also held chrT sites, so the batch-dependent fallback rows (ALT taken from other
-    # sites' classes, predict.py:102-109) may differ; every other row must agree up to QUAL rounding
-    assert rows == len(got) == len(want)
-    diff = 0
+    ref_rows = [l for l in bytes(z["vcf_bs1000"]).decode().splitlines() if l.startswith("chrS\t")]
+    assert rows == len(got) == len(ref_rows)
+    # The golden batch of 1000 also held chrT sites, and a fallback row takes its ALT from the other sites of its batch
+    # (predict.py:102-109), so the reference's text for a chrS-only batch is rebuilt from the reference's OWN probabilities of the chrS
+    # sites by the row formatter (byte-identical to predict() on 72 runs: tests/test_vcf.py).  Against that text every row must be
+    # equal, except a QUAL / GQ that a probability at most 1e-6 away from the GPU's explains - no budget of tolerated rows.
+    import torch
+    from nanosnp_amd.predict import COV_CHANNELS
+    from tests.helpers import qual_reachable
+    sel = np.flatnonzero(np.asarray(z["names"]) == "chrS")
+    x = z["x"][sel].astype(np.int32)
+    gt_ref, zy_ref = z["gt"][sel], z["zy"][sel]
+    table = host.ContigTable(["chrS"])
+    want_text, want_rows = host.vcf_format_batches(table, np.zeros(sel.size, np.int32), z["pos"][sel], z["refb"][sel],
+                                                   gt_ref.argmax(1).astype(np.uint8), zy_ref.argmax(1).astype(np.uint8), gt_ref.max(1), zy_ref.max(1),
+                                                   x[:, 16, COV_CHANNELS].astype(np.float32), batch_size=1000, score_mode=host.SCORE_FLOAT64)
+    want = want_text.decode().splitlines()
+    assert want_rows == len(want) == len(got)
+    # (the rebuilt text equals the reference's own rows wherever no other batch member is involved)
+    assert sum(a != b for a, b in zip(want, ref_rows)) <= 3 and all(a.split("\t")[:4] == b.split("\t")[:4] for a, b in zip(want, ref_rows))
+    gt_gpu, zy_gpu = m.predict(torch.from_numpy(x).cuda())
+    gt_gpu, zy_gpu = gt_gpu.cpu().numpy(), zy_gpu.cpu().numpy()
+    assert np.abs(gt_gpu - gt_ref).max() < 1e-6 and np.abs(zy_gpu - zy_ref).max() < 1e-6
+    site = {int(p): j for j, p in enumerate(z["pos"][sel])}
     for g, w in zip(got, want):
-        gf, wf = g.split("\t"), w.split("\t")
-        assert gf[:4] == wf[:4] and gf[6] == wf[6]
-        if gf[4] != wf[4]:
-            diff += 1
+        if g == w:
             continue
-        assert abs(float(gf[5]) - float(wf[5])) <= 0.0101
-    assert diff <= 3
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[:5] == wf[:5] and gf[6:9] == wf[6:9], (g, w)
+        gs, ws = gf[9].split(":"), wf[9].split(":")
+        assert gs[0] == ws[0] and gs[2:] == ws[2:], (g, w)
+        j = site[int(gf[1])]
+        assert qual_reachable(float(wf[5]), zy_gpu[j].max(), gt_gpu[j].max(), refcall=gf[6] == "RefCall", score_mode=host.SCORE_FLOAT64), (g, w)
 
 
 def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_weights):

@@ -22,7 +22,12 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_pileup_l1_rs4": "pileup_l1f", "k_pileup_l1_rs": "pileup_l1f", "k_pileup_head_rs": "pileup_head", "k_pileup_l0_rs32": "pileup_l0", "k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
+NAMES = {"k_pileup_l0_b3": "pileup_l0_bf16x3", "k_pileup_l1_b3": "pileup_l1f_bf16x3", "k_pileup_head_b3": "pileup_head_bf16x3",
+         "k_hap_features_L33": "hap_features", "k_hap_features_L11": "hap_features_L11",
+         "k_hap_gemm<0,0,false>": "hap_gemm_lstm", "k_hap_gemm<0,1,false>": "hap_gemm_lstm_f16x3", "k_hap_gemm<0,2,false>": "hap_gemm_lstm_bf16x3",
+         "k_hap_gemm<3,0,true>": "cat_conv", "k_hap_gemm<3,1,true>": "cat_conv_f16x3", "k_hap_gemm<3,2,true>": "cat_conv_bf16x3",
+         "k_cat_conv<0": "cat_conv", "k_cat_conv<1": "cat_conv_f16x3", "k_cat_conv<2": "cat_conv_bf16x3",
+         "k_pileup_l1_rs4": "pileup_l1f", "k_pileup_l1_rs": "pileup_l1f", "k_pileup_head_rs": "pileup_head", "k_pileup_l0_rs32": "pileup_l0", "k_pileup_l1f": "pileup_l1f", "k_pileup_l0": "pileup_l0", "k_pileup_proj1": "pileup_proj1", "k_pileup_l1": "pileup_l1",
          "k_pileup_head": "pileup_head", "k_encode_columns": "encode_columns", "k_hap_features": "hap_features",
          "k_pileup_post": "pileup_post", "k_select": "select_sites", "k_gather_windows": "gather_windows",
          "k_hap_gemm<0,false,false>": "hap_gemm_lstm", "k_hap_gemm<0,true,false>": "hap_gemm_lstm_f16x3",
@@ -35,7 +40,22 @@ def short(name):
     if not m:
         return name[:60].replace(",", ";")
     t = (m.group(2) or "").replace(" ", "")
-    return m.group(1) + (t if m.group(1) == "k_hap_gemm" else "")
+    return m.group(1) + (t if m.group(1) in ("k_hap_gemm", "k_cat_conv") else "")
+
+
+# FETCH_SIZE correction by access shape (MI355X_MICROARCH.md, HBM: 16 B/lane streaming reads are counted at exactly 1/2; "other access
+# widths are uncalibrated: calibrate on a known byte count in your own access pattern"): profiles/r04_fetch_calibration.json holds the
+# factors tools/fetch_calib.sh measured for this repository's shapes - k_hap_features reads rows of 33 (or groups of 5 x 11) int32 with
+# 4 B per lane, for which the counter tallies 1 / 1.65 (1 / 1.61) of the bytes, not 1 / 2.
+def fetch_factor(kernel):
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_calibration.json")))["shapes"]
+    except Exception:
+        cal = {}
+    shape = {"k_hap_features_L33": "k_calib_rows33<unsigned int>", "k_hap_features_L11": "k_calib_rows11"}.get(kernel)
+    if shape and shape in cal:
+        return cal[shape]["factor_bytes_per_counted_byte"], f"calibrated on {shape} (profiles/r04_fetch_calibration.json)"
+    return 2.0, "x2 (16 B/lane streaming reads)"
 
 
 def one(d, pat):
@@ -111,27 +131,36 @@ def main():
         for cname, d in (("FETCH_SIZE", args[2]), ("WRITE_SIZE", args[3])):
             acc = collections.defaultdict(list)
             grid = collections.defaultdict(int)
-            for r in csv.DictReader(open(one(d, "*counter_collection.csv"))):
+            rows_c = list(csv.DictReader(open(one(d, "*counter_collection.csv"))))
+            # k_hap_features is launched in two shapes (window length 33 and 11) that move 3x different bytes: told apart by their LDS size
+            lds_f = sorted({int(r["LDS_Block_Size"]) for r in rows_c if short(r["Kernel_Name"]) == "k_hap_features"})
+            for r in rows_c:
                 if r["Counter_Name"] == cname:
-                    acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-                    grid[short(r["Kernel_Name"])] += int(r["Grid_Size"])
+                    k = short(r["Kernel_Name"])
+                    if k == "k_hap_features" and len(lds_f) >= 2:
+                        k += "_L33" if int(r["LDS_Block_Size"]) == lds_f[-1] else "_L11"
+                    elif k == "k_hap_features":
+                        k += "_L33"
+                    acc[k].append(float(r["Counter_Value"]))
+                    grid[k] += int(r["Grid_Size"])
             for k, v in acc.items():
                 if k.startswith("k_"):
                     traffic[k][cname] = sum(v) / len(v)
                     traffic[k][cname + "_per_thread"] = sum(v) / max(grid[k], 1)      # (the column encode: one thread = one column)
                     traffic[k]["launches"] = len(v)
         summary = {"batch": batch, "precision": precision, "enc_group": enc_group, "D": Dd, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes",
-                   "correction": "KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1",
+                   "correction": "KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count) except where a kernel's entry names a calibrated factor, WRITE_SIZE x1",
                    "kernels": {}}
         for k, v in traffic.items():
-            rd = v.get("FETCH_SIZE", 0.0) * 1024 * 2
+            ff, fhow = fetch_factor(k)
+            rd = v.get("FETCH_SIZE", 0.0) * 1024 * ff
             wr = v.get("WRITE_SIZE", 0.0) * 1024
             name = next((n for p, n in NAMES.items() if k.startswith(p)), k)
-            summary["kernels"][name] = {"fetch_kib_raw": v.get("FETCH_SIZE"), "write_kib_raw": v.get("WRITE_SIZE"),
+            summary["kernels"][name] = {"fetch_kib_raw": v.get("FETCH_SIZE"), "write_kib_raw": v.get("WRITE_SIZE"), "fetch_factor": ff, "fetch_factor_source": fhow,
                                         "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                                         "hbm_bytes_per_launch": rd + wr, "launches": v.get("launches")}
             if name == "encode_columns":      # launches of different sizes (groups of batches): bytes per column travel with it
-                summary["kernels"][name]["hbm_bytes_per_column"] = v.get("FETCH_SIZE_per_thread", 0.0) * 1024 * 2 + v.get("WRITE_SIZE_per_thread", 0.0) * 1024
+                summary["kernels"][name]["hbm_bytes_per_column"] = v.get("FETCH_SIZE_per_thread", 0.0) * 1024 * ff + v.get("WRITE_SIZE_per_thread", 0.0) * 1024
         json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_traffic.json"), "w"), indent=1)
         rt = os.path.join(out_dir, "roofline_traffic.json")
         allw = {"workloads": {}}
