@@ -95,6 +95,10 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "pileup_precision"        0 fp32 (default) | 2 bf16x3 | 1 f16x3      PileupModel forward
  *   "hap_precision"           0 fp32 (default) | 2 bf16x3 | 1 f16x3      HaplotypeModel forward
  *   "cat_precision"           0 fp32 (default) | 2 bf16x3 | 1 f16x3      legacy CatModel forward
+ *   "cat_conv_lds"            1 (default) | 0                  legacy CatModel 3x3 convolutions: the pixel block + halo of a channel chunk staged in
+ *                                                              LDS once and read by all nine taps (fp32 and bf16x3), or the round-3 GEMM that gathers
+ *                                                              every tap from the image (the f16x3 mode always does); the two sum the same products in a
+ *                                                              different order
  *   "hap_pass_sites"          128..131072, multiple of 128     sites per internal pass of the HaplotypeModel forward (default 16384;
  *                                                              workspace ~195 KB per site = 3.2 GB per context at the default,
  *                                                              (re)allocated synchronously by this call and by nsnp_hap_load_weights,

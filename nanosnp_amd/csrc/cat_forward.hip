@@ -205,6 +205,235 @@ __global__ void k_cat_groups(const int32_t* __restrict__ r1, const int32_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution (+ 1x1 shortcut) as a GEMM whose B operand is staged ONCE per channel chunk.  The CONV mode of k_hap_gemm gathers
+// the B tile of every (tap, channel chunk) from the pixel image in global memory: the image is read nine times per tile (1.19 GB of
+// fetches per launch, served by L2 / the Infinity Cache) and every chunk pays the gather's address arithmetic.  Here a workgroup
+// (128 pixels x 128 output channels, the GEMM's 2 x 2 waves of 64 x 64) walks the channel chunks of C_in; for each it copies the
+// 128 pixels of its tile PLUS a halo of W + 1 pixels on either side (a 3x3 neighbourhood of a row-major image is a pixel-index
+// offset dy W + dx) into LDS once - double-buffered, the next chunk's block in flight during the last taps - and the nine taps are
+// nine row offsets into that block: the B fragment of a lane is one ds_read_b128 at row (site + halo + offset), or at an all-zero
+// row where the neighbour falls outside the image (crnn.py:92-96 pads with zeros).  Only the weight tiles (A) still stream per
+// chunk.  In the bf16x3 mode the block is split into its three bf16 planes while it is staged - once per channel chunk instead of
+// once per tap.  K order: channel chunk major, tap minor, the shortcut's chunks last (k_hap_gemm: tap major) - the same products,
+// summed in another order.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* w;        // weight images [row tile][nk_img][128][16] (bf16x3: 1.5 x), chunk kc = tap * cc_in + cc, then the shortcut's
+    const float* bias;
+    const float* x;        // pixel image [pixel tile][cc_in][128][16]
+    const float* sc;       // shortcut input image [pixel tile][cc_sc][128][16] (1x1 conv: read at the pixel itself) or null
+    float* out;            // [pixel tile][out_cc][128][16]
+    int cc_in, cc_sc, nk_img, conv_h, conv_w, n_rows, out_tile_stride;
+    long long n_pix, n_pix_alloc;
+};
+
+constexpr int CONV_HALO = 12;                          // W + 1 for the widths of this network (W = 11)
+constexpr int CONV_ROWS = TS + 2 * CONV_HALO + 1;      // staged pixels + the zero row
+
+template <int AR>              // 0 exact fp32 (v_mfma_f32_32x32x2_f32), 2 bf16x3 (six v_mfma_f32_32x32x16_bf16 per product)
+__global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
+{
+    constexpr bool B3 = AR == 2;
+    constexpr int ROWF = B3 ? 28 : LDK;                 // floats per LDS row: 112 B (3 planes x 16 bf16 + pad) / 80 B (16 floats + pad)
+    constexpr int TILE_W = B3 ? TILE_F * 3 / 2 : TILE_F;
+    constexpr int NPL = B3 ? 3 : 2;                     // 16-byte fragments per row half: three planes / two groups of four K-steps
+    __shared__ float As[2][TR][ROWF];
+    __shared__ float Hb[2][CONV_ROWS][ROWF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const bool small_rows = a.n_rows <= 64;
+    const int wr = small_rows ? 0 : wave >> 1, wc = wave & 1;
+    const int nct = small_rows ? 1 : 2;
+    const int nrt = a.n_rows <= 32 ? 1 : 2;
+    const int site0 = small_rows ? 32 * wave : 64 * wc;
+    const int W = a.conv_w, HW = a.conv_h * a.conv_w;
+    const int n_blocks = a.cc_in + a.cc_sc;
+    const int n_chunks = 9 * a.cc_in + a.cc_sc;
+    const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_W;
+
+    // ---- the lane's two sites: which of the nine taps stay inside their image -------------------------------------------------
+    int srow[2]; unsigned vmask[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int s = site0 + 32 * ct + li;
+        const long long pix = (long long)bx * TS + s;
+        const int rem = (int)(pix % HW);
+        const int py = rem / W, px = rem - py * W;
+        unsigned m = 0u;
+        if (pix < a.n_pix) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                m |= (unsigned)(yy >= 0 && yy < a.conv_h && xx >= 0 && xx < W) << t;
+            }
+        }
+        srow[ct] = s + CONV_HALO; vmask[ct] = m;
+    }
+
+    // ---- staging roles ---------------------------------------------------------------------------------------------------------
+    const int crow = tid >> 1, cq = (tid & 1) * 2;      // A: row, first of the thread's 16-byte pieces (fp32: 2 of 4, bf16x3: 3 of 6)
+    f32x4 ga[3];
+    auto gload_a = [&](int kc) {
+        if (B3) {
+            const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_W) + crow * 6 + (tid & 1) * 3;
+            ga[0] = pa[0]; ga[1] = pa[1]; ga[2] = pa[2];
+        } else {
+            const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_F) + crow * 4 + cq;
+            ga[0] = pa[0]; ga[1] = pa[1];
+        }
+    };
+    auto lstore_a = [&](int buf) {
+        f32x4* ra = reinterpret_cast<f32x4*>(&As[buf][crow][0]);
+        if (B3) { ra[(tid & 1) * 3] = ga[0]; ra[(tid & 1) * 3 + 1] = ga[1]; ra[(tid & 1) * 3 + 2] = ga[2]; }
+        else { ra[cq] = ga[0]; ra[cq + 1] = ga[1]; }
+    };
+    // block: task i = 2 row + half, i < 2 (TS + 2 HALO) = 304: the thread's tasks are tid and tid + 256
+    f32x4 gh[2][2];
+    auto gload_h = [&](int blk) {
+        const bool conv = blk < a.cc_in;
+        const float* __restrict__ img = conv ? a.x : a.sc;
+        const int cc = conv ? blk : blk - a.cc_in, ncc = conv ? a.cc_in : a.cc_sc;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i >> 1, half = i & 1;
+            const long long pix = (long long)bx * TS - CONV_HALO + row;
+            gh[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; gh[k][1] = gh[k][0];
+            if (i < 2 * (TS + 2 * CONV_HALO) && pix >= 0 && pix < a.n_pix_alloc) {
+                const f32x4* pr = reinterpret_cast<const f32x4*>(img + ((size_t)(pix >> 7) * ncc + cc) * TILE_F + (size_t)(pix & 127) * BK) + 2 * half;
+                gh[k][0] = pr[0]; gh[k][1] = pr[1];
+            }
+        }
+    };
+    auto lstore_h = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= 2 * (TS + 2 * CONV_HALO)) continue;
+            const int row = i >> 1, half = i & 1;
+            f32x4* rh = reinterpret_cast<f32x4*>(&Hb[buf][row][0]);
+            if (B3) {
+                b8_t p0, p1, p2;
+                split3_b8(gh[k][0], gh[k][1], p0, p1, p2);
+                rh[half] = __builtin_bit_cast(f32x4, p0); rh[2 + half] = __builtin_bit_cast(f32x4, p1); rh[4 + half] = __builtin_bit_cast(f32x4, p2);
+            } else { rh[2 * half] = gh[k][0]; rh[2 * half + 1] = gh[k][1]; }
+        }
+    };
+
+    // accumulators start at the bias of their rows
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int f = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;
+            f32x4 bz = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f < a.n_rows) bz = *reinterpret_cast<const f32x4*>(a.bias + f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { acc[rt][0][4 * r4 + g] = bz[g]; acc[rt][1][4 * r4 + g] = bz[g]; }
+        }
+
+    // ---- prologue: zero rows, block 0, weight chunk 0 ---------------------------------------------------------------------------
+    if (tid < 2 * ROWF) Hb[tid / ROWF][CONV_ROWS - 1][tid % ROWF] = 0.f;
+    gload_h(0); lstore_h(0);
+    gload_a(0); lstore_a(0);                            // chunk 0 = (tap 0, cc 0), or the first shortcut chunk when there is no conv part
+    __syncthreads();
+
+    int blk = 0, tap = 0, cur = 0, hb = 0;
+    for (int j = 0; j < n_chunks; ++j) {
+        const bool conv = blk < a.cc_in;
+        const int ntap = conv ? 9 : 1;
+        // successor chunk
+        int nblk = blk, ntp = tap + 1;
+        if (ntp == ntap) { nblk = blk + 1; ntp = 0; }
+        const bool have_next = j + 1 < n_chunks;
+        const int nkc = nblk < a.cc_in ? ntp * a.cc_in + nblk : 9 * a.cc_in + (nblk - a.cc_in);
+        const bool stage_next_block = have_next && ntp == 0;          // the last tap of a block: the next block's pixels go to LDS
+        // fragments of this chunk
+        const int t_eff = conv ? tap : 4;                              // the shortcut reads the pixel itself
+        const int off = (t_eff / 3 - 1) * W + (t_eff % 3 - 1);
+        f32x4 af[2][NPL], bf[2][NPL];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int row = ((vmask[ct] >> t_eff) & 1u) ? srow[ct] + off : CONV_ROWS - 1;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                bf[ct][p] = *reinterpret_cast<const f32x4*>(&Hb[hb][row][B3 ? (2 * p + lh) * 4 : lh * 8 + p * 4]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][B3 ? (2 * p + lh) * 4 : lh * 8 + p * 4]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (B3) {
+            constexpr int WP[6] = {0, 1, 2, 0, 1, 0}, XP[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g == 2) {                                          // global loads of the next chunk from inside the burst
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (have_next) gload_a(nkc);
+                    if (stage_next_block) gload_h(nblk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (ct >= nct || rt >= nrt) continue;
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, af[rt][WP[g]]), __builtin_bit_cast(b8_t, bf[ct][XP[g]]),
+                                                                               acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (have_next) gload_a(nkc);
+                    if (stage_next_block) gload_h(nblk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (ct >= nct || rt >= nrt) continue;
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][k >> 2][k & 3], bf[ct][k >> 2][k & 3], acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (have_next) lstore_a(cur ^ 1);
+        if (stage_next_block) lstore_h(hb ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        if (ntp == 0) hb ^= 1;
+        blk = nblk; tap = ntp;
+    }
+
+    // ---- epilogue: ReLU, rows < n_rows (the GEMM's LINEAR_RELU epilogue) ---------------------------------------------------------
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        if (ct >= nct) continue;
+        const int site = site0 + 32 * ct + li;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int f = 128 * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh;
+                if (f >= a.n_rows) continue;
+                f32x4 v;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] = fmaxf(acc[rt][ct][4 * r4 + g], 0.f);
+                float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK;
+                *reinterpret_cast<f32x4*>(o + (f & 15)) = v;
+            }
+    }
+}
+
 struct LstmDir { float* w; float* b; };
 struct CatBlock { float* w1; float* b1; float* w2; float* b2; int cin, cout, cc_in, cc_out; };
 
@@ -545,6 +774,17 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
             const CatBlock& b = cw.blk[i];
             const int rt = NSNP_CDIV(b.cout, TR);
             float* X = map[cur]; float* Y = map[(cur + 1) % 3]; float* O = map[(cur + 2) % 3];
+            if (AR != 1 && ctx->cat_conv_lds) {
+                // the LDS-staged convolution kernel (fp32 and bf16x3; the f16x3 mode keeps the gathering GEMM)
+                ConvArgs c;
+                c.conv_h = Hc; c.conv_w = CAT_L; c.n_pix = n_pix; c.n_pix_alloc = n_ptiles * TS; c.n_rows = b.cout;
+                c.w = wm(b.w1); c.bias = b.b1; c.x = X; c.sc = nullptr; c.cc_in = b.cc_in; c.cc_sc = 0; c.nk_img = 9 * b.cc_in;
+                c.out = Y; c.out_tile_stride = b.cc_out * TILE_F;
+                hipLaunchKernelGGL(k_cat_conv<AR == 1 ? 0 : AR>, dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, c);
+                c.w = wm(b.w2); c.bias = b.b2; c.x = Y; c.sc = X; c.cc_in = b.cc_out; c.cc_sc = b.cc_in; c.nk_img = 9 * b.cc_out + b.cc_in;
+                c.out = O;
+                hipLaunchKernelGGL(k_cat_conv<AR == 1 ? 0 : AR>, dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, c);
+            } else {
             StepLaunch L; StepArgs& a = L.z[0];
             memset(&a, 0, sizeof(a));
             a.conv_h = Hc; a.conv_w = CAT_L; a.n_pix = n_pix; a.n_rows = b.cout;
@@ -557,6 +797,7 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
             a.in1 = X; a.nk1 = b.cc_in; a.in1_tile_stride = b.cc_in * TILE_F; a.nk_img = a.nk0 + a.nk1;
             a.out = O; a.out_tile_stride = b.cc_out * TILE_F;
             launch_hap_gemm<MODE_LINEAR_RELU, AR, true>(ctx, s, L, (int)((unsigned)n_ptiles), rt, 1);
+            }
             cur = (cur + 2) % 3;
             if (CAT_POOL[i]) {
                 const int kh = CAT_POOL[i], Ho = (Hc - kh) / kh + 1;
