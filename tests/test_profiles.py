@@ -1,5 +1,6 @@
 """The bench lines committed under profiles/ (the evidence the round is judged by) keep the contract: required keys, every roofline
-fraction physical (executed work / time / peak, 0 < frac <= 1), value consistent with ms_per_step."""
+fraction physical (executed work / time / peak, 0 < frac <= 1), value consistent with ms_per_step, the run's own outputs checked
+against the oracle (parity_sample), HBM traffic of the HBM-bound kernels not below the bytes they provably move."""
 import glob
 import json
 import os
@@ -8,14 +9,19 @@ import pytest
 
 from tests.helpers import ROOT
 
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_line.json")))
+ROUND = "r04"
+LINES = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*_line.json")) if "e2e" not in p)
+
+
+def _load(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
 def test_committed_line(path):
-    d = json.load(open(path))
+    d = _load(path)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+              "config", "roofline", "cpu_baseline", "parity_sample", "shader_clock_mhz"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
     n = 0
@@ -24,13 +30,47 @@ def test_committed_line(path):
             assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1, k
             if "chip" in r:
                 assert 0 < r["chip"]["frac"] <= 1
+            # traffic is labelled as coming from the committed PMC passes, and an HBM-bound kernel cannot have moved fewer bytes than
+            # its algorithmic ones (the feature reduction's 712 MB against 1,005 MB provable was an average over two
+            # launch shapes under a correction calibrated for another access width)
+            if r.get("traffic") is not None:
+                assert "not from this run" in r["traffic_source"], k
+                if r["bound"] == "hbm":
+                    assert r["traffic"] >= 0.95 * r["algorithmic_bytes_per_launch"], (k, r["traffic"], r["algorithmic_bytes_per_launch"])
             n += 1
     assert n >= 2
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
-    assert d["value"] > 100 * c["value"] or "60x" in d["metric"] or d["value"] > 50 * c["value"]
+    assert d["value"] > 50 * c["value"]
+    # the line's own outputs were compared with the oracle, and a bf16x3 second value rides along with its own parity
+    assert d["parity_sample"]["ok"] is True and d["parity_sample"].get("tolerance", 1e-4) == 1e-4
+    assert 1500 < d["shader_clock_mhz"]["value"] < 2600
+    b3 = d.get("bf16x3") or (d.get("second_values") or {}).get("forward_only_bf16x3")
+    assert b3, "every line carries a bf16x3 second value"
+    ps = b3.get("parity_sample")
+    assert ps and ps["ok"] is True
 
 
-def test_all_four_workloads_have_a_line():
+def test_pileup_line_is_the_headline_configuration():
+    d = _load(os.path.join(ROOT, "profiles", f"{ROUND}_pileup_line.json"))
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["windows_resident_per_gpu"] == 1 << 20 and d["config"]["batch"] == 4096
+    assert d["config"]["batches_per_step"] == 256 and d["timed_region_s"] >= 1.0              # one step = one sweep of the pool, >= 1 s timed
+    assert len(d["repeats"]["values"]) == 3 and sorted(d["repeats"]["values"])[1] == round(d["value"])
+    p = d["parity_sample"]
+    assert p["sites"] >= 65536 and p["encode_bit_exact"] and p["calls_equal_own_argmax"] and p["max_abs_dp"] < 1e-4
+    e = d["error_vs_float64"]["modes"]
+    assert e["bf16x3"]["max_abs_error"] <= max(1.5 * e["fp32"]["max_abs_error"], 1e-6)      # full fp32 operand width: the fp32 path's own error
+    assert d["bf16x3"]["roofline"]["peak"] == 2500.0 and d["bf16x3"]["value"] > d["value"]
+
+
+def test_all_workloads_have_a_line():
     names = {os.path.basename(p) for p in LINES}
-    assert {"r03_pileup_line.json", "r03_haplotype_line.json", "r03_two_stage_line.json", "r03_deep60_line.json"} <= names
+    assert {f"{ROUND}_pileup_line.json", f"{ROUND}_haplotype_line.json", f"{ROUND}_two_stage_line.json", f"{ROUND}_deep60_line.json"} <= names
+    e2e = _load(os.path.join(ROOT, "profiles", f"{ROUND}_e2e_line.json"))
+    assert e2e["parity_sample"]["ok"] and "NOT the headline" in e2e["config"]["workload"] and e2e["bound_by"] in e2e["stage_busy_s_per_step"]
+
+
+def test_fetch_calibration_is_committed():
+    c = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_fetch_calibration.json")))["shapes"]
+    assert abs(c["k_calib_b128"]["factor_bytes_per_counted_byte"] - 2.0) < 0.02                # the documented wide-read case reproduces
+    assert 1.3 < c["k_calib_rows33<unsigned int>"]["factor_bytes_per_counted_byte"] < 2.0      # k_hap_features' shape does not follow it

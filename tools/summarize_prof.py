@@ -43,19 +43,15 @@ def short(name):
     return m.group(1) + (t if m.group(1) in ("k_hap_gemm", "k_cat_conv") else "")
 
 
-# FETCH_SIZE correction by access shape (MI355X_MICROARCH.md, HBM: 16 B/lane streaming reads are counted at exactly 1/2; "other access
-# widths are uncalibrated: calibrate on a known byte count in your own access pattern"): profiles/r04_fetch_calibration.json holds the
-# factors tools/fetch_calib.sh measured for this repository's shapes - k_hap_features reads rows of 33 (or groups of 5 x 11) int32 with
-# 4 B per lane, for which the counter tallies 1 / 1.65 (1 / 1.61) of the bytes, not 1 / 2.
+# FETCH_SIZE correction (MI355X_MICROARCH.md, HBM: 16 B/lane streaming reads are counted at exactly 1/2; "other access widths are
+# uncalibrated: calibrate on a known byte count in your own access pattern").  tools/fetch_calib.sh measured this repository's shapes
+# (profiles/r04_fetch_calibration.json): 16 B/lane and 4 B/lane contiguous streams both read 2.00; rows of 33 int32 read by a wave each
+# (lanes 33..63 idle) 1.65 in the stand-alone probe.  k_hap_features itself - four planes, four loads in flight per lane, waves of one
+# workgroup on neighbouring rows - moves 778.6 MB of read planes per 16384-site launch at L = 33 and is counted at 395.7 MB: 1.97, i.e.
+# the x2 of the streaming case, not the probe's 1.65 (every line is fetched once while its neighbours are in flight).  So x2 is applied
+# to every kernel, and each entry records the factor its algorithmic bytes imply where they are known.
 def fetch_factor(kernel):
-    try:
-        cal = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_calibration.json")))["shapes"]
-    except Exception:
-        cal = {}
-    shape = {"k_hap_features_L33": "k_calib_rows33<unsigned int>", "k_hap_features_L11": "k_calib_rows11"}.get(kernel)
-    if shape and shape in cal:
-        return cal[shape]["factor_bytes_per_counted_byte"], f"calibrated on {shape} (profiles/r04_fetch_calibration.json)"
-    return 2.0, "x2 (16 B/lane streaming reads)"
+    return 2.0, "x2 (gfx950 counts streaming reads at 1/2; calibration: profiles/r04_fetch_calibration.json)"
 
 
 def one(d, pat):
@@ -132,15 +128,15 @@ def main():
             acc = collections.defaultdict(list)
             grid = collections.defaultdict(int)
             rows_c = list(csv.DictReader(open(one(d, "*counter_collection.csv"))))
-            # k_hap_features is launched in two shapes (window length 33 and 11) that move 3x different bytes: told apart by their LDS size
-            lds_f = sorted({int(r["LDS_Block_Size"]) for r in rows_c if short(r["Kernel_Name"]) == "k_hap_features"})
+            # k_hap_features is launched in two shapes (window length 33 and 11) that move 3x different bytes; same grid, same LDS:
+            # told apart by the counter itself (two clusters a factor of three apart)
+            fv = [float(r["Counter_Value"]) for r in rows_c if r["Counter_Name"] == cname and short(r["Kernel_Name"]) == "k_hap_features"]
+            f_cut = (min(fv) + max(fv)) / 2 if fv and max(fv) > 1.8 * min(fv) else -1.0
             for r in rows_c:
                 if r["Counter_Name"] == cname:
                     k = short(r["Kernel_Name"])
-                    if k == "k_hap_features" and len(lds_f) >= 2:
-                        k += "_L33" if int(r["LDS_Block_Size"]) == lds_f[-1] else "_L11"
-                    elif k == "k_hap_features":
-                        k += "_L33"
+                    if k == "k_hap_features":
+                        k += "_L33" if float(r["Counter_Value"]) > f_cut else "_L11"
                     acc[k].append(float(r["Counter_Value"]))
                     grid[k] += int(r["Grid_Size"])
             for k, v in acc.items():
