@@ -541,7 +541,9 @@ __global__ __launch_bounds__(512, 1) void k_pileup_l1_b3(
     for (int s = 0; s < PSTEPS1; ++s) {
         const int t = dir ? PW - 1 - s : s;
         const int cur = s & 1;
+#ifndef NSNP_B3L1_NOSTAGE
         if (s + 1 < PSTEPS1) load_h0(dir ? t - 1 : t + 1);
+#endif
         const __bf16* h0b = h0s + (size_t)cur * NSG * 2 * FR_H + q * 128 + n * 8;
         const __bf16* hrb = h1x + (size_t)(cur ^ 1) * NSG * FR_H + q * 128 + n * 8;      // h1_{s-1}
         __bf16* hwb = h1x + (size_t)cur * NSG * FR_H + ((wave >> 2) * 4 + (wave & 3)) * 128 + n * 8 + 2 * q;   // h1_s
@@ -570,7 +572,11 @@ __global__ __launch_bounds__(512, 1) void k_pileup_l1_b3(
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     float cn;
+#ifdef NSNP_B3L1_NOCELL
+                    const float h = acc[ab][u][0] * 1e-3f + acc[ab][u][1] * 1e-4f; cn = acc[ab][u][2] + acc[ab][u][3];
+#else
                     const float h = nsnp_cell::lstm_cell(acc[ab][u][0], acc[ab][u][1], acc[ab][u][2], acc[ab][u][3], c[2 * sg + u], cn);
+#endif
                     c[2 * sg + u] = cn;
                     last_h[sg][u] = h;
                     __bf16 a, b, d; split3(h, a, b, d);
@@ -582,8 +588,12 @@ __global__ __launch_bounds__(512, 1) void k_pileup_l1_b3(
                 *reinterpret_cast<b2*>(w + 2048) = n2;
             }
         }
+#ifndef NSNP_B3L1_NOSTAGE
         if (s + 1 < PSTEPS1) store_h0(cur ^ 1);
+#endif
+#ifndef NSNP_B3L1_NOBAR
         lds_barrier();
+#endif
     }
     // H1c: fp32 [site][dir][unit]
 #pragma unroll

@@ -12,75 +12,74 @@ from __future__ import annotations
 import bisect
 import math
 
-MAJOR_CONTIGS = ["chr" + str(a) for a in list(range(1, 23)) + ["X", "Y"]] + [str(a) for a in list(range(1, 23)) + ["X", "Y"]]
+_CHROMOSOMES = [str(n) for n in range(1, 23)] + ["X", "Y"]
+MAJOR_CONTIGS = ["chr" + c for c in _CHROMOSOMES] + _CHROMOSOMES            # UCSC names first, then Ensembl names (select_hetesnp_homosnp.py:14)
+
+_INFO_HEADER = ('##INFO=<ID=P,Number=0,Type=Flag,Description="Result from pileup model">\n'
+                '##INFO=<ID=H,Number=0,Type=Flag,Description="Result from haplotype model">\n')
+_MIN_CALL_QUAL = 13.0        # scripts/merge.py:68,122: below it neither model's call is written
+
+
+def haplotype_alleles(ref: str, pair: str):
+    """The two genotype letters of a haplotype call (ACGT, D, I) against the site's reference base -> (ALT text, GT text), or None
+    when the merged file holds no row for the site.  Decision table of scripts/merge.py:82-111:
+
+        ref among the letters, both equal      -> None (homozygous reference)
+        ref among the letters                  -> the other letter, 0/1
+        both equal                             -> that letter, 1/1
+        two different non-reference letters    -> both, sorted, 1/2
+        then an indel letter in ALT ('D' is looked at before 'I'): one ALT allele -> None; two -> the other letter, 0/1"""
+    first, second = pair[0], pair[1]
+    if ref in pair:
+        if first == second:
+            return None
+        alt, zygosity = pair.replace(ref, ""), "0/1"
+    elif first == second:
+        alt, zygosity = first, "1/1"
+    else:
+        alt, zygosity = ",".join(sorted(pair)), "1/2"
+    for letter in "DI":
+        if letter in alt:
+            return (pair.replace(letter, ""), "0/1") if zygosity == "1/2" else None
+    return alt, zygosity
 
 
 def merge_calls(pileup_vcf_text: str, haplotype_csv_text: str, quality_threshold=15.0) -> str:
-    """scripts/merge.py:15-145.  Pileup calls with QUAL <= threshold are replaced by the haplotype call of
-    the same site when that one has QUAL >= 13 (INFO 'H'); the others keep the pileup call (INFO 'P') when
-    it is a variant with QUAL >= 13 (or above the threshold)."""
-    cat = {}
-    for row in haplotype_csv_text.splitlines():
-        if not row.strip():
+    """scripts/merge.py:15-145 as one pass with a decision per row.  A pileup row whose QUAL is at most the threshold is REPLACED by
+    the haplotype model's call of the same site when that call has QUAL >= 13 (INFO 'H', or no row at all: haplotype_alleles);
+    every other row stays as the pileup model wrote it (INFO 'P') provided it is a variant (FILTER != RefCall) whose QUAL is above
+    the threshold or at least 13.  Byte-identical to the reference's output (tests/test_next_rows.py)."""
+    calls = {}
+    for record in haplotype_csv_text.splitlines():
+        record = record.strip()
+        if record:
+            contig, position, letters, score = record.split("\t")
+            calls[contig, position] = (letters, score)
+    merged, header_pending = [], True
+    for raw in pileup_vcf_text.splitlines(keepends=True):
+        if raw.startswith("#"):
+            merged.append(raw)
+            if header_pending:
+                merged.append(_INFO_HEADER)
+                header_pending = False
             continue
-        ctg, pos, gt, qual = row.strip().split("\t")
-        cat[(ctg, pos)] = (gt, qual)
-    out = []
-    insert_hp = True
-    for line in pileup_vcf_text.splitlines(keepends=True):
-        if line.startswith("#"):
-            out.append(line)
-            if insert_hp:
-                out.append('##INFO=<ID=P,Number=0,Type=Flag,Description="Result from pileup model">\n')
-                out.append('##INFO=<ID=H,Number=0,Type=Flag,Description="Result from haplotype model">\n')
-                insert_hp = False
-            continue
-        fields = line.strip().split("\t")
-        ref, quality, filt, ctg, chr_offset = fields[3], float(fields[5]), fields[6], fields[0], int(fields[1])
-        depth, af = fields[-1].split(":")[-2:]
-        depth, af = int(depth), float(af)
-
-        def keep_pileup():
-            f2 = line.strip().split("\t")
-            f2[7] = "P"
-            out.append("\t".join(f2) + "\n")
-
-        if quality <= quality_threshold:
-            hit = cat.get((ctg, str(chr_offset)))
-            if hit is None:                                           # KeyError branch, merge.py:122-133
-                if filt != "RefCall" and quality >= 13:
-                    keep_pileup()
-                continue
-            gt, qual = hit[0], float(hit[1])
-            if qual < 13:                                             # merge.py:68-80
-                if filt != "RefCall" and quality >= 13:
-                    keep_pileup()
-                continue
-            if ref in gt:
-                if gt[0] == gt[1]:
-                    continue                                          # haplotype model says hom-ref
-                new_gt, new_zy = gt.replace(ref, ""), "0/1"
-            else:
-                if gt[0] == gt[1]:
-                    new_gt, new_zy = gt[0], "1/1"
-                else:
-                    new_gt, new_zy = ",".join(sorted(gt)), "1/2"
-            quality = qual
-            for sym in ("D", "I"):                                    # merge.py:100-111 ('D' test first, elif 'I')
-                if sym in new_gt:
-                    if new_zy in ("0/1", "1/1"):
-                        new_gt = None
-                    else:
-                        new_gt, new_zy = gt.replace(sym, ""), "0/1"
-                    break
-            if new_gt is None:
-                continue
-            out.append("{0}\t{1}\t.\t{2}\t{3}\t{4}\t{5}\t{6}\t{7}\t{8}\n".format(
-                ctg, chr_offset, ref, new_gt, str(quality), "PASS", "H", "GT:GQ:DP:AF",
-                new_zy + ":%s:%d:%f" % (str(int(quality)), depth, af)))
-        elif filt != "RefCall":
-            keep_pileup()
-    return "".join(out)
+        col = raw.strip().split("\t")
+        position, pileup_qual = int(col[1]), float(col[5])
+        sample = col[-1].split(":")
+        depth, allele_frequency = int(sample[-2]), float(sample[-1])
+        variant = col[6] != "RefCall"
+        hap = calls.get((col[0], str(position))) if pileup_qual <= quality_threshold else None
+        hap_qual = float(hap[1]) if hap is not None else None
+        if hap is not None and hap_qual >= _MIN_CALL_QUAL:
+            decided = haplotype_alleles(col[3], hap[0])
+            if decided is not None:
+                alt, zygosity = decided
+                merged.append(f"{col[0]}\t{position}\t.\t{col[3]}\t{alt}\t{hap_qual}\tPASS\tH\tGT:GQ:DP:AF\t"
+                              f"{zygosity}:{int(hap_qual)}:{depth:d}:{allele_frequency:f}\n")
+        elif variant and (pileup_qual > quality_threshold or pileup_qual >= _MIN_CALL_QUAL):
+            col[7] = "P"
+            merged.append("\t".join(col) + "\n")
+    return "".join(merged)
 
 
 def parse_vcf_for_groups(vcf_text: str, quality_threshold):

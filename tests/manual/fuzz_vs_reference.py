@@ -173,5 +173,44 @@ def fuzz_encode():
         print(seed, want.count(b"\n"), "sites, byte-identical:", open(pdf, "rb").read() == want)
 
 
+
+
+def fuzz_merge(rounds=200, seed=4242):
+    """nanosnp_amd.merge.merge_calls against the reference's scripts/merge.py Run on random pileup.vcf / haplotype.csv pairs: every
+    genotype-letter pair incl. D / I, qualities on both sides of 13 and of the threshold, RefCall rows, sites without a haplotype call"""
+    import argparse, importlib.util, os, random, tempfile
+    from nanosnp_amd.merge import merge_calls
+    spec = importlib.util.spec_from_file_location("refmerge", "/root/reference/scripts/merge.py")      # development container only
+    ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+    rng = random.Random(seed)
+    letters = "ACGTDI"
+    n_rows = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for r in range(rounds):
+            thr = rng.choice([15.0, 19.0, 0.0, 13.0, 30.0])
+            vcf = ["##fileformat=VCFv4.3\n", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSample\n"]
+            csv = []
+            pos = 0
+            for _ in range(rng.randint(1, 60)):
+                pos += rng.randint(1, 50)
+                ctg = rng.choice(["chr1", "chr2", "7"])
+                refb = rng.choice("ACGT")
+                q = rng.choice([0.0, 12.99, 13.0, 13.01, thr, thr + 0.01, round(rng.uniform(0, 60), 2)])
+                filt = rng.choice(["PASS", "PASS", "RefCall"])
+                vcf.append(f"{ctg}\t{pos}\t.\t{refb}\t{rng.choice('ACGT')}\t{q}\t{filt}\t.\tGT:GQ:DP:AF\t{rng.choice(['0/1', '1/1', '0/0'])}:{int(q)}:{rng.randint(1, 90)}:{rng.random():f}\n")
+                if rng.random() < 0.7:
+                    csv.append(f"{ctg}\t{pos}\t{rng.choice(letters)}{rng.choice(letters)}\t{rng.choice([12.99, 13.0, round(rng.uniform(0, 60), 2)])}\n")
+            vp, cp, op = (os.path.join(tmp, n) for n in ("p.vcf", "h.csv", "o.vcf"))
+            open(vp, "w").write("".join(vcf)); open(cp, "w").write("".join(csv))
+            if not csv:
+                continue                                   # (the reference returns early on an empty csv: merge.py:30-33)
+            ref.Run(argparse.Namespace(cat_predict=cp, output=op, pileup_vcf=vp, quality=thr))
+            want = open(op).read()
+            got = merge_calls("".join(vcf), "".join(csv), thr)
+            assert got == want, (r, thr)
+            n_rows += len(vcf) - 2
+    print(f"merge: {rounds} random file pairs ({n_rows} rows) byte-identical to scripts/merge.py Run")
+
+
 if __name__ == "__main__":
-    {"hapfeat": fuzz_hapfeat, "pileup": fuzz_pileup, "vcf": fuzz_vcf, "encode": fuzz_encode}[sys.argv[1]]()
+    {"hapfeat": fuzz_hapfeat, "pileup": fuzz_pileup, "vcf": fuzz_vcf, "encode": fuzz_encode, "merge": fuzz_merge}[sys.argv[1]]()
