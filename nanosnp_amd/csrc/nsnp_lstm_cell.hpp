@@ -21,18 +21,22 @@ constexpr float LOG2E = 1.4426950408889634f;
 // factor folded into image row R of an LSTM weight image and its bias (image row R: unit R / 4, gate R % 4 in the order i f g o)
 static inline float lstm_gate_scale(int R) { return (R & 3) == 2 ? -2.0f * LOG2E : -LOG2E; }
 
+// min(z, 64) as ONE v_med3_f32 (fminf costs a canonicalising v_max_f32 beside its v_min_f32 where the operand is a computed value);
+// the same bits for every z: below -3e38 the exponential is 0 either way
+__device__ __forceinline__ float cap64(float z) { return __builtin_amdgcn_fmed3f(z, -3.0e38f, 64.0f); }
+
 __device__ __forceinline__ float lstm_cell(float zi, float zf, float zg, float zo, float c_prev, float& c_new)
 {
     const float ei = __builtin_amdgcn_exp2f(zi);
     const float ef = __builtin_amdgcn_exp2f(zf);
     const float eo = __builtin_amdgcn_exp2f(zo);
-    const float eg = __builtin_amdgcn_exp2f(fminf(zg, 64.0f));
+    const float eg = __builtin_amdgcn_exp2f(cap64(zg));
     constexpr float K = -2.0f * LOG2E;
     const float tg = 1.0f + eg;                                    // (1 + e_i)(1 + e_g) = e_i t + t
     const float ig = __builtin_fmaf(-K, eg, K) * __builtin_amdgcn_rcpf(__builtin_fmaf(ei, tg, tg));
     const float fg = __builtin_amdgcn_rcpf(1.0f + ef);
     const float cn = __builtin_fmaf(fg, c_prev, ig);
-    const float ec = __builtin_amdgcn_exp2f(fminf(cn, 64.0f));
+    const float ec = __builtin_amdgcn_exp2f(cap64(cn));
     c_new = cn;
     const float tc = 1.0f + ec;
     return (1.0f - ec) * __builtin_amdgcn_rcpf(__builtin_fmaf(eo, tc, tc));

@@ -396,21 +396,22 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3p(
             bh[1][p] = *reinterpret_cast<const b8*>(hrow + p * 1024 + 512);
         }
         bx[0] = *reinterpret_cast<const b8*>(xrow);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the first product of a chain takes a literal zero as its C operand (an inline constant of the MFMA: no registers to clear)
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (__builtin_expect(lvl != 0, 0)) {                // rare: counts beyond one bf16 term - the extra products first (smallest terms first)
             bx[1] = *reinterpret_cast<const b8*>(xrow + 512);
             bx[2] = *reinterpret_cast<const b8*>(xrow + 1024);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][0], bx[2], acc[u]);
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][0], bx[2], zero4);
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][1], bx[1], acc[u]);
-        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][2], bx[0], acc[u]);
-        if (__builtin_expect(lvl != 0, 0)) {
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][2], bx[0], acc[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][0], bx[1], acc[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][2], bx[0], zero4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = mfma_b(Wih[u][1], bx[0], acc[u]);
