@@ -64,6 +64,9 @@ int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int6
 int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
                             int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases);
 
+/* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota */
+int nsnp_host_threads(void);
+
 /* ---- FASTA (+.fai) -------------------------------------------------------------------- */
 /* Loads one contig of a FASTA file into seq (capacity cap).  Uses the .fai when present
  * (ref_reader.cpp:9-33) and a linear scan otherwise.  Returns the contig length, or a
@@ -92,7 +95,7 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
                               int score_mode, char* out, int64_t cap, int64_t* n_rows);
 
 /* All batches of the predict loop at once (N sites cut into consecutive batches of batch_size, the reference's DataLoader
- * batches): byte-identical to nsnp_vcf_format_batch on each slice, formatted on nthreads OpenMP threads. */
+ * batches): byte-identical to nsnp_vcf_format_batch on each slice, formatted on nthreads OpenMP threads (0: nsnp_host_threads()). */
 int64_t nsnp_vcf_format_batches(int64_t N, int64_t batch_size, const char* names_blob, const int64_t* name_off,
                                 const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
                                 const uint8_t* gt_arg, const uint8_t* zy_arg,
@@ -106,6 +109,10 @@ int64_t nsnp_hap_csv_format(int64_t N, const char* names_blob, const int64_t* na
 
 /* calculate_score (predict.py:31-34); *ok = 0 where the Python code raises */
 double nsnp_calculate_score(float p, int score_mode, int* ok);
+
+/* test hook: the writers' printf-free decimal output ("%f", round(x, 2) as str(float)) against glibc printf on n pseudo-random
+ * doubles incl. exact ties; returns the number of differing texts (0), *first_bad the first such value */
+int64_t nsnp_vcf_fmt_selftest(uint64_t seed, int64_t n, double* first_bad);
 
 #ifdef __cplusplus
 }

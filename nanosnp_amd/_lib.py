@@ -286,6 +286,18 @@ class Context:
         n = int(n_sites.item())
         return center[:min(n, cap)], n
 
+    def pileup_select_sites_async(self, pos, flags, stream=None):
+        """select_sites without the host round trip: -> (center_idx int64 [M], entries behind the selected ones = 2^62; n_sites: device
+        int64 [1]).  The streamed pipeline reads the count through a pinned buffer one chunk later (nanosnp_amd/pipeline.py)."""
+        import torch
+        m = pos.shape[0]
+        center = torch.full((max(m, 1),), 1 << 62, dtype=torch.int64, device=pos.device)
+        n_sites = torch.zeros(1, dtype=torch.int64, device=pos.device)
+        check(self.lib.nsnp_pileup_select_sites(self.handle, _dptr(pos), _dptr(flags), m, _dptr(center), m,
+                                                _dptr(n_sites), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_select_sites")
+        return center, n_sites
+
     def pileup_gather_windows(self, counts, center_idx, stream=None):
         import torch
         n = center_idx.shape[0]

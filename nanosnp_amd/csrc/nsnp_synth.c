@@ -112,7 +112,7 @@ int64_t nsnp_synth_columns(uint64_t seed, int64_t M, double coverage, int max_de
     int64_t* chunk_bytes = (int64_t*)calloc((size_t)n_chunk + 1, sizeof(int64_t));
     if (!chunk_bytes) return NSNP_HOST_ENOMEM;
     for (int pass = 0; pass < 2; ++pass) {
-        #pragma omp parallel for schedule(dynamic, 16)
+        #pragma omp parallel for num_threads(nsnp_host_threads()) schedule(dynamic, 16)
         for (int64_t ch = 0; ch < n_chunk; ++ch) {
             rng_t r; rng_seed(&r, seed, (uint64_t)ch);
             const int64_t c0 = ch * CHUNK, c1 = (c0 + CHUNK < M) ? c0 + CHUNK : M;
@@ -147,7 +147,7 @@ int nsnp_synth_hap_planes(uint64_t seed, int64_t N, double coverage, int D, int 
                           int32_t* seq, int32_t* bq, int32_t* mq, int32_t* hap, int32_t* ref_row)
 {
     if (N < 0 || D <= 0 || L <= 0 || !seq || !bq || !mq || !hap || !ref_row) return NSNP_HOST_EINVAL;
-    #pragma omp parallel for schedule(dynamic, 64)
+    #pragma omp parallel for num_threads(nsnp_host_threads()) schedule(dynamic, 64)
     for (int64_t n = 0; n < N; ++n) {
         rng_t r; rng_seed(&r, seed ^ 0x5851F42D4C957F2Dull, (uint64_t)n);
         int32_t* s = seq + n * D * L; int32_t* b = bq + n * D * L;
@@ -211,7 +211,7 @@ int64_t nsnp_columns_to_mpileup_text(const char* contig, int64_t M, const int64_
     uint8_t is_read[256];
     memset(is_read, 0, sizeof is_read);
     for (const char* s = "ACGTNacgtn*#"; *s; ++s) is_read[(unsigned char)*s] = 1;
-    #pragma omp parallel for schedule(dynamic, 16)
+    #pragma omp parallel for num_threads(nsnp_host_threads()) schedule(dynamic, 16)
     for (int64_t ch = 0; ch < n_chunk; ++ch) {
         const int64_t c0 = ch * CHUNK, c1 = (c0 + CHUNK < M) ? c0 + CHUNK : M;
         int64_t n = 0;
@@ -225,7 +225,7 @@ int64_t nsnp_columns_to_mpileup_text(const char* contig, int64_t M, const int64_
     int64_t total = 0;
     for (int64_t ch = 0; ch < n_chunk; ++ch) { const int64_t n = cb[ch]; cb[ch] = total; total += n; }
     if (!out || cap < total) { free(cb); return -(total + 16); }
-    #pragma omp parallel for schedule(dynamic, 16)
+    #pragma omp parallel for num_threads(nsnp_host_threads()) schedule(dynamic, 16)
     for (int64_t ch = 0; ch < n_chunk; ++ch) {
         const int64_t c0 = ch * CHUNK, c1 = (c0 + CHUNK < M) ? c0 + CHUNK : M;
         char* p = out + cb[ch];

@@ -29,8 +29,12 @@ def _load():
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `make -C nanosnp_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()')")
+    # the OpenMP runtime the library links reads its environment when it is loaded: idle workers sleep instead of spinning (a team
+    # is woken once per text chunk; spinning workers would eat the CPU quota of a container between the chunks)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     lib = C.CDLL(_LIB_PATH)
     p = C.c_void_p
+    lib.nsnp_host_threads.restype = C.c_int
     lib.nsnp_synth_columns.restype = C.c_int64
     lib.nsnp_synth_columns.argtypes = [C.c_uint64, C.c_int64, C.c_double, C.c_int, C.c_double,
                                        C.c_int, p, p, C.c_int64, p]
@@ -278,24 +282,25 @@ def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, z
 
 
 def vcf_format_batches(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, batch_size=1000,
-                       score_mode=SCORE_FLOAT64, nthreads=None):
+                       score_mode=SCORE_FLOAT64, nthreads=None, as_view=False):
     """All batches of the predict loop in one native call (OpenMP over batches) -> (bytes, n_rows); byte-identical to
-    concatenating vcf_format_batch over consecutive slices of batch_size sites."""
+    concatenating vcf_format_batch over consecutive slices of batch_size sites.  as_view: a memoryview of the output buffer instead
+    of a bytes copy of it (12 MB per 200 k rows)."""
     l = _bind_vcf()
     N = len(pos)
     args = [np.ascontiguousarray(contig_id, np.int32), np.ascontiguousarray(pos, np.int64),
             np.ascontiguousarray(ref_base, np.uint8), np.ascontiguousarray(gt_arg, np.uint8),
             np.ascontiguousarray(zy_arg, np.uint8), np.ascontiguousarray(gt_prob, np.float32),
             np.ascontiguousarray(zy_prob, np.float32), np.ascontiguousarray(cov, np.float32)]
-    nthreads = int(nthreads or min(64, os.cpu_count() or 1))
-    cap = 128 * N + 256
+    nthreads = int(nthreads or 0)                      # 0: nsnp_host_threads() - affinity mask and cgroup quota
+    cap = 80 * N + 256
     rows = C.c_int64(0)
     while True:
         buf = np.empty(cap, np.uint8)
         n = l.nsnp_vcf_format_batches(N, int(batch_size), table.blob, _ptr(table.off), *[_ptr(a) for a in args], int(score_mode),
                                       _ptr(buf), cap, C.byref(rows), nthreads)
         if n >= 0:
-            return buf[:n].tobytes(), rows.value
+            return (memoryview(buf)[:n] if as_view else buf[:n].tobytes()), rows.value
         if n > -16:
             _check(n, "nsnp_vcf_format_batches")
         cap = -int(n)

@@ -98,14 +98,31 @@ class _HostSet:
         self.h2d_done = None
 
 
+class _DevSet:
+    """device buffers of one text chunk in flight (filled by the copy stream, read by the chunk's encode / select / call rows)"""
+    def __init__(self, cap_bytes, dev):
+        import torch
+        cap_cols = cap_bytes // 8 + 2
+        self.pos = torch.empty(cap_cols, dtype=torch.int64, device=dev)
+        self.off = torch.empty(cap_cols + 1, dtype=torch.int64, device=dev)
+        self.bases = torch.empty(cap_bytes, dtype=torch.uint8, device=dev)
+        self.free = None                               # event on the compute stream: the last kernels reading this set are done
+
+
 def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None, on_rows=None):
-    """The device part of stages s1 + s2 over the lines of text[lo:hi], chunk by chunk: a worker thread parses chunk k + 1
-    (libnanosnp_host.so, OpenMP, straight into pinned buffers) while this thread sends chunk k to the device and runs column encode
-    -> site selection -> PileupModel forward + argmax / max on it.  Every chunk is parsed with 16 lines of halo on either side
-    (re-parsed, not exchanged) and calls the sites centred in its own lines, so the result does not depend on where the cuts fall.
+    """The device part of stages s1 + s2 over the lines of text[lo:hi], chunk by chunk, three things at a time:
+
+        worker thread   parses chunk k + 1 (libnanosnp_host.so, OpenMP, straight into pinned buffers)
+        copy stream     sends chunk k to the device (double-buffered device sets)
+        compute stream  column encode -> site selection of chunk k, then PileupModel forward + argmax / max of chunk k - 1
+
+    The number of selected sites is data: it comes back through a pinned buffer and is read ONE CHUNK LATER (the forward of chunk
+    k - 1 is issued behind the encode of chunk k), so this thread never waits for work it has just issued and the device never
+    waits for this thread.  Every chunk is parsed with 16 lines of halo on either side (re-parsed, not exchanged) and calls the
+    sites centred in its own lines, so the result does not depend on where the cuts fall.
     Returns the call rows [n, 13] float64 (position, argmax / max of both heads, the eight coverage channels: all exact in float64)
     as a device tensor in position order - or, with on_rows, hands every chunk's rows to that callback as soon as they are issued
-    (call_contig formats the VCF rows of complete batches meanwhile) and returns None.  stats (a dict) receives per-stage busy times."""
+    and returns None.  stats (a dict) receives per-stage busy times."""
     import time
     from concurrent.futures import ThreadPoolExecutor
     import torch
@@ -114,96 +131,174 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     finder, arr = _as_bytes_like(text)
     hi = arr.size if hi is None else hi
     st = stats if stats is not None else {}
-    for k in ("parse_s", "h2d_s", "gpu_s", "text_bytes", "columns", "chunks"):
+    for k in ("parse_s", "h2d_s", "gpu_s", "text_bytes", "columns", "chunks", "setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s"):
         st.setdefault(k, 0.0)
+    t_enter = time.perf_counter()
     if hi <= lo:
         return torch.zeros((0, 13), dtype=torch.float64, device=dev)
     n_chunks = max(1, -(-(hi - lo) // int(chunk_bytes)))
     cuts = line_cuts(finder, n_chunks, lo, hi)
     ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(n_chunks) if cuts[k + 1] > cuts[k]]
     cap = max(b - a for a, b, _, _ in ranges) + 64
-    # pinned buffers are expensive to create (page-locking): kept on the model between calls
+    # pinned buffers are expensive to create (page-locking): kept on the model between calls, with their device twins
     sets = getattr(model, "_host_sets", None)
-    if not sets or sets[0].bases.numel() < cap or (len(sets) < 2 and len(ranges) > 1):
-        sets = [_HostSet(cap), _HostSet(cap)] if len(ranges) > 1 else [_HostSet(cap)]
+    # THREE host sets: the parser works two chunks ahead of the copy engine (it never waits for this thread between two chunks)
+    n_sets = min(3, len(ranges))
+    if not sets or sets[0].bases.numel() < cap or len(sets) < n_sets:
+        sets = [_HostSet(cap) for _ in range(n_sets)]
         model._host_sets = sets
+        model._dev_sets = None
+    dsets = getattr(model, "_dev_sets", None)
+    if not dsets or len(dsets) < min(2, len(ranges)) or dsets[0].bases.device != dev or dsets[0].bases.numel() < cap:
+        dsets = [_DevSet(sets[0].bases.numel(), dev) for _ in range(min(2, len(ranges)))]
+        model._dev_sets = dsets
+        model._copy_stream = torch.cuda.Stream(dev)
+    if len(getattr(model, "_meta_pin", ())) < len(ranges):
+        model._meta_pin = torch.zeros((len(ranges), 4), dtype=torch.int64, pin_memory=True)
+    meta_pin = model._meta_pin
+    copy_stream = model._copy_stream
+    main = torch.cuda.current_stream(dev)
     for hs_ in sets:
         hs_.h2d_done = None
+    for ds_ in dsets:
+        ds_.free = None
     d_seq = torch.from_numpy(np.ascontiguousarray(chr_seq)).to(dev)
-    stream = torch.cuda.current_stream(dev)
+    seq_len = int(chr_seq.size)
+    cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
+    copy_stream.wait_stream(main)                      # (whatever the caller queued before us may still read the device sets)
 
     def parse(k):
         t0 = time.perf_counter()
         a, b, _, _ = ranges[k]
         out = host.mpileup_parse_range(arr, a, b, out=sets[k % len(sets)].np)
-        return out, time.perf_counter() - t0
+        pos = out[0]
+        bad = bool(pos.size) and (int(pos.max()) > seq_len or int(pos.min()) < 1)
+        return out, bad, time.perf_counter() - t0
 
     rows_all = []
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ranges]
+    st["setup_s"] += time.perf_counter() - t_enter
+    tev = lambda: torch.cuda.Event(enable_timing=True)
+    ev = [dict(h0=tev(), h1=tev(), a0=tev(), a1=tev(), b0=tev(), b1=tev()) for _ in ranges]
+
+    def calls_of(job):
+        """the second half of a chunk: its site count is on the host by now"""
+        k, M, n_lo, n_hi, ds, counts, center, sel_done = job
+        t_w = time.perf_counter()
+        sel_done.synchronize()
+        st["wait_counts_s"] += time.perf_counter() - t_w
+        _, c_lo, c_hi, _ = meta_pin[k].tolist()
+        ev[k]["b0"].record(main)
+        if c_hi > c_lo:
+            centers = center[c_lo:c_hi]                                                   # ascending: the chunk's own sites are one run
+            gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(counts, centers)
+            # (index tensors made once, on the device: indexing with a Python list copies it from pageable memory every time, and
+            # that copy waits for everything queued on the device - the forward just issued included)
+            cov = counts.index_select(0, centers).index_select(1, cov_idx).to(torch.float64)      # predict.py:63
+            f64 = lambda t: t.to(torch.float64)[:, None]
+            rows_k = torch.cat([f64(ds.pos[:M].index_select(0, centers)), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1)
+            if on_rows is not None:
+                on_rows(rows_k)
+            else:
+                rows_all.append(rows_k)
+        ev[k]["b1"].record(main)
+        ds.free = torch.cuda.Event(); ds.free.record(main)
+
+    job = None
     with ThreadPoolExecutor(max_workers=1) as pool:
-        fut = pool.submit(parse, 0)
+        futs = [pool.submit(parse, j) for j in range(min(2, len(ranges)))]       # (one worker: the parses run one after the other)
         for k, (a, b, n_lo, n_hi) in enumerate(ranges):
-            (pos, col_off, bases), t_parse = fut.result()
-            hs = sets[k % len(sets)]
-            st["parse_s"] += t_parse; st["text_bytes"] += b - a; st["chunks"] += 1
-            M = int(pos.size)
-            if M and (int(pos.max()) > chr_seq.size or int(pos.min()) < 1):
+            t_w = time.perf_counter()
+            (pos, col_off, bases), bad, t_parse = futs[k].result()
+            t_i = time.perf_counter()
+            st["wait_parse_s"] += t_i - t_w
+            if bad:
                 raise ValueError(f"{contig}: position outside the reference sequence")
-            ev[k][0].record(stream)
-            d_pos = hs.pos[:M].to(dev, non_blocking=True)
-            d_off = hs.off[:M + 1].to(dev, non_blocking=True)
-            d_bases = hs.bases[:max(int(bases.size), 1)].to(dev, non_blocking=True)
-            ev[k][1].record(stream)
-            hs.h2d_done = ev[k][1]
-            if k + 1 < len(ranges):
-                nxt = sets[(k + 1) % len(sets)]
+            hs, ds = sets[k % len(sets)], dsets[k % len(dsets)]
+            st["parse_s"] += t_parse; st["text_bytes"] += b - a; st["chunks"] += 1
+            M, nb = int(pos.size), int(bases.size)
+            # ---- H2D on the copy stream, behind the last readers of this device set (chunk k - 2) ----
+            if ds.free is not None:
+                copy_stream.wait_event(ds.free)
+            with torch.cuda.stream(copy_stream):
+                ev[k]["h0"].record(copy_stream)
+                ds.pos[:M].copy_(hs.pos[:M], non_blocking=True)
+                ds.off[:M + 1].copy_(hs.off[:M + 1], non_blocking=True)
+                ds.bases[:max(nb, 1)].copy_(hs.bases[:max(nb, 1)], non_blocking=True)
+                ev[k]["h1"].record(copy_stream)
+            hs.h2d_done = ev[k]["h1"]
+            if k + 2 < len(ranges):
+                nxt = sets[(k + 2) % len(sets)]
                 if nxt.h2d_done is not None:
-                    nxt.h2d_done.synchronize()          # the copy engine is done with the set the parser is about to overwrite
-                fut = pool.submit(parse, k + 1)
+                    nxt.h2d_done.synchronize()          # the copy engine is done with the set the parser is about to overwrite (chunk k - 1)
+                futs.append(pool.submit(parse, k + 2))
+            # ---- first half of chunk k on the compute stream: encode + select, the counts on their way to the host ----
+            main.wait_event(ev[k]["h1"])
+            ev[k]["a0"].record(main)
             own = M - n_lo - n_hi
             st["columns"] += own
+            nxt_job = None
             if own > 0:
+                d_pos = ds.pos[:M]
                 d_ref = d_seq[d_pos - 1]
-                counts, depth, flags = ctx.pileup_encode_columns(d_bases, d_off, d_ref, min_af, min_coverage)
-                centers, n_loc = ctx.pileup_select_sites(d_pos, flags)
-                if n_loc:
-                    centers = centers[(centers >= n_lo) & (centers < M - n_hi)].contiguous()     # halo columns belong to the neighbours
-                    n_loc = int(centers.shape[0])
-                if n_loc:
-                    gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(counts, centers)
-                    cov = counts[centers][:, COV_CHANNELS].to(torch.float64)              # predict.py:63
-                    f64 = lambda t: t.to(torch.float64)[:, None]
-                    rows_k = torch.cat([f64(d_pos[centers]), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1)
-                    ev[k][2].record(stream)
-                    if on_rows is not None:
-                        on_rows(rows_k)
-                    else:
-                        rows_all.append(rows_k)
-            if own <= 0 or not n_loc:
-                ev[k][2].record(stream)
+                counts, depth, flags = ctx.pileup_encode_columns(ds.bases[:max(nb, 1)], ds.off[:M + 1], d_ref, min_af, min_coverage)
+                center, n_sel = ctx.pileup_select_sites_async(d_pos, flags)
+                # halo columns belong to the neighbours: the chunk's own centres are [c_lo, c_hi) of the ascending list
+                meta = torch.stack([n_sel[0], (center < n_lo).sum(), (center < M - n_hi).sum(), n_sel[0]])
+                meta_pin[k].copy_(meta, non_blocking=True)
+                sel_done = torch.cuda.Event(); sel_done.record(main)
+                nxt_job = (k, M, n_lo, n_hi, ds, counts, center, sel_done)
+            else:
+                ds.free = torch.cuda.Event(); ds.free.record(main)
+            ev[k]["a1"].record(main)
+            # ---- second half of chunk k - 1 ----
+            if job is not None:
+                calls_of(job)
+            job = nxt_job
+            st["issue_s"] += time.perf_counter() - t_i
+        if job is not None:
+            t_i = time.perf_counter()
+            calls_of(job)
+            st["issue_s"] += time.perf_counter() - t_i
+    t_d = time.perf_counter()
     torch.cuda.synchronize(dev)
-    for e0, e1, e2 in ev:
-        st["h2d_s"] += e0.elapsed_time(e1) * 1e-3
-        st["gpu_s"] += e1.elapsed_time(e2) * 1e-3
+    st["drain_s"] += time.perf_counter() - t_d
+    for e in ev:
+        st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
+        st["gpu_s"] += e["a0"].elapsed_time(e["a1"]) * 1e-3
+        if e["b0"].query() and e["b1"].query():
+            try:
+                st["gpu_s"] += e["b0"].elapsed_time(e["b1"]) * 1e-3
+            except RuntimeError:
+                pass                                   # (a chunk without columns of its own never recorded its second half)
     if on_rows is not None:
         return None
     return torch.cat(rows_all) if rows_all else torch.zeros((0, 13), dtype=torch.float64, device=dev)
 
 
-def _format_rows(r, contig, chr_seq, batch_size, score_mode):
-    """call rows [n, 13] (host float64) -> (VCF text, rows written) of the reference's predict loop over consecutive batches"""
-    n = r.shape[0]
-    site_pos = r[:, 0].astype(np.int64)
+def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False):
+    """call rows [n, 13] float64 (a device tensor, a host tensor or a numpy array) -> (VCF text, rows written) of the reference's
+    predict loop over consecutive batches.  Device rows are cut into their typed columns ON the device (six small kernels, 41 B per
+    site over the bus instead of 104 B and nine numpy passes)."""
+    import torch
+    if isinstance(r, torch.Tensor):
+        site_pos = r[:, 0].to(torch.int64).cpu().numpy()
+        ga, za = r[:, 1].to(torch.uint8).cpu().numpy(), r[:, 2].to(torch.uint8).cpu().numpy()
+        gm, zm = r[:, 3].to(torch.float32).cpu().numpy(), r[:, 4].to(torch.float32).cpu().numpy()
+        cov = r[:, 5:13].to(torch.float32).contiguous().cpu().numpy()
+    else:
+        site_pos = r[:, 0].astype(np.int64)
+        ga, za, gm, zm = r[:, 1].astype(np.uint8), r[:, 2].astype(np.uint8), r[:, 3].astype(np.float32), r[:, 4].astype(np.float32)
+        cov = r[:, 5:13].astype(np.float32)
+    n = site_pos.shape[0]
     site_ref = chr_seq[site_pos - 1] & 0xDF                                  # make_predict_data/main.cpp:91 upper-cases
     # the VCF rows depend on the batch boundary: one native call formats every batch (OpenMP over the batches)
-    return host.vcf_format_batches(host.ContigTable([contig]), np.zeros(n, np.int32), site_pos, site_ref, r[:, 1].astype(np.uint8),
-                                   r[:, 2].astype(np.uint8), r[:, 3].astype(np.float32), r[:, 4].astype(np.float32),
-                                   r[:, 5:13].astype(np.float32), batch_size=batch_size, score_mode=score_mode)
+    return host.vcf_format_batches(host.ContigTable([contig]), np.zeros(n, np.int32), site_pos, site_ref, ga, za, gm, zm, cov,
+                                   batch_size=batch_size, score_mode=score_mode, as_view=as_view)
 
 
 def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.12, min_coverage=6,
                 batch_size=1000, score_mode=host.SCORE_FLOAT64, chunk_bytes=64 << 20, stats=None):
-    """One contig: returns (vcf_rows: bytes, n_sites, n_rows).  model: pileup_model.LSTMNetwork; mpileup_text: bytes, mmap or a
+    """One contig: returns (vcf_rows: bytes-like - a memoryview of the formatter's buffer, no copy; bytes(...) it to keep it -, n_sites, n_rows).  model: pileup_model.LSTMNetwork; mpileup_text: bytes, mmap or a
     numpy uint8 array holding the contig's samtools-mpileup text.
 
     The text is worked off in chunks of whole lines (stream_contig: parse of chunk k + 1 on the host beside the device work of
@@ -237,7 +332,7 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
     if n_sites == 0:
         return b"", 0, 0
     t0 = time.perf_counter()
-    text, n_rows = _format_rows(rows.cpu().numpy(), contig, chr_seq, batch_size, score_mode)
+    text, n_rows = _format_rows(rows, contig, chr_seq, batch_size, score_mode, as_view=True)
     if stats is not None:
         stats["vcf_s"] = stats.get("vcf_s", 0.0) + time.perf_counter() - t0
         stats["sites"] = stats.get("sites", 0) + n_sites

@@ -139,6 +139,8 @@ def test_e2e_text_to_vcf_line():
     assert d["value"] > 1e4 and d["columns_per_s"] > 1e6 and abs(d["value"] - d["config"]["candidate_sites"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert len(d["stage_busy_s_per_step"]) == 4 and d["bound_by"] in d["stage_busy_s_per_step"] and d["cpu_baseline"]["value"] > 0
     assert d["config"]["text_bytes"] // d["config"]["chunk_bytes"] >= 5          # several chunks in flight
+    m = d["main_thread_s_per_step"]
+    assert set(m) >= {"wait_parse_s", "issue_s", "wait_counts_s", "vcf_s", "write_s"} and sum(m[k] for k in ("wait_parse_s", "issue_s", "vcf_s", "write_s")) <= d["ms_per_step"] * 1e-3 * 1.05
 
 
 @pytest.mark.parametrize("workload", ["pileup", "two-stage", "haplotype"])

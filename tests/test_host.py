@@ -139,3 +139,64 @@ def test_line_cuts_and_halo_ranges_of_the_streamed_pipeline():
     assert np.array_equal(pos, cols.pos) and np.array_equal(off, cols.col_off) and np.array_equal(bases, cols.bases) and pos.base is out[0]
     with pytest.raises(host.HostError):
         host.mpileup_parse_range(text, 0, len(text), out=(np.empty(10, np.int64), np.empty(11, np.int64), np.empty(len(text), np.uint8)))
+
+
+def test_the_vector_tokeniser_equals_the_portable_one_on_awkward_texts(monkeypatch):
+    """nsnp_mpileup_parse_into has an AVX2 path (inline scans, 32-byte copies) and a portable path (libc memchr / memcpy):
+    same arrays on CRLF line ends, runs of tabs, a last line without newline, lines without a quality field, further fields behind
+    the qualities, signed / padded positions, tokens longer than 32 bytes ending at the very end of the buffer, and a multi-megabyte
+    text that is cut over several threads"""
+    rng = np.random.default_rng(77)
+
+    def both(text):
+        res = []
+        for generic in ("1", "0"):
+            monkeypatch.setenv("NSNP_PARSE_GENERIC", generic)
+            try:
+                pos, off, bases = host.mpileup_parse_range(text, 0, len(text))
+                res.append((pos.copy(), off.copy(), bases.copy()))
+            except host.HostError as e:
+                res.append(str(e))
+        if isinstance(res[0], str) or isinstance(res[1], str):
+            assert isinstance(res[0], str) and isinstance(res[1], str), res
+            return None
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b)
+        return res[1]
+
+    def token(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGTacgt.,*#+-^$0123456789", np.uint8), n))
+
+    lines = []
+    for i in range(3000):
+        n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 200, int(rng.integers(1, 120))]))
+        tabs = b"\t" * int(rng.choice([1, 1, 1, 2, 3]))
+        pos = [b"%d" % (i + 1), b"+%d" % (i + 1), b" %d" % (i + 1), b"%019d" % (i + 1)][int(rng.choice([0, 0, 0, 1, 2, 3]))]
+        tail = [b"\t" + token(n), b"", b"\t" + token(n) + b"\t60\t17"][int(rng.choice([0, 0, 1, 2]))]
+        lines.append(b"chrZ" + tabs + pos + b"\tN\t%d\t" % n + token(n) + tail + [b"\n", b"\r\n"][int(rng.integers(0, 2))])
+    text = b"".join(lines)
+    r = both(text)
+    assert r is not None and r[0].size == 3000 and np.array_equal(r[0], np.arange(1, 3001))
+    assert both(text[:-1]) is not None and both(text[:-2]) is not None                    # last line without its newline
+    for cut in (1, 5, 17, 40):                                                            # the last token ends the buffer
+        t2 = b"".join(lines[:50]) + b"chrZ\t51\tN\t40\t" + token(cut + 31)
+        r2 = both(t2)
+        assert r2 is not None and r2[0].size == 51 and r2[1][-1] - r2[1][-2] == cut + 31
+    assert both(b"chrZ\t1\tN\t3\n") is None                                               # four fields: format error on both paths
+    assert both(b"\n\n\r\n") is not None and both(b"\n\n\r\n")[0].size == 0
+    cols = host.synth_columns(5, 60000, coverage=30)
+    big = cols.mpileup_text_native("chr20s")
+    assert len(big) > (4 << 20)
+    rb = both(big)
+    assert np.array_equal(rb[0], cols.pos) and np.array_equal(rb[1], cols.col_off) and np.array_equal(rb[2], cols.bases)
+
+
+def test_the_printf_free_decimal_output_equals_printf():
+    """nsnp_vcf.c formats round(x, 2) as str(float) and '%f' without printf: the hook compares both against glibc on 3 M values
+    (uniform, exact binary ties k / 2^j, neighbours of ties, negative, tiny, quotients of small integers)"""
+    import ctypes as C
+    l = host._bind_vcf()
+    l.nsnp_vcf_fmt_selftest.restype = C.c_int64
+    l.nsnp_vcf_fmt_selftest.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_double)]
+    bad = C.c_double(0)
+    assert l.nsnp_vcf_fmt_selftest(20261003, 3_000_000, C.byref(bad)) == 0, bad.value

@@ -76,10 +76,13 @@ def run(args, rank, world, local_rank):
 
     def one_pass(stats=None, cb=chunk):
         rows_text, n_sites, n_rows = call_contig(model, text, "chr20s", seq, chunk_bytes=cb, stats=stats)
+        t_w = time.perf_counter()
         if rank == 0:
             with open(out_path, "wb") as g:
                 g.write(host.vcf_header("chr20s\t%d\t8\t60\t61\n" % n_cols).encode())
                 g.write(rows_text)
+        if stats is not None:
+            stats["write_s"] = stats.get("write_s", 0.0) + time.perf_counter() - t_w
         return rows_text, n_sites, n_rows
 
     for _ in range(W):
@@ -132,7 +135,11 @@ def run(args, rank, world, local_rank):
                             "vcf_rows_per_s": n_rows / max(per["vcf_s"], 1e-9)},
             "bound_by": names[bound],
             "overlap": {"sum_of_stage_busy_s": round(sum(per.values()), 4), "wall_s_per_step": round(dt / K, 4),
-                        "note": "parse runs on a worker thread beside the device work of the previous chunk: wall < sum when they overlap"},
+                        "note": "three things at a time: the worker thread parses chunk k + 1 / k + 2, the copy stream sends chunk k, the compute "
+                                "stream runs encode + select of chunk k and the forward of chunk k - 1 (site counts are read one chunk late: no host "
+                                "round trip in the loop); wall < sum when they overlap.  main_thread_s_per_step: where the issuing thread spends the step "
+                                "(issue_s includes wait_counts_s)"},
+            "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "vcf_s", "write_s")},
             "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,
             "cpu_baseline": None,
         }
