@@ -64,8 +64,10 @@ int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int6
 int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
                             int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases);
 
-/* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota */
+/* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota (NSNP_HOST_THREADS in the
+ * environment overrides the automatic count); nsnp_host_set_threads(n > 0) fixes it for the process, n <= 0 returns to automatic */
 int nsnp_host_threads(void);
+void nsnp_host_set_threads(int n);
 
 /* ---- FASTA (+.fai) -------------------------------------------------------------------- */
 /* Loads one contig of a FASTA file into seq (capacity cap).  Uses the .fai when present

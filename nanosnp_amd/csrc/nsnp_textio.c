@@ -28,10 +28,21 @@
  * CPU quota (cpu.max of cgroup v2, cpu.cfs_quota_us of v1).  A container with 256 visible CPUs and a quota of 16 otherwise runs
  * 256-thread teams whose busy-waiting workers burn the quota, and the kernel then stalls EVERY thread of the process - the one
  * issuing GPU work included - until the next accounting period (seen as a 2x slower text-to-VCF pipeline). */
+static int g_host_threads_override = 0;
+
+/* n > 0: use exactly n threads from now on (one process per GPU on a shared host: the Python loader divides the budget by
+ * LOCAL_WORLD_SIZE); n <= 0: back to the automatic count */
+void nsnp_host_set_threads(int n) { g_host_threads_override = n > 1024 ? 1024 : n; }
+
 int nsnp_host_threads(void)
 {
     static int cached = 0;
+    if (g_host_threads_override > 0) return g_host_threads_override;
     if (cached > 0) return cached;
+    {
+        const char* e = getenv("NSNP_HOST_THREADS");
+        if (e && atoi(e) > 0) { cached = atoi(e) > 1024 ? 1024 : atoi(e); return cached; }
+    }
     int n = 1;
 #ifdef _OPENMP
     n = omp_get_max_threads();

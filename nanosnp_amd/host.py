@@ -35,6 +35,14 @@ def _load():
     lib = C.CDLL(_LIB_PATH)
     p = C.c_void_p
     lib.nsnp_host_threads.restype = C.c_int
+    lib.nsnp_host_set_threads.argtypes = [C.c_int]
+    # one process per GPU on a shared host (torchrun sets LOCAL_WORLD_SIZE): the ranks share the host's thread budget
+    try:
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        lws = 1
+    if lws > 1 and "NSNP_HOST_THREADS" not in os.environ:
+        lib.nsnp_host_set_threads(max(1, lib.nsnp_host_threads() // lws))
     lib.nsnp_synth_columns.restype = C.c_int64
     lib.nsnp_synth_columns.argtypes = [C.c_uint64, C.c_int64, C.c_double, C.c_int, C.c_double,
                                        C.c_int, p, p, C.c_int64, p]
