@@ -200,3 +200,21 @@ def test_the_printf_free_decimal_output_equals_printf():
     l.nsnp_vcf_fmt_selftest.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_double)]
     bad = C.c_double(0)
     assert l.nsnp_vcf_fmt_selftest(20261003, 3_000_000, C.byref(bad)) == 0, bad.value
+
+
+def test_host_thread_budget(tmp_path):
+    """nsnp_host_threads(): at least one, no more than the CPUs of the affinity mask; NSNP_HOST_THREADS overrides the automatic count
+    and LOCAL_WORLD_SIZE (one process per GPU on a shared host) divides it - both read when the library is loaded, so in a child"""
+    import subprocess, sys, os
+    n = host.lib().nsnp_host_threads()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    code = "from nanosnp_amd import host; print(host.lib().nsnp_host_threads())"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def child(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("NSNP_HOST_THREADS", "LOCAL_WORLD_SIZE")}
+        e.update(env)
+        return int(subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, check=True).stdout.split()[-1])
+    assert child(NSNP_HOST_THREADS="3") == 3
+    auto = child()
+    assert child(LOCAL_WORLD_SIZE="2") == max(1, auto // 2)
+    assert child(LOCAL_WORLD_SIZE="4096") == 1
