@@ -153,3 +153,37 @@ def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_wei
     want = call_contig(m, big, "chrB", seqb, chunk_bytes=1 << 30)
     got = call_contig(m, big, "chrB", seqb, chunk_bytes=256 << 10)
     assert got == want and want[1] > 500
+
+
+def test_streamed_pipeline_edge_inputs(pileup_weights):
+    """call_contig on the inputs a real run meets at its edges: no text, one line, fewer columns than a window, a last line without
+    its newline, CRLF line ends, a chunk size below one line (every line its own chunk), and the same contig again on the same model
+    after a larger one (the pinned / device buffer sets kept on the model are re-used): always the rows of the one-chunk run"""
+    from nanosnp_amd import host
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_contig
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    cols = host.synth_columns(20261212, 3000, coverage=30, het_rate=0.05)
+    text = bytes(cols.mpileup_text_native("chrE"))
+    seq = cols.ref.copy()
+    lines = text.split(b"\n")[:-1]
+    want = call_contig(m, text, "chrE", seq, chunk_bytes=1 << 30)
+    assert want[1] > 30 and want[2] > 0
+    want_rows = bytes(want[0])
+    assert call_contig(m, b"", "chrE", seq) == (b"", 0, 0)
+    for k in (1, 16, 32):                                           # fewer columns than a 33-column window: nothing to call
+        r = call_contig(m, b"\n".join(lines[:k]) + b"\n", "chrE", seq)
+        assert r[1] == 0 and bytes(r[0]) == b""
+    r = call_contig(m, text[:-1], "chrE", seq, chunk_bytes=50_000)  # the last line without its newline
+    assert bytes(r[0]) == want_rows and r[1:] == want[1:]
+    r = call_contig(m, b"\r\n".join(lines) + b"\r\n", "chrE", seq, chunk_bytes=40_000)
+    assert bytes(r[0]) == want_rows and r[1:] == want[1:]
+    r = call_contig(m, text, "chrE", seq, chunk_bytes=64)           # below one line: one line per chunk, ~3000 chunks
+    assert bytes(r[0]) == want_rows and r[1:] == want[1:]
+    big_cols = host.synth_columns(20261213, 30_000, coverage=30, het_rate=0.03)
+    big = call_contig(m, big_cols.mpileup_text_native("chrF"), "chrF", big_cols.ref.copy(), chunk_bytes=200_000)
+    assert big[1] > 300
+    r = call_contig(m, text, "chrE", seq, chunk_bytes=70_000)       # smaller again: the larger buffer sets are kept and re-used
+    assert bytes(r[0]) == want_rows and r[1:] == want[1:]
+    with pytest.raises(ValueError):
+        call_contig(m, text, "chrE", seq[:100])                     # positions beyond the reference sequence
