@@ -112,8 +112,8 @@ class _DevSet:
 def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None, on_rows=None):
     """The device part of stages s1 + s2 over the lines of text[lo:hi], chunk by chunk, three things at a time:
 
-        worker thread   parses chunk k + 1 (libnanosnp_host.so, OpenMP, straight into pinned buffers)
-        copy stream     sends chunk k to the device (double-buffered device sets)
+        worker thread   parses chunks k + 1 and k + 2 (libnanosnp_host.so, OpenMP, straight into one of three pinned buffer sets)
+        copy stream     sends chunk k to the device (two device buffer sets: chunk k + 2 waits for the last readers of chunk k)
         compute stream  column encode -> site selection of chunk k, then PileupModel forward + argmax / max of chunk k - 1
 
     The number of selected sites is data: it comes back through a pinned buffer and is read ONE CHUNK LATER (the forward of chunk
