@@ -87,6 +87,19 @@ class HapStage:
             if rc:
                 self._lib.check(rc, self.ctx.handle, "nsnp_hap_features")
 
+    def features_alone(self, b0, b1, int8=False, warm=32, timed=16):
+        """the L = 33 feature launch alone on the chip -> (total ms, launches) of `timed` launches behind `warm` untimed ones of the
+        same shape: the memory side of the chip takes tens of milliseconds to reach its clocks after an idle period (the first eight
+        launches after a synchronisation run 0.34 ms, the 130th 0.245: tools/feat_warm_probe.py), and inside a job the kernel never
+        meets a cold chip.  The timing accumulator is cleared first: launches of other shapes (L = 11) must not enter the average"""
+        for _ in range(warm):
+            self.features(b0, b1, int8=int8, which=(0,))
+        self.sync(); self.ctx.read_timing()
+        for _ in range(timed):
+            self.features(b0, b1, int8=int8, which=(0,))
+        self.sync()
+        return self.ctx.read_timing()["hap_features"]
+
     def forward(self, b0, b1):
         P = C.c_void_p
         rc = self.lib.nsnp_hap_forward(self.ctx.handle, P(self.xp.data_ptr()), P(self.xh.data_ptr()), b1 - b0,
@@ -225,7 +238,7 @@ def hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, feat_sites, workload="
         nbytes = hs.feature_bytes(feat_sites, 33)
         out["roofline_features"] = bc.roofline_hbm("k_hap_features (L = 33, int32 planes)", nbytes, feat_ms / feat_n, feat_n,
                                                    traffic=bc.committed_traffic(workload, "hap_features", D=hs.D),
-                                                   how="HIP events around every launch, one stream, nothing else running", sites_per_launch=feat_sites,
+                                                   how="HIP events around every launch, one stream, nothing else running, behind 32 untimed launches of the same shape (warm memory clocks)", sites_per_launch=feat_sites,
                                                    D=hs.D)
     return out
 
@@ -379,19 +392,12 @@ def run(args, rank, world, local_rank, deep60=False):
     # ---- after the timed region, alone on the chip: feature launches by window length, second / labelled values ----
     b0, b1 = hs.batch_range(0)
     nfe = b1 - b0
-    hs.sync(); hs.ctx.read_timing()
-    for _ in range(8):
-        hs.features(b0, b1, which=(0,))
-    hs.sync()
-    feat_ms, feat_n = hs.ctx.read_timing()["hap_features"]
+    feat_ms, feat_n = hs.features_alone(b0, b1)
     second = {}
     if rank == 0 or world > 1:
         # int8 read planes: same features bit for bit from a quarter of the input bytes
         if hs.planes8:
-            for _ in range(8):
-                hs.features(b0, b1, int8=True, which=(0,))
-            hs.sync()
-            ms8, n8 = hs.ctx.read_timing()["hap_features"]
+            ms8, n8 = hs.features_alone(b0, b1, int8=True)
             second["features_int8_planes"] = {"avg_launch_ms": ms8 / n8, "sites_per_s": nfe / (ms8 / n8 * 1e-3),
                                               "GB_per_s_of_its_own_bytes": hs.feature_bytes(nfe, 33, True) / (ms8 / n8 * 1e-3) / 1e9,
                                               "note": "nsnp_hap_features_i8, L = 33: own packed format, a quarter of the input bytes; the roofline above prices the int32 layout"}

@@ -152,10 +152,7 @@ def run(args, rank, world, local_rank):
         # rooflines: the dominant kernel of the whole job is the HaplotypeModel's fused step launch (80 % of the time)
         chain_ms, chain_n = tim["hap_lstm_chain"]
         b0, b1 = hs.batch_range(0)
-        for _ in range(4):
-            hs.features(b0, b1, which=(0,))
-        hs.sync()
-        feat_ms, feat_n = hs.ctx.read_timing()["hap_features"]
+        feat_ms, feat_n = hs.features_alone(b0, b1)      # (cleared first: the region's launches are L = 33 AND L = 11)
         roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, b1 - b0, "two-stage")
         excl, excl_n = ps.exclusive_pass(groups=2)
         pr = pileup_rooflines(ps, ptot, excl, excl_n, n2 * K, t2, 0, ps.G, "two-stage")
