@@ -99,6 +99,8 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *                                                              LDS once and read by all nine taps (fp32 and bf16x3), or the round-3 GEMM that gathers
  *                                                              every tap from the image (the f16x3 mode always does); the two sum the same products in a
  *                                                              different order
+ *   "hap_b3x"                 1 (default) | 0                  bf16x3 HaplotypeModel / CatModel LSTM steps: 256 x 256 workgroup tiles where the launch fills
+ *                                                              the chip with them, or always the 128 x 128 tiles of the other modes (bit-identical)
  *   "hap_pass_sites"          128..131072, multiple of 128     sites per internal pass of the HaplotypeModel forward (default 16384;
  *                                                              workspace ~195 KB per site = 3.2 GB per context at the default,
  *                                                              (re)allocated synchronously by this call and by nsnp_hap_load_weights,

@@ -30,6 +30,9 @@
 #ifndef NSNP_GEMM_MINW
 #define NSNP_GEMM_MINW 2
 #endif
+#ifndef NSNP_GEMM_B3X
+#define NSNP_GEMM_B3X 1          // bf16x3 LSTM steps on 256 x 256 workgroup tiles (k_hap_lstm_b3x) where the launch fills the chip with them
+#endif
 
 namespace {
 
@@ -433,11 +436,148 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
 }
 
 
+// ---- bf16x3 LSTM step on 256 x 256 workgroup tiles -------------------------------------------------------------------------------
+// In the bf16x3 mode a K chunk is 24 MFMAs per wave (768 matrix cycles) where the fp32 mode has 32 of four times the length: the
+// chunk's fixed costs - 20 KB from L2, the three-way split of the activations, the barrier, the fragment reads - weigh 2.7 times
+// as much, and k_hap_gemm<LSTM, 2> stands at 60 % MFMA-busy (tools/probes/gemm_b3_tile.hip reproduces it: 0.45-0.49 of the nominal
+// peak for the 128 x 128 tile, 0.56-0.57 for this one).  Here a workgroup of eight waves owns two row tiles x two site tiles: wave
+// (wr, wc) multiplies 64 rows (16 hidden units, all four gates) with the 128 sites of ONE site-tile image - 48 MFMAs per chunk and
+// barrier, 32 instead of 40 KB from L2 per 2 x 2 tiles, one split of an activation per 256 instead of 128 rows.  Same images, same
+// k order and product order per accumulator: bit-identical to k_hap_gemm<MODE_LSTM, 2>.  One workgroup per CU (96 KB of LDS).
+constexpr int BT = 256;
+__global__ __launch_bounds__(512, 1) void k_hap_lstm_b3x(const StepLaunch L)
+{
+    constexpr int TILE_W = TILE_F * 3 / 2;
+    __shared__ float As[2][BT][LDB3 / 2];
+    __shared__ float Bs[2][BT][LDB3 / 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const StepArgs& a = L.z[blockIdx.z];
+    const int nk = a.nk0 + a.nk1;
+
+    // staging: the 256 x 96 B of the two weight tile images = 1536 pieces of 16 B, three per thread; the 256 x 64 B of the two
+    // activation tile images = 512 halves of a site's 16 K positions, one per thread
+    const float* __restrict__ wsrc[3]; int arow[3], aslot[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = tid + 512 * i, r = p / 6, sl = p - 6 * r;
+        arow[i] = r; aslot[i] = (sl ^ ((r >> 3) & 1)) * 4;
+        wsrc[i] = a.w + ((size_t)(2 * by + (r >> 7)) * a.nk_img) * TILE_W + (size_t)(r & 127) * (LDB3 / 2) + sl * 4;
+    }
+    const int bsite = tid >> 1, bhalf = tid & 1;
+    const float* __restrict__ b0 = a.in0 ? a.in0 + (size_t)(2 * bx + (bsite >> 7)) * a.in0_tile_stride + (bsite & 127) * BK + bhalf * 8 : nullptr;
+    const float* __restrict__ b1 = a.in1 ? a.in1 + (size_t)(2 * bx + (bsite >> 7)) * a.in1_tile_stride + (bsite & 127) * BK + bhalf * 8 : nullptr;
+    f32x4 ga[3], gb0, gb1;
+    auto gload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ga[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + (size_t)kc * TILE_W);
+        const float* src = kc < a.nk0 ? b0 + (size_t)kc * TILE_F : b1 + (size_t)(kc - a.nk0) * TILE_F;
+        gb0 = *reinterpret_cast<const f32x4*>(src); gb1 = *reinterpret_cast<const f32x4*>(src + 4);
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(&As[buf][arow[i]][aslot[i]]) = ga[i];
+        b8_t p0, p1, p2;
+        split3_b8(gb0, gb1, p0, p1, p2);
+        b8_t* rb = reinterpret_cast<b8_t*>(&Bs[buf][bsite][0]);
+        const int hb = bhalf ^ ((bsite >> 3) & 1);
+        rb[hb] = p0; rb[2 + hb] = p1; rb[4 + hb] = p2;
+    };
+
+    // accumulators start at the bias of their rows (register 4 r4 + g of tile (rt, ct): row 256 by + 64 wr + 32 rt + 8 r4 + 4 lh + g)
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 bz = *reinterpret_cast<const f32x4*>(a.bias + BT * by + 64 * wr + 32 * rt + 8 * r4 + 4 * lh);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[rt][ct][4 * r4 + g] = bz[g];
+        }
+
+    gload(0);
+    lstore(0);
+    if (nk > 1) gload(1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        f32x4 af[2][3], bf[4][3];
+        auto read_frags3 = [&](int p) __attribute__((always_inline)) {
+            const int sl = (2 * p + (lh ^ ((li >> 3) & 1))) * 4;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][sl]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) bf[ct][p] = *reinterpret_cast<const f32x4*>(&Bs[cur][128 * wc + 32 * ct + li][sl]);
+        };
+        read_frags3(0); read_frags3(2);              // the first product is w0 . x2
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags3(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // six products, smallest first: (w plane, x plane) = (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
+        constexpr int WP[6] = {0, 1, 2, 0, 1, 0}, XP[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (g == 1 && kc + 1 < nk) {             // chunk kc + 1 (in the staging registers since the last iteration) -> LDS
+                __builtin_amdgcn_sched_barrier(0);
+                lstore(cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 3 && kc + 2 < nk) {             // chunk kc + 2 from memory
+                __builtin_amdgcn_sched_barrier(0);
+                gload(kc + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, af[rt][WP[g]]), __builtin_bit_cast(b8_t, bf[ct][XP[g]]),
+                                                                           acc[rt][ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- LSTM epilogue: rows are [unit][gate]; the wave's 16 units are chunk 4 by + wr of the output image of site tile 2 bx + wc; a lane
+    // writes positions p = lh * 8 + 4 * rt + r4 of its site (as k_hap_gemm) ----
+    const size_t img = (size_t)(4 * by + wr) * TILE_F;
+    const size_t tile = (size_t)(2 * bx + wc);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int site = 32 * ct + li;
+        float* cptr = a.cstate + tile * a.c_tile_stride + img + site * BK + lh * 8;
+        float* hptr = a.out + tile * a.out_tile_stride + img + site * BK + lh * 8;
+        f32x4 cv[2], hv[2];
+        if (a.first) { cv[0] = f32x4{0.f, 0.f, 0.f, 0.f}; cv[1] = cv[0]; }
+        else { cv[0] = *reinterpret_cast<const f32x4*>(cptr); cv[1] = *reinterpret_cast<const f32x4*>(cptr + 4); }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float cn;
+                hv[rt][r4] = lstm_cell(acc[rt][ct][4 * r4 + 0], acc[rt][ct][4 * r4 + 1], acc[rt][ct][4 * r4 + 2], acc[rt][ct][4 * r4 + 3], cv[rt][r4], cn);
+                cv[rt][r4] = cn;
+            }
+        *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
+        *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
+    }
+}
+
 // launch of the tile GEMM over n_tiles site tiles x n_rt row tiles x nz slices
 // AR: 0 exact fp32, 1 f16x3, 2 bf16x3 (k_hap_gemm); `true` / `false` of the round-2 callers still mean f16x3 / fp32
 template <int MODE, int AR, bool CONV = false>
 inline void launch_hap_gemm(nsnp_ctx* ctx, hipStream_t s, StepLaunch& L, int n_tiles, int n_rt, int nz)
 {
+    if constexpr (MODE == MODE_LSTM && AR == 2 && !CONV && NSNP_GEMM_B3X) {
+        // two row tiles x two site tiles per workgroup where the launch still fills the chip with them (one workgroup per CU)
+        if (ctx->hap_b3x && n_tiles % 2 == 0 && n_rt % 2 == 0 && (long long)(n_tiles / 2) * (n_rt / 2) * nz >= ctx->n_cu) {
+            hipLaunchKernelGGL(k_hap_lstm_b3x, dim3(n_tiles / 2, n_rt / 2, nz), dim3(512), 0, s, L);
+            return;
+        }
+    }
     // (the bf16x3 mode holds 48 KB of LDS per workgroup: three per CU, no ballast)
     hipLaunchKernelGGL((k_hap_gemm<MODE, AR, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
                        AR == 2 ? 0u : gemm_lds_ballast((long long)n_tiles * n_rt * nz, ctx->n_cu), s, L);

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04_profiles
 W=1; K=4
-ONLY="${ONLY:-pileup haplotype two-stage deep60 bf16x3 lines}"
+ONLY="${ONLY:-pileup haplotype two-stage deep60 bf16x3 hapb3 lines}"
 has() { case " $ONLY " in *" $1 "*) return 0;; *) return 1;; esac; }
 if has pileup; then
 bash tools/prof_run.sh r04p pileup --steps $K --warmup $W
@@ -32,6 +32,11 @@ if has bf16x3; then
 bash tools/prof_cmd.sh r04b3 stats,sqa,sqb,clk tools/fwd_probe.py 131072 2 3 > /dev/null
 python3 tools/summarize_sq.py r04_pileup_bf16x3 gpurun_out/prof_r04b3_sqa gpurun_out/prof_r04b3_sqb gpurun_out/prof_r04b3_clk > /dev/null
 python3 tools/summarize_prof.py r04_pileup_bf16x3 gpurun_out/prof_r04b3_stats > /dev/null
+fi
+if has hapb3; then
+# the bf16x3 HaplotypeModel forward alone (one pass of 16384 sites): SQ counters + clock of its kernels
+HAP_PROBE_REPS=1 bash tools/prof_cmd.sh r04hb3 sqa,sqb,clk tools/hap_probe.py 16384 2 > /dev/null
+python3 tools/summarize_sq.py r04_hap_forward_bf16x3 gpurun_out/prof_r04hb3_sqa gpurun_out/prof_r04hb3_sqb gpurun_out/prof_r04hb3_clk > /dev/null
 fi
 cp profiles/r04_* profiles/roofline_traffic.json gpurun_out/r04_profiles/
 if has lines; then
