@@ -422,7 +422,7 @@ def run(args, rank, world, local_rank, deep60=False):
                     # its own roofline against the dense bf16 MFMA peak, the six MFMAs of a product priced as executed
                     n_launch = bc.hap_lstm_launches()
                     spp = min(nfe, int(hs.ctx_pass_sites))
-                    sv["roofline"] = bc.roofline_mfma("k_hap_gemm<LSTM, bf16x3>", bc.hap_exec_flop() * 6 * spp / n_launch, ch_ms / ch_n / n_launch,
+                    sv["roofline"] = bc.roofline_mfma("k_hap_lstm_b3x (bf16x3 LSTM step, 256 x 256 tiles)", bc.hap_exec_flop() * 6 * spp / n_launch, ch_ms / ch_n / n_launch,
                                                       ch_n * n_launch, peak=bc.PEAK_F16_MFMA_TFLOPS, launches_per_pass=n_launch, sites_per_pass=spp,
                                                       how="one HIP event pair around the %d step launches of a pass, divided by %d" % (n_launch, n_launch))
                     if rank == 0 and not args.no_parity_sample:
