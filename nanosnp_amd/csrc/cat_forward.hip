@@ -249,7 +249,6 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
     const int nrt = a.n_rows <= 32 ? 1 : 2;
     const int site0 = small_rows ? 32 * wave : 64 * wc;
     const int W = a.conv_w, HW = a.conv_h * a.conv_w;
-    const int n_blocks = a.cc_in + a.cc_sc;
     const int n_chunks = 9 * a.cc_in + a.cc_sc;
     const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_W;
 
@@ -337,9 +336,16 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
 
     // ---- prologue: zero rows, block 0, weight chunk 0 ---------------------------------------------------------------------------
     if (tid < 2 * ROWF) Hb[tid / ROWF][CONV_ROWS - 1][tid % ROWF] = 0.f;
+    // chunk index (into the weight image) of the j-th chunk of the walk: blocks of nine taps over the channel chunks, then the shortcut's
+    auto chunk_kc = [&](int jj) {
+        const int nconv = 9 * a.cc_in;
+        if (jj < nconv) { const int b = jj / 9, t = jj - 9 * b; return t * a.cc_in + b; }
+        return jj;                                      // shortcut chunk s: 9 cc_in + s = its own position in the walk
+    };
     gload_h(0); lstore_h(0);
-    gload_a(0); lstore_a(0);                            // chunk 0 = (tap 0, cc 0), or the first shortcut chunk when there is no conv part
-    __syncthreads();
+    gload_a(chunk_kc(0)); lstore_a(0);                  // chunk 0 = (tap 0, cc 0), or the first shortcut chunk when there is no conv part
+    if (n_chunks > 1) gload_a(chunk_kc(1));             // weights travel TWO chunks ahead with one set of staging registers (as k_hap_gemm, PIPE 2):
+    __syncthreads();                                    // written to LDS early in the burst of the chunk before theirs, re-loaded later in the same burst
 
     int blk = 0, tap = 0, cur = 0, hb = 0;
     for (int j = 0; j < n_chunks; ++j) {
@@ -349,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
         int nblk = blk, ntp = tap + 1;
         if (ntp == ntap) { nblk = blk + 1; ntp = 0; }
         const bool have_next = j + 1 < n_chunks;
-        const int nkc = nblk < a.cc_in ? ntp * a.cc_in + nblk : 9 * a.cc_in + (nblk - a.cc_in);
         const bool stage_next_block = have_next && ntp == 0;          // the last tap of a block: the next block's pixels go to LDS
         // fragments of this chunk
         const int t_eff = conv ? tap : 4;                              // the shortcut reads the pixel itself
@@ -372,9 +377,14 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
             constexpr int WP[6] = {0, 1, 2, 0, 1, 0}, XP[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
-                if (g == 2) {                                          // global loads of the next chunk from inside the burst
+                if (g == 1 && have_next) {                             // weights of chunk j + 1 (in the staging registers) -> LDS
                     __builtin_amdgcn_sched_barrier(0);
-                    if (have_next) gload_a(nkc);
+                    lstore_a(cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (g == 3) {                                          // global loads from inside the burst: weights of chunk j + 2, pixels of the next block
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 2 < n_chunks) gload_a(chunk_kc(j + 2));
                     if (stage_next_block) gload_h(nblk);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -390,9 +400,14 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (k == 3) {
+                if (k == 1 && have_next) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (have_next) gload_a(nkc);
+                    lstore_a(cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (k == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 2 < n_chunks) gload_a(chunk_kc(j + 2));
                     if (stage_next_block) gload_h(nblk);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -406,7 +421,6 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (have_next) lstore_a(cur ^ 1);
         if (stage_next_block) lstore_h(hb ^ 1);
         __syncthreads();
         cur ^= 1;

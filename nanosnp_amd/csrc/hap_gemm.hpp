@@ -580,7 +580,11 @@ inline void launch_hap_gemm(nsnp_ctx* ctx, hipStream_t s, StepLaunch& L, int n_t
     }
     // (the bf16x3 mode holds 48 KB of LDS per workgroup: three per CU, no ballast)
     hipLaunchKernelGGL((k_hap_gemm<MODE, AR, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
+#ifdef NSNP_GEMM_FORCE_BALLAST
+                       (unsigned)NSNP_GEMM_FORCE_BALLAST, s, L);       // (A/B build: a fixed dynamic-LDS ballast = fewer workgroups per CU)
+#else
                        AR == 2 ? 0u : gemm_lds_ballast((long long)n_tiles * n_rt * nz, ctx->n_cu), s, L);
+#endif
 }
 
 // Weight images of the three arithmetic modes live at corresponding offsets of three arenas: fp32 at float offset o, the f16x3 copy
