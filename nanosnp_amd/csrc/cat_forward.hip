@@ -485,8 +485,8 @@ int shift_of(int cc) { int s = 0; while ((1 << s) < cc) ++s; return s; }
 // or in the storage order of a previous bidirectional layer's h (prev_lstm = true); recurrent columns in storage order
 void pack_lstm(float* img, float* bias, const float* const* q, int I, int nki, bool prev_lstm)
 {
-    const int H = CAT_NH, G = 4 * H, nkh = H / BK, nk = nki + nkh;
-    auto lstm_row = [H](int R) { return (R & 3) * H + (R >> 2); };
+    constexpr int H = CAT_NH; const int G = 4 * H, nkh = H / BK, nk = nki + nkh;
+    auto lstm_row = [](int R) { return (R & 3) * H + (R >> 2); };
     for (int by = 0; by < G / TR; ++by)
         for (int kc = 0; kc < nk; ++kc)
             for (int row = 0; row < TR; ++row)

@@ -138,6 +138,9 @@ int main()
         run<256, 128, 4, 2, 1>("256 x 128, 4 waves of 128 x 64", w, x, out);
         run<256, 128, 2, 2, 1>("256 x 128, 8 waves of 64 x 64", w, x, out);
         run<128, 256, 2, 2, 1>("128 x 256, 8 waves of 64 x 64", w, x, out);
+        run<256, 128, 2, 4, 2>("256 x 128, 4 waves of 64 x 128, 2 per CU", w, x, out);
+        run<128, 256, 4, 2, 2>("128 x 256, 4 waves of 128 x 64, 2 per CU", w, x, out);
+        run<128, 256, 2, 4, 2>("128 x 256, 4 waves of 64 x 128 (2 x 2), 2 per CU", w, x, out);
         run<256, 256, 4, 2, 1>("256 x 256, 8 waves of 128 x 64", w, x, out);
         run<256, 256, 2, 4, 1>("256 x 256, 8 waves of 64 x 128", w, x, out);
         run<256, 256, 2, 2, 1>("256 x 256, 16 waves of 64 x 64", w, x, out);
