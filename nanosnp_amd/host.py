@@ -31,7 +31,9 @@ def _load():
             "(or python -c 'import __graft_entry__ as g; g.build()')")
     # the OpenMP runtime the library links reads its environment when it is loaded: idle workers sleep instead of spinning (a team
     # is woken once per text chunk; spinning workers would eat the CPU quota of a container between the chunks)
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    # (a value the user has set is kept; NANOSNP_KEEP_OMP_ENV=1 leaves the environment alone altogether)
+    if os.environ.get("NANOSNP_KEEP_OMP_ENV") != "1":
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     lib = C.CDLL(_LIB_PATH)
     p = C.c_void_p
     lib.nsnp_host_threads.restype = C.c_int
