@@ -131,7 +131,7 @@ static int fmt_f6(char* dst, double af)
     return n + 6;
 }
 
-typedef struct { char* p; int64_t len, cap; int overflow; } sbuf;
+typedef struct { char* p; int64_t len, cap; int overflow, nomem; } sbuf;
 static void sb_put(sbuf* b, const char* s, int64_t n)
 {
     if (b->len + n > b->cap) { b->overflow = 1; b->len += n; return; }
@@ -147,7 +147,7 @@ static void emit(sbuf* b, const char* ctg, int ctg_len, int64_t pos, char sref, 
     char* line = stack;
     if (ctg_len > 256) {                                 /* (a contig name that long: rare enough for the heap) */
         line = (char*)malloc((size_t)ctg_len + 256);
-        if (!line) { b->overflow = 1; return; }
+        if (!line) { b->nomem = 1; return; }
     }
     int n = 0;
     memcpy(line, ctg, (size_t)ctg_len); n += ctg_len;
@@ -179,7 +179,7 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
                               int score_mode, char* out, int64_t cap, int64_t* n_rows)
 {
     if (B < 0 || !name_off || !n_rows) return NSNP_HOST_EINVAL;
-    sbuf sb = { out, 0, out ? cap : 0, 0 };
+    sbuf sb = { out, 0, out ? cap : 0, 0, 0 };
     int64_t rows = 0;
     for (int64_t j = 0; j < B; ++j) {
         const int g = gt_arg[j];
@@ -261,6 +261,7 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
         emit(&sb, ctg, ctg_len, pos[j], sref, alt_txt, qual, "PASS", zy, depth, af); ++rows;
     }
     *n_rows = rows;
+    if (sb.nomem) return NSNP_HOST_ENOMEM;
     if (sb.overflow) return -(sb.len + 16);
     return sb.len;
 }
@@ -340,7 +341,7 @@ int64_t nsnp_hap_csv_format(int64_t N, const char* names_blob, const int64_t* na
                             const float* gt_prob, int score_mode, char* out, int64_t cap)
 {
     if (N < 0 || !name_off) return NSNP_HOST_EINVAL;
-    sbuf sb = { out, 0, out ? cap : 0, 0 };
+    sbuf sb = { out, 0, out ? cap : 0, 0, 0 };
     for (int64_t j = 0; j < N; ++j) {
         int64_t q;
         if (gt_arg[j] > 20) return NSNP_HOST_ERANGE;
