@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3(
             xi[0] = p[16]; xi[1] = p[17];
         }
     };
+    int xdirty = 0;                                        // bit b: planes 1, 2 of this wave's image in buffer b hold the values of an earlier step
     auto stage_x = [&](const int (&xi)[8], int buf) __attribute__((always_inline)) {
         if (!stager) return;
         __bf16* row = xx + (size_t)(buf * NSG + wave) * FR_X + q * 128 + n * 8;
@@ -158,9 +159,17 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3(
         if (__builtin_expect(__ballot(big) == 0ull, 1)) {
             b8 p0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) p0[j] = (__bf16)(float)xi[j];          // predict.py:49 int -> float; planes 1, 2 are not read at level 0
+            for (int j = 0; j < 8; ++j) p0[j] = (__bf16)(float)xi[j];          // predict.py:49 int -> float
             *reinterpret_cast<b8*>(row) = p0;
+            // The step's level is the workgroup's (the largest of its site groups): a group below it multiplies its planes 1 and 2 as
+            // well, so they must be ZERO, not what an earlier step left there (they start as zeros: the loop in front of the first barrier)
+            if (xdirty & (1 << buf)) {
+                *reinterpret_cast<b8*>(row + 512) = b8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<b8*>(row + 1024) = b8{0, 0, 0, 0, 0, 0, 0, 0};
+                xdirty &= ~(1 << buf);
+            }
         } else {
+            xdirty |= 1 << buf;
             b8 p0, p1, p2;
             bool nz1 = false, nz2 = false;
 #pragma unroll
@@ -177,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3(
         if (lane == 0) xflag[buf * 4 + wave] = lvl;
     };
     if (tid < 8) xflag[tid] = 0;
+    for (int i = tid; i < 2 * NSG * FR_X / 8; i += 256) reinterpret_cast<b8*>(xx)[i] = b8{0, 0, 0, 0, 0, 0, 0, 0};
     // h_{-1} = 0: the buffer step 0 reads
     for (int i = tid; i < NSG * FR_H / 8; i += 256) reinterpret_cast<b8*>(hx + (size_t)NSG * FR_H)[i] = b8{0, 0, 0, 0, 0, 0, 0, 0};
     __syncthreads();
@@ -341,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3p(
             xi[0] = p[16]; xi[1] = p[17];
         }
     };
+    int xdirty = 0;                                        // bit b: planes 1, 2 of this wave's image in buffer b hold the values of an earlier step
     auto stage_x = [&](const int (&xi)[8], int buf) __attribute__((always_inline)) {
         if (!stager) return;
         __bf16* row = xx + (size_t)(buf * NSG + wave) * FR_X + q * 128 + n * 8;
@@ -353,7 +364,13 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3p(
 #pragma unroll
             for (int j = 0; j < 8; ++j) p0[j] = (__bf16)(float)xi[j];
             *reinterpret_cast<b8*>(row) = p0;
+            if (xdirty & (1 << buf)) {                     // (planes 1, 2 of a group below the workgroup's level must read as zeros: k_pileup_l0_b3)
+                *reinterpret_cast<b8*>(row + 512) = b8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<b8*>(row + 1024) = b8{0, 0, 0, 0, 0, 0, 0, 0};
+                xdirty &= ~(1 << buf);
+            }
         } else {
+            xdirty |= 1 << buf;
             b8 p0, p1, p2;
             bool nz1 = false, nz2 = false;
 #pragma unroll
@@ -370,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void k_pileup_l0_b3p(
         if (lane == 0) xflag[buf * 4 + wave] = lvl;
     };
     if (tid < 8) xflag[tid] = 0;
+    for (int i = tid; i < 2 * NSG * FR_X / 8; i += 256) reinterpret_cast<b8*>(xx)[i] = b8{0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < NSG * FR_H / 8; i += 256) reinterpret_cast<b8*>(hx + (size_t)NSG * FR_H)[i] = b8{0, 0, 0, 0, 0, 0, 0, 0};
     __syncthreads();
     auto t_of = [&](int s) { return dir ? PW - 1 - s : s; };

@@ -488,3 +488,45 @@ def test_bf16x3_mode_carries_the_full_fp32_operand_width(pileup_weights):
     sub, _ = c2.pileup_forward(xt[:16].contiguous())
     assert torch.equal(sub, g2[:16])
     c2.close(); c0.close()
+
+
+def test_bf16x3_split_levels_of_different_site_groups_in_one_workgroup(pileup_weights):
+    """The bf16x3 layer-0 kernels run a step at the split level of the LARGEST count any site group of the WORKGROUP staged for it
+    (1 term up to 256, 2 up to 65536, 3 beyond); a group below that level multiplies its own planes 1 and 2 as well, which must then be
+    zeros.  (Round 4, found by tools/b3_consistency.py: they held whatever an earlier step had left there - a workgroup with one
+    large-count site gave wrong probabilities, by up to 0.08, for the sites of its OTHER group.  Coverage beyond 256x only.)
+    8192 sites = the skewed two-group kernel, with large counts in the first group of some workgroups, the second group of others,
+    both, at single steps and at all steps; every site must equal, bit for bit, its result in a 16-site batch of its own group (one
+    group per workgroup), and the forced plain kernels with 2 and 4 groups per workgroup must agree; all against the oracle."""
+    import torch
+    from nanosnp_amd import _lib
+    from oracle import oracle
+    rng = np.random.default_rng(91)
+    n = 8192
+    x = (rng.integers(0, 60, (n, 33, 18)) - 12).astype(np.int32)
+    x[5, 3, 2] = 70000                                   # workgroup 0: group A at one step (three terms) ...
+    x[17] *= 300                                         # ... group B at every step (two terms)
+    x[40, 10:20, 1] = 1000                               # workgroup 1: group A only, ten steps
+    x[32 * 7 + 20, 32, 17] = -300                        # workgroup 7: group B only, last step
+    x[32 * 100 + 3, 0, 0] = 1 << 22; x[32 * 100 + 19, 0, 0] = 257       # workgroup 100: both groups, different levels, first step
+    x[4095, 16, 5] = 5000; x[4096, 16, 5] = -5000        # neighbours across workgroups
+    xt = torch.from_numpy(x).cuda()
+    c = _lib.Context(0); c.pileup_load_weights(pileup_weights); c.set_option("pileup_precision", 2)
+    g, z = c.pileup_forward(xt); torch.cuda.synchronize()
+    touched = sorted({s // 16 for s in (5, 17, 40, 32 * 7 + 20, 32 * 100 + 3, 32 * 100 + 19, 4095, 4096)} | {0, 1, 2, 3, 14, 15, 200, 201, 255, 256})
+    for grp in touched:                                  # the group itself and the other group of its workgroup
+        for gg in (grp, grp ^ 1):
+            a = 16 * gg
+            gs, zs = c.pileup_forward(xt[a:a + 16].contiguous())
+            assert torch.equal(gs, g[a:a + 16]) and torch.equal(zs, z[a:a + 16]), gg
+    for l0g in (1, 2, 4):
+        c.set_option("l0_site_groups", l0g)
+        g2, z2 = c.pileup_forward(xt)
+        assert torch.equal(g2, g) and torch.equal(z2, z), l0g
+    c.set_option("l0_site_groups", 0)
+    m = 640                                              # workgroups 0 .. 19 against the oracle (incl. 0, 1, 7)
+    og, oz = oracle.pileup_forward(pileup_weights, x[:m], nthreads=8)
+    assert np.abs(g[:m].cpu().numpy() - og).max() < PROB_ATOL and np.abs(z[:m].cpu().numpy() - oz).max() < PROB_ATOL
+    og, oz = oracle.pileup_forward(pileup_weights, x[3200:3232], nthreads=8)
+    assert np.abs(g[3200:3232].cpu().numpy() - og).max() < PROB_ATOL and np.abs(z[3200:3232].cpu().numpy() - oz).max() < PROB_ATOL
+    c.close()
