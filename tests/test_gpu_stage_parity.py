@@ -71,7 +71,8 @@ def test_parity_check_sees_a_corrupted_run():
     assert not r["ok"] and not r["calls_equal_own_argmax"]
 
 
-def test_concurrent_contexts_equal_their_sequential_results_bit_for_bit(pileup_weights):
+@pytest.mark.parametrize("precision", [0, 2], ids=["fp32", "bf16x3"])
+def test_concurrent_contexts_equal_their_sequential_results_bit_for_bit(pileup_weights, precision):
     """eight contexts on eight streams, ragged batch sizes, 20 rounds: the same bits as one after the other (tests/manual/soak.py)"""
     import torch
     from nanosnp_amd import _lib
@@ -80,6 +81,7 @@ def test_concurrent_contexts_equal_their_sequential_results_bit_for_bit(pileup_w
     streams = [torch.cuda.Stream() for _ in range(8)]
     for c in ctxs:
         c.pileup_load_weights(pileup_weights)
+        c.set_option("pileup_precision", precision)
     xs = [torch.from_numpy((rng.integers(0, 50, (int(rng.integers(100, 6000)), 33, 18)) - 10).astype(np.int32)).cuda() for _ in range(8)]
     seq = [c.pileup_forward(x) for c, x in zip(ctxs, xs)]
     torch.cuda.synchronize()

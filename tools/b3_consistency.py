@@ -12,24 +12,29 @@ from nanosnp_amd.fixtures import load_pileup_weights, seeded_hap_weights
 rng = np.random.default_rng(20261004)
 ctx = _lib.Context(0)
 ctx.pileup_load_weights(load_pileup_weights())
-ctx.set_option("pileup_precision", 2)
 N = 40000
 x = torch.from_numpy((rng.integers(0, 60, (N, 33, 18)) - 12).astype(np.int32)).cuda()
 x[5, 3, 2] = 70000; x[17] *= 300                       # the two- and three-term input levels
-gt, zy = ctx.pileup_forward(x); torch.cuda.synchronize()
-bad = 0
-for trial in range(12):
-    cuts = np.sort(rng.choice(np.arange(1, N), size=int(rng.integers(1, 9)), replace=False)).tolist()
-    edges = [0] + cuts + [N]
-    for a, b in zip(edges, edges[1:]):
-        g, z = ctx.pileup_forward(x[a:b])
-        if not (torch.equal(g, gt[a:b]) and torch.equal(z, zy[a:b])):
-            bad += 1; print("pileup bf16x3 differs on", a, b, float((g - gt[a:b]).abs().max()))
-for n in (1, 15, 16, 17, 31, 33, 4095, 4096, 4097, 8191, 8192, 8193):
-    g, z = ctx.pileup_forward(x[:n])
-    if not (torch.equal(g, gt[:n]) and torch.equal(z, zy[:n])):
-        bad += 1; print("pileup bf16x3 differs at n =", n)
-print("PileupModel bf16x3: sub-batch results", "identical" if not bad else f"DIFFER ({bad})")
+x[1000:1016, 5, 7] = 131008; x[1016, 9, 1] = -200000; x[20000, 16, :] = 3000
+bad_total = 0
+for prec in (int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("2", "0", "1"))):
+  ctx.set_option("pileup_precision", prec)
+  gt, zy = ctx.pileup_forward(x); torch.cuda.synchronize()
+  bad = 0
+  for trial in range(12):
+      cuts = np.sort(rng.choice(np.arange(1, N), size=int(rng.integers(1, 9)), replace=False)).tolist()
+      edges = [0] + cuts + [N]
+      for a, b in zip(edges, edges[1:]):
+          g, z = ctx.pileup_forward(x[a:b])
+          if not (torch.equal(g, gt[a:b]) and torch.equal(z, zy[a:b])):
+              bad += 1; print("pileup precision", prec, "differs on", a, b, float((g - gt[a:b]).abs().max()))
+  for n in (1, 15, 16, 17, 31, 33, 4095, 4096, 4097, 8191, 8192, 8193):
+      g, z = ctx.pileup_forward(x[:n])
+      if not (torch.equal(g, gt[:n]) and torch.equal(z, zy[:n])):
+          bad += 1; print("pileup precision", prec, "differs at n =", n)
+  print(f"PileupModel precision {prec}: sub-batch results", "identical" if not bad else f"DIFFER ({bad})")
+  bad_total += bad
+bad = bad_total
 
 h = _lib.Context(0)
 h.hap_load_weights(seeded_hap_weights(12, H=256))
