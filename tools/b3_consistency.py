@@ -36,6 +36,23 @@ for prec in (int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else (
   bad_total += bad
 bad = bad_total
 
+# windows addressed through centre indices into a counts array against the same windows gathered: same bits, every precision
+M = 60000
+counts = torch.from_numpy((rng.integers(0, 60, (M, 18)) - 12).astype(np.int32)).cuda()
+counts[1000:1040, 3] = 900; counts[30000, 0] = 1 << 21
+badw = 0
+for prec in (2, 0, 1):
+    ctx.set_option("pileup_precision", prec)
+    for n in (1, 17, 4095, 4096, 9000):
+        centers = torch.from_numpy(np.sort(rng.choice(np.arange(16, M - 16), size=n, replace=False))).cuda()
+        gw, zw = ctx.pileup_forward_windows(counts, centers)
+        xg = ctx.pileup_gather_windows(counts, centers)
+        gx, zx = ctx.pileup_forward(xg)
+        if not (torch.equal(gw, gx) and torch.equal(zw, zx)):
+            badw += 1; print("windows / gathered differ: precision", prec, "n", n)
+print("forward_windows against gathered windows:", "identical" if not badw else f"DIFFER ({badw})")
+bad += badw
+
 h = _lib.Context(0)
 h.hap_load_weights(seeded_hap_weights(12, H=256))
 h.set_option("hap_precision", 2)
