@@ -70,30 +70,6 @@ def line_cuts(text, n_parts, lo=0, hi=None):
     return cuts
 
 
-def chunk_cuts(text, lo, hi, chunk_bytes):
-    """Cuts of text[lo:hi] into chunks of whole lines for the streamed pipeline: about chunk_bytes each, but the first three an eighth,
-    a quarter and a half of that and the last two a half and a quarter - the pipeline of parse / copy / device stages fills with a
-    small chunk (the device starts after 1/8 of a parse, not a whole one) and drains with one (the forward behind the last parse is a
-    quarter as long).  Texts of up to two chunks are cut evenly."""
-    total = hi - lo
-    n_even = max(1, -(-total // chunk_bytes))
-    if n_even <= 2:
-        return line_cuts(text, n_even, lo, hi)
-    head = [chunk_bytes >> 3, chunk_bytes >> 2, chunk_bytes >> 1]
-    tail = [chunk_bytes >> 1, chunk_bytes >> 2]
-    middle = total - sum(head) - sum(tail)
-    n_mid = max(1, -(-middle // chunk_bytes))
-    sizes = head + [middle // n_mid] * n_mid + tail
-    cuts, at = [lo], lo
-    for sz in sizes[:-1]:
-        at = max(cuts[-1], min(hi, at + sz))
-        nl = text.find(b"\n", at, hi)
-        cuts.append(hi if nl < 0 else nl + 1)
-        at = cuts[-1]
-    cuts.append(hi)
-    return cuts
-
-
 def halo_range(text, lo, hi, halo=16):
     """[lo, hi) grown by up to `halo` whole lines on either side -> (lo_ext, hi_ext, lines added in front, lines added behind)"""
     n_txt = len(text)
@@ -160,8 +136,9 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     t_enter = time.perf_counter()
     if hi <= lo:
         return torch.zeros((0, 13), dtype=torch.float64, device=dev)
-    cuts = chunk_cuts(finder, lo, hi, int(chunk_bytes))
-    ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k + 1] > cuts[k]]
+    n_chunks = max(1, -(-(hi - lo) // int(chunk_bytes)))
+    cuts = line_cuts(finder, n_chunks, lo, hi)
+    ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(n_chunks) if cuts[k + 1] > cuts[k]]
     cap = max(b - a for a, b, _, _ in ranges) + 64
     # pinned buffers are expensive to create (page-locking): kept on the model between calls, with their device twins
     sets = getattr(model, "_host_sets", None)

@@ -141,22 +141,6 @@ def test_line_cuts_and_halo_ranges_of_the_streamed_pipeline():
         host.mpileup_parse_range(text, 0, len(text), out=(np.empty(10, np.int64), np.empty(11, np.int64), np.empty(len(text), np.uint8)))
 
 
-def test_chunk_cuts_of_the_streamed_pipeline_tile_the_text_with_a_ramp():
-    """pipeline.chunk_cuts: whole lines, the text tiled exactly, a short first chunk (an eighth of the nominal size) and short last ones"""
-    from nanosnp_amd.pipeline import chunk_cuts
-    text = b"".join(b"chrT\t%d\tN\t3\tAca\tIII\n" % (i + 1) for i in range(60000))
-    for cb in (1 << 14, 100_000, 1 << 20, 64):
-        c = chunk_cuts(text, 0, len(text), cb)
-        sizes = [b - a for a, b in zip(c, c[1:])]
-        assert c[0] == 0 and c[-1] == len(text) and all(x <= y for x, y in zip(c, c[1:])) and all(text[x - 1:x] == b"\n" for x in c[1:])
-        if len(text) > 2 * cb and cb > 1000:
-            assert sizes[0] <= cb // 8 + 64 and sizes[-1] <= cb // 4 + 64 and max(sizes) <= cb + 64
-    lo = text.find(b"\n", 5000) + 1; hi = text.find(b"\n", 700_000) + 1
-    c = chunk_cuts(text, lo, hi, 50_000)
-    assert c[0] == lo and c[-1] == hi and len(c) > 10
-    assert chunk_cuts(text, 0, len(text), 1 << 30) == [0, len(text)]
-
-
 def test_the_vector_tokeniser_equals_the_portable_one_on_awkward_texts(monkeypatch):
     """nsnp_mpileup_parse_into has an AVX2 path (inline scans, 32-byte copies) and a portable path (libc memchr / memcpy):
     same arrays on CRLF line ends, runs of tabs, a last line without newline, lines without a quality field, further fields behind
