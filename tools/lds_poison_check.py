@@ -51,4 +51,20 @@ for pattern in (0x7fc07fc0, 0xffffffff, 0x7f800000):
         if not same:
             bad += 1; print("DIFFERS after LDS poison %08x:" % pattern, k)
 print("results after LDS poisoning:", "identical" if not bad else f"{bad} DIFFER")
+# the same for the contexts' WORKSPACES in global memory: a pass over NaN / huge inputs leaves NaNs in every intermediate buffer (also
+# in the rows a later, smaller call pads its tiles with); the later call must not see them
+nan = float("nan")
+for prec in (0, 2, 1):
+    ctx.set_option("pileup_precision", prec); ctx.set_option("hap_precision", prec); ctx.set_option("cat_precision", prec)
+    ctx.hap_forward(torch.full_like(xp, nan), torch.full_like(xh, nan))
+    ctx.cat_forward(torch.full_like(g0, nan), torch.full_like(g1, nan))
+    ctx.pileup_forward(torch.full_like(x, 2 ** 30))
+torch.cuda.synchronize()
+got = everything()
+badw = 0
+for k, v in got.items():
+    if not all(torch.equal(a, c) for a, c in zip(v, base[k]) if a is not None):
+        badw += 1; print("DIFFERS after workspace poisoning:", k)
+print("results after workspace poisoning:", "identical" if not badw else f"{badw} DIFFER")
+bad += badw
 sys.exit(1 if bad else 0)
