@@ -1,0 +1,34 @@
+"""Results must not depend on how the work is cut into launches (workgroup shapes are chosen by launch size): the stress tools of
+tools/ as tests.  b3_consistency found the round-4 bug of the bf16x3 layer-0 kernels (stale split planes of a site group below its
+workgroup's level); lds_poison_check runs when its helper library has been built (hipcc -shared tools/probes/lds_poison.hip)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *args, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    return p.stdout
+
+
+def test_forward_results_do_not_depend_on_launch_shapes():
+    out = _run("b3_consistency.py")
+    assert out.count("identical") == 5 and "DIFFER" not in out, out
+
+
+def test_encode_results_do_not_depend_on_the_launch_partition():
+    out = _run("encode_consistency.py")
+    assert out.count("identical") == 4 and "DIFFER" not in out, out
+
+
+def test_no_kernel_reads_lds_or_workspace_it_never_wrote():
+    if not os.path.exists(os.path.join(ROOT, "build_tmp", "liblds_poison.so")):
+        pytest.skip("build_tmp/liblds_poison.so not built")
+    out = _run("lds_poison_check.py")
+    assert out.count("identical") == 2, out
