@@ -106,6 +106,8 @@ int main()
     for (int rep = 0; rep < 2; ++rep) {
         run<128, 128, 2, 2, 4>("128 x 128, 4 waves of 64 x 64 (the kernel)", w, x, out);
         run<128, 128, 2, 2, 3>("128 x 128, 4 waves of 64 x 64, 3 per CU", w, x, out);
+        run<128, 128, 2, 2, 2>("128 x 128, 4 waves of 64 x 64, bounds 2", w, x, out);
+        run<128, 256, 2, 2, 1>("128 x 256, 8 waves of 64 x 64, bounds 1", w, x, out);
         run<256, 128, 2, 2, 2>("256 x 128, 8 waves of 64 x 64", w, x, out);
         run<128, 256, 2, 2, 2>("128 x 256, 8 waves of 64 x 64", w, x, out);
         run<256, 256, 4, 2, 1>("256 x 256, 8 waves of 128 x 64", w, x, out);
