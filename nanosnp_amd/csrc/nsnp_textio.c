@@ -235,61 +235,213 @@ __attribute__((target("avx2"))) static inline const char* scan_byte_avx2(const c
  * collapse, cpp_aux.cpp:43-59), token 1 is the position, token 4 the column-5 string, and behind token 4 only the newline mask is
  * looked at.  No loop whose trip count depends on a field's length (the per-line memchr calls of the portable path cost 50 ns per
  * 90-byte line, mostly mispredicted exits and call overhead: 1.4 GB/s per thread). */
-__attribute__((target("avx2"))) static int tokenise_avx2(const char* p0, const char* end, const char* limit, rec_list* L)
+#ifndef NSNP_TOK_PREFETCH
+#define NSNP_TOK_PREFETCH 1024     /* bytes the tokenisers prefetch ahead of the block they look at */
+#endif
+/* the position token as an integer: up to 16 plain digits eight at a time (one unaligned 8-byte load per eight digits, the digits
+ * combined pairwise by multiplications - no loop over the digits); anything else (a sign, blanks, more digits) through parse_i64 */
+static inline uint64_t eight_digits(uint64_t v)              /* byte 0 = most significant digit, all bytes '0'..'9' */
+{
+    v -= 0x3030303030303030ull;
+    v = v * 10 + (v >> 8);
+    return (((v & 0x000000FF000000FFull) * 0x000F424000000064ull) + (((v >> 16) & 0x000000FF000000FFull) * 0x0000271000000001ull)) >> 32;
+}
+static inline int all_digits(uint64_t v)
+{
+    return ((v & 0xF0F0F0F0F0F0F0F0ull) == 0x3030303030303030ull) && ((((v + 0x0606060606060606ull) & 0xF0F0F0F0F0F0F0F0ull)) == 0x3030303030303030ull);
+}
+static inline int64_t parse_pos(const char* t1, const char* t1e, const char* text0)
+{
+    const int64_t n = t1e - t1;
+    if (n >= 1 && n <= 16 && t1e - 16 >= text0) {
+        uint64_t lo, hi = 0x3030303030303030ull;
+        memcpy(&lo, t1e - 8, 8);                                /* the last eight bytes in front of the token's end */
+        if (n < 8) lo = (lo & (~0ull << (8 * (8 - n)))) | (0x3030303030303030ull & ~(~0ull << (8 * (8 - n))));     /* bytes in front of the token: '0' */
+        else if (n > 8) {
+            memcpy(&hi, t1e - 16, 8);
+            if (n < 16) hi = (hi & (~0ull << (8 * (16 - n)))) | (0x3030303030303030ull & ~(~0ull << (8 * (16 - n))));
+        }
+        if (all_digits(lo) && all_digits(hi)) return (int64_t)(eight_digits(hi) * 100000000ull + eight_digits(lo));
+    }
+    return parse_i64(t1, t1e);
+}
+
+/* line grammar over the event bits of one 64-byte block (shared by the AVX2 and the AVX-512 front ends) */
+typedef struct { const char* line; const char* tok; const char* t1; const char* t1e; const char* t4; const char* t4e; int ntok; } tok_state;
+
+static inline __attribute__((always_inline)) int tok_block(tok_state* st, uint64_t nlm, uint64_t tbm, const char* base, const char* text0, rec_list* L)
+{
+    uint64_t live = ~0ull;
+    for (;;) {
+        const uint64_t ev = (st->ntok >= 5 ? nlm : (nlm | tbm)) & live;
+        if (!ev) return 0;
+        const int bit = __builtin_ctzll(ev);
+        live = bit == 63 ? 0ull : (~0ull << (bit + 1));
+        const char* e = base + bit;
+        if ((nlm >> bit) & 1) {
+            const char* le = (e > st->line && e[-1] == '\r') ? e - 1 : e;
+            if (st->ntok < 5 && le > st->tok) {               /* the line's last token ends at the line end */
+                if (st->ntok == 1) { st->t1 = st->tok; st->t1e = le; } else if (st->ntok == 4) { st->t4 = st->tok; st->t4e = le; }
+                ++st->ntok;
+            }
+            if (st->ntok >= 5) {
+                if (rec_push(L, parse_pos(st->t1, st->t1e, text0), st->t4, st->t4e - st->t4)) return 1;
+            } else if (le > st->line) return 2;               /* a non-empty line with fewer than five fields */
+            st->line = st->tok = e + 1; st->ntok = 0;
+        } else {                                              /* a tab (only looked at while ntok < 5) */
+            if (e > st->tok) {
+                if (st->ntok == 1) { st->t1 = st->tok; st->t1e = e; } else if (st->ntok == 4) { st->t4 = st->tok; st->t4e = e; }
+                ++st->ntok;
+            }
+            st->tok = e + 1;
+        }
+    }
+}
+
+/* masks of a block that is not wholly inside the text, and of the chunk's last block (a virtual newline behind its last byte) */
+static inline void tail_masks(const char* p0, int64_t off, int64_t len, int whole, uint64_t* nlm, uint64_t* tbm)
+{
+    const int64_t left = len - off;
+    if (!whole) {
+        *nlm = *tbm = 0;
+        for (int64_t k = 0; k < left && k < 64; ++k) { *nlm |= (uint64_t)(p0[off + k] == '\n') << k; *tbm |= (uint64_t)(p0[off + k] == '\t') << k; }
+    }
+    if (left < 64) {
+        const uint64_t keep = left > 0 ? (~0ull >> (64 - left)) : 0ull;
+        *nlm &= keep; *tbm &= keep;
+        if (len == 0 || p0[len - 1] != '\n') *nlm |= 1ull << left;         /* (left <= 63) */
+    }
+}
+
+__attribute__((target("avx2"))) static int tokenise_avx2(const char* p0, const char* end, const char* limit, const char* text0, rec_list* L)
 {
     const __m256i v_nl = _mm256_set1_epi8('\n'), v_tab = _mm256_set1_epi8('\t');
     const int64_t len = end - p0;
-    const char* line = p0;            /* start of the current line */
-    const char* tok = p0;             /* start of the current token (behind the last tab) */
-    int ntok = 0;                     /* non-empty tokens of the line so far */
-    const char* t1 = NULL; const char* t1e = NULL; const char* t4 = NULL; const char* t4e = NULL;
+    tok_state st = { p0, p0, NULL, NULL, NULL, NULL, 0 };
     for (int64_t off = 0; off <= len; off += 64) {
-        uint64_t nlm, tbm;
-        const int64_t left = len - off;                       /* bytes of the chunk in this block (may be 0: the virtual newline only) */
-        if (p0 + off + 64 <= limit) {
+        uint64_t nlm = 0, tbm = 0;
+        const int whole = p0 + off + 64 <= limit;
+        if (whole) {
             const __m256i a = _mm256_loadu_si256((const __m256i*)(p0 + off)), b = _mm256_loadu_si256((const __m256i*)(p0 + off + 32));
+            _mm_prefetch(p0 + off + NSNP_TOK_PREFETCH, _MM_HINT_T0);
             nlm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, v_nl)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, v_nl)) << 32);
             tbm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, v_tab)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, v_tab)) << 32);
-        } else {
-            nlm = tbm = 0;
-            for (int64_t k = 0; k < left && k < 64; ++k) { nlm |= (uint64_t)(p0[off + k] == '\n') << k; tbm |= (uint64_t)(p0[off + k] == '\t') << k; }
         }
-        if (left < 64) {                                      /* the chunk ends in this block: a virtual newline behind its last byte */
-            const uint64_t keep = left > 0 ? (~0ull >> (64 - left)) : 0ull;
-            nlm &= keep; tbm &= keep;
-            if (len == 0 || p0[len - 1] != '\n') nlm |= 1ull << left;      /* (left <= 63) */
-        }
-        uint64_t live = ~0ull;
-        for (;;) {
-            const uint64_t ev = (ntok >= 5 ? nlm : (nlm | tbm)) & live;
-            if (!ev) break;
-            const int bit = __builtin_ctzll(ev);
-            live = bit == 63 ? 0ull : (~0ull << (bit + 1));
-            const char* e = p0 + off + bit;
-            if ((nlm >> bit) & 1) {
-                const char* le = (e > line && e[-1] == '\r') ? e - 1 : e;
-                if (ntok < 5 && le > tok) {                   /* the line's last token ends at the line end */
-                    if (ntok == 1) { t1 = tok; t1e = le; } else if (ntok == 4) { t4 = tok; t4e = le; }
-                    ++ntok;
-                }
-                if (ntok >= 5) {
-                    int64_t v = 0; const char* d = t1;
-                    while (d < t1e && (unsigned)(*d - '0') <= 9u) { v = v * 10 + (*d - '0'); ++d; }
-                    if (d != t1e || t1e - t1 > 18) v = parse_i64(t1, t1e);
-                    if (rec_push(L, v, t4, t4e - t4)) return 1;
-                } else if (le > line) return 2;               /* a non-empty line with fewer than five fields */
-                line = tok = e + 1; ntok = 0;
-            } else {                                          /* a tab (only looked at while ntok < 5) */
-                if (e > tok) {
-                    if (ntok == 1) { t1 = tok; t1e = e; } else if (ntok == 4) { t4 = tok; t4e = e; }
-                    ++ntok;
-                }
-                tok = e + 1;
-            }
-        }
+        if (!whole || len - off < 64) tail_masks(p0, off, len, whole, &nlm, &tbm);
+        const int rc = tok_block(&st, nlm, tbm, p0 + off, text0, L);
+        if (rc) return rc;
     }
     return 0;
 }
+
+/* AVX-512 front end: one load and two compare-into-mask instructions per 64-byte block */
+__attribute__((target("avx512f,avx512bw"))) static int tokenise_avx512(const char* p0, const char* end, const char* limit, const char* text0, rec_list* L)
+{
+    const __m512i v_nl = _mm512_set1_epi8('\n'), v_tab = _mm512_set1_epi8('\t');
+    const int64_t len = end - p0;
+    tok_state st = { p0, p0, NULL, NULL, NULL, NULL, 0 };
+    for (int64_t off = 0; off <= len; off += 64) {
+        uint64_t nlm = 0, tbm = 0;
+        const int whole = p0 + off + 64 <= limit;
+        if (whole) {
+            const __m512i a = _mm512_loadu_si512((const void*)(p0 + off));
+            _mm_prefetch(p0 + off + NSNP_TOK_PREFETCH, _MM_HINT_T0);
+            nlm = _mm512_cmpeq_epi8_mask(a, v_nl); tbm = _mm512_cmpeq_epi8_mask(a, v_tab);
+        }
+        if (!whole || len - off < 64) tail_masks(p0, off, len, whole, &nlm, &tbm);
+        const int rc = tok_block(&st, nlm, tbm, p0 + off, text0, L);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* LINE-ORIENTED tokeniser (the default where AVX2 or AVX-512 is present).  The block-oriented one above walks every tab and newline of
+ * the text through one serial chain (next event = f(previous event): 15 ns per 90-byte line whatever computes the masks - AVX-512
+ * masks, an 8-digit SWAR position and software prefetch each changed nothing).  Here the masks of the 64 bytes AT THE LINE START give
+ * the four tabs that end contig / position / reference base / depth by four independent lowest-set-bit steps, the end of the column-5
+ * token and the newline come from one more mask step each (a second window for lines beyond 64 bytes); a line that does not look
+ * like "four non-empty fields, a tab, a non-empty fifth" in its first 64 bytes (runs of tabs, a short line, a field beyond the window)
+ * is handed to the portable tokeniser, one line at a time - same records in every case. */
+#define NSNP_TOKENISE_LINES(NAME, TARGET, MASKS64)                                                                                          \
+__attribute__((target(TARGET))) static int NAME(const char* p0, const char* end, const char* limit, const char* text0, rec_list* L)        \
+{                                                                                                                                           \
+    const char* p = p0;                                                                                                                     \
+    while (p < end) {                                                                                                                       \
+        if (p + 128 > limit) return tokenise_generic(p, end, L);            /* the last lines of the whole text: portable path */          \
+        uint64_t nl, tb;                                                                                                                    \
+        MASKS64(p, nl, tb);                                                                                                                 \
+        uint64_t x = tb;                                                                                                                    \
+        const int T0 = x ? __builtin_ctzll(x) : 64; x &= x - 1;                                                                             \
+        const int T1 = x ? __builtin_ctzll(x) : 64; x &= x - 1;                                                                             \
+        const int T2 = x ? __builtin_ctzll(x) : 64; x &= x - 1;                                                                             \
+        const int T3 = x ? __builtin_ctzll(x) : 64;                                                                                         \
+        const int N0 = nl ? __builtin_ctzll(nl) : 64;                                                                                       \
+        /* four non-empty fields in front of a non-empty fifth, all of it inside the window and in front of the first newline */           \
+        int fast = T3 < 62 && T0 > 0 && T1 > T0 + 1 && T2 > T1 + 1 && T3 > T2 + 1 && N0 > T3 + 1 && !((tb >> (T3 + 1)) & 1);                \
+        const char* e4 = NULL; const char* nlp = NULL;                                                                                      \
+        if (fast) {                                                                                                                         \
+            /* end of token 4: the first tab or newline behind T3 + 1; then the newline */                                                 \
+            const uint64_t m = (tb | nl) >> (T3 + 2);                                                                                       \
+            const char* q = p;                                                                                                              \
+            if (m) { e4 = p + T3 + 2 + __builtin_ctzll(m); }                                                                                \
+            else {                                                                                                                          \
+                for (q = p + 64; e4 == NULL; q += 64) {                                                                                     \
+                    if (q >= end) { e4 = end; break; }                                                                                      \
+                    if (q + 64 > limit) { const char* z = q; while (z < end && *z != '\t' && *z != '\n') ++z; e4 = z; break; }              \
+                    uint64_t n2, t2; MASKS64(q, n2, t2);                                                                                    \
+                    const uint64_t m2 = n2 | t2;                                                                                            \
+                    if (m2) { e4 = q + __builtin_ctzll(m2); break; }                                                                        \
+                }                                                                                                                           \
+            }                                                                                                                               \
+            if (e4 > end) e4 = end;                                                                                                         \
+            if (e4 < end && *e4 == '\n') nlp = e4;                                                                                          \
+            else if (e4 >= end) nlp = end;                                                                                                  \
+            else {                                                      /* a tab: further fields; the newline behind them */                \
+                const char* z = e4 + 1;                                                                                                     \
+                const int64_t zo = z - p;                                                                                                   \
+                if (zo < 64 && (nl >> zo)) nlp = z + __builtin_ctzll(nl >> zo);                                                             \
+                else {                                                                                                                      \
+                    for (q = zo < 64 ? p + 64 : z; nlp == NULL; ) {                                                                         \
+                        if (q >= end) { nlp = end; break; }                                                                                 \
+                        if (q + 64 > limit) { const char* y = q; while (y < end && *y != '\n') ++y; nlp = y; break; }                       \
+                        uint64_t n2, t2; MASKS64(q, n2, t2); (void)t2;                                                                      \
+                        if (n2) { nlp = q + __builtin_ctzll(n2); break; }                                                                   \
+                        q += 64;                                                                                                            \
+                    }                                                                                                                       \
+                    if (nlp > end) nlp = end;                                                                                               \
+                }                                                                                                                           \
+            }                                                                                                                               \
+            /* the line ends in front of a '\r' that precedes the newline (line_reader.cpp:95-127) */                                       \
+            const char* le = (nlp > p && nlp[-1] == '\r') ? nlp - 1 : nlp;                                                                  \
+            if (e4 > le) e4 = le;                                                                                                           \
+            if (e4 <= p + T3 + 1) fast = 0;                                                                                                 \
+        }                                                                                                                                   \
+        if (fast) {                                                                                                                         \
+            if (rec_push(L, parse_pos(p + T0 + 1, p + T1, text0), p + T3 + 1, e4 - (p + T3 + 1))) return 1;                                 \
+            p = nlp < end ? nlp + 1 : end;                                                                                                  \
+        } else {                                                                                                                            \
+            const char* z = memchr(p, '\n', (size_t)(end - p));                                                                             \
+            const char* next = z ? z + 1 : end;                                                                                             \
+            const int rc = tokenise_generic(p, next, L);                                                                                    \
+            if (rc) return rc;                                                                                                              \
+            p = next;                                                                                                                       \
+        }                                                                                                                                   \
+    }                                                                                                                                       \
+    return 0;                                                                                                                               \
+}
+
+#define NSNP_MASKS64_AVX2(ptr, nlv, tbv) do {                                                                                               \
+    const __m256i a_ = _mm256_loadu_si256((const __m256i*)(ptr)), b_ = _mm256_loadu_si256((const __m256i*)((ptr) + 32));                   \
+    const __m256i vn_ = _mm256_set1_epi8('\n'), vt_ = _mm256_set1_epi8('\t');                                                               \
+    (nlv) = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a_, vn_)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b_, vn_)) << 32); \
+    (tbv) = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a_, vt_)) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b_, vt_)) << 32); \
+} while (0)
+#define NSNP_MASKS64_AVX512(ptr, nlv, tbv) do {                                                                                             \
+    const __m512i a_ = _mm512_loadu_si512((const void*)(ptr));                                                                              \
+    (nlv) = _mm512_cmpeq_epi8_mask(a_, _mm512_set1_epi8('\n')); (tbv) = _mm512_cmpeq_epi8_mask(a_, _mm512_set1_epi8('\t'));                 \
+} while (0)
+NSNP_TOKENISE_LINES(tokenise_lines_avx2, "avx2", NSNP_MASKS64_AVX2)
+NSNP_TOKENISE_LINES(tokenise_lines_avx512, "avx512f,avx512bw", NSNP_MASKS64_AVX512)
 
 /* records -> pos / col_off / bases; tokens are copied 32 bytes at a time while 32 bytes of the thread's own output range and of the
  * text remain behind them (what the copy writes beyond a token is overwritten by the next token of the same thread) */
@@ -318,13 +470,20 @@ static void place_generic(const col_rec* r, int64_t m1, int64_t m0, int64_t o, i
     }
 }
 
-/* NSNP_PARSE_GENERIC=1 in the environment forces the portable path (tests compare the two) */
+/* 0 portable, 1 / 2 line-oriented AVX2 / AVX-512 (the default: the widest the CPU has), 3 / 4 block-oriented AVX2 / AVX-512.
+ * NSNP_PARSE_GENERIC in the environment: 1 forces the portable path, 2 the line-oriented AVX2 path, 3 / 4 the block-oriented ones
+ * (tests compare them all) */
 static int use_avx2(void)
 {
 #ifdef NSNP_HAVE_AVX2_PATH
     const char* e = getenv("NSNP_PARSE_GENERIC");
     if (e && e[0] == '1') return 0;
-    return __builtin_cpu_supports("avx2");
+    if (!__builtin_cpu_supports("avx2")) return 0;
+    const int has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+    if (e && e[0] == '2') return 1;
+    if (e && e[0] == '3') return 3;
+    if (e && e[0] == '4') return has512 ? 4 : 3;
+    return has512 ? 2 : 1;
 #else
     return 0;
 #endif
@@ -376,7 +535,10 @@ int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols
             }
             const int64_t m_before = tls.m, nb_before = tls.nb;
 #ifdef NSNP_HAVE_AVX2_PATH
-            bad = vec ? tokenise_avx2(cut[c], cut[c + 1], limit, &tls) : tokenise_generic(cut[c], cut[c + 1], &tls);
+            bad = vec == 2 ? tokenise_lines_avx512(cut[c], cut[c + 1], limit, text, &tls)
+                : vec == 1 ? tokenise_lines_avx2(cut[c], cut[c + 1], limit, text, &tls)
+                : vec == 3 ? tokenise_avx2(cut[c], cut[c + 1], limit, text, &tls)         /* (the block-oriented form: kept for the comparison tests) */
+                : vec == 4 ? tokenise_avx512(cut[c], cut[c + 1], limit, text, &tls) : tokenise_generic(cut[c], cut[c + 1], &tls);
 #else
             bad = tokenise_generic(cut[c], cut[c + 1], &tls);
 #endif

@@ -113,7 +113,7 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     """The device part of stages s1 + s2 over the lines of text[lo:hi], chunk by chunk, three things at a time:
 
         worker thread   parses chunks k + 1 and k + 2 (libnanosnp_host.so, OpenMP, straight into one of three pinned buffer sets)
-        copy stream     sends chunk k to the device (two device buffer sets: chunk k + 2 waits for the last readers of chunk k)
+        copy stream     sends chunk k to the device (three device buffer sets: chunk k + 3 waits for the last readers of chunk k)
         compute stream  column encode -> site selection of chunk k, then PileupModel forward + argmax / max of chunk k - 1
 
     The number of selected sites is data: it comes back through a pinned buffer and is read ONE CHUNK LATER (the forward of chunk
@@ -149,8 +149,12 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
         model._host_sets = sets
         model._dev_sets = None
     dsets = getattr(model, "_dev_sets", None)
-    if not dsets or len(dsets) < min(2, len(ranges)) or dsets[0].bases.device != dev or dsets[0].bases.numel() < cap:
-        dsets = [_DevSet(sets[0].bases.numel(), dev) for _ in range(min(2, len(ranges)))]
+    # THREE device sets as well: with two, the copy of chunk k + 2 waits for the forward of chunk k (the last reader of its set) and the
+    # encode of chunk k + 2 - in front of the forward of chunk k + 1 in stream order - waits for that copy: copies and forwards
+    # alternated (tools/e2e_timeline.py: 2.4 ms per chunk = copy 0.8 + encode 0.15 + forward 1.45); with three the copy runs beside
+    # the forward of chunk k + 1
+    if not dsets or len(dsets) < min(3, len(ranges)) or dsets[0].bases.device != dev or dsets[0].bases.numel() < cap:
+        dsets = [_DevSet(sets[0].bases.numel(), dev) for _ in range(min(3, len(ranges)))]
         model._dev_sets = dsets
         model._copy_stream = torch.cuda.Stream(dev)
     if len(getattr(model, "_meta_pin", ())) < len(ranges):
@@ -173,9 +177,17 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
         out = host.mpileup_parse_range(arr, a, b, out=sets[k % len(sets)].np)
         pos = out[0]
         bad = bool(pos.size) and (int(pos.max()) > seq_len or int(pos.min()) < 1)
-        return out, bad, time.perf_counter() - t0
+        t1 = time.perf_counter()
+        if trace is not None:
+            trace.append(("parse", k, t0, t1))
+        return out, bad, t1 - t0
 
     rows_all = []
+    trace = st.get("trace")                            # a list: receives (what, chunk, start, end) in host seconds; device spans are mapped onto the host clock
+    ev0 = torch.cuda.Event(enable_timing=True)
+    if trace is not None:
+        torch.cuda.synchronize(dev); ev0.record(main); torch.cuda.synchronize(dev)
+    t_ev0 = time.perf_counter()
     st["setup_s"] += time.perf_counter() - t_enter
     tev = lambda: torch.cuda.Event(enable_timing=True)
     ev = [dict(h0=tev(), h1=tev(), a0=tev(), a1=tev(), b0=tev(), b1=tev()) for _ in ranges]
@@ -207,10 +219,18 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     with ThreadPoolExecutor(max_workers=1) as pool:
         futs = [pool.submit(parse, j) for j in range(min(2, len(ranges)))]       # (one worker: the parses run one after the other)
         for k, (a, b, n_lo, n_hi) in enumerate(ranges):
+            if job is not None and not futs[k].done() and os.environ.get("NSNP_PIPE_NO_EARLY_CALLS") != "1":      # (the variable: A/B measurements)
+                # the parser is still busy with chunk k: the calls of chunk k - 1 go out now instead of behind the encode of chunk k
+                # (at the front of the text this starts the first forward a parse earlier)
+                t_i0 = time.perf_counter()
+                calls_of(job); job = None
+                st["issue_s"] += time.perf_counter() - t_i0
             t_w = time.perf_counter()
             (pos, col_off, bases), bad, t_parse = futs[k].result()
             t_i = time.perf_counter()
             st["wait_parse_s"] += t_i - t_w
+            if trace is not None:
+                trace.append(("main: wait parse", k, t_w, t_i))
             if bad:
                 raise ValueError(f"{contig}: position outside the reference sequence")
             hs, ds = sets[k % len(sets)], dsets[k % len(dsets)]
@@ -255,6 +275,8 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
                 calls_of(job)
             job = nxt_job
             st["issue_s"] += time.perf_counter() - t_i
+            if trace is not None:
+                trace.append(("main: issue", k, t_i, time.perf_counter()))
         if job is not None:
             t_i = time.perf_counter()
             calls_of(job)
@@ -262,6 +284,13 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     t_d = time.perf_counter()
     torch.cuda.synchronize(dev)
     st["drain_s"] += time.perf_counter() - t_d
+    if trace is not None:
+        for k, e in enumerate(ev):
+            for what, x0, x1 in (("h2d", "h0", "h1"), ("encode+select", "a0", "a1"), ("forward+rows", "b0", "b1")):
+                try:
+                    trace.append((what, k, t_ev0 + ev0.elapsed_time(e[x0]) * 1e-3, t_ev0 + ev0.elapsed_time(e[x1]) * 1e-3))
+                except RuntimeError:
+                    pass
     for e in ev:
         st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
         st["gpu_s"] += e["a0"].elapsed_time(e["a1"]) * 1e-3

@@ -14,12 +14,12 @@ big=np.fromfile('/tmp/nsnp_parse_probe.mpileup',np.uint8)
 n=len(big)
 out=(np.empty(n//8+2,np.int64),np.empty(n//8+3,np.int64),np.empty(n,np.uint8))
 for o in out: o[:]=0
-for g in "10":
+for g in "140":
     os.environ["NSNP_PARSE_GENERIC"]=g
     ts=[]
     for r in range(9):
         t=time.perf_counter(); p,_,_=host.mpileup_parse_range(big,0,n,out=out); ts.append(time.perf_counter()-t)
     ts.sort()
-    print(os.environ["NSNP_HOST_THREADS"], "threads", "generic" if g=="1" else "avx2", p.size, f"{n/1e6:.0f} MB  min {ts[0]*1e3:.2f} ms  median {ts[4]*1e3:.2f} ms  {n/ts[4]/1e9:.1f} GB/s")
+    print(os.environ["NSNP_HOST_THREADS"], "threads", {"1": "portable", "4": "block-oriented", "0": "line-oriented"}[g], p.size, f"{n/1e6:.0f} MB  min {ts[0]*1e3:.2f} ms  median {ts[4]*1e3:.2f} ms  {n/ts[4]/1e9:.1f} GB/s")
 PY
 done
