@@ -52,10 +52,15 @@ def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text,
 
 
 def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions, output_file,
-                      batch_size=1000, score_mode=host.SCORE_FLOAT64):
+                      batch_size=1000, score_mode=host.SCORE_FLOAT64, device_batch=16384):
     """ctx: a Context with hap weights loaded; planes_*: (seq, baseq, mapq, hap, ref_row) int32
-    arrays [N,D,33] / [N,D,11]; candidate_positions: "ctg:pos" strings (dataset_dev.py:331-333)."""
+    arrays [N,D,33] / [N,D,11]; candidate_positions: "ctg:pos" strings (dataset_dev.py:331-333).
+    batch_size is the reference's DataLoader batch (predict_dev.py:27-33): a haplotype.csv row does not depend on it (unlike a
+    pileup.vcf row), so the device works in passes of `device_batch` sites - the forward of 1,000 sites runs at 40 % of the rate of
+    16,384 - and the rows are written by one native call; a probability the reference's loop would fail on (score_mode 0, p = 1)
+    fails here as it does there, whatever the batch."""
     import torch
+    del batch_size
     n = len(candidate_positions)
     ctgs, poss = zip(*[p.split(":") for p in candidate_positions]) if n else ((), ())
     table = host.ContigTable(list(ctgs))
@@ -67,15 +72,17 @@ def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions,
         return [np.dtype(np.int8 if narrow else np.int32)] * 4 + [np.dtype(np.int32)]
     tp, th = dtypes(planes_pileup), dtypes(planes_haplotype)
     dev = torch.device("cuda", ctx.device)
+    ga_all, gm_all = [], []
+    for b0 in range(0, n, int(device_batch)):
+        sl = slice(b0, b0 + int(device_batch))
+        dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_pileup, tp)]
+        dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_haplotype, th)]
+        xp = ctx.hap_features(*dp)
+        xh = ctx.hap_features(*dh)
+        gt, _ = ctx.hap_forward(xp, xh)
+        gm, ga = gt.max(dim=1)
+        ga_all.append(ga.to(torch.uint8)); gm_all.append(gm)
     with open(output_file, "wb") as f:
-        for b0 in range(0, n, batch_size):
-            sl = slice(b0, b0 + batch_size)
-            dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_pileup, tp)]
-            dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_haplotype, th)]
-            xp = ctx.hap_features(*dp)
-            xh = ctx.hap_features(*dh)
-            gt, _ = ctx.hap_forward(xp, xh)
-            gm, ga = gt.max(dim=1)
-            f.write(host.hap_csv_format(table, table.ids[sl], pos[sl], ga.to(torch.uint8).cpu().numpy(),
-                                        gm.cpu().numpy(), score_mode))
+        if n:
+            f.write(host.hap_csv_format(table, table.ids, pos, torch.cat(ga_all).cpu().numpy(), torch.cat(gm_all).cpu().numpy(), score_mode))
     return n
