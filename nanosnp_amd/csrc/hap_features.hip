@@ -78,7 +78,11 @@ __global__ __launch_bounds__(HF_BLOCK, NSNP_HF_MINW) void k_hap_features(
             cntd = 0u;
         }
     };
+#ifdef NSNP_HF_NOLOAD
+    const int n_groups = D > 100000 ? (D + R - 1) / R : 0;      // (removal timing build: no row is loaded)
+#else
     const int n_groups = (D + R - 1) / R;
+#endif
     int since_flush = 0;
     for (int g0 = wave; g0 < n_groups; g0 += NW * U) {
         int sv[U], bv[U], mv[U], hv[U];
@@ -137,14 +141,21 @@ __global__ __launch_bounds__(HF_BLOCK, NSNP_HF_MINW) void k_hap_features(
             }
         }
         since_flush += U;
+#ifndef NSNP_HF_NOFLUSH
         if (since_flush > 31 - U) { flush(); since_flush = 0; }   // (uniform)
+#endif
     }
+#ifndef NSNP_HF_NOFLUSH
     flush();
+#endif
     __syncthreads();
     // pass C: the 105 x L outputs (row order of get_seq_baseq_mapq_feat, dataset_dev.py:51).  One thread per (read set, column) reads
     // its 13 sums once, forms the column total once and writes the set's 26 rows (a wave's stores of one row are consecutive floats):
     // 13 float64 divisions per thread instead of one output element at a time with up to six LDS reads each.
     float* __restrict__ o = out + (size_t)n * 105 * L;
+#ifdef NSNP_HF_NOOUT
+    if (D > 100000)                                  // (removal timing build: the output pass compiled but never run)
+#endif
     for (int i = tid; i < 4 * L; i += HF_BLOCK) {
         const int g = i / L, col = i - g * L;
         const long long* S = reinterpret_cast<const long long*>(sums) + (size_t)g * NSTAT * L + col;
