@@ -122,7 +122,9 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     sites centred in its own lines, so the result does not depend on where the cuts fall.
     Returns the call rows [n, 13] float64 (position, argmax / max of both heads, the eight coverage channels: all exact in float64)
     as a device tensor in position order - or, with on_rows, hands every chunk's rows to that callback as soon as they are issued
-    and returns None.  stats (a dict) receives per-stage busy times."""
+    and returns None.  stats (a dict) receives per-stage busy times (and, with a list under stats["trace"], the spans of every chunk's
+    parse / copy / encode / forward on one clock: tools/e2e_timeline.py).  The pinned and device buffer sets live on `model` between
+    calls: one call at a time per model (use one model per thread)."""
     import time
     from concurrent.futures import ThreadPoolExecutor
     import torch
