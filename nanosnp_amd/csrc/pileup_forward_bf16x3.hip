@@ -949,11 +949,13 @@ int nsnp_pileup_forward_bf16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* c
         }
         ScopedKernelTimer tm_head(ctx, NSNP_K_HEAD, s);
         const bool po = post && post->gt_arg;
+#ifndef NSNP_B3_NOHEAD                                  /* (removal timing build) */
         hipLaunchKernelGGL(k_pileup_head_b3, dim3((unsigned)NSNP_CDIV(n, 16 * HB3_WAVES)), dim3(64 * HB3_WAVES), HB3_STAGE_B8 * 16, s,
                            ctx->ws_h1c, n, (const __bf16*)pw.proj_w, pw.proj_b, (const __bf16*)pw.dense_w, pw.dense_b,
                            (const __bf16*)pw.head_w, pw.head_b, gt + base * NSNP_GT_CLASSES, zy + base * NSNP_ZY_CLASSES,
                            po ? post->gt_arg + base : nullptr, po ? post->zy_arg + base : nullptr,
                            po ? post->gt_max + base : nullptr, po ? post->zy_max + base : nullptr);
+#endif
     }
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
