@@ -568,20 +568,24 @@ __global__ __launch_bounds__(512, 1) void k_pileup_l1_b3(
         __bf16* hwb = h1x + (size_t)cur * NSG * FR_H + ((wave >> 2) * 4 + (wave & 3)) * 128 + n * 8 + 2 * q;   // h1_s
 
         // piece P = sg * 6 + k: k < 4 input K block k (direction k >> 1, K block k & 1 of its image), k >= 4 recurrent K block k - 4
-        b8 fr[3][3];
+#ifndef NSNP_B3L1_AHEAD
+#define NSNP_B3L1_AHEAD 2                  /* pieces the fragment reads run ahead of their MFMAs (A/B builds) */
+#endif
+        constexpr int AH = NSNP_B3L1_AHEAD;
+        b8 fr[AH + 1][3];
         auto fetch = [&](int P, int slot) {
             const int sg = P / 6, k = P % 6;
             const __bf16* r = k < 4 ? h0b + sg * (2 * FR_H) + (k >> 1) * FR_H + (k & 1) * 512 : hrb + sg * FR_H + (k - 4) * 512;
 #pragma unroll
             for (int p = 0; p < 3; ++p) fr[slot][p] = *reinterpret_cast<const b8*>(r + p * 1024);
         };
-        fetch(0, 0);
-        fetch(1, 1);
+#pragma unroll
+        for (int P = 0; P < AH; ++P) fetch(P, P);
         f32x4 acc[2][2];
 #pragma unroll
         for (int P = 0; P < 6 * NSG; ++P) {
-            const int sg = P / 6, k = P % 6, slot = P % 3, ab = sg & 1;
-            if (P + 2 < 6 * NSG) fetch(P + 2, (P + 2) % 3);
+            const int sg = P / 6, k = P % 6, slot = P % (AH + 1), ab = sg & 1;
+            if (P + AH < 6 * NSG) fetch(P + AH, (P + AH) % (AH + 1));
             if (k == 0) { acc[ab][0] = bias[0]; acc[ab][1] = bias[1]; }
             if (k < 4) six_products<2>(Wih[k], fr[slot], acc[ab]);
             else       six_products<2>(Whh[k - 4], fr[slot], acc[ab]);
