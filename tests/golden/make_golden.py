@@ -208,6 +208,36 @@ def group_pileup():
     print("pileup_fwd:", x.shape, "gt argmax histogram", np.bincount(gt.numpy().argmax(1), minlength=21))
 
 
+def group_pileup_ckpts():
+    """The other two checkpoints PileupModel/models/ ships (same architecture: config/hg001_mix_without_balance.yaml:6-20): their
+    weights + the reference's LSTMNetwork.predict on the SAME 256 inputs as pileup_fwd.npz -> pileup_fwd_hg001_e13.npz / _e186.npz"""
+    import torch
+    import yaml
+    _stub_modules()
+    sys.path.insert(0, os.path.join(REF, "PileupModel"))
+    from model import LSTMNetwork          # noqa: E402  (reference module)
+    from utils import AttrDict             # noqa: E402
+    cfg = AttrDict(yaml.load(open(os.path.join(REF, "PileupModel/config/hg001_mix_without_balance.yaml")), Loader=yaml.FullLoader))
+    x = np.load(os.path.join(GOLD, "pileup_fwd.npz"))["x"].astype(np.int32)
+    for tag, epoch in (("e13", 13), ("e186", 186)):
+        m = LSTMNetwork(cfg.model)
+        ck = torch.load(os.path.join(REF, f"PileupModel/models/hg001_mix_without_balance.epoch{epoch}.chkpt"), map_location="cpu",
+                        weights_only=False)
+        m.encoder.load_state_dict(ck["encoder"])
+        m.forward_layer.load_state_dict(ck["forward_layer"])
+        m.eval()
+        out = {}
+        for part in ("encoder", "forward_layer"):
+            for k, v in ck[part].items():
+                out[f"{part}.{k}"] = v.numpy().astype(np.float32)
+        with torch.no_grad():
+            gt, zy = m.predict(torch.from_numpy(x).type(torch.FloatTensor))   # predict.py:49-51
+        np.savez_compressed(os.path.join(GOLD, f"pileup_fwd_hg001_{tag}.npz"), gt=gt.numpy(), zy=zy.numpy(),
+                            epoch=np.int64(ck.get("epoch", -1)), **out)
+        wmax = max(float(np.abs(v).max()) for v in out.values())
+        print(f"pileup_fwd_hg001_{tag}: epoch {ck.get('epoch')}, max |W| {wmax:.3f}, gt argmax histogram", np.bincount(gt.numpy().argmax(1), minlength=21))
+
+
 # ------------------------------------------------------------------------------------------
 def group_hapfeat():
     from nanosnp_amd import host
@@ -727,7 +757,7 @@ def group_cat_large():
     print("cat_fwd_large: argmax histogram", np.bincount(gt.argmax(1), minlength=10), "max p %.3f .. %.3f" % (gt.max(1).min(), gt.max(1).max()))
 
 
-GROUPS = {"haparrange": group_haparrange, "twostage": group_twostage, "twostage_s2": group_twostage_s2, "next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "hapfeat": group_hapfeat,
+GROUPS = {"haparrange": group_haparrange, "twostage": group_twostage, "twostage_s2": group_twostage_s2, "next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "pileup_ckpts": group_pileup_ckpts, "hapfeat": group_hapfeat,
           "hapfwd": group_hapfwd, "cat": group_cat, "hapfwd_large": group_hapfwd_large, "cat_large": group_cat_large}
 
 if __name__ == "__main__":

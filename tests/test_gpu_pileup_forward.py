@@ -27,9 +27,25 @@ def _fwd(ctx, x_np):
     return gt.cpu().numpy(), zy.cpu().numpy()
 
 
-def test_golden_outputs_of_the_reference_model(model):
-    z = np.load(golden("pileup_fwd.npz"))
-    gt, zy = _fwd(model, z["x"])
+# the three checkpoints PileupModel/models/ ships (one architecture: config/ont_pileup.yaml = config/hg001_mix_without_balance.yaml:6-20):
+# (fixture with the reference's outputs, fixture with the weights) - ont_pileup keeps its weights in a file of their own
+CHECKPOINTS = {"ont_pileup": ("pileup_fwd.npz", "ont_pileup_weights.npz"),
+               "hg001_e13": ("pileup_fwd_hg001_e13.npz", "pileup_fwd_hg001_e13.npz"),
+               "hg001_e186": ("pileup_fwd_hg001_e186.npz", "pileup_fwd_hg001_e186.npz")}
+
+
+@pytest.mark.parametrize("ckpt", list(CHECKPOINTS))
+def test_golden_outputs_of_the_reference_model(model, pileup_weights, ckpt):
+    """LSTMNetwork.predict of the reference with every shipped checkpoint on the same 256 inputs, in all three arithmetics"""
+    from tests.helpers import load_pileup_weights
+    out_file, w_file = CHECKPOINTS[ckpt]
+    z = np.load(golden(out_file))
+    x = np.load(golden("pileup_fwd.npz"))["x"]
+    model.pileup_load_weights(load_pileup_weights(golden(w_file)))
+    try:
+        gt, zy = _fwd(model, x)
+    finally:
+        model.pileup_load_weights(pileup_weights)
     assert np.abs(gt - z["gt"]).max() < PROB_ATOL
     assert np.abs(zy - z["zy"]).max() < PROB_ATOL
     assert np.array_equal(gt.argmax(1), z["gt"].argmax(1))
@@ -490,7 +506,8 @@ def test_bf16x3_mode_carries_the_full_fp32_operand_width(pileup_weights):
     c2.close(); c0.close()
 
 
-def test_bf16x3_split_levels_of_different_site_groups_in_one_workgroup(pileup_weights):
+@pytest.mark.parametrize("ckpt", ["ont_pileup", "hg001_e186"])
+def test_bf16x3_split_levels_of_different_site_groups_in_one_workgroup(ckpt):
     """The bf16x3 layer-0 kernels run a step at the split level of the LARGEST count any site group of the WORKGROUP staged for it
     (1 term up to 256, 2 up to 65536, 3 beyond); a group below that level multiplies its own planes 1 and 2 as well, which must then be
     zeros.  (Round 4, found by tools/b3_consistency.py: they held whatever an earlier step had left there - a workgroup with one
@@ -501,6 +518,8 @@ def test_bf16x3_split_levels_of_different_site_groups_in_one_workgroup(pileup_we
     import torch
     from nanosnp_amd import _lib
     from oracle import oracle
+    from tests.helpers import load_pileup_weights
+    pileup_weights = load_pileup_weights(golden(CHECKPOINTS[ckpt][1]))      # epoch 186 holds the largest weights shipped (max |W| 2.32)
     rng = np.random.default_rng(91)
     n = 8192
     x = (rng.integers(0, 60, (n, 33, 18)) - 12).astype(np.int32)

@@ -49,10 +49,15 @@ def test_array_path_matches_the_reference_tensors(tag):
     assert np.array_equal(depth[centers], pd_depth)
 
 
-def test_pileup_forward_matches_reference_model_outputs():
-    w = load_pileup_weights()
-    z = np.load(golden("pileup_fwd.npz"))
-    gt, zy = oracle.pileup_forward(w, z["x"].astype(np.int32), nthreads=4)
+@pytest.mark.parametrize("out_file,w_file", [("pileup_fwd.npz", "ont_pileup_weights.npz"),
+                                             ("pileup_fwd_hg001_e13.npz", "pileup_fwd_hg001_e13.npz"),
+                                             ("pileup_fwd_hg001_e186.npz", "pileup_fwd_hg001_e186.npz")])
+def test_pileup_forward_matches_reference_model_outputs(out_file, w_file):
+    """all three checkpoints PileupModel/models/ ships, the same 256 inputs"""
+    w = load_pileup_weights(golden(w_file))
+    z = np.load(golden(out_file))
+    x = np.load(golden("pileup_fwd.npz"))["x"]
+    gt, zy = oracle.pileup_forward(w, x.astype(np.int32), nthreads=4)
     assert np.abs(gt - z["gt"]).max() < PROB_ATOL
     assert np.abs(zy - z["zy"]).max() < PROB_ATOL
     assert np.array_equal(gt.argmax(1), z["gt"].argmax(1))
