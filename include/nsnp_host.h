@@ -64,6 +64,14 @@ int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int6
 int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
                             int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases);
 
+/* nsnp_mpileup_parse_into for callers whose bookkeeping counts the LINES of the text (the streamed pipeline: chunks of whole lines
+ * with 16 lines of halo, "one line = one column"): n_lines_skipped receives the number of empty / CR-only lines the parser stepped
+ * over.  The reference aborts on such a line (main.cpp:162-172 -> cpp_aux.cpp:10-21); such a caller must refuse the text when the
+ * count is not zero. */
+int nsnp_mpileup_parse_lines(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
+                             int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases,
+                             int64_t* n_lines_skipped);
+
 /* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota (NSNP_HOST_THREADS in the
  * environment overrides the automatic count); nsnp_host_set_threads(n > 0) fixes it for the process, n <= 0 returns to automatic */
 int nsnp_host_threads(void);

@@ -174,7 +174,7 @@ int nsnp_mpileup_parse(const char* text, int64_t text_len, int64_t* n_cols, int6
  * copied.  cap_cols / cap_bytes: capacities of pos / col_off (cap_cols + 1) / bases; text_len / 8 columns and text_len bytes
  * always suffice.  NSNP_HOST_ERANGE when a capacity is too small (n_cols / n_bytes then hold what is needed). */
 typedef struct { int64_t pos; const char* tok; int64_t len; } col_rec;
-typedef struct { col_rec* r; int64_t cap, m, nb; } rec_list;
+typedef struct { col_rec* r; int64_t cap, m, nb, blank; } rec_list;       /* blank: empty / CR-only lines met (skipped) */
 
 static int rec_push(rec_list* L, int64_t pos, const char* tok, int64_t len)
 {
@@ -207,7 +207,7 @@ static int tokenise_generic(const char* p, const char* end, rec_list* L)
             const char* t4 = t3 ? next_tok(&q, le, &te) : NULL;
             if (!t4) return 2;
             if (rec_push(L, parse_i64(t1, t1e), t4, te - t4)) return 1;
-        }
+        } else ++L->blank;
         p = next;
     }
     return 0;
@@ -267,7 +267,7 @@ static inline int64_t parse_pos(const char* t1, const char* t1e, const char* tex
 }
 
 /* line grammar over the event bits of one 64-byte block (shared by the AVX2 and the AVX-512 front ends) */
-typedef struct { const char* line; const char* tok; const char* t1; const char* t1e; const char* t4; const char* t4e; int ntok; } tok_state;
+typedef struct { const char* line; const char* tok; const char* t1; const char* t1e; const char* t4; const char* t4e; int ntok; const char* end; } tok_state;
 
 static inline __attribute__((always_inline)) int tok_block(tok_state* st, uint64_t nlm, uint64_t tbm, const char* base, const char* text0, rec_list* L)
 {
@@ -287,6 +287,7 @@ static inline __attribute__((always_inline)) int tok_block(tok_state* st, uint64
             if (st->ntok >= 5) {
                 if (rec_push(L, parse_pos(st->t1, st->t1e, text0), st->t4, st->t4e - st->t4)) return 1;
             } else if (le > st->line) return 2;               /* a non-empty line with fewer than five fields */
+            else if (e < st->end) ++L->blank;                  /* (the virtual newline behind a chunk's last byte is not a line) */
             st->line = st->tok = e + 1; st->ntok = 0;
         } else {                                              /* a tab (only looked at while ntok < 5) */
             if (e > st->tok) {
@@ -317,7 +318,7 @@ __attribute__((target("avx2"))) static int tokenise_avx2(const char* p0, const c
 {
     const __m256i v_nl = _mm256_set1_epi8('\n'), v_tab = _mm256_set1_epi8('\t');
     const int64_t len = end - p0;
-    tok_state st = { p0, p0, NULL, NULL, NULL, NULL, 0 };
+    tok_state st = { p0, p0, NULL, NULL, NULL, NULL, 0, end };
     for (int64_t off = 0; off <= len; off += 64) {
         uint64_t nlm = 0, tbm = 0;
         const int whole = p0 + off + 64 <= limit;
@@ -339,7 +340,7 @@ __attribute__((target("avx512f,avx512bw"))) static int tokenise_avx512(const cha
 {
     const __m512i v_nl = _mm512_set1_epi8('\n'), v_tab = _mm512_set1_epi8('\t');
     const int64_t len = end - p0;
-    tok_state st = { p0, p0, NULL, NULL, NULL, NULL, 0 };
+    tok_state st = { p0, p0, NULL, NULL, NULL, NULL, 0, end };
     for (int64_t off = 0; off <= len; off += 64) {
         uint64_t nlm = 0, tbm = 0;
         const int whole = p0 + off + 64 <= limit;
@@ -489,8 +490,8 @@ static int use_avx2(void)
 #endif
 }
 
-int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
-                            int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases)
+static int parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
+                      int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases, int64_t* n_blank)
 {
     if (!text || text_len < 0 || !n_cols || !n_bytes || !pos || !col_off || !bases) return NSNP_HOST_EINVAL;
     int T = nsnp_host_threads();
@@ -513,10 +514,10 @@ int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols
      * thread and call is an mmap, its page faults and a munmap, all of them serialised on the process's address-space lock. */
     int64_t cm[1025], cb[1025];
     int err = 0, rc = 0;
-    int64_t m = 0, nb = 0;
+    int64_t m = 0, nb = 0, blank = 0;
     #pragma omp parallel num_threads(T)
     {
-        static __thread rec_list tls = { NULL, 0, 0, 0 };
+        static __thread rec_list tls = { NULL, 0, 0, 0, 0 };
 #ifdef _OPENMP
         const int team = omp_get_num_threads(), me = omp_get_thread_num();
 #else
@@ -524,7 +525,7 @@ int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols
 #endif
         /* (a team smaller than T: thread `me` takes the chunks me, me + team, ... - their records end to end in its one list) */
         int bad = 0;
-        tls.m = 0; tls.nb = 0;
+        tls.m = 0; tls.nb = 0; tls.blank = 0;
         for (int c = me; c < T && !bad; c += team) {
             const int64_t want = (cut[c + 1] - cut[c]) / 64 + 1024;
             if (tls.cap - tls.m < want) {
@@ -547,6 +548,10 @@ int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols
         if (bad) {
             #pragma omp atomic write
             err = bad;
+        }
+        if (tls.blank) {
+            #pragma omp atomic
+            blank += tls.blank;
         }
         #pragma omp barrier
         #pragma omp single
@@ -573,8 +578,26 @@ int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols
         }
     }
     *n_cols = m; *n_bytes = nb;
+    if (n_blank) *n_blank = blank;
     if (!rc) col_off[m] = nb;
     return rc;
+}
+
+int nsnp_mpileup_parse_into(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
+                            int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases)
+{
+    return parse_into(text, text_len, cap_cols, cap_bytes, n_cols, n_bytes, pos, col_off, bases, NULL);
+}
+
+/* the same, for callers that count LINES of the text themselves (the streamed pipeline cuts the text into chunks with 16 lines of
+ * halo and takes "one line = one column" for granted): n_lines_skipped receives the number of empty / CR-only lines the parser
+ * stepped over - the reference aborts on such a line (cpp_aux.cpp:10-21 via main.cpp:162-172), a caller whose bookkeeping depends
+ * on the line count must refuse the text when it is not zero */
+int nsnp_mpileup_parse_lines(const char* text, int64_t text_len, int64_t cap_cols, int64_t cap_bytes,
+                             int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases, int64_t* n_lines_skipped)
+{
+    if (!n_lines_skipped) return NSNP_HOST_EINVAL;
+    return parse_into(text, text_len, cap_cols, cap_bytes, n_cols, n_bytes, pos, col_off, bases, n_lines_skipped);
 }
 
 int64_t nsnp_fasta_load_contig(const char* fasta_path, const char* contig, uint8_t* seq, int64_t cap)

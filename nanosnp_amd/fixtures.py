@@ -1,7 +1,8 @@
 """Weights and synthetic model inputs used by bench.py, __graft_entry__.smoke(), tools/ and the tests.
 
 * ``load_pileup_weights`` -- the values of the shipped ``PileupModel/models/ont_pileup.chkpt`` as a fixture
-  (``tests/golden/ont_pileup_weights.npz``, written by tests/golden/make_golden.py from the checkpoint; data, not code).
+  (``nanosnp_amd/data/ont_pileup_weights.npz``, shipped with the package; written by tests/golden/make_golden.py from the
+  checkpoint; data, not code).  Nothing here reads the test tree.
 * ``seeded_hap_weights`` / ``seeded_cat_weights`` -- stand-ins for the HaplotypeModel checkpoints that are absent from
   the reference tree (``.MISSING_LARGE_BLOBS``): numpy PCG64 streams (stable across platforms) in state-dict order, the
   exact arrays tests/golden/make_golden.py loaded into the reference's modules when it recorded their outputs.
@@ -13,8 +14,7 @@ import os
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 PILEUP_WEIGHT_KEYS = (
     [f"encoder.lstm.{n}_l{l}{d}" for l in (0, 1) for d in ("", "_reverse")
@@ -29,7 +29,7 @@ PILEUP_WEIGHT_KEYS = (
 
 def load_pileup_weights(path=None):
     """The 24 tensors LSTMNetwork.predict uses, in state-dict order."""
-    z = np.load(path or os.path.join(GOLDEN, "ont_pileup_weights.npz"))
+    z = np.load(path or os.path.join(DATA, "ont_pileup_weights.npz"))
     return [np.ascontiguousarray(z[k], dtype=np.float32) for k in PILEUP_WEIGHT_KEYS]
 
 

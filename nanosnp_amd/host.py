@@ -24,16 +24,21 @@ class HostError(RuntimeError):
     pass
 
 
+class HostRangeError(HostError):
+    """an output buffer was too small; n_cols / n_bytes hold what the input needs"""
+    def __init__(self, msg, n_cols, n_bytes):
+        super().__init__(msg)
+        self.n_cols, self.n_bytes = int(n_cols), int(n_bytes)
+
+
 def _load():
     if not os.path.exists(_LIB_PATH):
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `make -C nanosnp_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()')")
-    # the OpenMP runtime the library links reads its environment when it is loaded: idle workers sleep instead of spinning (a team
-    # is woken once per text chunk; spinning workers would eat the CPU quota of a container between the chunks)
-    # (a value the user has set is kept; NANOSNP_KEEP_OMP_ENV=1 leaves the environment alone altogether)
-    if os.environ.get("NANOSNP_KEEP_OMP_ENV") != "1":
-        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    # The library never touches the process environment.  Its OpenMP teams are woken once per text chunk; under a container CPU
+    # quota idle workers that spin between the chunks eat the quota, so APPLICATIONS (bench.py, tools/e2e_bench.py) export
+    # OMP_WAIT_POLICY=passive before anything loads an OpenMP runtime - see recommend_omp_env() and INTEGRATION.md.
     lib = C.CDLL(_LIB_PATH)
     p = C.c_void_p
     lib.nsnp_host_threads.restype = C.c_int
@@ -62,6 +67,15 @@ def _load():
 
 
 _lib = None
+
+
+def recommend_omp_env(environ=None):
+    """For the `if __name__ == "__main__"` part of an application, BEFORE torch / numpy / this library are imported: idle OpenMP workers
+    sleep instead of spinning (OMP_WAIT_POLICY=passive unless the user set a policy).  A library import must not do this for the
+    process, and it has no effect once libgomp is initialised - hence a function the application calls, first thing."""
+    env = os.environ if environ is None else environ
+    env.setdefault("OMP_WAIT_POLICY", "passive")
+    return env
 
 
 def lib():
@@ -175,27 +189,33 @@ def mpileup_parse(text: bytes):
     return pos, col_off, bases[:B]
 
 
-def mpileup_parse_range(buf, lo, hi, out=None):
+def mpileup_parse_range(buf, lo, hi, out=None, strict_lines=False):
     """The lines of buf[lo:hi] (any buffer: bytes, mmap, numpy uint8; lo / hi on line boundaries) -> (pos, col_off, bases) without
     copying the text, every line tokenised once (nsnp_mpileup_parse_into).  out = (pos, col_off, bases) numpy arrays to fill (e.g.
     views of pinned host tensors); the returned arrays are views of their first M / M + 1 / B elements.  Without `out` the arrays
-    are allocated at the always-sufficient bounds (hi - lo) / 8 columns and hi - lo bytes and trimmed."""
+    are allocated at the always-sufficient bounds (hi - lo) / 8 columns and hi - lo bytes and trimmed.  Buffers that are too small
+    raise HostRangeError (n_cols / n_bytes = what the lines need).  strict_lines: an empty / CR-only line is an error instead of being
+    stepped over (nsnp_mpileup_parse_lines: for callers that count lines themselves; the reference aborts on such a line)."""
     a = np.frombuffer(buf, np.uint8) if not isinstance(buf, np.ndarray) else buf
     n = int(hi) - int(lo)
     if n <= 0:
         return np.empty(0, np.int64), np.zeros(1, np.int64), np.empty(0, np.uint8)
-    fn = lib().nsnp_mpileup_parse_into
+    fn = lib().nsnp_mpileup_parse_lines
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.POINTER(C.c_int64)]
     if out is None:
         out = (np.empty(n // 8 + 2, np.int64), np.empty(n // 8 + 3, np.int64), np.empty(n, np.uint8))
     pos, col_off, bases = out
-    n_cols, n_bytes = C.c_int64(0), C.c_int64(0)
+    n_cols, n_bytes, n_skipped = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     rc = fn(C.c_void_p(a.ctypes.data + int(lo)), n, min(pos.size, col_off.size - 1), bases.size, C.byref(n_cols), C.byref(n_bytes),
-            _ptr(pos), _ptr(col_off), _ptr(bases))
+            _ptr(pos), _ptr(col_off), _ptr(bases), C.byref(n_skipped))
     if rc == NSNP_ERANGE:
-        raise HostError(f"mpileup_parse_range: output buffers too small ({n_cols.value} columns, {n_bytes.value} bytes needed)")
-    _check(rc, "nsnp_mpileup_parse_into")
+        raise HostRangeError(f"mpileup_parse_range: output buffers too small ({n_cols.value} columns, {n_bytes.value} bytes needed)",
+                             n_cols.value, n_bytes.value)
+    _check(rc, "nsnp_mpileup_parse_lines")
+    if strict_lines and n_skipped.value:
+        raise HostError(f"mpileup text holds {n_skipped.value} empty line(s): malformed input (every line must be one pileup column)")
     M, B = n_cols.value, n_bytes.value
     return pos[:M], col_off[:M + 1], bases[:B]
 

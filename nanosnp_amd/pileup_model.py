@@ -82,7 +82,7 @@ class LSTMNetwork:
             self._loaded = True
 
     def load_weight_list(self, tensors):
-        """24 arrays in state-dict order (tests/golden/ont_pileup_weights.npz order)."""
+        """24 arrays in state-dict order (nanosnp_amd/data/ont_pileup_weights.npz order)."""
         self.ctx.pileup_load_weights(tensors)
         self._loaded = True
         return self

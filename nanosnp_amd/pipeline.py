@@ -86,11 +86,17 @@ def halo_range(text, lo, hi, halo=16):
     return a, b, n_lo, n_hi
 
 
+def _cols_for(cap_bytes):
+    """columns budgeted for a chunk of cap_bytes of text: one per 24 bytes (a samtools line at 30x is ~90 bytes; a valid line cannot
+    be shorter than 10).  A chunk with more lines than that grows its buffer sets once, when the parser reports it (NSNP_HOST_ERANGE)."""
+    return cap_bytes // 24 + 1024
+
+
 class _HostSet:
     """pinned host buffers of one text chunk in flight (the parser writes straight into them, the copy engine reads them)"""
-    def __init__(self, cap_bytes):
+    def __init__(self, cap_bytes, cap_cols=None):
         import torch
-        cap_cols = cap_bytes // 8 + 2
+        cap_cols = int(cap_cols or _cols_for(cap_bytes))
         self.pos = torch.empty(cap_cols, dtype=torch.int64, pin_memory=True)
         self.off = torch.empty(cap_cols + 1, dtype=torch.int64, pin_memory=True)
         self.bases = torch.empty(cap_bytes, dtype=torch.uint8, pin_memory=True)
@@ -100,9 +106,9 @@ class _HostSet:
 
 class _DevSet:
     """device buffers of one text chunk in flight (filled by the copy stream, read by the chunk's encode / select / call rows)"""
-    def __init__(self, cap_bytes, dev):
+    def __init__(self, cap_bytes, dev, cap_cols=None):
         import torch
-        cap_cols = cap_bytes // 8 + 2
+        cap_cols = int(cap_cols or _cols_for(cap_bytes))
         self.pos = torch.empty(cap_cols, dtype=torch.int64, device=dev)
         self.off = torch.empty(cap_cols + 1, dtype=torch.int64, device=dev)
         self.bases = torch.empty(cap_bytes, dtype=torch.uint8, device=dev)
@@ -146,7 +152,7 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     sets = getattr(model, "_host_sets", None)
     # THREE host sets: the parser works two chunks ahead of the copy engine (it never waits for this thread between two chunks)
     n_sets = min(3, len(ranges))
-    if not sets or sets[0].bases.numel() < cap or len(sets) < n_sets:
+    if not sets or min(s_.bases.numel() for s_ in sets) < cap or len(sets) < n_sets:
         sets = [_HostSet(cap) for _ in range(n_sets)]
         model._host_sets = sets
         model._dev_sets = None
@@ -155,8 +161,8 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     # encode of chunk k + 2 - in front of the forward of chunk k + 1 in stream order - waits for that copy: copies and forwards
     # alternated (tools/e2e_timeline.py: 2.4 ms per chunk = copy 0.8 + encode 0.15 + forward 1.45); with three the copy runs beside
     # the forward of chunk k + 1
-    if not dsets or len(dsets) < min(3, len(ranges)) or dsets[0].bases.device != dev or dsets[0].bases.numel() < cap:
-        dsets = [_DevSet(sets[0].bases.numel(), dev) for _ in range(min(3, len(ranges)))]
+    if not dsets or len(dsets) < min(3, len(ranges)) or dsets[0].bases.device != dev or min(d_.bases.numel() for d_ in dsets) < cap:
+        dsets = [_DevSet(cap, dev) for _ in range(min(3, len(ranges)))]
         model._dev_sets = dsets
         model._copy_stream = torch.cuda.Stream(dev)
     if len(getattr(model, "_meta_pin", ())) < len(ranges):
@@ -176,7 +182,13 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     def parse(k):
         t0 = time.perf_counter()
         a, b, _, _ = ranges[k]
-        out = host.mpileup_parse_range(arr, a, b, out=sets[k % len(sets)].np)
+        try:
+            out = host.mpileup_parse_range(arr, a, b, out=sets[k % len(sets)].np, strict_lines=True)
+        except host.HostRangeError as e:
+            # more (shorter) lines than budgeted: this set grows - the parser owns it right now (the copy engine was waited for before
+            # this parse was submitted) - and the chunk is parsed again; the device twin grows on the main thread before the copy
+            sets[k % len(sets)] = _HostSet(max(cap, e.n_bytes), e.n_cols + e.n_cols // 4 + 1024)
+            out = host.mpileup_parse_range(arr, a, b, out=sets[k % len(sets)].np, strict_lines=True)
         pos = out[0]
         bad = bool(pos.size) and (int(pos.max()) > seq_len or int(pos.min()) < 1)
         t1 = time.perf_counter()
@@ -238,6 +250,9 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
             hs, ds = sets[k % len(sets)], dsets[k % len(dsets)]
             st["parse_s"] += t_parse; st["text_bytes"] += b - a; st["chunks"] += 1
             M, nb = int(pos.size), int(bases.size)
+            if M + 1 > ds.off.numel() or nb > ds.bases.numel():
+                torch.cuda.synchronize(dev)                       # (rare: every reader of the old set is done before it is dropped)
+                ds = dsets[k % len(dsets)] = _DevSet(max(nb, ds.bases.numel()), dev, max(M + M // 4 + 1024, ds.pos.numel()))
             # ---- H2D on the copy stream, behind the last readers of this device set (chunk k - 2) ----
             if ds.free is not None:
                 copy_stream.wait_event(ds.free)

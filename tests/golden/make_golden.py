@@ -13,7 +13,7 @@ top-level modules named model/optim/utils/options):
   encode   oracle/_ref (the reference's dna_sv_tensor programs compiled from the reference
            tree) on synthetic + adversarial mpileup text  -> encode_*.{mpileup,fa,pd}.gz
   pileup   PileupModel/model.py LSTMNetwork.predict with the shipped ont_pileup.chkpt
-           (CPU torch)                                    -> ont_pileup_weights.npz, pileup_fwd.npz
+           (CPU torch)                                    -> nanosnp_amd/data/ont_pileup_weights.npz, pileup_fwd.npz
   hapfeat  HaplotypeModel/dataset_dev.get_frequency_feature -> hap_features.npz
   hapfwd   HaplotypeModel/model_dev.LSTMNetwork.predict with seeded weights
            (trained weights are absent upstream)          -> hap_fwd_h32.npz, hap_fwd_h256.npz
@@ -186,7 +186,7 @@ def group_pileup():
         w["encoder." + k] = v.numpy().astype(np.float32)
     for k, v in ck["forward_layer"].items():
         w["forward_layer." + k] = v.numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(GOLD, "ont_pileup_weights.npz"), **w)
+    np.savez_compressed(os.path.join(ROOT, "nanosnp_amd", "data", "ont_pileup_weights.npz"), **w)
 
     # inputs: G2 windows (seed 20260001) encoded by the oracle + hand-made edge windows
     N = 224

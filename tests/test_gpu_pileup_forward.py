@@ -4,6 +4,9 @@ import numpy as np
 import pytest
 
 from tests.helpers import PROB_ATOL, golden
+from nanosnp_amd.fixtures import DATA
+
+WEIGHTS_NPZ = __import__("os").path.join(DATA, "ont_pileup_weights.npz")
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +32,7 @@ def _fwd(ctx, x_np):
 
 # the three checkpoints PileupModel/models/ ships (one architecture: config/ont_pileup.yaml = config/hg001_mix_without_balance.yaml:6-20):
 # (fixture with the reference's outputs, fixture with the weights) - ont_pileup keeps its weights in a file of their own
-CHECKPOINTS = {"ont_pileup": ("pileup_fwd.npz", "ont_pileup_weights.npz"),
+CHECKPOINTS = {"ont_pileup": ("pileup_fwd.npz", None),
                "hg001_e13": ("pileup_fwd_hg001_e13.npz", "pileup_fwd_hg001_e13.npz"),
                "hg001_e186": ("pileup_fwd_hg001_e186.npz", "pileup_fwd_hg001_e186.npz")}
 
@@ -41,7 +44,7 @@ def test_golden_outputs_of_the_reference_model(model, pileup_weights, ckpt):
     out_file, w_file = CHECKPOINTS[ckpt]
     z = np.load(golden(out_file))
     x = np.load(golden("pileup_fwd.npz"))["x"]
-    model.pileup_load_weights(load_pileup_weights(golden(w_file)))
+    model.pileup_load_weights(load_pileup_weights(golden(w_file) if w_file else None))
     try:
         gt, zy = _fwd(model, x)
     finally:
@@ -150,7 +153,7 @@ def test_reference_style_interface(pileup_weights):
     """nanosnp_amd.pileup_model.LSTMNetwork mirrors PileupModel/model.py + predict.py:208-214"""
     import torch
     from nanosnp_amd.pileup_model import LSTMNetwork
-    m = LSTMNetwork.from_npz(golden("ont_pileup_weights.npz")).to("cuda").eval()
+    m = LSTMNetwork.from_npz(WEIGHTS_NPZ).to("cuda").eval()
     z = np.load(golden("pileup_fwd.npz"))
     feature_tensor = torch.from_numpy(z["x"].astype(np.int32)).type(torch.FloatTensor).to("cuda")   # predict.py:49
     gt, zy = m.predict(feature_tensor)
@@ -519,7 +522,7 @@ def test_bf16x3_split_levels_of_different_site_groups_in_one_workgroup(ckpt):
     from nanosnp_amd import _lib
     from oracle import oracle
     from tests.helpers import load_pileup_weights
-    pileup_weights = load_pileup_weights(golden(CHECKPOINTS[ckpt][1]))      # epoch 186 holds the largest weights shipped (max |W| 2.32)
+    pileup_weights = load_pileup_weights(golden(CHECKPOINTS[ckpt][1]) if CHECKPOINTS[ckpt][1] else None)      # epoch 186 holds the largest weights shipped (max |W| 2.32)
     rng = np.random.default_rng(91)
     n = 8192
     x = (rng.integers(0, 60, (n, 33, 18)) - 12).astype(np.int32)

@@ -187,3 +187,39 @@ def test_streamed_pipeline_edge_inputs(pileup_weights):
     assert bytes(r[0]) == want_rows and r[1:] == want[1:]
     with pytest.raises(ValueError):
         call_contig(m, text, "chrE", seq[:100])                     # positions beyond the reference sequence
+
+
+def test_streamed_pipeline_refuses_blank_lines_and_grows_its_column_buffers(pileup_weights):
+    """(a) the pipeline's halo bookkeeping takes one line = one column: an empty line (which the tolerant parser steps over) near a
+    chunk cut would shift the chunk's own range - the text is refused (the reference aborts on such a line); (b) the pinned / device
+    column buffers are budgeted at 24 text bytes per line and grow when a chunk holds more, shorter lines: a shallow contig of 19-byte
+    lines gives the rows of its one-chunk run at every chunk size"""
+    from nanosnp_amd import host
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_contig
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    cols = host.synth_columns(20261313, 3000, coverage=30, het_rate=0.05)
+    text = bytes(cols.mpileup_text_native("chrE"))
+    seq = cols.ref.copy()
+    lines = text.split(b"\n")[:-1]
+    want = call_contig(m, text, "chrE", seq, chunk_bytes=1 << 30)
+    cut = len(b"\n".join(lines[:1500])) + 1
+    for at in (1490, 1500, 1510, 5, 2999):
+        bad = b"\n".join(lines[:at]) + b"\n\n" + b"\n".join(lines[at:]) + b"\n"
+        for cb in (1 << 30, cut):
+            with pytest.raises(host.HostError, match="empty line"):
+                call_contig(m, bad, "chrE", seq, chunk_bytes=cb)
+    r = call_contig(m, text, "chrE", seq, chunk_bytes=cut)          # the model is usable afterwards
+    assert bytes(r[0]) == bytes(want[0]) and r[1:] == want[1:]
+    # (b) 60,000 lines of 19 bytes, no quality field (only columns 0, 1 and 4 are read: main.cpp:162-172)
+    n = 60_000
+    shallow = b"".join(b"c\t%d\tN\t6\t%s\n" % (i + 1, b"AAACCC" if i % 37 == 0 else (b"AAAAAg" if i % 11 == 0 else b"AaAaAa")) for i in range(n))
+    assert len(shallow) < 24 * n
+    seq2 = np.full(n, ord("A"), np.uint8)
+    m2 = LSTMNetwork().load_weight_list(pileup_weights)             # fresh buffer sets
+    st = {}
+    one = call_contig(m2, shallow, "c", seq2, chunk_bytes=1 << 30, stats=st)
+    assert one[1] > 1000 and st["columns"] == n
+    for cb in (300_000, 50_000):
+        r = call_contig(m2, shallow, "c", seq2, chunk_bytes=cb)
+        assert bytes(r[0]) == bytes(one[0]) and r[1:] == one[1:], cb

@@ -2,7 +2,11 @@
 import numpy as np
 import pytest
 
+import os
+
 from nanosnp_amd import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_synth_is_deterministic_and_thread_independent(monkeypatch):
@@ -190,6 +194,44 @@ def test_the_vector_tokeniser_equals_the_portable_one_on_awkward_texts(monkeypat
     assert len(big) > (4 << 20)
     rb = both(big)
     assert np.array_equal(rb[0], cols.pos) and np.array_equal(rb[1], cols.col_off) and np.array_equal(rb[2], cols.bases)
+
+
+def test_strict_line_parse_and_range_errors(monkeypatch):
+    """mpileup_parse_range(strict_lines=True) - what the streamed pipeline uses, whose halo bookkeeping counts lines - refuses empty and
+    CR-only lines on every tokeniser path and keeps accepting everything else; buffers that are too small raise HostRangeError with
+    the sizes the text needs, and the second call with those sizes succeeds"""
+    cols = host.synth_columns(9, 500, coverage=30)
+    text = bytes(cols.mpileup_text_native("chrQ"))
+    lines = text.split(b"\n")[:-1]
+    blanked = [b"\n".join(lines[:250]) + b"\n\n" + b"\n".join(lines[250:]) + b"\n",            # inside
+               b"\n" + text, text + b"\n", b"\r\n".join(lines[:7]) + b"\r\n\r\n" + b"\r\n".join(lines[7:]) + b"\r\n"]
+    for generic in ("1", "2", "3", "4", "0"):
+        monkeypatch.setenv("NSNP_PARSE_GENERIC", generic)
+        pos, off, bases = host.mpileup_parse_range(text, 0, len(text), strict_lines=True)
+        assert np.array_equal(pos, cols.pos) and np.array_equal(bases, cols.bases)
+        pos2, _, _ = host.mpileup_parse_range(text[:-1], 0, len(text) - 1, strict_lines=True)          # no final newline: not a blank line
+        assert np.array_equal(pos2, cols.pos)
+        for t in blanked:
+            assert host.mpileup_parse_range(t, 0, len(t))[0].size == 500                                # tolerant form: stepped over
+            with pytest.raises(host.HostError, match="empty line"):
+                host.mpileup_parse_range(t, 0, len(t), strict_lines=True)
+    monkeypatch.delenv("NSNP_PARSE_GENERIC")
+    small = (np.empty(100, np.int64), np.empty(101, np.int64), np.empty(len(text), np.uint8))
+    with pytest.raises(host.HostRangeError) as ei:
+        host.mpileup_parse_range(text, 0, len(text), out=small)
+    assert ei.value.n_cols == 500 and ei.value.n_bytes == cols.bases.size
+    fit = (np.empty(ei.value.n_cols, np.int64), np.empty(ei.value.n_cols + 1, np.int64), np.empty(ei.value.n_bytes, np.uint8))
+    pos, off, bases = host.mpileup_parse_range(text, 0, len(text), out=fit)
+    assert np.array_equal(pos, cols.pos) and np.array_equal(off, cols.col_off) and np.array_equal(bases, cols.bases)
+
+
+def test_importing_the_host_library_leaves_the_environment_alone():
+    """a library import must not export OMP_WAIT_POLICY for the whole process; applications call recommend_omp_env()"""
+    import subprocess, sys
+    code = ("import os; os.environ.pop('OMP_WAIT_POLICY', None); from nanosnp_amd import host; host.lib(); "
+            "assert 'OMP_WAIT_POLICY' not in os.environ; e = host.recommend_omp_env({}); assert e == {'OMP_WAIT_POLICY': 'passive'}; "
+            "assert host.recommend_omp_env({'OMP_WAIT_POLICY': 'active'})['OMP_WAIT_POLICY'] == 'active'")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
 
 
 def test_the_printf_free_decimal_output_equals_printf():
