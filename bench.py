@@ -52,12 +52,13 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--windows", type=int, default=N_POOL, help="windows resident per GPU (BASELINE configs[1]: 1M)")
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60", "e2e"],
+    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60", "e2e", "hap-e2e"],
                     help="pileup = BASELINE configs[1] (the metric's configuration); haplotype = configs[2]: haplotype features + "
                          "HaplotypeModel fwd (+ the legacy crnn.py CatModel fwd) on 150 k G3 sites; two-stage = configs[3]: stage 2 + stage 5 "
                          "on a chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0; deep60 = configs[4]: "
                          "60x columns + D = 180 read planes + fp16-split conv weights; e2e = a labelled text-to-VCF measurement: samtools-mpileup text of a synthetic contig "
-                         "on the page cache -> host parse beside H2D + encode + forward -> pileup.vcf (tools/e2e_bench.py)")
+                         "on the page cache -> host parse beside H2D + encode + forward -> pileup.vcf (tools/e2e_bench.py); hap-e2e = the same for stage 5: a haplotype "
+                         "site file on the page cache -> pinned staging beside H2D beside features + HaplotypeModel fwd -> haplotype.csv (tools/hap_e2e_bench.py)")
     ap.add_argument("--encode-group", type=int, default=32, help="batches encoded per column-encode launch (on the encode stream, into a "
                     "ring of count buffers; the kernel is twice as efficient per byte at >= 1 M columns)")
     ap.add_argument("--hap-sites", type=int, default=0, help="haplotype / deep60 workloads: sites resident per job (0 = the workload's default)")
@@ -195,6 +196,7 @@ def cpu_baseline(cols, batch, weights, target_s):
 
 def main():
     args = parse_args()
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")        # an application's choice, made before any OpenMP runtime loads (nanosnp_amd.host.recommend_omp_env)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -219,6 +221,9 @@ def main():
     if args.workload == "e2e":
         from tools.e2e_bench import run as run_e2e
         sys.exit(run_e2e(args, rank, world, local_rank))
+    if args.workload == "hap-e2e":
+        from tools.hap_e2e_bench import run as run_hap_e2e
+        sys.exit(run_hap_e2e(args, rank, world, local_rank))
     if args.workload in ("haplotype", "deep60"):
         from tools.hap_bench import run as run_hap
         sys.exit(run_hap(args, rank, world, local_rank, deep60=args.workload == "deep60"))
@@ -345,7 +350,7 @@ def main():
                        "batch": batch, "windows_resident_per_gpu": n_windows, "batches_per_step": bps, "sites_per_step": bps * batch,
                        "streams": stage.S, "encode_batches_per_launch": stage.G, "coverage": args.coverage,
                        "precision": {0: "fp32", 1: "f16x3", 2: "bf16x3"}[args.precision],
-                       "weights": "ont_pileup.chkpt values (tests/golden fixture)",
+                       "weights": "ont_pileup.chkpt values (nanosnp_amd/data/ont_pileup_weights.npz)",
                        "parallelism": f"site-sharded x{world}, rooted gather of calls",
                        "world_size_observed": dist.get_world_size() if world > 1 else 1, "gather": args.gather,
                        **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: not a scaling number"} if args.share_gpu else {})},

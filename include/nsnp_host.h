@@ -72,6 +72,23 @@ int nsnp_mpileup_parse_lines(const char* text, int64_t text_len, int64_t cap_col
                              int64_t* n_cols, int64_t* n_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases,
                              int64_t* n_lines_skipped);
 
+/* ---- staging for the streamed stage-5 pipeline (nanosnp_amd/pipeline.py stream_haplotype) ------------------------------------
+ * Replaces the HDF5 reads + per-site Python of HaplotypeModel/dataset_dev.py:92-172 behind predict_dev.py:31-32's DataLoader. */
+
+/* n values of elem_src bytes (4 = int32 as the reference's bins hold them, 1 = int8) from a file (fd >= 0, byte offset src_off: pread,
+ * page cache -> destination in one copy) or from memory (fd < 0: src + src_off) into dst as elem_dst-byte values, all host threads at
+ * once.  4 -> 1 narrows; *n_out_of_range receives the number of values outside [-128, 127] (the caller then stages that pass as
+ * int32).  1 -> 4 is not offered. */
+int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, int64_t n, void* dst, int elem_dst,
+                      int64_t* n_out_of_range);
+
+/* n zero-padded fields of `width` bytes holding "ctg:pos" (candidate_positions / haplotype_positions of a bin, write_to_bins.py:49-52)
+ * -> pos[n], ctg[n] = index of the contig among n_names names (blob + n_names + 1 offsets), -1 when it is not among them.
+ * NSNP_HOST_EFORMAT when a field does not split into exactly two parts at ':' or the position is not a decimal integer (the
+ * reference raises there: dataset_dev.py:109-110). */
+int nsnp_parse_ctg_pos(const uint8_t* rows, int64_t n, int width, const char* names_blob, const int64_t* names_off, int n_names,
+                       int64_t* pos, int32_t* ctg);
+
 /* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota (NSNP_HOST_THREADS in the
  * environment overrides the automatic count); nsnp_host_set_threads(n > 0) fixes it for the process, n <= 0 returns to automatic */
 int nsnp_host_threads(void);

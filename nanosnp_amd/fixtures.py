@@ -86,6 +86,10 @@ def seeded_hap_weights(seed, F=105, H=256, n_layers=3, n_gt=10, n_zy=3, ih_scale
     return out
 
 
+# the seeded HaplotypeModel weights tests/golden/make_golden.py `twostage` loaded into the reference's module when it wrote two_stage.npz
+TWO_STAGE_HAP_WEIGHTS = dict(seed=13, H=256, ih_scale=0.03, head_scale=120.0)
+
+
 # ---- legacy CatModel (HaplotypeModel/model.py:201-360, crnn.py:84-190) ---------------------------
 CAT_CHANNELS = (10, 32, 64, 128, 128, 256, 256)
 

@@ -61,6 +61,10 @@ def _load():
                                        C.POINTER(C.c_int64), p, p, p]
     lib.nsnp_fasta_load_contig.restype = C.c_int64
     lib.nsnp_fasta_load_contig.argtypes = [C.c_char_p, C.c_char_p, p, C.c_int64]
+    lib.nsnp_stage_values.restype = C.c_int
+    lib.nsnp_stage_values.argtypes = [C.c_int, p, C.c_int64, C.c_int, C.c_int64, p, C.c_int, C.POINTER(C.c_int64)]
+    lib.nsnp_parse_ctg_pos.restype = C.c_int
+    lib.nsnp_parse_ctg_pos.argtypes = [p, C.c_int64, C.c_int, C.c_char_p, p, C.c_int, p, p]
     lib.nsnp_pd_parse.restype = C.c_int64
     lib.nsnp_pd_parse.argtypes = [C.c_char_p, C.c_int64, p, p, p, p, p, C.c_int64]
     return lib
@@ -218,6 +222,39 @@ def mpileup_parse_range(buf, lo, hi, out=None, strict_lines=False):
         raise HostError(f"mpileup text holds {n_skipped.value} empty line(s): malformed input (every line must be one pileup column)")
     M, B = n_cols.value, n_bytes.value
     return pos[:M], col_off[:M + 1], bases[:B]
+
+
+def stage_values(dst, n, src=None, fd=-1, src_off=0, src_dtype=np.int32):
+    """n values of src_dtype (int32 / int8) from a file descriptor at byte offset src_off, or from the numpy array `src` (C-contiguous;
+    src_off in bytes), into the first n elements of dst (a numpy array of int32 or int8: e.g. the view of a pinned tensor), on all host
+    threads (nsnp_stage_values).  int32 -> int8 narrows; returns the number of values that did not fit int8 (0 in every other case)."""
+    es, ed = np.dtype(src_dtype).itemsize, dst.dtype.itemsize
+    if dst.size < n or not dst.flags["C_CONTIGUOUS"]:
+        raise HostError("stage_values: destination too small or not contiguous")
+    if src is not None:
+        if not src.flags["C_CONTIGUOUS"] or src.dtype.itemsize != es or src_off + n * es > src.nbytes:
+            raise HostError("stage_values: source must be a C-contiguous array of src_dtype holding n values behind src_off")
+    elif fd < 0:
+        raise HostError("stage_values: a file descriptor or a source array is needed")
+    bad = C.c_int64(0)
+    rc = lib().nsnp_stage_values(int(fd) if src is None else -1, None if src is None else C.c_void_p(src.ctypes.data), int(src_off), es, int(n),
+                                 C.c_void_p(dst.ctypes.data), ed, C.byref(bad))
+    _check(rc, "nsnp_stage_values")
+    return bad.value
+
+
+def parse_ctg_pos(rows, table):
+    """rows: uint8 [n, width] zero-padded "ctg:pos" fields (a bin's candidate_positions / haplotype_positions, any leading shape);
+    table: ContigTable -> (pos int64 [...], ctg int32 [...]; -1 = a contig the table does not hold).  HostError on a field the
+    reference's str.split(":") / int() would raise on (dataset_dev.py:109-110,153-154)."""
+    a = np.ascontiguousarray(rows, np.uint8)
+    lead, width = a.shape[:-1], a.shape[-1]
+    n = int(np.prod(lead, dtype=np.int64))
+    pos = np.empty(lead, np.int64); ctg = np.empty(lead, np.int32)
+    if n:
+        _check(lib().nsnp_parse_ctg_pos(_ptr(a), n, int(width), table.blob, _ptr(table.off), len(table.off) - 1, _ptr(pos), _ptr(ctg)),
+               "nsnp_parse_ctg_pos (a position field is not 'ctg:pos')")
+    return pos, ctg
 
 
 def fasta_load_contig(path, contig):

@@ -52,37 +52,23 @@ def predict_pileup(model, x, contig_names, positions, reference_bases, fai_text,
 
 
 def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions, output_file,
-                      batch_size=1000, score_mode=host.SCORE_FLOAT64, device_batch=16384):
-    """ctx: a Context with hap weights loaded; planes_*: (seq, baseq, mapq, hap, ref_row) int32
-    arrays [N,D,33] / [N,D,11]; candidate_positions: "ctg:pos" strings (dataset_dev.py:331-333).
+                      batch_size=1000, score_mode=host.SCORE_FLOAT64, device_batch=16384, narrow=True, stats=None):
+    """ctx: a Context with hap weights loaded; planes_*: (seq, baseq, mapq, hap, ref_row) integer arrays [N,D,33] / [N,D,11] in host
+    memory (numpy or memmap; int32 as the reference's bins hold them, or int8); candidate_positions: "ctg:pos" strings
+    (dataset_dev.py:331-333).  The sites are STREAMED (nanosnp_amd.hap_pipeline.stream_haplotype): passes of `device_batch` sites are
+    staged into pinned buffers on all host cores (int32 planes narrowed to int8 on the way when every value fits: a quarter of the
+    bytes over PCIe, the same features bit for bit), copied on a copy stream and reduced + forwarded on the compute stream, three
+    passes in flight; nothing is pageable, nothing blocks per pass.
     batch_size is the reference's DataLoader batch (predict_dev.py:27-33): a haplotype.csv row does not depend on it (unlike a
     pileup.vcf row), so the device works in passes of `device_batch` sites - the forward of 1,000 sites runs at 40 % of the rate of
     16,384 - and the rows are written by one native call; a probability the reference's loop would fail on (score_mode 0, p = 1)
     fails here as it does there, whatever the batch."""
-    import torch
+    from .hap_pipeline import HapArraySource, stream_haplotype
     del batch_size
     n = len(candidate_positions)
-    ctgs, poss = zip(*[p.split(":") for p in candidate_positions]) if n else ((), ())
-    table = host.ContigTable(list(ctgs))
-    pos = np.array([int(p) for p in poss], np.int64)
-    # read planes handed over as int8 arrays (every value fits: base codes, HP, qualities <= 93, padding -2) cross PCIe
-    # and HBM at a quarter of the bytes, same features bit for bit (nsnp_hap_features_i8); reference rows stay int32
-    def dtypes(planes):
-        narrow = all(a.dtype == np.int8 for a in planes[:4])
-        return [np.dtype(np.int8 if narrow else np.int32)] * 4 + [np.dtype(np.int32)]
-    tp, th = dtypes(planes_pileup), dtypes(planes_haplotype)
-    dev = torch.device("cuda", ctx.device)
-    ga_all, gm_all = [], []
-    for b0 in range(0, n, int(device_batch)):
-        sl = slice(b0, b0 + int(device_batch))
-        dp = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_pileup, tp)]
-        dh = [torch.from_numpy(np.ascontiguousarray(a[sl], dtype=t)).to(dev) for a, t in zip(planes_haplotype, th)]
-        xp = ctx.hap_features(*dp)
-        xh = ctx.hap_features(*dh)
-        gt, _ = ctx.hap_forward(xp, xh)
-        gm, ga = gt.max(dim=1)
-        ga_all.append(ga.to(torch.uint8)); gm_all.append(gm)
+    src = HapArraySource(planes_pileup, planes_haplotype, list(candidate_positions))
+    calls = stream_haplotype(ctx, src, None, pass_sites=int(device_batch), narrow=narrow, stats=stats)
     with open(output_file, "wb") as f:
         if n:
-            f.write(host.hap_csv_format(table, table.ids, pos, torch.cat(ga_all).cpu().numpy(), torch.cat(gm_all).cpu().numpy(), score_mode))
+            f.write(host.hap_csv_format(calls.table, calls.contig_id, calls.pos, calls.gt_arg, calls.gt_max, score_mode))
     return n

@@ -55,6 +55,51 @@ def write_arrays(path, arrays: dict):
             f.write(a.tobytes())
 
 
+def create_arrays(path, specs: dict) -> dict:
+    """Lays out a site file for arrays that are filled piece by piece (the reference appends to its EArrays chunk by chunk:
+    write_to_bins.py:53-63): specs = {name: (dtype, shape)}; returns {name: writable numpy.memmap}.  Flush / delete the maps to finish."""
+    items = []
+    for name, (dt, shape) in specs.items():
+        dt = np.dtype(dt)
+        if len(shape) > 4 or len(name.encode()) > 32:
+            raise SiteFileError(f"array {name!r}: at most 4 dimensions and 32-byte names")
+        items.append((name, dt, tuple(int(v) for v in shape)))
+    off = len(MAGIC) + 8 + _REC.size * len(items)
+    recs, offs = [], []
+    for name, dt, shape in items:
+        off = (off + 63) & ~63
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        recs.append(_REC.pack(name.encode(), dt.str.encode(), len(shape), 0, *(list(shape) + [0] * (4 - len(shape))), off, nbytes))
+        offs.append(off)
+        off += nbytes
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<II", len(items), 0))
+        for r in recs:
+            f.write(r)
+        f.truncate(max(off, f.tell()))
+    return {name: (np.memmap(path, dtype=dt, mode="r+", offset=o, shape=shape) if int(np.prod(shape, dtype=np.int64)) else np.empty(shape, dt))
+            for (name, dt, shape), o in zip(items, offs)}
+
+
+def array_index(path) -> dict:
+    """{name: (dtype, shape, byte offset, nbytes)} of a site file, without touching the data (the streamed stage-5 reader preads the
+    planes straight into pinned buffers: nanosnp_amd/pipeline.py)."""
+    with open(path, "rb") as f:
+        head = f.read(len(MAGIC) + 8)
+        if len(head) < len(MAGIC) + 8 or head[:8] != MAGIC:
+            raise SiteFileError(f"{path}: not an NSNPBIN1 file")
+        n, = struct.unpack_from("<I", head, 8)
+        recs = [_REC.unpack(f.read(_REC.size)) for _ in range(n)]
+    out = {}
+    for name, dt, ndim, _, s0, s1, s2, s3, off, nbytes in recs:
+        shape = (s0, s1, s2, s3)[:ndim]
+        dtype = np.dtype(dt.rstrip(b"\0").decode())
+        if int(np.prod(shape, dtype=np.int64)) * dtype.itemsize != nbytes:
+            raise SiteFileError(f"{path}: array {name!r} has inconsistent size")
+        out[name.rstrip(b"\0").decode()] = (dtype, tuple(int(v) for v in shape), int(off), int(nbytes))
+    return out
+
+
 def read_arrays(path, mmap=True) -> dict:
     """Returns {name: array}; with ``mmap`` the arrays are read-only views of the file."""
     with open(path, "rb") as f:
@@ -157,22 +202,31 @@ HAP_PLANES = ("haplotype_sequences", "haplotype_hap", "haplotype_baseq", "haplot
 
 
 def write_haplotype_bin(path, candidate_positions, haplotype_positions, planes: dict, max_haplotype_depth=None,
-                        max_pileup_depth=None):
-    """planes: the eight padded int32 arrays of write_to_bins.py (``haplotype_*`` [N,Dh,11], ``pileup_*`` [N,Dp,33], padding
+                        max_pileup_depth=None, plane_dtype="int8"):
+    """planes: the eight padded integer arrays of write_to_bins.py (``haplotype_*`` [N,Dh,11], ``pileup_*`` [N,Dp,33], padding
     -2).  Sites are sorted by the integer position of ``ctg:pos`` (write_to_bins.py:5-8; stable here) and depth is cut to
-    ``max_*_depth`` (:39-42,54-61)."""
+    ``max_*_depth`` (:39-42,54-61).
+    plane_dtype: "int8" (default) stores the read planes as int8 when EVERY value of all eight fits (base codes -2..4, HP -2..3, base
+    qualities <= 93, mapping qualities <= 60 from minimap2: they do; a plane holding e.g. mapq 255 makes the whole file int32) - a
+    quarter of the file, of the bytes over PCIe and of the feature kernel's HBM reads, same features bit for bit
+    (nsnp_hap_features_i8); "int32" writes the reference's dtype (write_to_bins.py:44-47).  Readers accept both."""
     cand = [c if isinstance(c, str) else bytes(c).decode() for c in candidate_positions]
     n = len(cand)
     order = np.argsort(np.array([int(c.split(":")[1]) for c in cand], np.int64), kind="stable") if n else np.empty(0, np.int64)
+    if plane_dtype not in ("int8", "int32"):
+        raise SiteFileError("plane_dtype must be 'int8' or 'int32'")
     arrays = {}
     for name in HAP_PLANES:
-        a = np.ascontiguousarray(planes[name], dtype=np.int32)
-        if a.ndim != 3 or a.shape[0] != n:
-            raise SiteFileError(f"{name}: expected int32 [N,D,L] with N = {n}")
+        a = np.asarray(planes[name])
+        if a.ndim != 3 or a.shape[0] != n or a.dtype.kind != "i":
+            raise SiteFileError(f"{name}: expected an integer array [N,D,L] with N = {n}")
         cut = max_haplotype_depth if name.startswith("haplotype") else max_pileup_depth
         if cut is not None and cut < a.shape[1]:
             a = a[:, :cut]
         arrays[name] = a[order]
+    fits = all(a.size == 0 or (int(a.min()) >= -128 and int(a.max()) <= 127) for a in arrays.values())
+    dt = np.int8 if (plane_dtype == "int8" and fits) else np.int32
+    arrays = {k: np.ascontiguousarray(a, dtype=dt) for k, a in arrays.items()}
     width_c = max([len(c) for c in cand] + [1])
     cp = np.zeros((n, width_c), np.uint8)
     for i, j in enumerate(order):

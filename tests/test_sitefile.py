@@ -79,15 +79,20 @@ def test_haplotype_bin_sorts_by_position_and_cuts_depth(tmp_path):
         a[:, d - 3:] = -2
         planes[name] = a
     p = tmp_path / "ctgA_1000_1400.bin"
-    sitefile.write_haplotype_bin(p, cand, hpos, planes, max_haplotype_depth=10, max_pileup_depth=64)
-    c2, h2, pl2 = sitefile.read_haplotype_bin(p)
     order = np.argsort(posn, kind="stable")
-    assert c2 == [cand[i] for i in order] and h2 == [hpos[i] for i in order]
-    for name in sitefile.HAP_PLANES:
-        want = planes[name][order]
-        if name.startswith("haplotype"):
-            want = want[:, :10]
-        assert pl2[name].dtype == np.int32 and np.array_equal(pl2[name], want)
+    big = {k: v.copy() for k, v in planes.items()}
+    big["pileup_mapq"][2, 0, 0] = 255                                       # one value beyond int8: the whole file stays int32
+    for kw, src, want_dtype in (({}, planes, np.int8), ({"plane_dtype": "int32"}, planes, np.int32), ({}, big, np.int32)):
+        sitefile.write_haplotype_bin(p, cand, hpos, src, max_haplotype_depth=10, max_pileup_depth=64, **kw)
+        c2, h2, pl2 = sitefile.read_haplotype_bin(p)
+        assert c2 == [cand[i] for i in order] and h2 == [hpos[i] for i in order]
+        for name in sitefile.HAP_PLANES:
+            want = src[name][order]
+            if name.startswith("haplotype"):
+                want = want[:, :10]
+            assert pl2[name].dtype == want_dtype and np.array_equal(pl2[name], want)
+        idx = sitefile.array_index(p)
+        assert idx["pileup_mapq"][:2] == (np.dtype(want_dtype), (n, dp, 33)) and idx["pileup_mapq"][2] % 64 == 0
     (tmp_path / "nope.bin").write_bytes(b"NSNPBIN1" + bytes(8))            # a valid container without the arrays
     with pytest.raises(sitefile.SiteFileError):
         sitefile.read_haplotype_bin(tmp_path / "nope.bin")

@@ -8,7 +8,7 @@ import numpy as np
 from nanosnp_amd import host, merge
 from tests.helpers import PROB_ATOL, golden, seeded_hap_weights
 
-TWO_STAGE_HAP_WEIGHTS = dict(seed=13, H=256, ih_scale=0.03, head_scale=120.0)      # what make_golden.py twostage loads
+from nanosnp_amd.fixtures import TWO_STAGE_HAP_WEIGHTS      # noqa: E402  what make_golden.py twostage loads
 
 
 def _fixture():
