@@ -231,11 +231,20 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
     """Sites [lo, hi) of `source` (HapBinSource / HapArraySource) through haplotype features + HaplotypeModel forward + argmax / max,
     pass by pass, staging / H2D / compute overlapped (module docstring).  ctx: a Context with hap weights loaded (its hap_precision
     option selects the arithmetic).  reference: a DeviceReference (needed unless the source carries its own reference rows).
-    narrow: int32 planes are narrowed to int8 while they are staged when every value of the pass fits (bit-identical features from a
-    quarter of the bytes); False sends them as int32.
+    narrow: int32 planes are narrowed to int8 while they are staged when every value fits (bit-identical features from a quarter of
+    the bytes); False sends them as int32.
 
     Returns HapCalls (numpy arrays in site order; with keep_probabilities also the [n, 10] probabilities).  stats (dict) receives
     per-station busy times and byte counts.  The buffer sets are kept on ctx between calls: one call at a time per context."""
+    return stream_segments(ctx, [(source, lo, hi)], reference, pass_sites, narrow, stats, keep_probabilities)[0]
+
+
+def stream_segments(ctx, segments, reference=None, pass_sites=16384, narrow=True, stats=None, keep_probabilities=False, on_segment=None):
+    """stream_haplotype over several (source, lo, hi) segments - the bins of a directory - as ONE pipeline: the first pass of segment
+    f + 1 is staged and copied while the last passes of segment f compute, so a directory of bins pays the pipeline's fill and drain
+    once, not once per file.  on_segment(index, HapCalls), when given, is called on a writer thread as soon as the calls of a segment
+    are back on the host, in segment order, while later segments are still computing (predict_haplotype_bins formats and writes the
+    csv rows there).  Returns the list of HapCalls."""
     import time
     from concurrent.futures import ThreadPoolExecutor
     import torch
@@ -244,30 +253,50 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
     for k in ("stage_s", "h2d_s", "gpu_s", "bytes_staged", "bytes_h2d", "sites", "passes", "passes_int8", "wait_stage_s", "issue_s", "drain_s", "setup_s"):
         st.setdefault(k, 0.0)
     t_enter = time.perf_counter()
-    hi = source.n if hi is None else min(int(hi), source.n)
-    lo = max(0, int(lo))
-    n = max(0, hi - lo)
-    if source.ref_rows is None and reference is None:
-        raise ValueError("stream_haplotype: the source carries no reference rows: a DeviceReference is needed")
+    segs = []
+    for source, lo, hi in segments:
+        hi = source.n if hi is None else min(int(hi), source.n)
+        lo = max(0, int(lo or 0))
+        if source.ref_rows is None and reference is None:
+            raise ValueError("stream_haplotype: the source carries no reference rows: a DeviceReference is needed")
+        segs.append((source, lo, max(lo, hi)))
     names = reference if reference is not None else _LocalNames()
-    if n == 0:
-        return HapCalls(names.table, np.empty(0, np.int32), np.empty(0, np.int64), np.empty(0, np.uint8), np.empty(0, np.float32),
-                        np.empty((0, 10), np.float32) if keep_probabilities else None)
-    P = int(max(1, min(pass_sites, n)))
-    Dp, Dh = source.Dp, source.Dh
-    want8 = bool(narrow) or source.elem == 1
-    elem = 1 if want8 else source.elem                   # bytes per value in the staging sets and over PCIe
-    passes = [(a, min(hi, a + P)) for a in range(lo, hi, P)]
+    seg_off = np.concatenate([[0], np.cumsum([hi - lo for _, lo, hi in segs])]).astype(np.int64)
+    n = int(seg_off[-1])
+    P = int(max(1, pass_sites))
+    # the passes of all segments in order; the very first one is a quarter pass (the pipeline's fill: nothing computes while it is
+    # staged and copied)
+    passes = []
+    for f, (source, lo, hi) in enumerate(segs):
+        a = lo
+        while a < hi:
+            b = min(hi, a + (max(1, P // 4) if not passes and hi - lo > P else P))
+            passes.append((f, a, b, int(seg_off[f]) + a - lo))
+            a = b
+    last_pass_of = {f: k for k, (f, _, _, _) in enumerate(passes)}
+    empty = lambda: HapCalls(names.table, np.empty(0, np.int32), np.empty(0, np.int64), np.empty(0, np.uint8), np.empty(0, np.float32),
+                             np.empty((0, 10), np.float32) if keep_probabilities else None)
+    if not passes:
+        out = [empty() for _ in segs]
+        if on_segment is not None:
+            for f, c in enumerate(out):
+                on_segment(f, c)
+        return out
+    Pmax = max(b - a for _, a, b, _ in passes)
+    Dp, Dh = max(s_.Dp for s_, _, _ in segs), max(s_.Dh for s_, _, _ in segs)
+    e_of = lambda src: 1 if (narrow or src.elem == 1) else src.elem              # bytes per value in the staging sets and over PCIe
+    elem = max(e_of(s_) for s_, lo, hi in segs if hi > lo)
     n_sets = min(3, len(passes))
     # pinned buffers are expensive to create (page-locking): kept on the context between calls, with their device twins
     hsets = getattr(ctx, "_hap_host_sets", None)
-    if not hsets or len(hsets) < n_sets or not all(s_.fits(P, Dp, Dh, elem) for s_ in hsets):
-        hsets = [_Set(P, Dp, Dh, elem) for _ in range(n_sets)]
+    if not hsets or len(hsets) < n_sets or not all(s_.fits(Pmax, Dp, Dh, elem) for s_ in hsets):
+        hsets = [_Set(Pmax, Dp, Dh, elem) for _ in range(n_sets)]
         ctx._hap_host_sets = hsets
     dsets = getattr(ctx, "_hap_dev_sets", None)
-    if not dsets or len(dsets) < n_sets or not all(s_.fits(P, Dp, Dh, elem) for s_ in dsets):
-        dsets = [_Set(P, Dp, Dh, elem, dev) for _ in range(n_sets)]
+    if not dsets or len(dsets) < n_sets or not all(s_.fits(Pmax, Dp, Dh, elem) for s_ in dsets):
+        dsets = [_Set(Pmax, Dp, Dh, elem, dev) for _ in range(n_sets)]
         ctx._hap_dev_sets = dsets
+    if getattr(ctx, "_hap_copy_stream", None) is None:
         ctx._hap_copy_stream = torch.cuda.Stream(dev)
     copy_stream = ctx._hap_copy_stream
     main = torch.cuda.current_stream(dev)
@@ -290,13 +319,14 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
     def stage(k):
         """pass k -> host set k % n_sets (worker thread)"""
         t0 = time.perf_counter()
-        a, b = passes[k]
+        f, a, b, o = passes[k]
+        source = segs[f][0]
         m = b - a
         hs = hsets[k % n_sets]
-        e_out = elem
+        e_out = e_of(source)
         nbytes = 0
         for name in PILEUP_PLANES + HAPLOTYPE_PLANES:
-            cnt = m * (Dp * 33 if name.startswith("pileup") else Dh * 11)
+            cnt = m * (source.Dp * 33 if name.startswith("pileup") else source.Dh * 11)
             v = hs.planes[name].numpy()[:cnt * e_out].view(np.int8 if e_out == 1 else np.int32)
             if source.stage_plane(name, a, b, v):
                 raise _NarrowOverflow(name)              # a value outside int8 (e.g. a mapping quality of 255)
@@ -309,7 +339,7 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
             names.add_names([bytes(r).rstrip(b"\0").split(b":")[0].decode() for r in cand_f[cc < 0]])
             cp, cc = host.parse_ctg_pos(cand_f, names.table)
         hs.cand_pos.numpy()[:m] = cp; hs.cand_ctg.numpy()[:m] = cc
-        cand_pos_all[a - lo:b - lo] = cp; cand_ctg_all[a - lo:b - lo] = cc
+        cand_pos_all[o:o + m] = cp; cand_ctg_all[o:o + m] = cc
         if source.ref_rows is not None:
             hs.ref_p.numpy()[:m] = source.ref_rows[0][a:b]; hs.ref_h.numpy()[:m] = source.ref_rows[1][a:b]
         else:
@@ -317,36 +347,55 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
             hs.hap_pos.numpy()[:m] = hp; hs.hap_ctg.numpy()[:m] = hc
         return e_out, nbytes, time.perf_counter() - t0
 
+    def calls_of(f, done=None):
+        """the calls of segment f as host arrays (writer thread: waits for the segment's last copies first)"""
+        if done is not None:
+            done.synchronize()
+        o0, o1 = int(seg_off[f]), int(seg_off[f + 1])
+        c = HapCalls(names.table, cand_ctg_all[o0:o1].copy(), cand_pos_all[o0:o1].copy(), h_ga[o0:o1].numpy().copy(), h_gm[o0:o1].numpy().copy(),
+                     probs[o0:o1].cpu().numpy() if probs is not None else None)
+        if on_segment is not None:
+            on_segment(f, c)
+        return c
+
     tev = lambda: torch.cuda.Event(enable_timing=True)
     ev = [dict(h0=tev(), h1=tev(), c0=tev(), c1=tev()) for _ in passes]
     st["setup_s"] += time.perf_counter() - t_enter
-    with ThreadPoolExecutor(max_workers=1) as pool:
+    seg_futs = [None] * len(segs)
+    next_seg = 0                                         # segments up to here have had their writer job submitted (in order)
+    with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as writer:
         futs = [pool.submit(stage, j) for j in range(min(2, len(passes)))]
-        for k, (a, b) in enumerate(passes):
+        for k, (f, a, b, o) in enumerate(passes):
+            source = segs[f][0]
             m = b - a
             t_w = time.perf_counter()
             try:
                 e_out, nbytes, t_stage = futs[k].result()
             except _NarrowOverflow:
                 # int32 planes that do not fit int8 after all: the whole call is done again with the planes as they are (the writer
-                # of nanosnp_amd.sitefile stores int8 whenever it can, so this is a file of reference dtype holding e.g. mapq 255)
+                # of nanosnp_amd.sitefile stores int8 whenever it can, so this is a file of reference dtype holding e.g. mapq 255).
+                # Segments whose rows have already gone out through on_segment are not repeated.
                 for f_ in futs[k + 1:]:
                     f_.cancel()
                 pool.shutdown(wait=True)
+                writer.shutdown(wait=True)
                 torch.cuda.synchronize(dev)
                 st["narrow_restarts"] = st.get("narrow_restarts", 0) + 1
-                return stream_haplotype(ctx, source, reference, lo, hi, pass_sites, False, stats, keep_probabilities)
+                head = [sf.result() for sf in seg_futs[:next_seg]]
+                cb = (lambda i, c: on_segment(i + next_seg, c)) if on_segment is not None else None
+                return head + stream_segments(ctx, segs[next_seg:], reference, pass_sites, False, stats, keep_probabilities, cb)
             t_i = time.perf_counter()
             st["wait_stage_s"] += t_i - t_w; st["stage_s"] += t_stage; st["bytes_staged"] += nbytes
             st["passes"] += 1; st["passes_int8"] += int(e_out == 1); st["sites"] += m
             hs, ds = hsets[k % n_sets], dsets[k % n_sets]
+            Dps, Dhs = source.Dp, source.Dh
             # ---- H2D on the copy stream, behind the last readers of this device set (pass k - 3) ----
             if ds.free is not None:
                 copy_stream.wait_event(ds.free)
             with torch.cuda.stream(copy_stream):
                 ev[k]["h0"].record(copy_stream)
                 for name in PILEUP_PLANES + HAPLOTYPE_PLANES:
-                    cnt = m * (Dp * 33 if name.startswith("pileup") else Dh * 11) * e_out
+                    cnt = m * (Dps * 33 if name.startswith("pileup") else Dhs * 11) * e_out
                     ds.planes[name][:cnt].copy_(hs.planes[name][:cnt], non_blocking=True)
                 ds.cand_pos[:m].copy_(hs.cand_pos[:m], non_blocking=True); ds.cand_ctg[:m].copy_(hs.cand_ctg[:m], non_blocking=True)
                 if source.ref_rows is not None:
@@ -371,33 +420,44 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
                 ref_h = reference.rows(ds.hap_ctg[:m], ds.hap_pos[:m] - 1)
             tdt = torch.int8 if e_out == 1 else torch.int32
             pl = lambda name, D, L: ds.planes[name][:m * D * L * e_out].view(tdt).view(m, D, L)
-            xp = ctx.hap_features(*[pl(nm, Dp, 33) for nm in PILEUP_PLANES], ref_p)
-            xh = ctx.hap_features(*[pl(nm, Dh, 11) for nm in HAPLOTYPE_PLANES], ref_h)
+            xp = ctx.hap_features(*[pl(nm, Dps, 33) for nm in PILEUP_PLANES], ref_p)
+            xh = ctx.hap_features(*[pl(nm, Dhs, 11) for nm in HAPLOTYPE_PLANES], ref_h)
             gt, _ = ctx.hap_forward(xp, xh)
             gm, ga = gt.max(dim=1)                                                # predict_dev.py:40-43
-            d_ga[a - lo:b - lo] = ga.to(torch.uint8); d_gm[a - lo:b - lo] = gm
+            d_ga[o:o + m] = ga.to(torch.uint8); d_gm[o:o + m] = gm
             if probs is not None:
-                probs[a - lo:b - lo] = gt
-            h_ga[a - lo:b - lo].copy_(d_ga[a - lo:b - lo], non_blocking=True); h_gm[a - lo:b - lo].copy_(d_gm[a - lo:b - lo], non_blocking=True)
+                probs[o:o + m] = gt
+            h_ga[o:o + m].copy_(d_ga[o:o + m], non_blocking=True); h_gm[o:o + m].copy_(d_gm[o:o + m], non_blocking=True)
             ev[k]["c1"].record(main)
             ds.free = torch.cuda.Event(); ds.free.record(main)
+            # ---- segments that are complete with this pass (and empty ones in front of the next): their calls go to the writer thread ----
+            if last_pass_of[f] == k:
+                while next_seg <= f:
+                    seg_futs[next_seg] = writer.submit(calls_of, next_seg, ds.free if next_seg == f else None)
+                    next_seg += 1
             st["issue_s"] += time.perf_counter() - t_i
-    t_d = time.perf_counter()
-    torch.cuda.synchronize(dev)
-    st["drain_s"] += time.perf_counter() - t_d
+        t_d = time.perf_counter()
+        torch.cuda.synchronize(dev)
+        while next_seg < len(segs):                      # (empty segments behind the last pass)
+            seg_futs[next_seg] = writer.submit(calls_of, next_seg, None)
+            next_seg += 1
+        out = [sf.result() for sf in seg_futs]
+        st["drain_s"] += time.perf_counter() - t_d
     for e in ev:
         st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
         st["gpu_s"] += e["c0"].elapsed_time(e["c1"]) * 1e-3
-    return HapCalls(names.table, cand_ctg_all, cand_pos_all, h_ga[:n].numpy().copy(), h_gm[:n].numpy().copy(),
-                    probs.cpu().numpy() if probs is not None else None)
+    return out
 
 
 def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16384, narrow=True, score_mode=host.SCORE_FLOAT64, stats=None):
-    """The reference's ``predict(model, test_data, reference_path, ...)`` (predict_dev.py:27-48) over haplotype site files: every file of
-    bin_paths (a directory - os.listdir order, as the reference iterates it - or a list of paths) is streamed through
-    stream_haplotype and its rows ``ctg \\t pos \\t GT \\t qual`` appended to output_file.  reference: a DeviceReference or a dict
-    {contig: sequence} (uploaded once).  Under torch.distributed every rank works on its shard of every file and rank 0 writes.
-    Returns the number of rows written (on rank 0; 0 elsewhere)."""
+    """The reference's ``predict(model, test_data, reference_path, ...)`` (predict_dev.py:27-48) over haplotype site files: the files of
+    bin_paths (a directory - os.listdir order, as the reference iterates it - or a list of paths) go through ONE pipeline
+    (stream_segments: the first pass of the next file is staged while the last passes of this one compute) and the rows
+    ``ctg \t pos \t GT \t qual`` of every file are formatted and appended to output_file on a writer thread as soon as the file's calls
+    are back, while later files compute.  reference: a DeviceReference or a dict {contig: sequence} (uploaded once).
+    Under torch.distributed every rank works on its shard_range of every file, the calls travel to rank 0 in one rooted gather and
+    rank 0 writes.  Returns the number of rows written (on rank 0; 0 elsewhere)."""
+    import time
     import torch
     import torch.distributed as tdist
     from .dist import gather_varlen, shard_range
@@ -409,36 +469,52 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
     ref = reference if isinstance(reference, DeviceReference) else DeviceReference(reference, ctx.device)
     sharded = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
+    st = stats if stats is not None else {}
+    st.setdefault("csv_s", 0.0)
+    sources = []
     total = 0
     f = open(output_file, "wb") if rank == 0 else None
     try:
         for p in paths:
-            src = HapBinSource(p)
-            try:
-                a, b = shard_range(src.n, rank, world)
-                calls = stream_haplotype(ctx, src, ref, a, b, pass_sites=pass_sites, narrow=narrow, stats=stats)
-            finally:
-                src.close()
-            tbl, ctg, pos, ga, gm = calls[:5]
-            if sharded:
-                # contig ids index every rank's OWN name table (ranks can meet unknown contigs in different orders): the tables are
-                # merged first, every rank renumbers its ids, then the numbers travel as one [n, 4] float64 block (all exact)
-                lists = [None] * world
-                tdist.all_gather_object(lists, list(ref.names))
-                merged = list(dict.fromkeys(n_ for lst in lists for n_ in lst))
-                remap = np.array([merged.index(n_) for n_ in ref.names] + [0], np.float64)
-                backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
-                blk = np.stack([remap[ctg], pos.astype(np.float64), ga.astype(np.float64), gm.astype(np.float64)], 1) if pos.size else np.zeros((0, 4))
-                allb = gather_varlen(torch.from_numpy(blk).to(backend_dev))
-                if rank != 0:
-                    continue
-                allb = allb.cpu().numpy()
-                tbl = host.ContigTable(merged)
-                ctg, pos, ga, gm = allb[:, 0].astype(np.int32), allb[:, 1].astype(np.int64), allb[:, 2].astype(np.uint8), allb[:, 3].astype(np.float32)
+            sources.append(HapBinSource(p))
+        segments = [(s_,) + shard_range(s_.n, rank, world) for s_ in sources]
+
+        def write_rows(tbl, ctg, pos, ga, gm):
+            nonlocal total
+            t0 = time.perf_counter()
             if pos.size:
                 f.write(host.hap_csv_format(tbl, ctg, pos, ga, gm, score_mode))
                 total += int(pos.size)
+            st["csv_s"] += time.perf_counter() - t0
+
+        if not sharded:
+            stream_segments(ctx, segments, ref, pass_sites, narrow, st, on_segment=lambda i, c: write_rows(*c[:5]))
+        else:
+            calls = stream_segments(ctx, segments, ref, pass_sites, narrow, st)
+            # contig ids index every rank's OWN name table (ranks can meet unknown contigs in different orders): the tables are merged
+            # first, every rank renumbers its ids, then the numbers of all files travel as ONE [n, 4] float64 block (all exact);
+            # the root cuts it back into files (every rank knows every shard size: shard_range)
+            lists = [None] * world
+            tdist.all_gather_object(lists, list(ref.names))
+            merged = list(dict.fromkeys(n_ for lst in lists for n_ in lst))
+            remap = np.array([merged.index(n_) for n_ in ref.names] + [0], np.float64)
+            backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
+            blks = [np.stack([remap[c.contig_id], c.pos.astype(np.float64), c.gt_arg.astype(np.float64), c.gt_max.astype(np.float64)], 1)
+                    for c in calls if c.pos.size]
+            blk = np.concatenate(blks) if blks else np.zeros((0, 4))
+            allb = gather_varlen(torch.from_numpy(blk).to(backend_dev))
+            if rank == 0:
+                allb = allb.cpu().numpy()
+                tbl = host.ContigTable(merged)
+                sizes = [[hi - lo for lo, hi in (shard_range(s_.n, r, world) for s_ in sources)] for r in range(world)]
+                start = np.concatenate([[0], np.cumsum([sum(sz) for sz in sizes])])
+                within = [np.concatenate([[0], np.cumsum(sz)]) for sz in sizes]
+                for i in range(len(sources)):
+                    rows = np.concatenate([allb[start[r] + within[r][i]:start[r] + within[r][i + 1]] for r in range(world)])
+                    write_rows(tbl, rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int64), rows[:, 2].astype(np.uint8), rows[:, 3].astype(np.float32))
     finally:
+        for s_ in sources:
+            s_.close()
         if f:
             f.close()
     return total

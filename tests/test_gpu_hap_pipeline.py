@@ -92,7 +92,8 @@ def test_streamed_stage5_is_independent_of_pass_size_dtype_and_narrowing(tmp_pat
         want = want if want is not None else got
         assert got == want, (path, kw)
         ps = kw.get("pass_sites", 16384)
-        assert st["passes"] == -(-n // min(ps, n)) and st["passes_int8"] == (0 if kw.get("narrow") is False else st["passes"])
+        want_passes = 1 if n <= ps else 1 + -(-(n - max(1, ps // 4)) // ps)           # (the first pass of a run is a quarter pass)
+        assert st["passes"] == want_passes and st["passes_int8"] == (0 if kw.get("narrow") is False else st["passes"])
         per_site = (33 + 11) * 90 * (4 if kw.get("narrow") is False else 1) * 4
         assert st["bytes_staged"] == n * per_site
     assert want.count(b"\n") == n
@@ -145,6 +146,30 @@ def test_streamed_stage5_edge_inputs(tmp_path, hctx):
     assert predict_haplotype_bins(hctx, [px], ref_all, str(out)) == 6                    # the context is usable afterwards
     with pytest.raises(ValueError):
         stream_haplotype(hctx, srcx, None)                                              # a bin carries no reference rows
+
+
+def test_a_directory_of_bins_is_one_pipeline(tmp_path, hctx):
+    """several files through predict_haplotype_bins = the concatenation of their single-file csvs (files of different depth, an empty
+    one in the middle, one that needs the int32 restart at the end: rows already written are not repeated)"""
+    from nanosnp_amd.hap_pipeline import DeviceReference, predict_haplotype_bins
+    specs = [("a.bin", 150, 61, dict(D=90)), ("b.bin", 0, 62, dict(D=90)), ("c.bin", 77, 63, dict(D=40)), ("d.bin", 1, 64, dict(D=90)),
+             ("e.bin", 90, 65, dict(D=90, dtype="int32", mapq255=True))]
+    paths, refs = [], {}
+    for name, n, seed, kw in specs:
+        p, r, *_ = _make_bin(tmp_path, n, seed, name=name, contig="ctg" + name[0].upper(), **kw)
+        paths.append(p); refs.update(r)
+    ref = DeviceReference(refs, 0)
+    singles = b""
+    for p in paths:
+        o = tmp_path / "one.csv"
+        predict_haplotype_bins(hctx, [p], ref, str(o), pass_sites=64)
+        singles += o.read_bytes()
+    for ps in (64, 16384, 50):
+        o = tmp_path / "all.csv"
+        st = {}
+        assert predict_haplotype_bins(hctx, paths, ref, str(o), pass_sites=ps, stats=st) == 318
+        assert o.read_bytes() == singles, ps
+        assert st.get("narrow_restarts") == 1 and st["sites"] >= 318
 
 
 def _rank_worker(rank, world, port, tmp, q):
