@@ -81,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather", default="torch", choices=["torch", "rccl-abi"], help="final merge through one torch.distributed collective "
                     "(default) or through the library's own RCCL entry nsnp_gather_results (validated at world size 1 only)")
     ap.add_argument("--share-gpu", action="store_true", help="test configuration: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--workloads", default="all", help="pileup workload only: after the headline's timed region, short runs of the other BASELINE "
+                    "configurations in the same process, reported under \"workloads\" in the same line (tools/workloads.py): 'all' (default), 'none', or a "
+                    "comma-separated subset of haplotype,two_stage,deep60,hap_e2e,e2e")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU/gloo dry run of the multi-rank plumbing (spawn, barrier, "
                     "max-over-ranks timing, rooted gather, one JSON line); no kernels, value is null -- tests/test_dist.py")
     return ap.parse_args(argv)
@@ -337,6 +340,16 @@ def main():
         stage.set_precision(0)
         del ref_gt, ref_zy
 
+    # ---- the other BASELINE configurations, short runs in this process (every rank takes part: their merges are collectives) ----
+    sub, sub_ok = {}, True
+    if args.workloads != "none":
+        from tools.workloads import PLAN, run_all
+        only = None if args.workloads == "all" else set(args.workloads.split(","))
+        if only is not None and not only <= {p[0] for p in PLAN}:
+            print(f"bench.py: --workloads: unknown name in {sorted(only)}", file=sys.stderr)
+            sys.exit(2)
+        sub, sub_ok = run_all(args, rank, world, local_rank, only)
+
     exit_code = 0
     if rank == 0:
         out = {
@@ -378,11 +391,17 @@ def main():
             out["parity_sample"] = None
         out["cpu_baseline"] = cpu_baseline(stage.cols, batch, stage.weights, args.cpu_seconds) if (not args.no_cpu_baseline and world == 1) else None
         assert merged is not None and merged.shape[0] == n_done * world
+        if sub:
+            out["workloads"] = sub
+            out["workloads_note"] = ("short runs of the other BASELINE configurations in this process after the headline's timed region, on reduced resident "
+                                     "pools (tools/workloads.py); each is the full line of `bench.py --workload NAME`; `value` above is configs[1] alone")
         print(json.dumps(out))
         for who in (out, out.get("bf16x3") or {}):
             if who.get("parity_sample") is not None and not who["parity_sample"]["ok"]:
                 print("bench.py: parity_sample FAILED: " + json.dumps(who["parity_sample"]), file=sys.stderr)
                 exit_code = 1
+    if not sub_ok:
+        exit_code = 1                                # (a sub-workload's parity sample failed or it raised: its own message is on stderr)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

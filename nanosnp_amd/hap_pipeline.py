@@ -449,14 +449,16 @@ def stream_segments(ctx, segments, reference=None, pass_sites=16384, narrow=True
     return out
 
 
-def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16384, narrow=True, score_mode=host.SCORE_FLOAT64, stats=None):
+def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16384, narrow=True, score_mode=host.SCORE_FLOAT64, stats=None,
+                           distributed=True):
     """The reference's ``predict(model, test_data, reference_path, ...)`` (predict_dev.py:27-48) over haplotype site files: the files of
     bin_paths (a directory - os.listdir order, as the reference iterates it - or a list of paths) go through ONE pipeline
     (stream_segments: the first pass of the next file is staged while the last passes of this one compute) and the rows
     ``ctg \t pos \t GT \t qual`` of every file are formatted and appended to output_file on a writer thread as soon as the file's calls
     are back, while later files compute.  reference: a DeviceReference or a dict {contig: sequence} (uploaded once).
     Under torch.distributed every rank works on its shard_range of every file, the calls travel to rank 0 in one rooted gather and
-    rank 0 writes.  Returns the number of rows written (on rank 0; 0 elsewhere)."""
+    rank 0 writes (distributed=False: this process alone does the whole job even inside a process group).  Returns the number of rows
+    written (on rank 0; 0 elsewhere)."""
     import time
     import torch
     import torch.distributed as tdist
@@ -467,7 +469,7 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
     else:
         paths = [str(p) for p in bin_paths]
     ref = reference if isinstance(reference, DeviceReference) else DeviceReference(reference, ctx.device)
-    sharded = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+    sharded = bool(distributed) and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
     st = stats if stats is not None else {}
     st.setdefault("csv_s", 0.0)

@@ -35,8 +35,27 @@ def _run(*argv, env=None, timeout=900):
     return json.loads(lines[0])
 
 
+SMALL_POOLS = dict(NSNP_TWO_STAGE_N2="40960", NSNP_TWO_STAGE_N5="4096", NSNP_HAP_N="4096", NSNP_CAT_N="2048", NSNP_DEEP_WINDOWS="40960",
+                   NSNP_HAPE2E_SITES="6000", NSNP_E2E_COLS="400000", NSNP_E2E_CHUNK_MB="4")
+
+
 def test_bench_line_schema():
-    d = _run("--gpus", "1", "--steps", "4", "--warmup", "1", "--windows", "131072", "--cpu-seconds", "1.5")
+    d = _run("--gpus", "1", "--steps", "4", "--warmup", "1", "--windows", "131072", "--cpu-seconds", "1.5", "--hap-batch", "2048", env=dict(os.environ, **SMALL_POOLS))
+    # the other BASELINE configurations ride in the same line (tools/workloads.py): every one with a value, a parity sample that holds, a CPU
+    # baseline, and - where a device kernel dominates - a roofline fraction
+    w = d["workloads"]
+    assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e"}
+    for name, line in w.items():
+        assert "error" not in line, (name, line.get("error"))
+        sm = line["summary"]
+        assert sm["value"] > 0 and sm["ms_per_step"] > 0 and sm["parity_ok"] is True and sm["cpu_baseline_value"] > 0, (name, sm)
+        assert line["parity_sample"]["ok"] and line["n_gpus"] == 1
+        if name in ("haplotype", "two_stage", "deep60"):
+            assert 0 < sm["dominant_kernel_frac"] <= 1 and _fractions_are_physical(line) >= 2, name
+    ar = w["haplotype"]["roofline_arrange"]
+    assert ar["bound"] == "hbm" and 0 < ar["frac"] <= 1 and ar["parity"]["ok"] and ar["sites_per_launch"] == 2048
+    he = w["hap_e2e"]
+    assert he["parity_sample"]["timed_run_equals_the_one_pass_run"] and he["parity_sample"]["two_stage_fixture"]["ok"] and 0 < he["fraction_of_hbm_resident_rate"] <= 1.2
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -152,7 +171,8 @@ def test_two_ranks_through_the_launcher_on_one_gpu(workload):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "65536",
-                          "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--hap-batch", "2048", "--workload", workload],
+                          "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--hap-batch", "2048", "--workload", workload,
+                          "--workloads", "none"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -172,7 +192,26 @@ def test_two_ranks_through_the_launcher_on_one_gpu(workload):
 def test_bench_with_the_library_gather_entry():
     """--gather rccl-abi: the final merge through nsnp_comm_init + nsnp_gather_results (one rank here)"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "65536", "--gather", "rccl-abi",
-                          "--no-cpu-baseline", "--no-second-precision"], capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--no-second-precision", "--workloads", "none"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["gather"] == "rccl-abi" and d["value"] > 1e6
+
+
+def test_two_ranks_with_the_other_configurations_in_the_same_line():
+    """the default line's "workloads" under two ranks (sharing GPU 0, collectives over gloo): the sub-runs reuse the process group of the
+    headline, every rank takes part in their gathers, rank 0 reports them; hap_e2e shards the sites of the FILE over the ranks"""
+    env = dict(os.environ, **SMALL_POOLS)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "65536",
+                          "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--hap-batch", "2048",
+                          "--workloads", "two_stage,hap_e2e,haplotype"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and set(d["workloads"]) == {"two_stage", "hap_e2e", "haplotype"}
+    for name, line in d["workloads"].items():
+        assert "error" not in line and line["n_gpus"] == 2 and line["config"]["world_size_observed"] == 2 and line["summary"]["parity_ok"] is True, name
+    assert d["workloads"]["hap_e2e"]["parity_sample"]["rows"] == 6000

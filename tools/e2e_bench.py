@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 N_COLS = 6_000_000
 
 
-def run(args, rank, world, local_rank):
+def run(args, rank, world, local_rank, emit=None):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -43,7 +43,7 @@ def run(args, rank, world, local_rank):
     from nanosnp_amd.pileup_model import LSTMNetwork
     from nanosnp_amd.pipeline import call_contig
     from tools import bench_common as bc
-    if world > 1:
+    if world > 1 and emit is None:                      # (embedded in the default bench line: the process group exists already)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -52,7 +52,7 @@ def run(args, rank, world, local_rank):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    n_cols = int(os.environ.get("NSNP_E2E_COLS", N_COLS))
+    n_cols = int(os.environ.get("NSNP_E2E_COLS", getattr(args, "e2e_cols", 0) or N_COLS))
     chunk = int(os.environ.get("NSNP_E2E_CHUNK_MB", 64)) << 20
     weights = load_pileup_weights()
     model = LSTMNetwork(device=local_rank).load_weight_list(weights)
@@ -145,14 +145,18 @@ def run(args, rank, world, local_rank):
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cols, weights, args.cpu_seconds)
-        print(json.dumps(out))
+        if emit is not None:
+            emit(out)
+        else:
+            print(json.dumps(out))
         if parity is not None and not parity["ok"]:
             print("bench.py: parity_sample FAILED: " + json.dumps(parity), file=sys.stderr)
             exit_code = 1
     text.close(); f.close()
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if emit is None:
+            dist.destroy_process_group()
     if rank == 0:
         for pth in (path, out_path):
             try:

@@ -154,6 +154,68 @@ class HapStage:
                 "what": "probabilities and calls the timed region's own run left behind for `sites` sites (read planes -> haplotype features -> "
                         "HaplotypeModel forward) against oracle/liboracle.so on the same read planes"}
 
+    def arrange_alone(self, b0, b1, R=64, warm=8, timed=16):
+        """k_hap_arrange (H1 + H2: centre filter, stable sort by centre HP, pad with -2, depth cut) alone on the chip, on read matrices
+        made from the sites [b0, b1) of the pool: the site's reads in a random order in the first rows of an [R, 33] matrix, n_reads of
+        them valid (the rest zeros), the way the stage-4 builder hands them over.  -> roofline dict with its own parity: the arranged
+        planes give the features of the pool's planes bit for bit (the reduction is invariant under the order of equal-HP reads)."""
+        import numpy as np
+        t, dev, D, L = self.torch, self.dev, self.D, 33
+        n = b1 - b0
+        g = t.Generator(device=dev); g.manual_seed(7)
+        seq, bq, mq, hap, ref = [p[b0:b1] for p in self.planes[0]]
+        valid = seq[:, :, L // 2] > -2                                         # padding rows of the pool's planes
+        depth = valid.sum(1).to(t.int32)
+        R = int(max(R, int(depth.max().item())))
+        key = t.rand((n, D), generator=g, device=dev) + (~valid).float() * 2    # a random order of the real reads, padding behind them
+        perm = key.argsort(1)
+        def mat(p):
+            q = p.gather(1, perm[:, :, None].expand(-1, -1, L))
+            q = t.where((q == -2), t.zeros_like(q), q)                          # (rows behind n_reads; never looked at)
+            out = t.zeros((n, R, L), dtype=t.int32, device=dev)
+            out[:, :min(R, D)] = q[:, :R]
+            return out
+        ms_, mb, mm, mh = mat(seq), mat(bq), mat(mq), mat(hap)
+        outs = [t.empty((n, D, L), dtype=t.int32, device=dev) for _ in range(4)]
+        dout = t.empty(n, dtype=t.int32, device=dev)
+        P = C.c_void_p
+        def launch():
+            rc = self.lib.nsnp_hap_arrange_reads(self.ctx.handle, P(ms_.data_ptr()), P(mb.data_ptr()), P(mm.data_ptr()), P(mh.data_ptr()), P(depth.data_ptr()),
+                                                 n, R, L, D, *[P(o.data_ptr()) for o in outs], P(dout.data_ptr()), P(self.stream.cuda_stream))
+            if rc:
+                self._lib.check(rc, self.ctx.handle, "nsnp_hap_arrange_reads")
+        t.cuda.synchronize(dev)
+        for _ in range(warm):
+            launch()
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        e0.record(self.stream)
+        for _ in range(timed):
+            launch()
+        e1.record(self.stream)
+        self.sync()
+        avg_ms = e0.elapsed_time(e1) / timed
+        # parity: depth, and the features of the arranged planes against the features of the pool's own planes
+        with t.cuda.stream(self.stream):
+            fa = self.ctx.hap_features(outs[0], outs[1], outs[2], outs[3], ref.contiguous(), stream=self.stream)
+            fb = self.ctx.hap_features(seq.contiguous(), bq.contiguous(), mq.contiguous(), hap.contiguous(), ref.contiguous(), stream=self.stream)
+        self.sync()
+        # centre-HP order of the arranged rows: non-decreasing over the kept rows, padding behind
+        hp_c = outs[3][:, :, L // 2]
+        kept = t.arange(D, device=dev)[None, :] < dout[:, None]
+        sorted_ok = bool((((hp_c[:, 1:] >= hp_c[:, :-1]) | ~kept[:, 1:]).all()).item()) and bool(((hp_c == -2) == ~kept).all().item())
+        ok = bool(t.equal(fa, fb)) and bool(t.equal(dout, t.minimum(depth, t.full_like(depth, D)))) and sorted_ok
+        nbytes = int(depth.sum().item()) * 4 * L * 4 + n * (4 * D * L * 4 + 8)
+        from tools import bench_common as bc
+        r = bc.roofline_hbm("k_hap_arrange (L = 33: centre filter + stable HP sort + pad / cut to D)", nbytes, avg_ms, timed,
+                            how="one HIP event pair around %d back-to-back launches on one stream, nothing else running, behind %d untimed ones" % (timed, warm),
+                            sites_per_launch=n, D_out=D, rows_of_the_read_matrices=R, mean_reads_per_site=float(depth.float().mean().item()))
+        r["algorithmic_bytes"] = "the valid rows of the four int32 read matrices in (n_reads x 33 x 4 B x 4) + the four padded [D, 33] int32 planes out + n_reads and depth"
+        r["parity"] = {"ok": ok, "what": "depth = min(n_reads, D); kept rows in non-decreasing centre-HP order with the -2 padding behind them; haplotype features of the "
+                                         "arranged planes bit-identical to the features of the pool's own planes (against the reference's "
+                                         "single_group_pileup_haplotype_feature: tests/test_gpu_hap.py, tests/golden/hap_arrange.npz)"}
+        r["sites_per_s"] = n / (avg_ms * 1e-3)
+        return r
+
     def feature_bytes(self, n, L, int8=False):
         """algorithmic bytes of one feature launch: four read planes + the reference row in, [105, L] fp32 out"""
         return n * (4 * (1 if int8 else 4) * self.D * L + 4 * L + 105 * L * 4)
@@ -282,7 +344,7 @@ def cpu_baseline_hap(hs, target_s, deep=None):
     return out
 
 
-def run(args, rank, world, local_rank, deep60=False):
+def run(args, rank, world, local_rank, deep60=False, emit=None):
     import torch
     import torch.distributed as dist
     from tools import bench_common as bc
@@ -295,7 +357,7 @@ def run(args, rank, world, local_rank, deep60=False):
         print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible", file=sys.stderr)
         return 3
     from nanosnp_amd.dist import gather_results
-    if world > 1:
+    if world > 1 and emit is None:                      # (embedded in the default bench line: the process group exists already)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -307,14 +369,15 @@ def run(args, rank, world, local_rank, deep60=False):
 
     cov, D = (60.0, 180) if deep60 else (30.0, 90)
     n_hap = int(os.environ.get("NSNP_HAP_N", args.hap_sites or (N_HAP_DEEP if deep60 else N_HAP)))
+    reduced = n_hap < (N_HAP_DEEP if deep60 else N_HAP)
     hb = min(args.hap_batch, n_hap)
     hs = HapStage(local_rank, n_hap, hb, cov, D, 20260400 + 1000 * rank, int8_copy=not deep60)
-    n_cat = int(os.environ.get("NSNP_CAT_N", min(n_hap, 65_536)))
+    n_cat = int(os.environ.get("NSNP_CAT_N", getattr(args, "cat_sites", 0) or min(n_hap, 65_536)))
     cs = CatStage(local_rank, n_cat, min(hb, n_cat), 1 if deep60 else 0)
     ps = None
     if deep60:
         from tools.pileup_stage import PileupStage
-        n_win = int(os.environ.get("NSNP_DEEP_WINDOWS", N_WIN_DEEP))
+        n_win = int(os.environ.get("NSNP_DEEP_WINDOWS", getattr(args, "deep_windows", 0) or N_WIN_DEEP))
         ps = PileupStage(local_rank, n_win, batch=args.batch, streams=args.streams, coverage=cov, seed=20260700 + rank,
                          enc_group=args.encode_group)
     wb = min(WIN_BATCHES_PER_STEP, ps.n_batches) if ps else 0
@@ -450,6 +513,8 @@ def run(args, rank, world, local_rank, deep60=False):
 
     if rank == 0:
         roofs = hap_rooflines(hs, chain_ms, chain_n, feat_ms, feat_n, nfe, "deep60" if deep60 else "haplotype")
+        if not deep60:
+            roofs["roofline_arrange"] = hs.arrange_alone(b0, b1)
         if deep60:
             from tools.pileup_stage import pileup_rooflines
             excl, excl_n = ps.exclusive_pass()
@@ -472,6 +537,7 @@ def run(args, rank, world, local_rank, deep60=False):
                                    ("BASELINE configs[2]: HaplotypeModel fwd on paired-haplotype windows - %d G3 sites (int32 read planes [N,90,33] + [N,90,11]) "
                                     "resident in HBM, haplotype features + model_dev.LSTMNetwork.predict (fp32), %d sites per step; legacy crnn.py CatModel "
                                     "forward reported beside it" % (n_hap, hb)),
+                       **({"REDUCED_POOL": "a short run inside the default bench line: the configuration's pool is %d sites" % (N_HAP_DEEP if deep60 else N_HAP)} if reduced else {}),
                        "hap_sites_resident_per_gpu": n_hap, "hap_sites_per_step": hb, "D": D, "coverage": cov,
                        "weights": "seeded (trained HaplotypeModel / CatModel checkpoints are absent upstream)",
                        "parallelism": f"site-sharded x{world} (every rank its own pool), rooted gather of calls",
@@ -502,13 +568,17 @@ def run(args, rank, world, local_rank, deep60=False):
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_deep(ps, hs, cs, args.cpu_seconds) if deep60 else cpu_baseline_hap(hs, args.cpu_seconds)
         assert merged[0].shape[0] == n_hap * world
-        print(json.dumps(out))
+        if emit is not None:
+            emit(out)
+        else:
+            print(json.dumps(out))
         if out["parity_sample"] is not None and not out["parity_sample"]["ok"]:
             print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
             exit_code = 1
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if emit is None:
+            dist.destroy_process_group()
     return exit_code
 
 

