@@ -124,7 +124,9 @@ def test_haplotype_workload_line():
     assert d["config"]["hap_sites_resident_per_gpu"] == 6000 and d["config"]["D"] == 90 and "workload" in d["config"]
     assert d["sites_timed"]["haplotype_sites"] == 2048 + 1904 + 2048          # batches 1, 2 (the ragged last one), 0 of the pool
     assert abs(d["value"] - d["sites_timed"]["haplotype_sites"] / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
-    assert _fractions_are_physical(d) == 2
+    assert _fractions_are_physical(d) == 3                      # fused LSTM step (MFMA), feature reduction (HBM), read arrangement (HBM)
+    ar = d["roofline_arrange"]
+    assert ar["bound"] == "hbm" and ar["parity"]["ok"] and ar["sites_per_launch"] == 2048 and ar["kernel"].startswith("k_hap_arrange")
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches_per_pass"] == 83
     assert d["roofline_features"]["bound"] == "hbm"
     s = d["second_values"]

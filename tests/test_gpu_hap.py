@@ -48,6 +48,37 @@ def test_int8_planes_give_the_same_features(gpu_ctx):
         gpu_ctx.hap_features(narrow[0], narrow[1].to(torch.int32), narrow[2], narrow[3], narrow[4])
 
 
+@pytest.mark.parametrize("D", [1, 2, 7, 90, 91, 300, 1000])
+@pytest.mark.parametrize("narrow", [False, True])
+def test_adversarial_planes_at_the_pileup_window(gpu_ctx, D, narrow):
+    """L = 33 on planes that are NOT sorted by haplotype tag, on rows that belong to several read sets or to none, with the tag only in
+    column 32, with odd and tiny depths, with depths beyond the flush period of the packed sums, and (int32) with qualities the packed
+    fields cannot hold: bit-identical to the oracle.  (Written for the round-5 kernel experiments - two rows per wave step, LDS-staged
+    persistent workgroups: docs/rounds/r05.md - which it caught nothing wrong with and which were dropped for being slower.)"""
+    import torch
+    from oracle import oracle
+    rng = np.random.default_rng(100 + D)
+    N, L = 24, 33
+    seq = rng.integers(-2, 5, (N, D, L)).astype(np.int32)
+    hap = rng.integers(0, 4, (N, D, 1)).astype(np.int32) * (rng.random((N, D, L)) < 0.9)      # one tag per row, zeros sprinkled in
+    hap[0] = rng.integers(-2, 4, (D, L))                                                     # site 0: every row a mix of tags
+    hap[1] = 0; hap[1, :, 32] = rng.integers(0, 4, D)                                        # site 1: the tag only in column 32
+    hap[2] = np.sort(rng.integers(1, 4, D))[:, None]                                         # site 2: sorted, as the reference's bins are
+    hap[3] = 0                                                                               # site 3: no row in any set
+    bq = rng.integers(0, 94, (N, D, L)).astype(np.int32); mq = rng.integers(0, 61, (N, D, L)).astype(np.int32)
+    seq[4, D // 2:] = -2; hap[4, D // 2:] = -2; bq[4, D // 2:] = -2; mq[4, D // 2:] = -2     # site 4: padding rows behind the reads
+    if not narrow:
+        bq[5] = rng.integers(0, 2**30, (D, L)); mq[5, ::3] = rng.integers(2040, 2056, mq[5, ::3].shape)   # beyond the 16-bit fields
+        bq[6, :, 32] = 2**31 - 1
+    ref = rng.integers(0, 5, (N, L)).astype(np.int32)
+    dt = np.int8 if narrow else np.int32
+    dev = [torch.from_numpy(a.astype(dt)).cuda() for a in (seq, bq, mq, hap)] + [torch.from_numpy(ref).cuda()]
+    got = gpu_ctx.hap_features(*dev)
+    torch.cuda.synchronize()
+    want = oracle.hap_features_batch(seq, bq, mq, hap, ref, nthreads=4)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 def test_mixed_hp_rows_and_large_values(gpu_ctx):
     """a row with several HP values belongs to several read sets (np.any semantics); int32-range
     qualities need 64-bit sums"""
