@@ -146,6 +146,12 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
         return torch.zeros((0, 13), dtype=torch.float64, device=dev)
     n_chunks = max(1, -(-(hi - lo) // int(chunk_bytes)))
     cuts = line_cuts(finder, n_chunks, lo, hi)
+    if n_chunks >= 3:
+        # the pipeline's fill: nothing computes while the first chunk is parsed and copied - it is half a chunk (the other half goes
+        # to a chunk of its own behind it)
+        half = finder.find(b"\n", lo + (cuts[1] - lo) // 2, cuts[1])
+        if half >= 0 and lo < half + 1 < cuts[1]:
+            cuts = [lo, half + 1] + cuts[1:]
     ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(n_chunks) if cuts[k + 1] > cuts[k]]
     cap = max(b - a for a, b, _, _ in ranges) + 64
     # pinned buffers are expensive to create (page-locking): kept on the model between calls, with their device twins
