@@ -102,6 +102,12 @@ def run(args, rank, world, local_rank, emit=None):
         tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
+    per_rank = None
+    if world > 1:
+        mine = {k: round(stats.get(k, 0.0) / K, 4) for k in ("parse_s", "wait_parse_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "vcf_s")}
+        mine["rank"] = rank
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     # ---- labelled second value: the same text with the PileupModel forward in the bf16x3 arithmetic ----
     second = None
     if not args.no_second_precision:
@@ -189,6 +195,7 @@ def run(args, rank, world, local_rank, emit=None):
                                 "(issue_s includes wait_counts_s)"},
             "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "vcf_s", "write_s")},
             **({"bf16x3": second} if second else {}),
+            **({"per_rank_s_per_step": per_rank} if per_rank else {}),
             "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,
             "cpu_baseline": None,
         }

@@ -233,6 +233,12 @@ def _run(args, rank, world, local_rank, emit, created):
                 "passes_per_step": st.get("passes", 0) / steps, "int8_passes_per_step": st.get("passes_int8", 0) / steps}
 
     dt, st = timed(p8, K)
+    per_rank = None
+    if world > 1:
+        mine = {k: round(st.get(k, 0.0) / K, 4) for k in ("stage_s", "wait_stage_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "csv_s")}
+        mine["rank"] = rank
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     csv_all = open(out_path, "rb").read() if rank == 0 else b""
     csv_timed = csv_all[:len(csv_all) // K]                     # the rows of the first of the K files (all K must be equal)
     files_equal = csv_all == csv_timed * K
@@ -317,6 +323,7 @@ def _run(args, rank, world, local_rank, emit, created):
                        **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: device time is serialised, not a scaling number"} if args.share_gpu else {})},
             **{k: head[k] for k in ("stage_busy_s_per_step", "bound_by", "h2d_GB_per_s", "staging_GB_per_s_of_bytes_written", "bytes_over_pcie_per_site",
                                     "pcie_bound_sites_per_s_at_the_measured_h2d_rate", "main_thread_s_per_step", "passes_per_step", "int8_passes_per_step")},
+            **({"per_rank_s_per_step": per_rank} if per_rank else {}),
             "hbm_resident_sites_per_s": resident,
             "fraction_of_hbm_resident_rate": head["value"] / world / resident,
             "second_values": seconds,

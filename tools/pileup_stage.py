@@ -294,5 +294,8 @@ def pileup_rooflines(stage, tot, excl, excl_n, sites_per_gpu, dt, precision, enc
                             traffic=bc.committed_traffic(workload, "encode_columns", batch=batch, columns=enc_group * stage.mcols),
                             how="HIP events around every launch, nothing else running; one launch encodes %d batches = %d columns"
                                 % (enc_group, enc_group * stage.mcols), batches_per_launch=enc_group, columns_per_launch=enc_group * stage.mcols)
+        vb = bc.valu_issue_bound("k_encode_columns", stage.coverage, enc_group * stage.mcols, excl["encode_columns"])
+        if vb:
+            e["second_bound"] = vb
         out["roofline_encode"] = e
     return out
