@@ -152,7 +152,7 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
         half = finder.find(b"\n", lo + (cuts[1] - lo) // 2, cuts[1])
         if half >= 0 and lo < half + 1 < cuts[1]:
             cuts = [lo, half + 1] + cuts[1:]
-    ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(n_chunks) if cuts[k + 1] > cuts[k]]
+    ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k + 1] > cuts[k]]
     cap = max(b - a for a, b, _, _ in ranges) + 64
     # pinned buffers are expensive to create (page-locking): kept on the model between calls, with their device twins
     sets = getattr(model, "_host_sets", None)
