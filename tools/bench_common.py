@@ -157,9 +157,10 @@ def roofline_hbm(kernel, bytes_per_launch, avg_launch_ms, launches, *, traffic=N
 
 def valu_issue_bound(kernel, coverage, columns_per_launch, avg_launch_ms, clock_mhz=2400.0):
     """Second, truthful bound of a kernel that is limited by vector-instruction issue rather than by HBM: the time the
-    kernel's VALU wave-instructions need on the chip's 1,024 SIMDs at one wave64 instruction per 2 cycles per SIMD (the rate at which a
-    SIMD-32 issues them with two or more waves resident: MI355X_MICROARCH.md, wave scheduling / cycle-constants table) over the measured
-    launch time.  The instruction count is a property of kernel + data: SQ_INSTS_VALU / SQ_WAVES of the newest committed counter pass of
+    kernel's VALU wave-instructions need on the chip's 1,024 SIMDs at one wave64 instruction per 4 cycles per SIMD over the measured
+    launch time.  (4 cycles: the same counter pass reads SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycle per instruction - the
+    kernel's vector work is 32-bit integer / logic / address arithmetic, none of it the packed-fp32 forms that reach the 157 TFLOP/s
+    vector peak at twice that rate.)  The instruction count is a property of kernel + data: SQ_INSTS_VALU / SQ_WAVES of the newest committed counter pass of
     this kernel at this coverage (profiles/r*_encode_*_<cov>x_sq_counters.json: counters are NOT from this run, the duration is)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_encode_*_%dx_sq_counters.json" % int(coverage))))
@@ -168,17 +169,18 @@ def valu_issue_bound(kernel, coverage, columns_per_launch, avg_launch_ms, clock_
             k = json.load(open(f))["kernels"][kernel]
             c = k["counters_per_launch"]
             per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+            cyc = 4.0 * c.get("SQ_ACTIVE_INST_VALU", c["SQ_INSTS_VALU"]) / c["SQ_INSTS_VALU"]      # cycles a wave's vector instruction holds the port
             salu_per_wave = c.get("SQ_INSTS_SALU", 0.0) / c["SQ_WAVES"]
         except Exception:
             continue
         waves = columns_per_launch / 64.0
-        cycles = per_wave * waves * 2.0 / 1024.0
+        cycles = per_wave * waves * cyc / 1024.0
         t_min_ms = cycles / (clock_mhz * 1e3)
         return {"bound": "valu-issue", "frac": t_min_ms / avg_launch_ms, "valu_wave_instructions_per_64_columns": round(per_wave, 1),
-                "salu_instructions_per_64_columns": round(salu_per_wave, 1), "cycles_per_wave_instruction": 2, "simds": 1024, "clock_mhz": clock_mhz,
+                "salu_instructions_per_64_columns": round(salu_per_wave, 1), "cycles_per_wave_instruction": round(cyc, 2), "simds": 1024, "clock_mhz": clock_mhz,
                 "min_launch_ms_at_full_issue": t_min_ms, "avg_launch_ms": avg_launch_ms,
                 "counters_from": os.path.basename(f) + " (a committed rocprofv3 --pmc pass, not this run; the launch time is this run's)",
-                "what": "time the kernel's vector instructions need if every SIMD issued one per 2 cycles without a stall, over the measured time: how "
+                "what": "time the kernel's vector instructions need if every SIMD's vector port were busy every cycle, over the measured time: how "
                         "close the kernel is to the bound it actually runs into (it moves 0.6 vector instructions per input byte; its HBM fraction "
                         "beside this one says how far that bound is from the memory system's)"}
     return None
