@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
         f32x4 af[2][NPL], bf[2][NPL];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
+            if (ct >= nct) continue;                                    // (row tiles of <= 64 rows: the second column tile does not exist - no read of it)
             const int row = ((vmask[ct] >> t_eff) & 1u) ? srow[ct] + off : CONV_ROWS - 1;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)

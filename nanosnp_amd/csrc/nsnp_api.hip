@@ -125,6 +125,8 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "pileup_precision") == 0) {
         if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->precision = (int)value;
+        // the bf16x3 layout of H0 is 1.5 x the fp32 one: a workspace that is already reserved grows now (synchronous), not inside a forward
+        if (value == 2 && ctx->ws_h0 && ctx->ws_h0_floats < 192) return nsnp_ctx_reserve(ctx, ctx->chunk_sites);
         return NSNP_OK;
     }
     if (strcmp(name, "fused_l1") == 0) {
@@ -225,6 +227,7 @@ static void free_ws(nsnp_ctx* ctx)
     if (ctx->ws_xp1) (void)hipFree(ctx->ws_xp1);
     if (ctx->ws_h1c) (void)hipFree(ctx->ws_h1c);
     ctx->ws_h0 = ctx->ws_xp1 = ctx->ws_h1c = nullptr;
+    ctx->ws_h0_floats = 0;
 }
 
 extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
@@ -255,14 +258,17 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
 extern "C" int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites)
 {
     if (!ctx || max_sites <= 0) return NSNP_EINVAL;
-    if (ctx->ws_h0 && ctx->chunk_sites == max_sites) return NSNP_OK;
+    // H0: 512 B per site and step on the fp32 / f16x3 paths, 768 B (three bf16 planes) on the bf16x3 path: the larger layout is
+    // allocated only for a context that has selected pileup_precision 2 (the option re-reserves when it is set: below)
+    const int h0_floats = ctx->precision == 2 ? 192 : 128;
+    if (ctx->ws_h0 && ctx->chunk_sites == max_sites && ctx->ws_h0_floats >= h0_floats) return NSNP_OK;
     NSNP_HIP(ctx, hipSetDevice(ctx->device));
     NSNP_HIP(ctx, hipDeviceSynchronize());
     free_ws(ctx);
     ctx->chunk_sites = max_sites;
     const size_t n = (size_t)max_sites;
-    // H0: 512 B per site and step on the fp32 / f16x3 paths, 768 B (three bf16 planes) on the bf16x3 path: sized for the larger
-    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, (n + 64) * PW * 192 * sizeof(float)));
+    NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h0, (n + 64) * PW * h0_floats * sizeof(float)));
+    ctx->ws_h0_floats = h0_floats;
     // ws_xp1 (34.8 KB per site) only exists for the legacy unfused layer-1 path: nsnp_ctx_need_xp1 allocates it on first use
     NSNP_HIP(ctx, hipMalloc((void**)&ctx->ws_h1c, (n + 64) * 128 * sizeof(float)));
     return NSNP_OK;

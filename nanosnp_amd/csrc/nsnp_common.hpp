@@ -111,7 +111,8 @@ struct nsnp_ctx {
     int l1_stagger;     // fp32 register-stationary layer 1: waves 4-7 run a group's next-step input part ahead of its cell (default 0)
     // workspace (sized by nsnp_ctx_reserve)
     int64_t chunk_sites;
-    float*  ws_h0;      // [chunk][33][128]
+    float*  ws_h0;      // [chunk][33][128] (fp32 / f16x3) or [chunk][33][192] (bf16x3: three bf16 planes)
+    int     ws_h0_floats;   // floats per site and step ws_h0 is allocated for (128 or 192)
     float*  ws_xp1;     // [2][chunk*17][256]
     float*  ws_h1c;     // [chunk][128]
     PileupWeightsDev pw;

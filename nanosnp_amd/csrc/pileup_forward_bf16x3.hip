@@ -917,7 +917,7 @@ int nsnp_pileup_forward_bf16x3(nsnp_ctx* ctx, const int32_t* x, const int64_t* c
     if (N == 0) return NSNP_OK;
     int rc = set_lds_attr_b3(ctx);
     if (rc) return rc;
-    if (!ctx->ws_h0) { rc = nsnp_ctx_reserve(ctx, ctx->chunk_sites); if (rc) return rc; }
+    if (!ctx->ws_h0 || ctx->ws_h0_floats < 192) { rc = nsnp_ctx_reserve(ctx, ctx->chunk_sites); if (rc) return rc; }
     const PileupWeightsB3& pw = ctx->pwb3;
     const PileupWeightsDev& p32 = ctx->pw;            // the fp32 path's layer-1 bias image (accumulator layout, gate rows scaled alike)
     __bf16* H0 = reinterpret_cast<__bf16*>(ctx->ws_h0);            // 768 B per site and step (nsnp_ctx_reserve sizes for it)
