@@ -11,7 +11,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-COMMON="--workload $WL --no-cpu-baseline --no-second-precision --no-parity-sample --repeat 1"
+COMMON="--workload $WL --no-cpu-baseline --no-second-precision --no-parity-sample --repeat 1 --workloads none"
 run() { # name, rocprof args..., -- bench args
   local name=$1; shift
   rocprofv3 "$@" --output-format csv -d $OUT/prof_${TAG}_$name -o run -- python3 bench.py $COMMON $BENCH_ARGS > $OUT/prof_${TAG}_$name.json 2> $OUT/prof_${TAG}_$name.err
