@@ -9,7 +9,7 @@ import pytest
 
 from tests.helpers import ROOT
 
-ROUND = "r04"
+ROUND = "r05"
 LINES = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*_line.json")) if "e2e" not in p)
 
 
@@ -28,6 +28,9 @@ def test_committed_line(path):
     for k, r in d.items():
         if k.startswith("roofline") and r:
             assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1, k
+            if "second_bound" in r:                              # the encode's truthful bound beside its HBM fraction
+                sb = r["second_bound"]
+                assert sb["bound"] == "valu-issue" and r["frac"] < sb["frac"] <= 1 and "not this run" in sb["counters_from"]
             if "chip" in r:
                 assert 0 < r["chip"]["frac"] <= 1
             # traffic is labelled as coming from the committed PMC passes, and an HBM-bound kernel cannot have moved fewer bytes than
@@ -52,7 +55,15 @@ def test_committed_line(path):
 
 
 def test_pileup_line_is_the_headline_configuration():
-    d = _load(os.path.join(ROOT, "profiles", f"{ROUND}_pileup_line.json"))
+    d = _load(os.path.join(ROOT, "profiles", f"{ROUND}_default_line.json"))
+    # the default command carries every other configuration as a sub-line (tools/workloads.py)
+    w = d["workloads"]
+    assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e"}
+    for name, line in w.items():
+        sm = line["summary"]
+        assert "error" not in line and sm["value"] > 0 and sm["parity_ok"] is True and sm["cpu_baseline_value"] > 0, name
+    assert 0 < w["haplotype"]["roofline_arrange"]["frac"] <= 1 and w["haplotype"]["roofline_arrange"]["parity"]["ok"]
+    assert "second_bound" in d["roofline_encode"]
     assert "configs[1]" in d["config"]["workload"] and d["config"]["windows_resident_per_gpu"] == 1 << 20 and d["config"]["batch"] == 4096
     assert d["config"]["batches_per_step"] == 256 and d["timed_region_s"] >= 1.0              # one step = one sweep of the pool, >= 1 s timed
     assert len(d["repeats"]["values"]) == 3 and sorted(d["repeats"]["values"])[1] == round(d["value"])
@@ -65,12 +76,26 @@ def test_pileup_line_is_the_headline_configuration():
 
 def test_all_workloads_have_a_line():
     names = {os.path.basename(p) for p in LINES}
-    assert {f"{ROUND}_pileup_line.json", f"{ROUND}_haplotype_line.json", f"{ROUND}_two_stage_line.json", f"{ROUND}_deep60_line.json"} <= names
+    assert {f"{ROUND}_default_line.json", f"{ROUND}_haplotype_line.json", f"{ROUND}_two_stage_line.json", f"{ROUND}_deep60_line.json"} <= names
     e2e = _load(os.path.join(ROOT, "profiles", f"{ROUND}_e2e_line.json"))
     assert e2e["parity_sample"]["ok"] and "NOT the headline" in e2e["config"]["workload"] and e2e["bound_by"] in e2e["stage_busy_s_per_step"]
+    assert e2e["bf16x3"]["parity_sample"]["ok"]
+    # stage 5 from host memory: >= 0.8 x the HBM-resident rate, csv identical across pass sizes, dtypes and to the reference's rows
+    h = _load(os.path.join(ROOT, "profiles", f"{ROUND}_hap_e2e_line.json"))
+    assert h["parity_sample"]["ok"] and h["parity_sample"]["timed_run_equals_the_one_pass_run"] and h["parity_sample"]["two_stage_fixture"]["ok"]
+    assert h["fraction_of_hbm_resident_rate"] >= 0.8 and h["bound_by"].startswith("device")
+    for k in ("int32_file_narrowed_while_staged", "int32_file_sent_as_int32"):
+        assert h["second_values"][k]["fraction_of_hbm_resident_rate"] >= 0.8, k
+    assert h["second_values"]["int32_file_sent_as_int32"]["bytes_over_pcie_per_site"] > 63360
+
+
+def test_host_scaling_table_is_committed():
+    t = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_host_scaling.json")))
+    rows = {(r["workload"], r["ranks"]) for r in t["rows"]}
+    assert rows == {(w, n) for w in ("e2e", "hap-e2e") for n in (1, 2, 4, 8)} and "not a scaling number" in t["what"]
 
 
 def test_fetch_calibration_is_committed():
-    c = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_fetch_calibration.json")))["shapes"]
+    c = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_calibration.json")))["shapes"]
     assert abs(c["k_calib_b128"]["factor_bytes_per_counted_byte"] - 2.0) < 0.02                # the documented wide-read case reproduces
     assert 1.3 < c["k_calib_rows33<unsigned int>"]["factor_bytes_per_counted_byte"] < 2.0      # k_hap_features' shape does not follow it
