@@ -36,24 +36,58 @@ __global__ __launch_bounds__(ARR_BLOCK) void k_hap_arrange(
     }
     for (int d = tid; d < D_out; d += ARR_BLOCK) src[d] = -1;
     __syncthreads();
-    int kept = 0;
-    for (int r = tid; r < R; r += ARR_BLOCK) {
+    // stable rank of every kept row among the kept rows; with R <= 64 the four waves split the comparisons of a row (row r = lane,
+    // wave w compares with rows q = w mod 4) and add their partial ranks in LDS
+    int32_t* rank_acc = src + D_out;                      // [R]
+    for (int r = tid; r < R; r += ARR_BLOCK) rank_acc[r] = 0;
+    __syncthreads();
+    const int nsplit = R <= 64 ? ARR_BLOCK / 64 : 1;
+    for (int r = nsplit > 1 ? (tid & 63) : tid; r < R; r += nsplit > 1 ? R : ARR_BLOCK) {
         const int32_t k = key[r];
         if (k == 0x7fffffff) continue;
-        int rank = 0;                   // stable rank among the kept rows
-        for (int q = 0; q < R; ++q) {
+        int rank = 0;
+        for (int q = nsplit > 1 ? (tid >> 6) : 0; q < R; q += nsplit) {
             const int32_t kq = key[q];
             rank += (kq < k) || (kq == k && q < r);
         }
-        if (rank < D_out) src[rank] = r;
+        if (nsplit > 1) atomicAdd(&rank_acc[r], rank); else rank_acc[r] = rank;
     }
     __syncthreads();
-    if (depth_out && tid == 0) {
-        for (int r = 0; r < R; ++r) kept += key[r] != 0x7fffffff;
-        depth_out[n] = kept < D_out ? kept : D_out;
+    for (int r = tid; r < R; r += ARR_BLOCK)
+        if (key[r] != 0x7fffffff && rank_acc[r] < D_out) src[rank_acc[r]] = r;
+    if (depth_out && tid < 64) {
+        int kept = 0;
+        for (int r = tid; r < R; r += 64) kept += key[r] != 0x7fffffff;
+        for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+        if (tid == 0) depth_out[n] = kept < D_out ? kept : D_out;
     }
+    __syncthreads();
     const size_t obase = (size_t)n * D_out * L;
-    for (int e = tid; e < D_out * L; e += ARR_BLOCK) {
+    const int total = D_out * L;
+    const float inv_l = 1.0f / (float)L;                  // e / L for e < 2^22: (e + 0.5) / L is at least 0.5 / L away from an integer
+    // two output elements per thread and trip where the plane's base allows 8-byte stores (D_out x L even, or an even site): the
+    // output - mostly -2 padding at 30x (30 reads in 90 rows) - is 3/4 of the kernel's bytes
+    if (((obase & 1) == 0) && ((total & 1) == 0)) {
+        for (int e = 2 * tid; e < total; e += 2 * ARR_BLOCK) {
+            int32_t va[2], vb[2], vc[2], vh[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = (int)(((float)(e + k) + 0.5f) * inv_l), l = (e + k) - d * L;
+                const int r = src[d];
+                va[k] = vb[k] = vc[k] = vh[k] = -2;             // write_to_bins.py:15-30: constant_values=-2
+                if (r >= 0) {
+                    const size_t i = ibase + (size_t)r * L + l;
+                    va[k] = seq[i]; vb[k] = bq[i]; vc[k] = mq[i]; vh[k] = hap[i];
+                }
+            }
+            *reinterpret_cast<int2*>(oseq + obase + e) = int2{va[0], va[1]};
+            *reinterpret_cast<int2*>(obq + obase + e) = int2{vb[0], vb[1]};
+            *reinterpret_cast<int2*>(omq + obase + e) = int2{vc[0], vc[1]};
+            *reinterpret_cast<int2*>(ohap + obase + e) = int2{vh[0], vh[1]};
+        }
+        return;
+    }
+    for (int e = tid; e < total; e += ARR_BLOCK) {
         const int d = e / L, l = e - d * L;
         const int r = src[d];
         int32_t a = -2, b = -2, c = -2, h = -2;         // write_to_bins.py:15-30: constant_values=-2
@@ -74,7 +108,7 @@ extern "C" int nsnp_hap_arrange_reads(nsnp_ctx* ctx, const int32_t* seq, const i
     if (!ctx || N < 0 || R <= 0 || L <= 0 || D_out <= 0) return NSNP_EINVAL;
     if (N > 0 && (!seq || !bq || !mq || !hap || !oseq || !obq || !omq || !ohap)) return NSNP_EINVAL;
     if (N == 0) return NSNP_OK;
-    const size_t lds = (size_t)(R + D_out) * sizeof(int32_t);
+    const size_t lds = (size_t)(2 * R + D_out) * sizeof(int32_t);
     if (lds > 64 * 1024) return NSNP_ESHAPE;
     hipLaunchKernelGGL(k_hap_arrange, dim3((unsigned)N), dim3(ARR_BLOCK), lds, (hipStream_t)stream,
                        seq, bq, mq, hap, n_reads, R, L, D_out, oseq, obq, omq, ohap, depth);
