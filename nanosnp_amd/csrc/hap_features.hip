@@ -21,13 +21,29 @@
 
 namespace {
 
+#ifndef NSNP_HF_U
+#define NSNP_HF_U 4
+#endif
 constexpr int HF_BLOCK = 256;
 constexpr int HF_MAX_L = 64;
 constexpr int NSTAT = 13;          // per read set: cnt A C G T D, baseq sum A C G T, mapq sum A C G T
 
 // PT: element type of the read planes, int32 (what the reference's bins hold) or int8 (every value of the four planes
-// fits: base codes -2..4, HP -2..3, base quality <= 93, mapping quality <= 60; a quarter of the PCIe and HBM bytes)
-template <typename PT>
+// fits: base codes -2..4, HP -2..3, base quality <= 93, mapping quality <= 60; a quarter of the PCIe and HBM bytes).
+// LT: the window length as a compile-time constant (33, 11) or 0 = the runtime L (any L <= 64): with LT the row stride is a
+// constant and the loads of a wave's four row groups share one address register with immediate offsets.
+//
+// Round 5: the kernel sits AT its vector-issue bound (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.176 per wave at six waves per SIMD =
+// 1.05 of the port: profiles/r05_haplotype_sq_counters.json; ~2,000 vector instructions per wave and site), so the body was
+// rewritten for instruction count, same sums bit for bit:
+//   * counts: ONE 64-bit register per read set with eight 8-bit fields indexed by min(s + 2, 7) - padding, deletion, not covering,
+//     A, C, G, T, junk - so that an element's count (deletions included) is one shift and one 64-bit add with no test of the code;
+//   * qualities: a non-base element contributes b = m = 0, so its shift amount needs no select;
+//   * the test for qualities the 16-bit fields cannot hold (never in a BAM) is one OR per element and one ballot per four rows
+//     instead of two compares, a ballot and a branch per element;
+//   * the row groups whose rows all exist run without per-load predicates (the last, ragged trip keeps them);
+//   * the flush adds every field unconditionally (an add of zero costs less than the test for it).
+template <typename PT, int LT>
 // six waves per SIMD (80 registers) with four row groups in flight measured best: 272 us per 16384 sites at L = 33 against 296 at
 // five waves, 321 with two groups in flight, 286-334 with six or eight groups (fewer waves)
 #ifndef NSNP_HF_MINW
@@ -35,18 +51,16 @@ template <typename PT>
 #endif
 __global__ __launch_bounds__(HF_BLOCK, NSNP_HF_MINW) void k_hap_features(
     const PT* __restrict__ seq, const PT* __restrict__ bq, const PT* __restrict__ mq,
-    const PT* __restrict__ hap, const int32_t* __restrict__ ref_row, int D, int L, float* __restrict__ out)
+    const PT* __restrict__ hap, const int32_t* __restrict__ ref_row, int D, int L_rt, float* __restrict__ out)
 {
     extern __shared__ unsigned long long hf_lds[];
     unsigned long long* sums = hf_lds;                                   // [4][NSTAT][L] int64
+    const int L = LT ? LT : L_rt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = blockIdx.x;
     const size_t plane = (size_t)n * D * L;
     const PT* __restrict__ seq_n = seq + plane; const PT* __restrict__ bq_n = bq + plane;
     const PT* __restrict__ mq_n = mq + plane; const PT* __restrict__ hap_n = hap + plane;
-#ifndef NSNP_HF_U
-#define NSNP_HF_U 4
-#endif
     constexpr int NW = HF_BLOCK / 64, U = NSNP_HF_U;      // waves per workgroup, row groups of a wave in flight together
     const int R = L > 32 ? 1 : 64 / L;            // rows per group
     const int r = lane / L, col = lane - r * L;   // this lane's row of the group and column
@@ -57,25 +71,22 @@ __global__ __launch_bounds__(HF_BLOCK, NSNP_HF_MINW) void k_hap_features(
     for (int i = tid; i < 4 * NSTAT * L; i += HF_BLOCK) sums[i] = 0ull;
     __syncthreads();
 
-    uint32_t cntp[4] = {0u, 0u, 0u, 0u};          // per read set: counts of A C G T, 8 bits each
-    uint32_t cntd = 0u;                           // deletions: 8 bits per read set
-    unsigned long long qb[4] = {0ull, 0ull, 0ull, 0ull}, qm[4] = {0ull, 0ull, 0ull, 0ull};   // base / mapping quality sums of A C G T, 16 bits each
+    // per read set: counts (eight 8-bit fields by min(s + 2, 7): -2 padding, -1 deletion, 0 not covering, A C G T, junk), base / mapping
+    // quality sums of A C G T (16 bits each)
+    unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull}, qb[4] = {0ull, 0ull, 0ull, 0ull}, qm[4] = {0ull, 0ull, 0ull, 0ull};
     auto flush = [&]() {
         if (active) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const unsigned long long c = (cntp[g] >> (8 * k)) & 0xffu, b = (qb[g] >> (16 * k)) & 0xffffu, m = (qm[g] >> (16 * k)) & 0xffffu;
-                    if (c) atomicAdd(&sums[(g * NSTAT + k) * L + col], c);
-                    if (b) atomicAdd(&sums[(g * NSTAT + 5 + k) * L + col], b);
-                    if (m) atomicAdd(&sums[(g * NSTAT + 9 + k) * L + col], m);
+                    atomicAdd(&sums[(g * NSTAT + k) * L + col], (cnt[g] >> (8 * (k + 3))) & 0xffull);
+                    atomicAdd(&sums[(g * NSTAT + 5 + k) * L + col], (qb[g] >> (16 * k)) & 0xffffull);
+                    atomicAdd(&sums[(g * NSTAT + 9 + k) * L + col], (qm[g] >> (16 * k)) & 0xffffull);
                 }
-                const unsigned long long dl = (cntd >> (8 * g)) & 0xffu;
-                if (dl) atomicAdd(&sums[(g * NSTAT + 4) * L + col], dl);
-                cntp[g] = 0u; qb[g] = 0ull; qm[g] = 0ull;
+                atomicAdd(&sums[(g * NSTAT + 4) * L + col], (cnt[g] >> 8) & 0xffull);
+                cnt[g] = 0ull; qb[g] = 0ull; qm[g] = 0ull;
             }
-            cntd = 0u;
         }
     };
 #ifdef NSNP_HF_NOLOAD
@@ -83,61 +94,87 @@ __global__ __launch_bounds__(HF_BLOCK, NSNP_HF_MINW) void k_hap_features(
 #else
     const int n_groups = (D + R - 1) / R;
 #endif
+    const int n_full = D / R;                     // groups whose R rows all exist
     int since_flush = 0;
     for (int g0 = wave; g0 < n_groups; g0 += NW * U) {
         int sv[U], bv[U], mv[U], hv[U];
+        if (g0 + NW * (U - 1) < n_full) {
+            // every row of the trip exists: ONE unsigned lane offset on the uniform plane base, constant strides (with LT: immediate
+            // offsets of the load instructions - no address arithmetic per load).  Idle lanes (lane >= R x L) read element 0 of the
+            // trip's rows - rows that exist - and their values are dropped below.
+            const uint32_t o0 = active ? (uint32_t)((g0 * R + r) * L + col) * (uint32_t)sizeof(PT) : 0u;
+            const uint32_t stride = (uint32_t)(NW * R * L) * (uint32_t)sizeof(PT);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t o = o0 + (uint32_t)u * stride;
+                sv[u] = (int)*reinterpret_cast<const PT*>(reinterpret_cast<const char*>(seq_n) + o);
+                hv[u] = (int)*reinterpret_cast<const PT*>(reinterpret_cast<const char*>(hap_n) + o);
+                bv[u] = (int)*reinterpret_cast<const PT*>(reinterpret_cast<const char*>(bq_n) + o);
+                mv[u] = (int)*reinterpret_cast<const PT*>(reinterpret_cast<const char*>(mq_n) + o);
+            }
+            if (!active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { sv[u] = 0; hv[u] = 0; }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int d = (g0 + NW * u) * R + r;
+                const bool on = active && d < D;
+                const int o = on ? d * L + col : 0;                   // (uniform plane base + 32-bit lane offset)
+                sv[u] = on ? (int)seq_n[o] : 0; hv[u] = on ? (int)hap_n[o] : 0;
+                bv[u] = on ? (int)bq_n[o] : 0; mv[u] = on ? (int)mq_n[o] : 0;
+            }
+        }
+        // qualities of the elements that are counted; one test per trip for values the 16-bit fields cannot hold (never in a BAM)
+        uint32_t orbm = 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int d = (g0 + NW * u) * R + r;
-            const bool on = active && d < D;
-            const int o = on ? d * L + col : 0;                   // (uniform plane base + 32-bit lane offset)
-            sv[u] = on ? (int)seq_n[o] : 0; hv[u] = on ? (int)hap_n[o] : 0;
-            bv[u] = on ? (int)bq_n[o] : 0; mv[u] = on ? (int)mq_n[o] : 0;
+            const bool base = (unsigned)(sv[u] - 1) < 4u;             // 0 (not covering), -1, -2 (padding) and foreign codes sum no quality
+            bv[u] = base ? bv[u] : 0; mv[u] = base ? mv[u] : 0;
+            orbm |= (uint32_t)bv[u] | (uint32_t)mv[u];
+        }
+        if (__ballot(orbm >= 2048u)) {
+            // (rare) such a quality goes straight into the LDS sums, for every set of its row - exact for any int32 input
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (g0 + NW * u >= n_groups) break;                   // (uniform)
+                const unsigned long long h1 = __ballot(hv[u] == 1), h2 = __ballot(hv[u] == 2), h3 = __ballot(hv[u] == 3);
+                const bool big = (unsigned)bv[u] >= 2048u || (unsigned)mv[u] >= 2048u;      // (then the element is a base: the others are 0)
+                if (big) {
+                    const bool in[4] = {true, R == 1 ? h1 != 0ull : ((uint32_t)(h1 >> rsh) & wm) != 0u,
+                                        R == 1 ? h2 != 0ull : ((uint32_t)(h2 >> rsh) & wm) != 0u,
+                                        R == 1 ? h3 != 0ull : ((uint32_t)(h3 >> rsh) & wm) != 0u};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) if (in[g]) {
+                        atomicAdd(&sums[(g * NSTAT + 5 + (sv[u] - 1)) * L + col], (unsigned long long)(long long)bv[u]);
+                        atomicAdd(&sums[(g * NSTAT + 9 + (sv[u] - 1)) * L + col], (unsigned long long)(long long)mv[u]);
+                    }
+                    bv[u] = 0; mv[u] = 0;
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (g0 + NW * u >= n_groups) break;                   // (uniform)
-            const int s = sv[u];                                  // 0 (not covering) and -2 (padding) match nothing
-            const bool base = (unsigned)(s - 1) < 4u;
-            int b = bv[u], m = mv[u];
-            // a quality that the 16-bit fields cannot take (never in a BAM): straight into the LDS sums, for every set of its row
-            const bool big = base && ((unsigned)b >= 2048u || (unsigned)m >= 2048u);
+            const int s = sv[u];
             const unsigned long long h1 = __ballot(hv[u] == 1), h2 = __ballot(hv[u] == 2), h3 = __ballot(hv[u] == 3);
-            const unsigned long long anybig = __ballot(big);
-            const uint32_t c1 = base ? 1u << (8 * (s - 1)) : 0u;
-            const int sh = base ? 16 * (s - 1) : 0;
-            if (anybig) {
-                // (rare) membership per lane, exact adds
-                const bool in1 = R == 1 ? h1 != 0ull : ((uint32_t)(h1 >> rsh) & wm) != 0u;
-                const bool in2 = R == 1 ? h2 != 0ull : ((uint32_t)(h2 >> rsh) & wm) != 0u;
-                const bool in3 = R == 1 ? h3 != 0ull : ((uint32_t)(h3 >> rsh) & wm) != 0u;
-                if (big) {
-                    const bool in[4] = {true, in1, in2, in3};
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) if (in[g]) {
-                        atomicAdd(&sums[(g * NSTAT + 5 + (s - 1)) * L + col], (unsigned long long)(long long)b);
-                        atomicAdd(&sums[(g * NSTAT + 9 + (s - 1)) * L + col], (unsigned long long)(long long)m);
-                    }
-                    b = 0; m = 0;
-                }
-            }
-            const unsigned long long b64 = base ? (unsigned long long)(uint32_t)b << sh : 0ull;
-            const unsigned long long m64 = base ? (unsigned long long)(uint32_t)m << sh : 0ull;
-            const bool del = s == -1;
-            cntp[0] += c1; qb[0] += b64; qm[0] += m64;
+            const uint32_t code = min((uint32_t)(s + 2), 7u);     // any foreign code (s < -2 wraps around) lands in the junk field
+            const unsigned long long c64 = 1ull << (8 * code);
+            const uint32_t sh = (uint32_t)(16 * s - 16) & 63u;    // (a non-base element shifts zeros: any amount will do)
+            const unsigned long long b64 = (unsigned long long)(uint32_t)bv[u] << sh, m64 = (unsigned long long)(uint32_t)mv[u] << sh;
+            cnt[0] += c64; qb[0] += b64; qm[0] += m64;
             if (R == 1) {
-                // one row per wave: the sets are uniform
-                uint32_t dbits = 1u;
-                if (h1) { cntp[1] += c1; qb[1] += b64; qm[1] += m64; dbits |= 1u << 8; }
-                if (h2) { cntp[2] += c1; qb[2] += b64; qm[2] += m64; dbits |= 1u << 16; }
-                if (h3) { cntp[3] += c1; qb[3] += b64; qm[3] += m64; dbits |= 1u << 24; }
-                cntd += del ? dbits : 0u;
+                // one row per wave: the sets are uniform - REAL scalar branches (the empty asm keeps hipcc from turning each of them
+                // into six selects: a row of the reference's bins is in one of the three sets, so two of three bodies are skipped)
+                if (h1) { asm volatile("" ::: "memory"); cnt[1] += c64; qb[1] += b64; qm[1] += m64; }
+                if (h2) { asm volatile("" ::: "memory"); cnt[2] += c64; qb[2] += b64; qm[2] += m64; }
+                if (h3) { asm volatile("" ::: "memory"); cnt[3] += c64; qb[3] += b64; qm[3] += m64; }
             } else {
                 const bool in1 = ((uint32_t)(h1 >> rsh) & wm) != 0u, in2 = ((uint32_t)(h2 >> rsh) & wm) != 0u, in3 = ((uint32_t)(h3 >> rsh) & wm) != 0u;
-                cntp[1] += in1 ? c1 : 0u; qb[1] += in1 ? b64 : 0ull; qm[1] += in1 ? m64 : 0ull;
-                cntp[2] += in2 ? c1 : 0u; qb[2] += in2 ? b64 : 0ull; qm[2] += in2 ? m64 : 0ull;
-                cntp[3] += in3 ? c1 : 0u; qb[3] += in3 ? b64 : 0ull; qm[3] += in3 ? m64 : 0ull;
-                cntd += del ? (1u | (in1 ? 1u << 8 : 0u) | (in2 ? 1u << 16 : 0u) | (in3 ? 1u << 24 : 0u)) : 0u;
+                cnt[1] += in1 ? c64 : 0ull; qb[1] += in1 ? b64 : 0ull; qm[1] += in1 ? m64 : 0ull;
+                cnt[2] += in2 ? c64 : 0ull; qb[2] += in2 ? b64 : 0ull; qm[2] += in2 ? m64 : 0ull;
+                cnt[3] += in3 ? c64 : 0ull; qb[3] += in3 ? b64 : 0ull; qm[3] += in3 ? m64 : 0ull;
             }
         }
         since_flush += U;
@@ -198,8 +235,12 @@ int hap_features_impl(nsnp_ctx* ctx, const PT* seq, const PT* bq, const PT* mq, 
     const size_t lds = (size_t)4 * NSTAT * L * 8;
     if (lds > 64 * 1024) return NSNP_ESHAPE;
     ScopedKernelTimer tm(ctx, NSNP_K_HAPFEAT, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_hap_features<PT>, dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream,
-                       seq, bq, mq, hap, ref_row, D, L, out);
+    if (L == 33)
+        hipLaunchKernelGGL((k_hap_features<PT, 33>), dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream, seq, bq, mq, hap, ref_row, D, L, out);
+    else if (L == 11)
+        hipLaunchKernelGGL((k_hap_features<PT, 11>), dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream, seq, bq, mq, hap, ref_row, D, L, out);
+    else
+        hipLaunchKernelGGL((k_hap_features<PT, 0>), dim3((unsigned)N), dim3(HF_BLOCK), lds, (hipStream_t)stream, seq, bq, mq, hap, ref_row, D, L, out);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }
