@@ -229,25 +229,31 @@ struct ConvArgs {
 };
 
 constexpr int CONV_HALO = 12;                          // W + 1 for the widths of this network (W = 11)
-constexpr int CONV_ROWS = TS + 2 * CONV_HALO + 1;      // staged pixels + the zero row
+constexpr int CONV_ROWS = TS + 2 * CONV_HALO + 1;      // staged pixels + the zero row (one pixel tile per workgroup)
 
-template <int AR>              // 0 exact fp32 (v_mfma_f32_32x32x2_f32), 2 bf16x3 (six v_mfma_f32_32x32x16_bf16 per product)
+// NPT = pixel tiles (of 128) per workgroup.  2 for the blocks with <= 64 output channels (round 5): their waves had 8 / 16 MFMAs
+// between two barriers at 128 pixels (0.47 / 0.65 of the peak against 0.75-0.78 for the wide blocks); with 256 pixels a wave owns 64
+// pixels x all rows = 16 / 32.  Same products in the same order per accumulator: bit-identical.
+template <int AR, int NPT>     // AR: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 2 bf16x3 (six v_mfma_f32_32x32x16_bf16 per product)
 __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
 {
     constexpr bool B3 = AR == 2;
+    constexpr int PIX = NPT * TS;                       // pixels of the workgroup
+    constexpr int ROWS = PIX + 2 * CONV_HALO + 1;       // staged pixels + halo + the zero row
+    constexpr int NHT = (2 * (PIX + 2 * CONV_HALO) + 255) / 256;     // staging tasks (row, half) per thread
     constexpr int ROWF = B3 ? 28 : LDK;                 // floats per LDS row: 112 B (3 planes x 16 bf16 + pad) / 80 B (16 floats + pad)
     constexpr int TILE_W = B3 ? TILE_F * 3 / 2 : TILE_F;
     constexpr int NPL = B3 ? 3 : 2;                     // 16-byte fragments per row half: three planes / two groups of four K-steps
     __shared__ float As[2][TR][ROWF];
-    __shared__ float Hb[2][CONV_ROWS][ROWF];
+    __shared__ float Hb[2][ROWS][ROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int bx = blockIdx.x, by = blockIdx.y;
-    const bool small_rows = a.n_rows <= 64;
+    const bool small_rows = NPT == 2 || a.n_rows <= 64;
     const int wr = small_rows ? 0 : wave >> 1, wc = wave & 1;
-    const int nct = small_rows ? 1 : 2;
+    const int nct = (small_rows && NPT == 1) ? 1 : 2;
     const int nrt = a.n_rows <= 32 ? 1 : 2;
-    const int site0 = small_rows ? 32 * wave : 64 * wc;
+    const int site0 = NPT == 2 ? 64 * wave : (small_rows ? 32 * wave : 64 * wc);
     const int W = a.conv_w, HW = a.conv_h * a.conv_w;
     const int n_chunks = 9 * a.cc_in + a.cc_sc;
     const float* __restrict__ wt = a.w + (size_t)by * a.nk_img * TILE_W;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int s = site0 + 32 * ct + li;
-        const long long pix = (long long)bx * TS + s;
+        const long long pix = (long long)bx * PIX + s;
         const int rem = (int)(pix % HW);
         const int py = rem / W, px = rem - py * W;
         unsigned m = 0u;
@@ -288,19 +294,19 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
         if (B3) { ra[(tid & 1) * 3] = ga[0]; ra[(tid & 1) * 3 + 1] = ga[1]; ra[(tid & 1) * 3 + 2] = ga[2]; }
         else { ra[cq] = ga[0]; ra[cq + 1] = ga[1]; }
     };
-    // block: task i = 2 row + half, i < 2 (TS + 2 HALO) = 304: the thread's tasks are tid and tid + 256
-    f32x4 gh[2][2];
+    // block: task i = 2 row + half, i < 2 (PIX + 2 HALO) = 304 (560 with two pixel tiles): the thread's tasks are tid, tid + 256, ...
+    f32x4 gh[NHT][2];
     auto gload_h = [&](int blk) {
         const bool conv = blk < a.cc_in;
         const float* __restrict__ img = conv ? a.x : a.sc;
         const int cc = conv ? blk : blk - a.cc_in, ncc = conv ? a.cc_in : a.cc_sc;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NHT; ++k) {
             const int i = tid + 256 * k;
             const int row = i >> 1, half = i & 1;
-            const long long pix = (long long)bx * TS - CONV_HALO + row;
+            const long long pix = (long long)bx * PIX - CONV_HALO + row;
             gh[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; gh[k][1] = gh[k][0];
-            if (i < 2 * (TS + 2 * CONV_HALO) && pix >= 0 && pix < a.n_pix_alloc) {
+            if (i < 2 * (PIX + 2 * CONV_HALO) && pix >= 0 && pix < a.n_pix_alloc) {
                 const f32x4* pr = reinterpret_cast<const f32x4*>(img + ((size_t)(pix >> 7) * ncc + cc) * TILE_F + (size_t)(pix & 127) * BK) + 2 * half;
                 gh[k][0] = pr[0]; gh[k][1] = pr[1];
             }
@@ -308,9 +314,9 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
     };
     auto lstore_h = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NHT; ++k) {
             const int i = tid + 256 * k;
-            if (i >= 2 * (TS + 2 * CONV_HALO)) continue;
+            if (i >= 2 * (PIX + 2 * CONV_HALO)) continue;
             const int row = i >> 1, half = i & 1;
             f32x4* rh = reinterpret_cast<f32x4*>(&Hb[buf][row][0]);
             if (B3) {
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
         }
 
     // ---- prologue: zero rows, block 0, weight chunk 0 ---------------------------------------------------------------------------
-    if (tid < 2 * ROWF) Hb[tid / ROWF][CONV_ROWS - 1][tid % ROWF] = 0.f;
+    if (tid < 2 * ROWF) Hb[tid / ROWF][ROWS - 1][tid % ROWF] = 0.f;
     // chunk index (into the weight image) of the j-th chunk of the walk: blocks of nine taps over the channel chunks, then the shortcut's
     auto chunk_kc = [&](int jj) {
         const int nconv = 9 * a.cc_in;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             if (ct >= nct) continue;                                    // (row tiles of <= 64 rows: the second column tile does not exist - no read of it)
-            const int row = ((vmask[ct] >> t_eff) & 1u) ? srow[ct] + off : CONV_ROWS - 1;
+            const int row = ((vmask[ct] >> t_eff) & 1u) ? srow[ct] + off : ROWS - 1;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 bf[ct][p] = *reinterpret_cast<const f32x4*>(&Hb[hb][row][B3 ? (2 * p + lh) * 4 : lh * 8 + p * 4]);
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
     for (int ct = 0; ct < 2; ++ct) {
         if (ct >= nct) continue;
         const int site = site0 + 32 * ct + li;
+        if ((long long)bx * PIX + site >= a.n_pix_alloc) continue;     // (two pixel tiles per workgroup: the last one may hold one)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
                 f32x4 v;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) v[g] = fmaxf(acc[rt][ct][4 * r4 + g], 0.f);
-                float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK;
+                float* o = a.out + (size_t)((size_t)bx * NPT + (site >> 7)) * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + (site & 127) * BK;
                 *reinterpret_cast<f32x4*>(o + (f & 15)) = v;
             }
     }
@@ -795,10 +802,16 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
                 c.conv_h = Hc; c.conv_w = CAT_L; c.n_pix = n_pix; c.n_pix_alloc = n_ptiles * TS; c.n_rows = b.cout;
                 c.w = wm(b.w1); c.bias = b.b1; c.x = X; c.sc = nullptr; c.cc_in = b.cc_in; c.cc_sc = 0; c.nk_img = 9 * b.cc_in;
                 c.out = Y; c.out_tile_stride = b.cc_out * TILE_F;
-                hipLaunchKernelGGL(k_cat_conv<AR == 1 ? 0 : AR>, dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, c);
+                // blocks of <= 64 output channels: two pixel tiles per workgroup (option "cat_conv_pix2", default 1)
+                // (fp32 only: the bf16x3 form needs 92 KB of LDS at 256 pixels - one workgroup per CU - and measured 2 % slower)
+                const bool pix2 = AR == 0 && ctx->cat_conv_pix2 && b.cout <= 64;
+                const unsigned gx = pix2 ? (unsigned)((n_ptiles + 1) / 2) : (unsigned)n_ptiles;
+                if (pix2) hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);
+                else hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
                 c.w = wm(b.w2); c.bias = b.b2; c.x = Y; c.sc = X; c.cc_in = b.cc_out; c.cc_sc = b.cc_in; c.nk_img = 9 * b.cc_out + b.cc_in;
                 c.out = O;
-                hipLaunchKernelGGL(k_cat_conv<AR == 1 ? 0 : AR>, dim3((unsigned)n_ptiles, rt, 1), dim3(256), 0, s, c);
+                if (pix2) hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);
+                else hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
             } else {
             StepLaunch L; StepArgs& a = L.z[0];
             memset(&a, 0, sizeof(a));

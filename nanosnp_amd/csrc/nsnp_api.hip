@@ -45,6 +45,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->hap_precision = 0;      // fp32); 1 opts into the f16x3 split (3 fp16 MFMAs per product, ~1e-6 from fp32)
     ctx->cat_precision = 0;
     ctx->cat_conv_lds = 1;
+    ctx->cat_conv_pix2 = 1;
     ctx->hap_b3x = 1;
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
@@ -100,6 +101,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "hap_b3x") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->hap_b3x = (int)value;
+        return NSNP_OK;
+    }
+    if (strcmp(name, "cat_conv_pix2") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->cat_conv_pix2 = (int)value;
         return NSNP_OK;
     }
     if (strcmp(name, "cat_conv_lds") == 0) {

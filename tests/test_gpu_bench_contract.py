@@ -98,7 +98,8 @@ def test_bench_line_schema():
     assert e["fp32"]["sites"] == e["bf16x3"]["sites"] == e["f16x3"]["sites"] == 2048
     assert e["bf16x3"]["max_abs_error"] <= max(1.5 * e["fp32"]["max_abs_error"], 1e-6) and e["bf16x3"]["max_abs_error"] < 3e-6
     assert b["roofline"]["peak"] == 2500.0 and 0 < b["roofline"]["frac"] <= 1 and 0 < b["roofline"]["chip"]["frac"] <= 1
-    assert b["roofline"]["executed_flop_per_launch"] in (4096 * 2 * 33 * 256 * (32 * 3 + 64 * 6) * 2, 4096 * 2 * 17 * 256 * 192 * 6 * 2)
+    nl = b["sites_per_forward_launch"]                            # bf16x3: 16,384 sites per forward launch (four pool batches)
+    assert nl == 4 * 4096 and b["roofline"]["executed_flop_per_launch"] in (nl * 2 * 33 * 256 * (32 * 3 + 64 * 6) * 2, nl * 2 * 17 * 256 * 192 * 6 * 2)
 
 
 def test_two_stage_workload_line():

@@ -13,6 +13,7 @@ ctx.cat_load_weights(seeded_cat_weights(21))
 prec = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx.set_option("cat_precision", prec)
 ctx.set_option("cat_conv_lds", int(os.environ.get("CONVLDS", "1")))
+ctx.set_option("cat_conv_pix2", int(os.environ.get("PIX2", "1")))
 ctx.enable_timing(True)
 g0, g1 = synth_cat_groups(5, 256)
 reps = (N + 255) // 256
