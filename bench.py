@@ -377,6 +377,9 @@ def main():
             out.setdefault("roofline", None)
             out["kernel_avg_ms_in_region"] = {k: round(v[0] / v[1], 5) for k, v in sorted(tot.items())}
             out["kernel_exclusive_ms"] = {k: round(v, 5) for k, v in sorted(excl.items())}
+            out["kernel_exclusive_note"] = ("HIP-event time per launch with the chip to the kernel (one stream, after the timed region); ~3 % above the "
+                                            "rocprofv3 kernel-trace durations of the same launches (event overhead), and NOT additive to ms_per_step: in "
+                                            "the timed region the launches of 32 streams overlap each other's tails")
             out["kernel_timing"] = {"streams_with_events": stage.timed_streams, "launches_timed_in_region": {k: v[1] for k, v in sorted(tot.items())}}
         else:
             out["roofline"] = None
