@@ -7,7 +7,9 @@ this package holds only the host-side mirror of the reference's interface for th
     haplotype_model.LSTMNetwork  HaplotypeModel/model_dev.py LSTMNetwork (predict only)
     pipeline                     mpileup text -> column encode -> windows -> PileupModel -> pileup.vcf in one pass
                                  (dna_sv_tensor make_candidate_snp_tensor + make_predict_data + predict.py)
-    predict                      PileupModel/predict.py / HaplotypeModel/predict_dev.py loops
+    hap_pipeline                 haplotype site files -> pinned staging / H2D / features + HaplotypeModel -> haplotype.csv, streamed
+                                 (HaplotypeModel/predict_dev.py + dataset_dev.py TestDataset behind a DataLoader)
+    predict                      PileupModel/predict.py / HaplotypeModel/predict_dev.py loops on arrays
     readmatrix                   stage-4 read x position matrices from a pysam-like alignment file (create_pileup_haplotype.py)
     merge                        stage-4 group selection and the final merge (select_hetesnp_homosnp.py, scripts/merge.py)
     sitefile                     flat binary containers in place of the HDF5 bins
@@ -17,4 +19,4 @@ this package holds only the host-side mirror of the reference's interface for th
 There is no CPU fallback: without the built extension and a gfx950 device every compute entry
 point raises.  The CPU restatement under ``oracle/`` is test infrastructure only.
 """
-__version__ = "0.1.0"
+__version__ = "0.5.0"
