@@ -77,8 +77,8 @@ int nsnp_mpileup_parse_lines(const char* text, int64_t text_len, int64_t cap_col
 
 /* n values of elem_src bytes (4 = int32 as the reference's bins hold them, 1 = int8) from a file (fd >= 0, byte offset src_off: pread,
  * page cache -> destination in one copy) or from memory (fd < 0: src + src_off) into dst as elem_dst-byte values, all host threads at
- * once.  4 -> 1 narrows; *n_out_of_range receives the number of values outside [-128, 127] (the caller then stages that pass as
- * int32).  1 -> 4 is not offered. */
+ * once.  4 -> 1 and 4 -> 2 narrow; *n_out_of_range receives the number of values outside [-128, 127] / [-32768, 32767] (the caller
+ * then stages as int32).  Widening is not offered. */
 int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, int64_t n, void* dst, int elem_dst,
                       int64_t* n_out_of_range);
 
@@ -88,6 +88,13 @@ int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, in
  * reference raises there: dataset_dev.py:109-110). */
 int nsnp_parse_ctg_pos(const uint8_t* rows, int64_t n, int width, const char* names_blob, const int64_t* names_off, int n_names,
                        int64_t* pos, int32_t* ctg);
+
+/* n zero-padded fields of `width` bytes holding "ctg:pos:ref33" (the `position` array of a .pd.bin, make_bin_predict_data.py:94-97) as
+ * PileupModel/dataset.py:127-132 reads them (strip, split at ':' into three parts, int(pos), ord(seq[16])) -> pos[n], ctg[n] (index
+ * among the names, -1 = not there), ref_base[n].  NSNP_HOST_EFORMAT where the reference raises (not three parts, a position that is
+ * not an integer, a sequence shorter than 17). */
+int nsnp_parse_ctg_pos_ref(const uint8_t* rows, int64_t n, int width, const char* names_blob, const int64_t* names_off, int n_names,
+                           int64_t* pos, int32_t* ctg, uint8_t* ref_base);
 
 /* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota (NSNP_HOST_THREADS in the
  * environment overrides the automatic count); nsnp_host_set_threads(n > 0) fixes it for the process, n <= 0 returns to automatic */

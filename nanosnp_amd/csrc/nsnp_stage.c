@@ -51,14 +51,29 @@ static int64_t narrow_block(const int32_t* restrict s, int8_t* restrict d, int64
     return c;
 }
 
+/* int32 -> int16 likewise */
+static int64_t narrow_block16(const int32_t* restrict s, int16_t* restrict d, int64_t n)
+{
+    int32_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t v = s[i];
+        d[i] = (int16_t)v;
+        bad |= (v + 32768) & ~65535;
+    }
+    if (!bad) return 0;
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; ++i) c += (s[i] < -32768 || s[i] > 32767);
+    return c;
+}
+
 int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, int64_t n, void* dst, int elem_dst,
                       int64_t* n_out_of_range)
 {
     if (n < 0 || src_off < 0 || (fd < 0 && !src && n) || (!dst && n)) return NSNP_HOST_EINVAL;
-    if (!((elem_src == 4 && (elem_dst == 4 || elem_dst == 1)) || (elem_src == 1 && elem_dst == 1))) return NSNP_HOST_EINVAL;
+    if (!((elem_src == 4 && (elem_dst == 4 || elem_dst == 2 || elem_dst == 1)) || (elem_src == elem_dst && (elem_src == 1 || elem_src == 2)))) return NSNP_HOST_EINVAL;
     if (n_out_of_range) *n_out_of_range = 0;
     if (n == 0) return 0;
-    const int narrow = elem_src == 4 && elem_dst == 1;
+    const int narrow = elem_src == 4 && elem_dst < 4;
     const int64_t per = STAGE_BLOCK / elem_src;                          /* values per work item */
     const int64_t items = (n + per - 1) / per;
     int T = nsnp_host_threads();
@@ -84,13 +99,15 @@ int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, in
                 if (fd >= 0) my_err = pread_all(fd, d, vn * elem_src, src_off + v0 * elem_src);
                 else memcpy(d, (const char*)src + src_off + v0 * elem_src, (size_t)(vn * elem_src));
             } else if (fd < 0) {
-                my_bad += narrow_block((const int32_t*)((const char*)src + src_off) + v0, (int8_t*)dst + v0, vn);
+                const int32_t* sp = (const int32_t*)((const char*)src + src_off) + v0;
+                my_bad += elem_dst == 1 ? narrow_block(sp, (int8_t*)dst + v0, vn) : narrow_block16(sp, (int16_t*)dst + v0, vn);
             } else {
                 const int64_t sv = SCRATCH / 4;
                 for (int64_t a = 0; a < vn && !my_err; a += sv) {
                     const int64_t m = a + sv <= vn ? sv : vn - a;
                     my_err = pread_all(fd, scratch, m * 4, src_off + (v0 + a) * 4);
-                    if (!my_err) my_bad += narrow_block(scratch, (int8_t*)dst + v0 + a, m);
+                    if (!my_err) my_bad += elem_dst == 1 ? narrow_block(scratch, (int8_t*)dst + v0 + a, m)
+                                                        : narrow_block16(scratch, (int16_t*)dst + v0 + a, m);
                 }
             }
         }
@@ -140,6 +157,50 @@ int nsnp_parse_ctg_pos(const uint8_t* rows, int64_t n, int width, const char* na
         if (!ok) { BAD(); continue; }
         pos[i] = neg ? -v : v;
         /* contig (the table is short: a bin holds one contig, a run a few dozen) */
+        int id = -1;
+        for (int k = 0; k < n_names; ++k) {
+            const int64_t a = names_off[k], b = names_off[k + 1];
+            if (b - a == cl && memcmp(names_blob + a, r, (size_t)cl) == 0) { id = k; break; }
+        }
+        ctg[i] = id;
+    }
+#undef BAD
+    return err ? NSNP_HOST_EFORMAT : 0;
+}
+
+/* "ctg:pos:ref33" in a zero-padded field of `width` bytes (the `position` array of a .pd.bin: make_bin_predict_data.py:94-97), read as
+ * PileupModel/dataset.py:127-132 reads it: strip, split at ':' into exactly three parts, int(pos), ord(seq[16]).  The contig is looked
+ * up among n_names names; -1 when it is not there (the caller learns the name: a VCF row carries it). */
+int nsnp_parse_ctg_pos_ref(const uint8_t* rows, int64_t n, int width, const char* names_blob, const int64_t* names_off, int n_names,
+                           int64_t* pos, int32_t* ctg, uint8_t* ref_base)
+{
+    if (n < 0 || width <= 0 || (n && (!rows || !pos || !ctg || !ref_base)) || n_names < 0 || (n_names && (!names_blob || !names_off))) return NSNP_HOST_EINVAL;
+    int err = 0;
+#define BAD() do { _Pragma("omp atomic write") err = 1; } while (0)
+    int T = nsnp_host_threads();
+    if ((int64_t)T > n / 4096 + 1) T = (int)(n / 4096 + 1);
+    #pragma omp parallel for num_threads(T) schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t* r = rows + i * (int64_t)width;
+        const uint8_t* e = r + width;
+        while (e > r && e[-1] == 0) --e;                                 /* numpy 'S' fields are zero-padded */
+        while (r < e && (*r == ' ' || (*r >= 9 && *r <= 13))) ++r;       /* .strip() */
+        while (e > r && (e[-1] == ' ' || (e[-1] >= 9 && e[-1] <= 13))) --e;
+        const uint8_t* c1 = (const uint8_t*)memchr(r, ':', (size_t)(e - r));
+        const uint8_t* c2 = c1 ? (const uint8_t*)memchr(c1 + 1, ':', (size_t)(e - c1 - 1)) : NULL;
+        if (!c2 || memchr(c2 + 1, ':', (size_t)(e - c2 - 1)) || e - (c2 + 1) < 17) { BAD(); continue; }
+        const uint8_t* p = c1 + 1; const uint8_t* q = c2;
+        while (p < q && (*p == ' ' || (*p >= 9 && *p <= 13))) ++p;
+        while (q > p && (q[-1] == ' ' || (q[-1] >= 9 && q[-1] <= 13))) --q;
+        int neg = 0;
+        if (p < q && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+        if (p >= q || q - p > 18) { BAD(); continue; }
+        int64_t v = 0; int ok = 1;
+        for (; p < q; ++p) { if (*p < '0' || *p > '9') { ok = 0; break; } v = v * 10 + (*p - '0'); }
+        if (!ok) { BAD(); continue; }
+        pos[i] = neg ? -v : v;
+        ref_base[i] = c2[1 + 16];
+        const int cl = (int)(c1 - r);
         int id = -1;
         for (int k = 0; k < n_names; ++k) {
             const int64_t a = names_off[k], b = names_off[k + 1];

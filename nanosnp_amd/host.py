@@ -65,6 +65,8 @@ def _load():
     lib.nsnp_stage_values.argtypes = [C.c_int, p, C.c_int64, C.c_int, C.c_int64, p, C.c_int, C.POINTER(C.c_int64)]
     lib.nsnp_parse_ctg_pos.restype = C.c_int
     lib.nsnp_parse_ctg_pos.argtypes = [p, C.c_int64, C.c_int, C.c_char_p, p, C.c_int, p, p]
+    lib.nsnp_parse_ctg_pos_ref.restype = C.c_int
+    lib.nsnp_parse_ctg_pos_ref.argtypes = [p, C.c_int64, C.c_int, C.c_char_p, p, C.c_int, p, p, p]
     lib.nsnp_pd_parse.restype = C.c_int64
     lib.nsnp_pd_parse.argtypes = [C.c_char_p, C.c_int64, p, p, p, p, p, C.c_int64]
     return lib
@@ -229,9 +231,10 @@ def mpileup_parse_range(buf, lo, hi, out=None, strict_lines=False):
 
 
 def stage_values(dst, n, src=None, fd=-1, src_off=0, src_dtype=np.int32):
-    """n values of src_dtype (int32 / int8) from a file descriptor at byte offset src_off, or from the numpy array `src` (C-contiguous;
-    src_off in bytes), into the first n elements of dst (a numpy array of int32 or int8: e.g. the view of a pinned tensor), on all host
-    threads (nsnp_stage_values).  int32 -> int8 narrows; returns the number of values that did not fit int8 (0 in every other case)."""
+    """n values of src_dtype (int32 / int16 / int8) from a file descriptor at byte offset src_off, or from the numpy array `src`
+    (C-contiguous; src_off in bytes), into the first n elements of dst (a numpy array of int32, int16 or int8: e.g. the view of a pinned
+    tensor), on all host threads (nsnp_stage_values).  int32 -> int16 / int8 narrows; returns the number of values that did not fit (0 in
+    every other case)."""
     es, ed = np.dtype(src_dtype).itemsize, dst.dtype.itemsize
     if dst.size < n or not dst.flags["C_CONTIGUOUS"]:
         raise HostError("stage_values: destination too small or not contiguous")
@@ -259,6 +262,19 @@ def parse_ctg_pos(rows, table):
         _check(lib().nsnp_parse_ctg_pos(_ptr(a), n, int(width), table.blob, _ptr(table.off), len(table.off) - 1, _ptr(pos), _ptr(ctg)),
                "nsnp_parse_ctg_pos (a position field is not 'ctg:pos')")
     return pos, ctg
+
+
+def parse_ctg_pos_ref(rows, table):
+    """rows: uint8 [n, width] zero-padded "ctg:pos:ref33" fields (the `position` array of a .pd.bin) -> (pos int64 [n], ctg int32 [n]
+    (-1 = a contig the table does not hold), ref_base uint8 [n] = ord(seq[16])): PileupModel/dataset.py:127-132.  HostError where
+    the reference raises."""
+    a = np.ascontiguousarray(rows, np.uint8)
+    n, width = a.shape
+    pos = np.empty(n, np.int64); ctg = np.empty(n, np.int32); refb = np.empty(n, np.uint8)
+    if n:
+        _check(lib().nsnp_parse_ctg_pos_ref(_ptr(a), n, int(width), table.blob, _ptr(table.off), len(table.off) - 1, _ptr(pos), _ptr(ctg), _ptr(refb)),
+               "nsnp_parse_ctg_pos_ref (a position field is not 'ctg:pos:ref33')")
+    return pos, ctg, refb
 
 
 def fasta_load_contig(path, contig):

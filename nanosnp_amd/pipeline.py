@@ -422,3 +422,185 @@ def call_variants(model, contigs, fasta_path, fai_text, output_file, **kw):
         if f:
             f.close()
     return total
+
+
+# ---- .pd.bin site files -> pileup.vcf, streamed (PileupModel/predict.py:37-195 over PredictDataset files) ------------------------------
+class _SiteSet:
+    """buffers of one pass of a site file in flight: the [P,33,18] window matrices (as bytes: int16 or int32 views per pass)"""
+    def __init__(self, P, dev=None):
+        import torch
+        kw = dict(pin_memory=True) if dev is None else dict(device=dev)
+        self.P = P
+        self.x = torch.empty(P * 33 * 18 * 4, dtype=torch.uint8, **kw)
+        self.h2d_done = None
+        self.free = None
+
+
+def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=1000, score_mode=host.SCORE_FLOAT64, pass_sites=65536,
+                        narrow=True, stats=None):
+    """The reference's ``predict(model, testing_paths, reference_index_file, batch_size, output_file, device)`` (PileupModel/predict.py:
+    37-195) over this repository's ``.pd.bin`` site files (sitefile.write_pileup_bin / pd_to_bin: the arrays of make_bin_predict_data.py:
+    90-100): every file's windows are STREAMED - a worker thread `pread`s passes of `pass_sites` windows from the page cache into one of
+    three pinned sets on all host cores (int32 counts narrowed to int16 on the way when they fit - they do: half the bytes over PCIe -
+    else int32) and parses the ``ctg:pos:ref33`` fields natively (dataset.py:127-132), a copy stream sends the pass, the compute stream
+    runs the PileupModel forward + argmax / max + the coverage slice of predict.py:63 and sends the calls (42 bytes per site) back; the
+    files are one pipeline, and the rows of a file are formatted (one native call over the reference's batches of `batch_size` sites,
+    which restart with every file as its DataLoader does) and appended on a writer thread while the next file computes.
+    testing_paths: a list of paths, or a directory (its ``*.bin`` files in os.listdir order: predict.py:215).  Returns rows written."""
+    import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from . import sitefile
+    from .hap_pipeline import _LocalNames
+    ctx = model.ctx
+    dev = torch.device("cuda", ctx.device)
+    st = stats if stats is not None else {}
+    for k in ("stage_s", "h2d_s", "gpu_s", "vcf_s", "bytes_h2d", "sites", "passes", "passes_int16", "wait_stage_s", "issue_s", "drain_s"):
+        st.setdefault(k, 0.0)
+    if isinstance(testing_paths, (str, os.PathLike)):
+        d = str(testing_paths)
+        paths = [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".bin")] if os.path.isdir(d) else [d]
+    else:
+        paths = [str(p) for p in testing_paths]
+    files = []
+    for p in paths:
+        idx = sitefile.array_index(p)
+        if "position_matrix" not in idx or "position" not in idx or idx["position_matrix"][0] != np.dtype(np.int32) or idx["position_matrix"][1][1:] != (33, 18):
+            raise sitefile.SiteFileError(f"{p}: not a pileup site file (position_matrix int32 [N,33,18] + position)")
+        files.append(dict(path=p, n=idx["position_matrix"][1][0], x_off=idx["position_matrix"][2], fd=os.open(p, os.O_RDONLY),
+                          position=sitefile.read_arrays(p, mmap=True)["position"]))
+    P = int(max(1, pass_sites))
+    seg_off = np.concatenate([[0], np.cumsum([f["n"] for f in files])]).astype(np.int64)
+    n_total = int(seg_off[-1])
+    passes = []
+    for fi, f in enumerate(files):
+        a = 0
+        while a < f["n"]:
+            b = min(f["n"], a + (max(1, P // 4) if not passes and f["n"] > P else P))       # the very first pass: a quarter (the pipeline's fill)
+            passes.append((fi, a, b, int(seg_off[fi]) + a))
+            a = b
+    last_pass_of = {fi: k for k, (fi, _, _, _) in enumerate(passes)}
+    names = _LocalNames()
+    total_rows = 0
+    out = open(output_file, "wb")
+    try:
+        out.write(host.vcf_header(fai_text).encode())
+        if passes:
+            n_sets = min(3, len(passes))
+            hsets = getattr(model, "_site_host_sets", None)
+            if not hsets or len(hsets) < n_sets or hsets[0].P < P:
+                hsets = [_SiteSet(P) for _ in range(n_sets)]
+                model._site_host_sets = hsets
+                model._site_dev_sets = [_SiteSet(P, dev) for _ in range(n_sets)]
+                model._site_copy_stream = torch.cuda.Stream(dev)
+            dsets, copy_stream = model._site_dev_sets, model._site_copy_stream
+            main = torch.cuda.current_stream(dev)
+            for s_ in hsets:
+                s_.h2d_done = None
+            for s_ in dsets:
+                s_.free = None
+            copy_stream.wait_stream(main)
+            res = getattr(model, "_site_results", None)
+            if res is None or res["ga"].numel() < n_total:
+                mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+                res = dict(ga=mk(n_total, torch.uint8), za=mk(n_total, torch.uint8), gm=mk(n_total, torch.float32), zm=mk(n_total, torch.float32),
+                           cov=mk((n_total, 8), torch.float32))
+                model._site_results = res
+            pos_all = np.empty(n_total, np.int64); ctg_all = np.empty(n_total, np.int32); refb_all = np.empty(n_total, np.uint8)
+            centers = (torch.arange(P, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
+            cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
+            elem = [2 if narrow else 4]                 # int16 until a pass does not fit (then int32 for the rest of the run)
+            lock = threading.Lock()
+
+            def stage(k):
+                t0 = time.perf_counter()
+                fi, a, b, o = passes[k]
+                f, m = files[fi], b - a
+                hs = hsets[k % n_sets]
+                e = elem[0]
+                v = hs.x.numpy()[:m * 594 * e].view(np.int16 if e == 2 else np.int32)
+                if host.stage_values(v, m * 594, fd=f["fd"], src_off=f["x_off"] + a * 594 * 4):
+                    with lock:
+                        elem[0] = 4                     # a count beyond int16 (never at real coverage): this pass and the later ones go as int32
+                    e = 4
+                    v = hs.x.numpy()[:m * 594 * 4].view(np.int32)
+                    host.stage_values(v, m * 594, fd=f["fd"], src_off=f["x_off"] + a * 594 * 4)
+                fields = np.asarray(f["position"][a:b]).reshape(m, -1)
+                p_, c_, r_ = host.parse_ctg_pos_ref(fields, names.table)
+                if (c_ < 0).any():
+                    names.add_names([bytes(r).rstrip(b"\0").strip().split(b":")[0].decode() for r in fields[c_ < 0]])
+                    p_, c_, r_ = host.parse_ctg_pos_ref(fields, names.table)
+                pos_all[o:o + m] = p_; ctg_all[o:o + m] = c_; refb_all[o:o + m] = r_
+                return e, time.perf_counter() - t0
+
+            def rows_of(fi, done):
+                """writer thread: the VCF rows of file fi (the reference's batches restart with every file)"""
+                nonlocal total_rows
+                if done is not None:
+                    done.synchronize()
+                t0 = time.perf_counter()
+                o0, o1 = int(seg_off[fi]), int(seg_off[fi + 1])
+                if o1 > o0:
+                    text, rows = host.vcf_format_batches(names.table, ctg_all[o0:o1], pos_all[o0:o1], refb_all[o0:o1], res["ga"][o0:o1].numpy(),
+                                                         res["za"][o0:o1].numpy(), res["gm"][o0:o1].numpy(), res["zm"][o0:o1].numpy(),
+                                                         res["cov"][o0:o1].numpy(), batch_size=batch_size, score_mode=score_mode, as_view=True)
+                    out.write(text)
+                    total_rows += rows
+                st["vcf_s"] += time.perf_counter() - t0
+
+            tev = lambda: torch.cuda.Event(enable_timing=True)
+            ev = [dict(h0=tev(), h1=tev(), c0=tev(), c1=tev()) for _ in passes]
+            seg_futs, next_seg = [], 0
+            with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as writer:
+                futs = [pool.submit(stage, j) for j in range(min(2, len(passes)))]
+                for k, (fi, a, b, o) in enumerate(passes):
+                    m = b - a
+                    t_w = time.perf_counter()
+                    e, t_stage = futs[k].result()
+                    t_i = time.perf_counter()
+                    st["wait_stage_s"] += t_i - t_w; st["stage_s"] += t_stage
+                    st["passes"] += 1; st["passes_int16"] += int(e == 2); st["sites"] += m
+                    hs, ds = hsets[k % n_sets], dsets[k % n_sets]
+                    nb = m * 594 * e
+                    if ds.free is not None:
+                        copy_stream.wait_event(ds.free)
+                    with torch.cuda.stream(copy_stream):
+                        ev[k]["h0"].record(copy_stream)
+                        ds.x[:nb].copy_(hs.x[:nb], non_blocking=True)
+                        ev[k]["h1"].record(copy_stream)
+                    hs.h2d_done = ev[k]["h1"]
+                    st["bytes_h2d"] += nb
+                    if k + 2 < len(passes):
+                        nxt = hsets[(k + 2) % n_sets]
+                        if nxt.h2d_done is not None:
+                            nxt.h2d_done.synchronize()
+                        futs.append(pool.submit(stage, k + 2))
+                    main.wait_event(ev[k]["h1"])
+                    ev[k]["c0"].record(main)
+                    x = ds.x[:nb].view(torch.int16 if e == 2 else torch.int32).view(m, 33, 18)
+                    if e == 2:
+                        x = x.to(torch.int32)                                         # (1.2 KB read + 2.4 KB written per site: ~1 ns of the forward's 51)
+                    gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(x.view(m * 33, 18), centers[:m])
+                    cov = x[:, 16, :].index_select(1, cov_idx).to(torch.float32)       # predict.py:63 on a FloatTensor
+                    for key, val in (("ga", ga), ("za", za), ("gm", gm), ("zm", zm), ("cov", cov)):
+                        res[key][o:o + m].copy_(val, non_blocking=True)
+                    ev[k]["c1"].record(main)
+                    ds.free = torch.cuda.Event(); ds.free.record(main)
+                    if last_pass_of[fi] == k:
+                        while next_seg <= fi:
+                            seg_futs.append(writer.submit(rows_of, next_seg, ds.free if next_seg == fi else None)); next_seg += 1
+                    st["issue_s"] += time.perf_counter() - t_i
+                t_d = time.perf_counter()
+                torch.cuda.synchronize(dev)
+                for sf in seg_futs:
+                    sf.result()
+                st["drain_s"] += time.perf_counter() - t_d
+            for e_ in ev:
+                st["h2d_s"] += e_["h0"].elapsed_time(e_["h1"]) * 1e-3
+                st["gpu_s"] += e_["c0"].elapsed_time(e_["c1"]) * 1e-3
+    finally:
+        out.close()
+        for f in files:
+            os.close(f["fd"])
+    return total_rows

@@ -223,3 +223,64 @@ def test_streamed_pipeline_refuses_blank_lines_and_grows_its_column_buffers(pile
     for cb in (300_000, 50_000):
         r = call_contig(m2, shallow, "c", seq2, chunk_bytes=cb)
         assert bytes(r[0]) == bytes(one[0]) and r[1:] == one[1:], cb
+
+
+def test_streamed_pd_bin_files_write_the_array_path_vcf(tmp_path, pileup_weights):
+    """pipeline.predict_pileup_bins (PileupModel/predict.py:37-195 over .pd.bin files, streamed: pread -> pinned -> copy stream -> forward
+    -> calls -> rows) against predict.predict_pileup on the same arrays (itself held to the reference's VCF above): byte-identical for
+    every pass size, with the counts narrowed to int16 or sent as int32, for several files in one run (the reference's batches restart
+    with every file), an empty file among them, a count beyond int16, and a directory argument (its *.bin files in os.listdir order)"""
+    import os
+    from nanosnp_amd import sitefile
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import predict_pileup_bins
+    from nanosnp_amd.predict import predict_pileup
+    z = np.load(golden("pileup_vcf_modes.npz"))
+    x = z["x"].astype(np.int32)
+    names, pos, refb = list(z["names"]), z["pos"], z["refb"]
+    fai = bytes(z["fai"]).decode()
+    position = [f"{c}:{int(p)}:{'N' * 16}{chr(int(r))}{'N' * 16}" for c, p, r in zip(names, pos, refb)]
+    n = x.shape[0]
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    cuts = [0, n // 3, n // 3, n - 5, n]                               # three files + an empty one
+    d = tmp_path / "bins"; d.mkdir()
+    files, want = [], b""
+    for i in range(4):
+        a, b = cuts[i], cuts[i + 1]
+        p = d / f"part{i}.pd.bin"
+        sitefile.write_pileup_bin(p, x[a:b], position[a:b])
+        files.append(str(p))
+        o = tmp_path / "arr.vcf"
+        predict_pileup(m, x[a:b], names[a:b], pos[a:b], refb[a:b], fai, str(o), batch_size=100)
+        body = o.read_bytes()
+        header = host.vcf_header(fai).encode()
+        assert body.startswith(header)
+        want += body[len(header):]
+    want = header + want
+    for kw in (dict(), dict(pass_sites=64), dict(pass_sites=7), dict(narrow=False), dict(narrow=False, pass_sites=50), dict(pass_sites=n)):
+        o = tmp_path / "stream.vcf"
+        st = {}
+        rows = predict_pileup_bins(m, files, fai, str(o), batch_size=100, stats=st, **kw)
+        assert o.read_bytes() == want, kw
+        assert rows == want.count(b"\n") - header.count(b"\n") and st["sites"] == n
+        assert st["passes_int16"] == (0 if kw.get("narrow") is False else st["passes"])
+    # a directory: the reference takes os.listdir order and only names ending in .bin (predict.py:215)
+    (d / "notes.txt").write_text("not a bin")
+    order = [os.path.join(str(d), f) for f in os.listdir(d) if f.endswith(".bin")]
+    o1, o2 = tmp_path / "dir.vcf", tmp_path / "list.vcf"
+    predict_pileup_bins(m, str(d), fai, str(o1), batch_size=100)
+    predict_pileup_bins(m, order, fai, str(o2), batch_size=100)
+    assert o1.read_bytes() == o2.read_bytes()
+    # a count beyond int16: that pass and the later ones travel as int32, same rows as narrow=False
+    xb = x[:200].copy(); xb[150, 3, 2] = 40000
+    pb = tmp_path / "big.pd.bin"
+    sitefile.write_pileup_bin(pb, xb, position[:200])
+    st = {}
+    predict_pileup_bins(m, [str(pb)], fai, str(o1), batch_size=100, pass_sites=64, stats=st)
+    predict_pileup_bins(m, [str(pb)], fai, str(o2), batch_size=100, narrow=False)
+    assert o1.read_bytes() == o2.read_bytes() and 0 < st["passes_int16"] < st["passes"]
+    # a malformed position field: the reference raises (dataset.py:127)
+    sitefile.write_pileup_bin(pb, x[:3], ["chr1:5:" + "A" * 33, "chr1:6", "chr1:7:" + "A" * 33])
+    with pytest.raises(host.HostError):
+        predict_pileup_bins(m, [str(pb)], fai, str(o1))
+    assert predict_pileup_bins(m, files, fai, str(o1), batch_size=100) == want.count(b"\n") - header.count(b"\n")      # the model is usable afterwards
