@@ -52,13 +52,14 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=32)
     ap.add_argument("--windows", type=int, default=N_POOL, help="windows resident per GPU (BASELINE configs[1]: 1M)")
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60", "e2e", "hap-e2e"],
+    ap.add_argument("--workload", default="pileup", choices=["pileup", "haplotype", "two-stage", "deep60", "e2e", "hap-e2e", "pd-e2e"],
                     help="pileup = BASELINE configs[1] (the metric's configuration); haplotype = configs[2]: haplotype features + "
                          "HaplotypeModel fwd (+ the legacy crnn.py CatModel fwd) on 150 k G3 sites; two-stage = configs[3]: stage 2 + stage 5 "
                          "on a chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0; deep60 = configs[4]: "
                          "60x columns + D = 180 read planes + fp16-split conv weights; e2e = a labelled text-to-VCF measurement: samtools-mpileup text of a synthetic contig "
                          "on the page cache -> host parse beside H2D + encode + forward -> pileup.vcf (tools/e2e_bench.py); hap-e2e = the same for stage 5: a haplotype "
-                         "site file on the page cache -> pinned staging beside H2D beside features + HaplotypeModel fwd -> haplotype.csv (tools/hap_e2e_bench.py)")
+                         "site file on the page cache -> pinned staging beside H2D beside features + HaplotypeModel fwd -> haplotype.csv (tools/hap_e2e_bench.py); pd-e2e = stage 2 from "
+                         ".pd.bin window files: pread + int16 narrowing beside H2D beside PileupModel fwd -> pileup.vcf (tools/pd_e2e_bench.py; one rank)")
     ap.add_argument("--encode-group", type=int, default=32, help="batches encoded per column-encode launch (on the encode stream, into a "
                     "ring of count buffers; the kernel is twice as efficient per byte at >= 1 M columns)")
     ap.add_argument("--hap-sites", type=int, default=0, help="haplotype / deep60 workloads: sites resident per job (0 = the workload's default)")
@@ -200,9 +201,10 @@ def cpu_baseline(cols, batch, weights, target_s):
 def main():
     args = parse_args()
     # an application's choice, made before any OpenMP runtime loads (nanosnp_amd.host.recommend_omp_env): idle OpenMP workers spin briefly,
-    # then sleep - measured on the e2e workload under a 16-core quota: always spinning 50 ms per contig, never spinning 30-33, 30k-100k spins 21.9
+    # then sleep - measured on the e2e workload under a 16-core quota: always spinning 50 ms per contig, never spinning 30-33, 5k-100k spins 22;
+    # the site-file pipelines are throttled by the quota at 100k (idle teams spin 1.6 ms per region) and not at 5k
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    os.environ.setdefault("GOMP_SPINCOUNT", "100000")
+    os.environ.setdefault("GOMP_SPINCOUNT", "5000")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -230,6 +232,9 @@ def main():
     if args.workload == "hap-e2e":
         from tools.hap_e2e_bench import run as run_hap_e2e
         sys.exit(run_hap_e2e(args, rank, world, local_rank))
+    if args.workload == "pd-e2e":
+        from tools.pd_e2e_bench import run as run_pd_e2e
+        sys.exit(run_pd_e2e(args, rank, world, local_rank))
     if args.workload in ("haplotype", "deep60"):
         from tools.hap_bench import run as run_hap
         sys.exit(run_hap(args, rank, world, local_rank, deep60=args.workload == "deep60"))

@@ -96,6 +96,10 @@ int nsnp_parse_ctg_pos(const uint8_t* rows, int64_t n, int width, const char* na
 int nsnp_parse_ctg_pos_ref(const uint8_t* rows, int64_t n, int width, const char* names_blob, const int64_t* names_off, int n_names,
                            int64_t* pos, int32_t* ctg, uint8_t* ref_base);
 
+/* out[i, c] = (float) x[i, row, channels[c]] for n staged windows [n, rows, width] of int16 (elem 2) or int32 (elem 4) values: the
+ * coverage slice of PileupModel/predict.py:63 taken on the host from the staged pass (OpenMP); NSNP_HOST_EINVAL on a bad shape. */
+int nsnp_window_channels(const void* x, int elem, int64_t n, int rows, int width, int row, const int32_t* channels, int n_ch, float* out);
+
 /* threads the host routines use: the OpenMP default cut to the affinity mask and to a cgroup CPU quota (NSNP_HOST_THREADS in the
  * environment overrides the automatic count); nsnp_host_set_threads(n > 0) fixes it for the process, n <= 0 returns to automatic */
 int nsnp_host_threads(void);

@@ -231,14 +231,23 @@ class Context:
               self.handle, "nsnp_pileup_forward_windows")
         return gt, zy
 
-    def pileup_forward_windows_calls(self, counts, center_idx, stream=None):
-        """forward + argmax / max of both heads in one call -> (gt, zy, gt_arg, zy_arg, gt_max, zy_max)"""
+    def pileup_forward_windows_calls(self, counts, center_idx, stream=None, calls_out=None):
+        """forward + argmax / max of both heads in one call -> (gt, zy, gt_arg, zy_arg, gt_max, zy_max).  calls_out = (gt_arg uint8 [n],
+        zy_arg uint8 [n], gt_max float32 [n], zy_max float32 [n]): device tensors, or PINNED host tensors - the heads kernel then writes
+        the 10 bytes per site straight into host memory (hipHostMalloc memory is mapped on the device) and no D2H copy is needed; they
+        are valid on the host once an event recorded behind this call has completed."""
         import torch
         n = center_idx.shape[0]
         dev = counts.device
         gt = torch.empty((n, 21), dtype=torch.float32, device=dev); zy = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        ga = torch.empty(n, dtype=torch.uint8, device=dev); za = torch.empty(n, dtype=torch.uint8, device=dev)
-        gm = torch.empty(n, dtype=torch.float32, device=dev); zm = torch.empty(n, dtype=torch.float32, device=dev)
+        if calls_out is None:
+            ga = torch.empty(n, dtype=torch.uint8, device=dev); za = torch.empty(n, dtype=torch.uint8, device=dev)
+            gm = torch.empty(n, dtype=torch.float32, device=dev); zm = torch.empty(n, dtype=torch.float32, device=dev)
+        else:
+            ga, za, gm, zm = calls_out
+            for t, dt in ((ga, torch.uint8), (za, torch.uint8), (gm, torch.float32), (zm, torch.float32)):
+                if t.dtype != dt or t.numel() < n or not t.is_contiguous() or not (t.is_cuda or t.is_pinned()):
+                    raise NanoSNPError("calls_out: contiguous uint8 / uint8 / float32 / float32 tensors of n elements, on the device or pinned")
         check(self.lib.nsnp_pileup_forward_windows_calls(self.handle, _dptr(counts), _dptr(center_idx), n, _dptr(gt), _dptr(zy), _dptr(ga),
                                                          _dptr(za), _dptr(gm), _dptr(zm), _stream_ptr(stream)),
               self.handle, "nsnp_pileup_forward_windows_calls")

@@ -77,8 +77,8 @@ int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, in
     const int64_t per = STAGE_BLOCK / elem_src;                          /* values per work item */
     const int64_t items = (n + per - 1) / per;
     int T = nsnp_host_threads();
-    if ((int64_t)T > items) T = (int)items;
-    if (T < 1) T = 1;
+    if (items < 2 || T < 1) T = 1;                   /* the whole team or one thread: libgomp ends the pooled threads a smaller team leaves out, and the next
+                                                        full team pays for creating them again (measured: +1 ms per pass of the streamed pipelines) */
     int err = 0;
     int64_t bad_total = 0;
     #pragma omp parallel num_threads(T)
@@ -136,7 +136,7 @@ int nsnp_parse_ctg_pos(const uint8_t* rows, int64_t n, int width, const char* na
     int err = 0;
 #define BAD() do { _Pragma("omp atomic write") err = 1; } while (0)
     int T = nsnp_host_threads();
-    if ((int64_t)T > n / 4096 + 1) T = (int)(n / 4096 + 1);
+    if (n < 4 * 4096) T = 1;                         /* the whole team or one thread (see nsnp_stage_values) */
     #pragma omp parallel for num_threads(T) schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         const uint8_t* r = rows + i * (int64_t)width;
@@ -178,7 +178,7 @@ int nsnp_parse_ctg_pos_ref(const uint8_t* rows, int64_t n, int width, const char
     int err = 0;
 #define BAD() do { _Pragma("omp atomic write") err = 1; } while (0)
     int T = nsnp_host_threads();
-    if ((int64_t)T > n / 4096 + 1) T = (int)(n / 4096 + 1);
+    if (n < 4 * 4096) T = 1;                         /* the whole team or one thread (see nsnp_stage_values) */
     #pragma omp parallel for num_threads(T) schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         const uint8_t* r = rows + i * (int64_t)width;
@@ -210,4 +210,30 @@ int nsnp_parse_ctg_pos_ref(const uint8_t* rows, int64_t n, int width, const char
     }
 #undef BAD
     return err ? NSNP_HOST_EFORMAT : 0;
+}
+
+/* out[i, c] = (float) x[i, row, channels[c]] for n staged windows [n, rows, width] of int16 or int32 values: the coverage slice of
+ * PileupModel/predict.py:63 (x[:, 16, [0,1,2,3,9,10,11,12]] of the FloatTensor) taken from the staged pass on the host, so that no
+ * D2H copy carries it (every value is a count: exact in float32). */
+int nsnp_window_channels(const void* x, int elem, int64_t n, int rows, int width, int row, const int32_t* channels, int n_ch, float* out)
+{
+    if (n < 0 || (elem != 2 && elem != 4) || rows <= 0 || width <= 0 || row < 0 || row >= rows || n_ch <= 0 || !channels || (n && (!x || !out)))
+        return NSNP_HOST_EINVAL;
+    for (int c = 0; c < n_ch; ++c)
+        if (channels[c] < 0 || channels[c] >= width) return NSNP_HOST_EINVAL;
+    const int64_t stride = (int64_t)rows * width, base = (int64_t)row * width;
+    int T = nsnp_host_threads();
+    if (n < 2 * 8192) T = 1;                         /* the whole team or one thread (see nsnp_stage_values) */
+    #pragma omp parallel for num_threads(T) schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        float* o = out + i * n_ch;
+        if (elem == 2) {
+            const int16_t* r = (const int16_t*)x + i * stride + base;
+            for (int c = 0; c < n_ch; ++c) o[c] = (float)r[channels[c]];
+        } else {
+            const int32_t* r = (const int32_t*)x + i * stride + base;
+            for (int c = 0; c < n_ch; ++c) o[c] = (float)r[channels[c]];
+        }
+    }
+    return 0;
 }

@@ -67,6 +67,8 @@ def _load():
     lib.nsnp_parse_ctg_pos.argtypes = [p, C.c_int64, C.c_int, C.c_char_p, p, C.c_int, p, p]
     lib.nsnp_parse_ctg_pos_ref.restype = C.c_int
     lib.nsnp_parse_ctg_pos_ref.argtypes = [p, C.c_int64, C.c_int, C.c_char_p, p, C.c_int, p, p, p]
+    lib.nsnp_window_channels.restype = C.c_int
+    lib.nsnp_window_channels.argtypes = [p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, p, C.c_int, p]
     lib.nsnp_pd_parse.restype = C.c_int64
     lib.nsnp_pd_parse.argtypes = [C.c_char_p, C.c_int64, p, p, p, p, p, C.c_int64]
     return lib
@@ -77,14 +79,16 @@ _lib = None
 
 def recommend_omp_env(environ=None):
     """For the `if __name__ == "__main__"` part of an application, BEFORE torch / numpy / this library are imported: idle OpenMP workers
-    spin briefly, then sleep (OMP_WAIT_POLICY=passive with GOMP_SPINCOUNT=100000, unless the user set them).  The host routines wake
+    spin briefly, then sleep (OMP_WAIT_POLICY=passive with GOMP_SPINCOUNT=5000, unless the user set them).  The host routines wake
     a team once per text chunk / staging pass: under a container CPU quota workers that always spin eat the quota (50 ms per 6 M-column
-    contig on 16 cores), workers that never spin pay a wake-up per region (30-33 ms), a short spin bridges the gaps between chunks
-    (21.9 ms).  A library import must not do this for the process, and it has no effect once libgomp is initialised - hence a
+    contig on 16 cores), workers that never spin pay a wake-up per region (30-33 ms), a short spin bridges the gaps between the regions
+    of one chunk (22 ms with 5,000 to 100,000 spins) - and the shortest of those leaves the quota to the threads that work: the streamed
+    site-file pipeline (three regions per pass, a pass every 3 ms) used 4.0 core-seconds per 0.29 s run and was throttled by the
+    16-core quota twice per run with 100,000 spins (about 1.6 ms of `pause` per idle thread), 2.5 core-seconds and never with 5,000.  A library import must not do this for the process, and it has no effect once libgomp is initialised - hence a
     function the application calls, first thing."""
     env = os.environ if environ is None else environ
     env.setdefault("OMP_WAIT_POLICY", "passive")
-    env.setdefault("GOMP_SPINCOUNT", "100000")
+    env.setdefault("GOMP_SPINCOUNT", "5000")
     return env
 
 
@@ -248,6 +252,20 @@ def stage_values(dst, n, src=None, fd=-1, src_off=0, src_dtype=np.int32):
                                  C.c_void_p(dst.ctypes.data), ed, C.byref(bad))
     _check(rc, "nsnp_stage_values")
     return bad.value
+
+
+def window_channels(x, n, row, channels, out=None):
+    """x: staged windows, a C-contiguous int16 / int32 array holding [n, 33, 18] values -> float32 [n, len(channels)] =
+    x[:, row, channels] (the coverage slice of PileupModel/predict.py:63), on all host threads (nsnp_window_channels)."""
+    ch = np.ascontiguousarray(channels, np.int32)
+    if x.dtype.itemsize not in (2, 4) or not x.flags["C_CONTIGUOUS"] or x.size < n * 594:
+        raise HostError("window_channels: x must be a C-contiguous int16 / int32 array of n x 33 x 18 values")
+    out = np.empty((n, ch.size), np.float32) if out is None else out
+    if out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size < n * ch.size:
+        raise HostError("window_channels: out must be a C-contiguous float32 array of n x len(channels)")
+    _check(lib().nsnp_window_channels(C.c_void_p(x.ctypes.data), x.dtype.itemsize, int(n), 33, 18, int(row), _ptr(ch), int(ch.size),
+                                      C.c_void_p(out.ctypes.data)), "nsnp_window_channels")
+    return out
 
 
 def parse_ctg_pos(rows, table):

@@ -441,9 +441,10 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     """The reference's ``predict(model, testing_paths, reference_index_file, batch_size, output_file, device)`` (PileupModel/predict.py:
     37-195) over this repository's ``.pd.bin`` site files (sitefile.write_pileup_bin / pd_to_bin: the arrays of make_bin_predict_data.py:
     90-100): every file's windows are STREAMED - a worker thread `pread`s passes of `pass_sites` windows from the page cache into one of
-    three pinned sets on all host cores (int32 counts narrowed to int16 on the way when they fit - they do: half the bytes over PCIe -
-    else int32) and parses the ``ctg:pos:ref33`` fields natively (dataset.py:127-132), a copy stream sends the pass, the compute stream
-    runs the PileupModel forward + argmax / max + the coverage slice of predict.py:63 and sends the calls (42 bytes per site) back; the
+    three pinned sets on all host cores (int16 counts as they are; the int32 counts of a reference-layout file narrowed to int16 on the
+    way when they fit - they do: half the bytes over PCIe - else int32) and parses the ``ctg:pos:ref33`` fields natively (dataset.py:127-132), a copy stream sends the pass, the compute stream
+    runs the PileupModel forward whose heads kernel writes argmax / max (10 bytes per site) straight into pinned host memory (the coverage
+    slice of predict.py:63 is taken from the staged pass on the host: the H2D copy of a pass is the only copy-engine work); the
     files are one pipeline, and the rows of a file are formatted (one native call over the reference's batches of `batch_size` sites,
     which restart with every file as its DataLoader does) and appended on a writer thread while the next file computes.
     testing_paths: a list of paths, or a directory (its ``*.bin`` files in os.listdir order: predict.py:215).  Returns rows written."""
@@ -456,7 +457,7 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     ctx = model.ctx
     dev = torch.device("cuda", ctx.device)
     st = stats if stats is not None else {}
-    for k in ("stage_s", "h2d_s", "gpu_s", "vcf_s", "bytes_h2d", "sites", "passes", "passes_int16", "wait_stage_s", "issue_s", "drain_s"):
+    for k in ("stage_s", "h2d_s", "gpu_s", "vcf_s", "bytes_h2d", "sites", "passes", "passes_int16", "wait_stage_s", "issue_s", "drain_s", "stage_values_s", "stage_coverage_s", "stage_fields_s", "gpu_idle_s"):
         st.setdefault(k, 0.0)
     if isinstance(testing_paths, (str, os.PathLike)):
         d = str(testing_paths)
@@ -466,9 +467,11 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     files = []
     for p in paths:
         idx = sitefile.array_index(p)
-        if "position_matrix" not in idx or "position" not in idx or idx["position_matrix"][0] != np.dtype(np.int32) or idx["position_matrix"][1][1:] != (33, 18):
-            raise sitefile.SiteFileError(f"{p}: not a pileup site file (position_matrix int32 [N,33,18] + position)")
+        if ("position_matrix" not in idx or "position" not in idx or idx["position_matrix"][0] not in (np.dtype(np.int32), np.dtype(np.int16))
+                or idx["position_matrix"][1][1:] != (33, 18)):
+            raise sitefile.SiteFileError(f"{p}: not a pileup site file (position_matrix int16 / int32 [N,33,18] + position)")
         files.append(dict(path=p, n=idx["position_matrix"][1][0], x_off=idx["position_matrix"][2], fd=os.open(p, os.O_RDONLY),
+                          elem=idx["position_matrix"][0].itemsize,
                           position=sitefile.read_arrays(p, mmap=True)["position"]))
     P = int(max(1, pass_sites))
     seg_off = np.concatenate([[0], np.cumsum([f["n"] for f in files])]).astype(np.int64)
@@ -504,12 +507,13 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
             res = getattr(model, "_site_results", None)
             if res is None or res["ga"].numel() < n_total:
                 mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
-                res = dict(ga=mk(n_total, torch.uint8), za=mk(n_total, torch.uint8), gm=mk(n_total, torch.float32), zm=mk(n_total, torch.float32),
-                           cov=mk((n_total, 8), torch.float32))
+                res = dict(ga=mk(n_total, torch.uint8), za=mk(n_total, torch.uint8), gm=mk(n_total, torch.float32), zm=mk(n_total, torch.float32))
                 model._site_results = res
             pos_all = np.empty(n_total, np.int64); ctg_all = np.empty(n_total, np.int32); refb_all = np.empty(n_total, np.uint8)
+            cov_all = np.empty((n_total, len(COV_CHANNELS)), np.float32)
             centers = (torch.arange(P, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
-            cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
+            # the rows of a file have a whole file's compute time to be written: a quarter of the host threads, the staging keeps the rest busy
+            writer_threads = max(1, host.lib().nsnp_host_threads() // 4)
             elem = [2 if narrow else 4]                 # int16 until a pass does not fit (then int32 for the rest of the run)
             lock = threading.Lock()
 
@@ -518,21 +522,28 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                 fi, a, b, o = passes[k]
                 f, m = files[fi], b - a
                 hs = hsets[k % n_sets]
-                e = elem[0]
+                e = 2 if f["elem"] == 2 else elem[0]
                 v = hs.x.numpy()[:m * 594 * e].view(np.int16 if e == 2 else np.int32)
-                if host.stage_values(v, m * 594, fd=f["fd"], src_off=f["x_off"] + a * 594 * 4):
+                if f["elem"] == 2:                      # int16 on disk (sitefile.write_pileup_bin's default): straight into the pinned set
+                    host.stage_values(v, m * 594, fd=f["fd"], src_off=f["x_off"] + a * 594 * 2, src_dtype=np.int16)
+                elif host.stage_values(v, m * 594, fd=f["fd"], src_off=f["x_off"] + a * 594 * 4):
                     with lock:
                         elem[0] = 4                     # a count beyond int16 (never at real coverage): this pass and the later ones go as int32
                     e = 4
                     v = hs.x.numpy()[:m * 594 * 4].view(np.int32)
                     host.stage_values(v, m * 594, fd=f["fd"], src_off=f["x_off"] + a * 594 * 4)
+                t1 = time.perf_counter()
+                host.window_channels(v, m, 16, COV_CHANNELS, out=cov_all[o:o + m])      # predict.py:63, from the staged pass: no D2H carries it
+                t2 = time.perf_counter()
                 fields = np.asarray(f["position"][a:b]).reshape(m, -1)
                 p_, c_, r_ = host.parse_ctg_pos_ref(fields, names.table)
-                if (c_ < 0).any():
-                    names.add_names([bytes(r).rstrip(b"\0").strip().split(b":")[0].decode() for r in fields[c_ < 0]])
+                while (c_ < 0).any():                   # a contig not seen before: one name per round (contigs are few, the parse is native)
+                    names.add_names([bytes(fields[int(np.argmax(c_ < 0))]).rstrip(b"\0").strip().split(b":")[0].decode()])
                     p_, c_, r_ = host.parse_ctg_pos_ref(fields, names.table)
                 pos_all[o:o + m] = p_; ctg_all[o:o + m] = c_; refb_all[o:o + m] = r_
-                return e, time.perf_counter() - t0
+                t3 = time.perf_counter()
+                st["stage_values_s"] += t1 - t0; st["stage_coverage_s"] += t2 - t1; st["stage_fields_s"] += t3 - t2
+                return e, t3 - t0
 
             def rows_of(fi, done):
                 """writer thread: the VCF rows of file fi (the reference's batches restart with every file)"""
@@ -544,13 +555,16 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                 if o1 > o0:
                     text, rows = host.vcf_format_batches(names.table, ctg_all[o0:o1], pos_all[o0:o1], refb_all[o0:o1], res["ga"][o0:o1].numpy(),
                                                          res["za"][o0:o1].numpy(), res["gm"][o0:o1].numpy(), res["zm"][o0:o1].numpy(),
-                                                         res["cov"][o0:o1].numpy(), batch_size=batch_size, score_mode=score_mode, as_view=True)
+                                                         cov_all[o0:o1], batch_size=batch_size, score_mode=score_mode, as_view=True,
+                                                         nthreads=writer_threads if fi + 1 < len(files) else 0)   # the last file: nothing else runs
                     out.write(text)
                     total_rows += rows
                 st["vcf_s"] += time.perf_counter() - t0
 
             tev = lambda: torch.cuda.Event(enable_timing=True)
-            ev = [dict(h0=tev(), h1=tev(), c0=tev(), c1=tev()) for _ in passes]
+            # h1 is what the main thread waits on before a host set is staged again: a blocking event, so that the wait sleeps (the host
+            # threads are the scarce resource of this pipeline: under a 16-core quota the staging + row threads use 13-14 of them)
+            ev = [dict(h0=tev(), h1=torch.cuda.Event(enable_timing=True, blocking=True), c0=tev(), c1=tev()) for _ in passes]
             seg_futs, next_seg = [], 0
             with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as writer:
                 futs = [pool.submit(stage, j) for j in range(min(2, len(passes)))]
@@ -571,34 +585,44 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                         ev[k]["h1"].record(copy_stream)
                     hs.h2d_done = ev[k]["h1"]
                     st["bytes_h2d"] += nb
+                    t_c = time.perf_counter()
                     if k + 2 < len(passes):
                         nxt = hsets[(k + 2) % n_sets]
                         if nxt.h2d_done is not None:
                             nxt.h2d_done.synchronize()
                         futs.append(pool.submit(stage, k + 2))
+                    t_s = time.perf_counter()
                     main.wait_event(ev[k]["h1"])
                     ev[k]["c0"].record(main)
                     x = ds.x[:nb].view(torch.int16 if e == 2 else torch.int32).view(m, 33, 18)
                     if e == 2:
                         x = x.to(torch.int32)                                         # (1.2 KB read + 2.4 KB written per site: ~1 ns of the forward's 51)
-                    gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(x.view(m * 33, 18), centers[:m])
-                    cov = x[:, 16, :].index_select(1, cov_idx).to(torch.float32)       # predict.py:63 on a FloatTensor
-                    for key, val in (("ga", ga), ("za", za), ("gm", gm), ("zm", zm), ("cov", cov)):
-                        res[key][o:o + m].copy_(val, non_blocking=True)
+                    # argmax / max of both heads (10 bytes per site) are written by the heads kernel straight into the pinned result arrays:
+                    # the H2D copy of a pass is the only copy-engine work of the run
+                    ctx.pileup_forward_windows_calls(x.view(m * 33, 18), centers[:m],
+                                                     calls_out=(res["ga"][o:o + m], res["za"][o:o + m], res["gm"][o:o + m], res["zm"][o:o + m]))
                     ev[k]["c1"].record(main)
-                    ds.free = torch.cuda.Event(); ds.free.record(main)
+                    ds.free = torch.cuda.Event(blocking=last_pass_of[fi] == k); ds.free.record(main)   # blocking: the writer thread sleeps on it
                     if last_pass_of[fi] == k:
                         while next_seg <= fi:
                             seg_futs.append(writer.submit(rows_of, next_seg, ds.free if next_seg == fi else None)); next_seg += 1
-                    st["issue_s"] += time.perf_counter() - t_i
+                    t_e = time.perf_counter()
+                    st["issue_s"] += t_e - t_i
+                    if "trace" in st:
+                        st["trace"].append((k, m, t_w, t_i, t_c, t_s, t_e, t_stage))
                 t_d = time.perf_counter()
                 torch.cuda.synchronize(dev)
                 for sf in seg_futs:
                     sf.result()
                 st["drain_s"] += time.perf_counter() - t_d
-            for e_ in ev:
+            for k, e_ in enumerate(ev):
                 st["h2d_s"] += e_["h0"].elapsed_time(e_["h1"]) * 1e-3
                 st["gpu_s"] += e_["c0"].elapsed_time(e_["c1"]) * 1e-3
+                if k:                                    # compute stream idle between two passes: waiting for a copy or for the host
+                    gap = ev[k - 1]["c1"].elapsed_time(e_["c0"]) * 1e-3
+                    st["gpu_idle_s"] += gap
+                    if "gaps" in st and gap > 5e-4:
+                        st["gaps"].append((k, round(gap * 1e3, 2), round(ev[k - 1]["c1"].elapsed_time(e_["h1"]), 2), round(e_["h0"].elapsed_time(e_["h1"]), 2)))
     finally:
         out.close()
         for f in files:

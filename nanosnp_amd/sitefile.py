@@ -125,13 +125,22 @@ def read_arrays(path, mmap=True) -> dict:
 
 
 # ---- <chr>.pd.bin ------------------------------------------------------------------------------------------------
-def write_pileup_bin(path, position_matrix, position, alt_info=None):
-    """position_matrix int32 [N,33,18]; position: N strings ``ctg:pos:ref33``; alt_info: N strings or None.
-    Row order is the caller's (the reference appends in input order: make_bin_predict_data.py:59-77)."""
-    x = np.ascontiguousarray(position_matrix, dtype=np.int32)
+def write_pileup_bin(path, position_matrix, position, alt_info=None, matrix_dtype="int16"):
+    """position_matrix integer [N,33,18]; position: N strings ``ctg:pos:ref33``; alt_info: N strings or None.
+    Row order is the caller's (the reference appends in input order: make_bin_predict_data.py:59-77).
+    matrix_dtype "int16" (default): the counts are stored as int16 when every one of them fits (a count is at most the read depth, and
+    the column encoder caps the depth at 144 reads: they always do), else as int32, the reference's Int32Atom (make_bin_predict_data.py:
+    92) - half the file, half the page-cache bytes the streamed predict loop stages and no narrowing on the way; "int32" keeps int32."""
+    x = np.ascontiguousarray(position_matrix)
+    if x.dtype.kind not in "iu":
+        raise SiteFileError("position_matrix must hold integers")
+    if matrix_dtype not in ("int16", "int32"):
+        raise SiteFileError("matrix_dtype: 'int16' or 'int32'")
     n = x.shape[0]
     if x.shape[1:] != (33, 18) or len(position) != n:
         raise SiteFileError("position_matrix must be [N,33,18] with one position string per row")
+    fits16 = x.dtype.itemsize <= 2 and x.dtype != np.uint16 or (x.size == 0 or (int(x.min()) >= -32768 and int(x.max()) <= 32767))
+    x = np.ascontiguousarray(x, dtype=np.int16 if (matrix_dtype == "int16" and fits16) else np.int32)
     pos = np.zeros((n, POSITION_WIDTH), np.uint8)
     for i, p in enumerate(position):
         b = p.encode() if isinstance(p, str) else bytes(p)
@@ -164,7 +173,8 @@ def read_pileup_bin(path, mmap=True):
             names.append(ctg); pos.append(int(p)); refb.append(ord(seq[16]))
         except (ValueError, IndexError) as e:
             raise SiteFileError(f"{path}: bad position string {s!r}") from e
-    return names, np.asarray(pos, np.int64), np.asarray(refb, np.uint8), a["position_matrix"]
+    x = a["position_matrix"]
+    return names, np.asarray(pos, np.int64), np.asarray(refb, np.uint8), (x if x.dtype == np.int32 else np.asarray(x, np.int32))
 
 
 def read_alt_info(path):
@@ -175,7 +185,7 @@ def read_alt_info(path):
     return [blob[offs[i]:offs[i + 1]].decode() for i in range(len(offs) - 1)]
 
 
-def pd_to_bin(pd_text: bytes, path):
+def pd_to_bin(pd_text: bytes, path, matrix_dtype="int16"):
     """``.pd`` text -> site file: ``transform_one_input`` of make_bin_predict_data.py:48-77 (594 ints, position string,
     alt_info per line).  Lines whose tensor field does not hold 594 integers are rejected, as ``np.array(...).reshape`` would."""
     xs, positions, alts = [], [], []
@@ -192,7 +202,7 @@ def pd_to_bin(pd_text: bytes, path):
         positions.append(fields[1].strip())
         alts.append(fields[2].strip())
     x = np.stack(xs) if xs else np.empty((0, 33, 18), np.int32)
-    write_pileup_bin(path, x, positions, alts)
+    write_pileup_bin(path, x, positions, alts, matrix_dtype=matrix_dtype)
     return len(xs)
 
 

@@ -244,12 +244,14 @@ def test_streamed_pd_bin_files_write_the_array_path_vcf(tmp_path, pileup_weights
     m = LSTMNetwork().load_weight_list(pileup_weights)
     cuts = [0, n // 3, n // 3, n - 5, n]                               # three files + an empty one
     d = tmp_path / "bins"; d.mkdir()
-    files, want = [], b""
+    files, files32, want = [], [], b""
+    (tmp_path / "bins32").mkdir()
     for i in range(4):
         a, b = cuts[i], cuts[i + 1]
         p = d / f"part{i}.pd.bin"
-        sitefile.write_pileup_bin(p, x[a:b], position[a:b])
-        files.append(str(p))
+        sitefile.write_pileup_bin(p, x[a:b], position[a:b])                                  # int16 counts on disk (the default)
+        sitefile.write_pileup_bin(tmp_path / "bins32" / p.name, x[a:b], position[a:b], matrix_dtype="int32")   # the reference's Int32Atom layout
+        files.append(str(p)); files32.append(str(tmp_path / "bins32" / p.name))
         o = tmp_path / "arr.vcf"
         predict_pileup(m, x[a:b], names[a:b], pos[a:b], refb[a:b], fai, str(o), batch_size=100)
         body = o.read_bytes()
@@ -260,10 +262,15 @@ def test_streamed_pd_bin_files_write_the_array_path_vcf(tmp_path, pileup_weights
     for kw in (dict(), dict(pass_sites=64), dict(pass_sites=7), dict(narrow=False), dict(narrow=False, pass_sites=50), dict(pass_sites=n)):
         o = tmp_path / "stream.vcf"
         st = {}
-        rows = predict_pileup_bins(m, files, fai, str(o), batch_size=100, stats=st, **kw)
+        rows = predict_pileup_bins(m, files32, fai, str(o), batch_size=100, stats=st, **kw)
         assert o.read_bytes() == want, kw
         assert rows == want.count(b"\n") - header.count(b"\n") and st["sites"] == n
         assert st["passes_int16"] == (0 if kw.get("narrow") is False else st["passes"])
+        st = {}
+        assert predict_pileup_bins(m, files, fai, str(o), batch_size=100, stats=st, **kw) == rows and o.read_bytes() == want, kw
+        assert st["passes_int16"] == st["passes"]                                            # int16 files travel as they are
+        mixed = [files[0], files32[1], files32[2], files[3]]
+        assert predict_pileup_bins(m, mixed, fai, str(o), batch_size=100, **kw) == rows and o.read_bytes() == want, kw
     # a directory: the reference takes os.listdir order and only names ending in .bin (predict.py:215)
     (d / "notes.txt").write_text("not a bin")
     order = [os.path.join(str(d), f) for f in os.listdir(d) if f.endswith(".bin")]
@@ -274,7 +281,8 @@ def test_streamed_pd_bin_files_write_the_array_path_vcf(tmp_path, pileup_weights
     # a count beyond int16: that pass and the later ones travel as int32, same rows as narrow=False
     xb = x[:200].copy(); xb[150, 3, 2] = 40000
     pb = tmp_path / "big.pd.bin"
-    sitefile.write_pileup_bin(pb, xb, position[:200])
+    sitefile.write_pileup_bin(pb, xb, position[:200])                                        # does not fit int16: stored as int32
+    assert sitefile.array_index(pb)["position_matrix"][0] == np.int32 and sitefile.array_index(files[0])["position_matrix"][0] == np.int16
     st = {}
     predict_pileup_bins(m, [str(pb)], fai, str(o1), batch_size=100, pass_sites=64, stats=st)
     predict_pileup_bins(m, [str(pb)], fai, str(o2), batch_size=100, narrow=False)

@@ -64,6 +64,68 @@ def test_position_fields():
     assert np.array_equal(pos, np.arange(100_000)) and (ctg == 1).all()
 
 
+def test_pd_position_fields_and_int16_staging(tmp_path):
+    """the two host pieces of pipeline.predict_pileup_bins: the `position` strings of a .pd.bin read as PileupModel/dataset.py:127-132
+    reads them (strip, split(':') into exactly three parts, int(pos), ord(seq[16])), and int32 counts narrowed to int16 while staged"""
+    tbl = host.ContigTable(["chr1", "chr10"])
+    seq = "ACGTACGTACGTACGT" + "G" + "TTTTTTTTTTTTTTTT"
+    fields = [f"chr1:12:{seq}", f" chr10: 7 :{seq[:16]}c{seq[17:]} ", f"chrUn:+99:{'N' * 33}", f"chr1:-5:{seq[:17]}", f"chr1:000123:{seq}extra"]
+    rows = np.zeros((len(fields), sitefile.POSITION_WIDTH), np.uint8)
+    for i, f in enumerate(fields):
+        rows[i, :len(f)] = np.frombuffer(f.encode(), np.uint8)
+    pos, ctg, refb = host.parse_ctg_pos_ref(rows, tbl)
+    want = [(f.strip().split(":")) for f in fields]
+    assert pos.tolist() == [int(w[1]) for w in want] == [12, 7, 99, -5, 123]
+    assert refb.tolist() == [ord(w[2][16]) for w in want] and ctg.tolist() == [0, 1, -1, 0, 0]
+    for bad in ("chr1:12", f"chr1:12:{seq}:x", f"chr1:1x:{seq}", f"chr1::{seq}", "chr1:12:" + seq[:16], f"chr1:1.0:{seq}", ""):
+        r = rows[:2].copy(); r[1] = 0; r[1, :len(bad)] = np.frombuffer(bad.encode(), np.uint8)
+        with pytest.raises(host.HostError):
+            host.parse_ctg_pos_ref(r, tbl)
+    assert [a.shape for a in host.parse_ctg_pos_ref(np.zeros((0, 83), np.uint8), tbl)] == [(0,)] * 3
+    many = np.zeros((50_000, 83), np.uint8)
+    txt = [f"chr10:{i * 3}:{seq}" for i in range(50_000)]
+    for i, f in enumerate(txt):
+        many[i, :len(f)] = np.frombuffer(f.encode(), np.uint8)
+    pos, ctg, refb = host.parse_ctg_pos_ref(many, tbl)
+    assert np.array_equal(pos, np.arange(50_000) * 3) and (ctg == 1).all() and (refb == ord("G")).all()
+    # int32 -> int16: exact when every value fits, counted when not; from a file and from memory
+    rng = np.random.default_rng(2)
+    a = rng.integers(-300, 301, 2_000_003).astype(np.int32)
+    a[[0, 7, 1_999_999]] = (32767, -32768, 1234)
+    p = tmp_path / "c.bin"
+    with open(p, "wb") as f:
+        f.write(b"y" * 128); f.write(a.tobytes())
+    fd = os.open(p, os.O_RDONLY)
+    try:
+        for off, n in ((0, a.size), (3, 1_000_001), (a.size - 1, 1), (9, 0)):
+            d = np.full(n + 2, 77, np.int16)
+            assert host.stage_values(d, n, fd=fd, src_off=128 + 4 * off) == 0 and np.array_equal(d[:n], a[off:off + n]) and (d[n:] == 77).all()
+            assert host.stage_values(d, n, src=a, src_off=4 * off) == 0 and np.array_equal(d[:n], a[off:off + n])
+        b = a.copy(); b[[1, 1_000_000, 2_000_002]] = (32768, -32769, 1 << 20)
+        d = np.empty(b.size, np.int16)
+        assert host.stage_values(d, b.size, src=b) == 3 and host.stage_values(d, 1_000_000, src=b) == 1
+        a16 = a.astype(np.int16)
+        d = np.empty(500, np.int16)
+        assert host.stage_values(d, 500, src=a16, src_off=6, src_dtype=np.int16) == 0 and np.array_equal(d, a16[3:503])
+        with pytest.raises(host.HostError):
+            host.stage_values(np.empty(4, np.int32), 4, src=a16, src_dtype=np.int16)             # widening is not offered
+    finally:
+        os.close(fd)
+    # the coverage slice of predict.py:63 from a staged pass (int16 or int32 values), as float32
+    ch = [0, 1, 2, 3, 9, 10, 11, 12]
+    for dt in (np.int16, np.int32):
+        x = rng.integers(-40, 4000, (20_001, 33, 18)).astype(dt)
+        assert np.array_equal(host.window_channels(x.reshape(-1), 20_001, 16, ch), x[:, 16, ch].astype(np.float32))
+        out = np.full((5, 8), -1, np.float32)
+        host.window_channels(x.reshape(-1), 3, 0, ch, out=out)
+        assert np.array_equal(out[:3], x[:3, 0, ch]) and (out[3:] == -1).all()
+    assert host.window_channels(np.zeros(0, np.int16), 0, 16, ch).shape == (0, 8)
+    for bad in (lambda: host.window_channels(np.zeros(594, np.int16), 1, 16, [18]), lambda: host.window_channels(np.zeros(594, np.int16), 1, 33, ch),
+                lambda: host.window_channels(np.zeros(593, np.int16), 1, 16, ch), lambda: host.window_channels(np.zeros(594, np.int8), 1, 16, ch)):
+        with pytest.raises(host.HostError):
+            bad()
+
+
 def test_reference_rows_follow_the_reference_quirks_on_any_device():
     """DeviceReference.rows (torch gather; here on CPU tensors) against host.haplotype_ref_rows: lower-case / N / IUPAC bases, positions
     past the end, NEGATIVE 0-based indices that wrap like Python indexing, unknown contigs, an empty contig"""

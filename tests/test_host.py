@@ -229,7 +229,7 @@ def test_importing_the_host_library_leaves_the_environment_alone():
     """a library import must not export OMP_WAIT_POLICY for the whole process; applications call recommend_omp_env()"""
     import subprocess, sys
     code = ("import os; os.environ.pop('OMP_WAIT_POLICY', None); from nanosnp_amd import host; host.lib(); "
-            "assert 'OMP_WAIT_POLICY' not in os.environ; e = host.recommend_omp_env({}); assert e == {'OMP_WAIT_POLICY': 'passive', 'GOMP_SPINCOUNT': '100000'}; "
+            "assert 'OMP_WAIT_POLICY' not in os.environ; e = host.recommend_omp_env({}); assert e == {'OMP_WAIT_POLICY': 'passive', 'GOMP_SPINCOUNT': '5000'}; "
             "assert host.recommend_omp_env({'OMP_WAIT_POLICY': 'active'})['OMP_WAIT_POLICY'] == 'active'")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
 

@@ -1,5 +1,6 @@
 """Flat binary site containers (nanosnp_amd/sitefile.py) against the arrays the reference's HDF5 bins hold."""
 import gzip
+import os
 
 import numpy as np
 import pytest
@@ -50,6 +51,34 @@ def test_pd_to_bin_holds_what_the_reference_bin_holds(tmp_path, name):
         ctg, q, seq = position_s.strip().split(":")
         assert (names[i], pos[i], refb[i]) == (ctg, int(q), ord(seq[16]))
         assert alts[i] == alt_s.strip()
+
+
+def test_pileup_bin_counts_are_int16_on_disk_when_they_fit(tmp_path):
+    """write_pileup_bin's default keeps the counts as int16 (half the file and half the bytes the streamed predict loop stages) unless a
+    value does not fit, or the caller asks for the reference's Int32Atom; read_pileup_bin hands out int32 either way"""
+    rng = np.random.default_rng(5)
+    x = rng.integers(-144, 145, (37, 33, 18)).astype(np.int32)
+    position = [f"chr1:{i + 1}:{'ACGT' * 8}A" for i in range(37)]
+    sizes = {}
+    for md, want in (("int16", np.int16), ("int32", np.int32)):
+        p = tmp_path / f"{md}.bin"
+        sitefile.write_pileup_bin(p, x, position, matrix_dtype=md)
+        assert sitefile.array_index(p)["position_matrix"][0] == want
+        got = sitefile.read_pileup_bin(p)[3]
+        assert got.dtype == np.int32 and np.array_equal(got, x)
+        sizes[md] = os.path.getsize(p)
+    assert abs(sizes["int32"] - sizes["int16"] - x.size * 2) < 64                        # arrays start on 64-byte boundaries
+    for edge, want in ((32767, np.int16), (-32768, np.int16), (32768, np.int32), (-32769, np.int32)):
+        y = x.copy(); y[5, 16, 3] = edge
+        sitefile.write_pileup_bin(tmp_path / "e.bin", y, position)
+        assert sitefile.array_index(tmp_path / "e.bin")["position_matrix"][0] == want
+        assert np.array_equal(sitefile.read_pileup_bin(tmp_path / "e.bin")[3], y)
+    sitefile.write_pileup_bin(tmp_path / "s.bin", x.astype(np.int16), position)            # int16 in, int16 out
+    assert np.array_equal(sitefile.read_pileup_bin(tmp_path / "s.bin")[3], x)
+    with pytest.raises(sitefile.SiteFileError):
+        sitefile.write_pileup_bin(tmp_path / "f.bin", x.astype(np.float32), position)
+    with pytest.raises(sitefile.SiteFileError):
+        sitefile.write_pileup_bin(tmp_path / "f.bin", x, position, matrix_dtype="int8")
 
 
 def test_pileup_bin_rejects_malformed_input(tmp_path):

@@ -99,6 +99,17 @@ def cat_conv_alg_flop(rows=40, L=11):
     return total
 
 
+def cgroup_cpu_stat():
+    """(throttled periods, throttled thread-microseconds, cpu microseconds used) of this cgroup so far, or None outside cgroup v2: the
+    difference around a timed region says whether a CPU quota stalled it (a streamed pipeline that keeps 16 host threads spinning is
+    frozen for the rest of a 100 ms period when the quota runs out: 10-20 ms holes in the GPU timeline)"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)), int(d.get("usage_usec", 0))
+    except (OSError, ValueError):
+        return None
+
+
 def usable_cores():
     """cores this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
