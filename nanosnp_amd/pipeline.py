@@ -454,10 +454,12 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     import torch
     from . import sitefile
     from .hap_pipeline import _LocalNames
+    t_begin = time.perf_counter()
     ctx = model.ctx
     dev = torch.device("cuda", ctx.device)
     st = stats if stats is not None else {}
-    for k in ("stage_s", "h2d_s", "gpu_s", "vcf_s", "bytes_h2d", "sites", "passes", "passes_int16", "wait_stage_s", "issue_s", "drain_s", "stage_values_s", "stage_coverage_s", "stage_fields_s", "gpu_idle_s"):
+    for k in ("stage_s", "h2d_s", "gpu_s", "vcf_s", "bytes_h2d", "sites", "passes", "passes_int16", "wait_stage_s", "issue_s", "drain_s", "stage_values_s",
+              "stage_coverage_s", "stage_fields_s", "gpu_idle_s", "setup_s", "account_s"):
         st.setdefault(k, 0.0)
     if isinstance(testing_paths, (str, os.PathLike)):
         d = str(testing_paths)
@@ -504,10 +506,15 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
             for s_ in dsets:
                 s_.free = None
             copy_stream.wait_stream(main)
+            # pinned result arrays: one slot per file in flight (computing / being written / next), not one per run - pinning memory costs
+            # about 0.5 ms per MB and a run may hold hundreds of files
+            max_n = max(f["n"] for f in files)
+            n_slots = 3
             res = getattr(model, "_site_results", None)
-            if res is None or res["ga"].numel() < n_total:
+            if res is None or res["ga"].numel() < n_slots * max_n:
                 mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
-                res = dict(ga=mk(n_total, torch.uint8), za=mk(n_total, torch.uint8), gm=mk(n_total, torch.float32), zm=mk(n_total, torch.float32))
+                res = dict(ga=mk(n_slots * max_n, torch.uint8), za=mk(n_slots * max_n, torch.uint8), gm=mk(n_slots * max_n, torch.float32),
+                           zm=mk(n_slots * max_n, torch.float32))
                 model._site_results = res
             pos_all = np.empty(n_total, np.int64); ctg_all = np.empty(n_total, np.int32); refb_all = np.empty(n_total, np.uint8)
             cov_all = np.empty((n_total, len(COV_CHANNELS)), np.float32)
@@ -552,9 +559,11 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                     done.synchronize()
                 t0 = time.perf_counter()
                 o0, o1 = int(seg_off[fi]), int(seg_off[fi + 1])
+                r0 = (fi % n_slots) * max_n
+                r1 = r0 + (o1 - o0)
                 if o1 > o0:
-                    text, rows = host.vcf_format_batches(names.table, ctg_all[o0:o1], pos_all[o0:o1], refb_all[o0:o1], res["ga"][o0:o1].numpy(),
-                                                         res["za"][o0:o1].numpy(), res["gm"][o0:o1].numpy(), res["zm"][o0:o1].numpy(),
+                    text, rows = host.vcf_format_batches(names.table, ctg_all[o0:o1], pos_all[o0:o1], refb_all[o0:o1], res["ga"][r0:r1].numpy(),
+                                                         res["za"][r0:r1].numpy(), res["gm"][r0:r1].numpy(), res["zm"][r0:r1].numpy(),
                                                          cov_all[o0:o1], batch_size=batch_size, score_mode=score_mode, as_view=True,
                                                          nthreads=writer_threads if fi + 1 < len(files) else 0)   # the last file: nothing else runs
                     out.write(text)
@@ -568,6 +577,7 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
             seg_futs, next_seg = [], 0
             with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as writer:
                 futs = [pool.submit(stage, j) for j in range(min(2, len(passes)))]
+                st["setup_s"] += time.perf_counter() - t_begin
                 for k, (fi, a, b, o) in enumerate(passes):
                     m = b - a
                     t_w = time.perf_counter()
@@ -599,8 +609,11 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                         x = x.to(torch.int32)                                         # (1.2 KB read + 2.4 KB written per site: ~1 ns of the forward's 51)
                     # argmax / max of both heads (10 bytes per site) are written by the heads kernel straight into the pinned result arrays:
                     # the H2D copy of a pass is the only copy-engine work of the run
+                    if a == 0 and fi >= n_slots and fi - n_slots < len(seg_futs):
+                        seg_futs[fi - n_slots].result()                                # the rows of the file that had this result slot are written
+                    r = (fi % n_slots) * max_n + a
                     ctx.pileup_forward_windows_calls(x.view(m * 33, 18), centers[:m],
-                                                     calls_out=(res["ga"][o:o + m], res["za"][o:o + m], res["gm"][o:o + m], res["zm"][o:o + m]))
+                                                     calls_out=(res["ga"][r:r + m], res["za"][r:r + m], res["gm"][r:r + m], res["zm"][r:r + m]))
                     ev[k]["c1"].record(main)
                     ds.free = torch.cuda.Event(blocking=last_pass_of[fi] == k); ds.free.record(main)   # blocking: the writer thread sleeps on it
                     if last_pass_of[fi] == k:
@@ -615,6 +628,7 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                 for sf in seg_futs:
                     sf.result()
                 st["drain_s"] += time.perf_counter() - t_d
+            t_a = time.perf_counter()
             for k, e_ in enumerate(ev):
                 st["h2d_s"] += e_["h0"].elapsed_time(e_["h1"]) * 1e-3
                 st["gpu_s"] += e_["c0"].elapsed_time(e_["c1"]) * 1e-3
@@ -623,6 +637,7 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                     st["gpu_idle_s"] += gap
                     if "gaps" in st and gap > 5e-4:
                         st["gaps"].append((k, round(gap * 1e3, 2), round(ev[k - 1]["c1"].elapsed_time(e_["h1"]), 2), round(e_["h0"].elapsed_time(e_["h1"]), 2)))
+            st["account_s"] += time.perf_counter() - t_a
     finally:
         out.close()
         for f in files:

@@ -165,6 +165,25 @@ def test_e2e_text_to_vcf_line():
     assert set(m) >= {"wait_parse_s", "issue_s", "wait_counts_s", "vcf_s", "write_s"} and sum(m[k] for k in ("wait_parse_s", "issue_s", "vcf_s", "write_s")) <= d["ms_per_step"] * 1e-3 * 1.05
 
 
+def test_pd_e2e_site_files_to_vcf_line():
+    """bench.py --workload pd-e2e (a labelled measurement): .pd.bin window files on the page cache -> pinned staging / H2D / forward with the
+    calls written into pinned memory -> VCF; both on-disk layouts, the bounding station, the host-CPU account, parity against the one-pass run
+    and the oracle"""
+    env = dict(os.environ, NSNP_PDE2E_SITES="150000")
+    d = _run("--workload", "pd-e2e", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1.5", env=env)
+    assert d["scaling"] == "strong" and d["unit"] == "sites/s" and d["config"]["sites"] == 150000 and "NOT the headline" in d["config"]["workload"]
+    par = d["parity_sample"]
+    assert par["ok"] and par["timed_run_equals_the_one_pass_run"] and par["the_K_files_gave_equal_rows"] and par["file_windows_equal_the_oracle_encode"]
+    assert par["max_abs_dp_vs_oracle"] <= par["tolerance"] == 1e-4
+    assert abs(d["value"] - 150000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6 and 0.0 < d["fraction_of_hbm_resident_rate"] <= 1.05
+    assert len(d["stage_busy_s_per_step"]) == 4 and d["bound_by"] in d["stage_busy_s_per_step"] and d["cpu_baseline"]["value"] > 0
+    assert d["bytes_over_pcie_per_site"] == 1188
+    sv = d["second_values"]
+    assert set(sv) == {"int32_counts_on_disk_narrowed_while_staged", "int32_counts_on_disk_sent_as_int32"}
+    assert all(v["vcf_equals_the_int16_run"] and v["value"] > 0 for v in sv.values())
+    assert sv["int32_counts_on_disk_sent_as_int32"]["bytes_over_pcie_per_site"] == 2376
+
+
 @pytest.mark.parametrize("workload", ["pileup", "two-stage", "haplotype"])
 def test_two_ranks_through_the_launcher_on_one_gpu(workload):
     """`bench.py --gpus 2` end to end on the one-GPU box: the parent starts the ranks, both run the real kernels on GPU 0, the

@@ -96,6 +96,8 @@ def _run(args, rank, world, local_rank, emit, created):
         for _ in range(W):
             predict_pileup_bins(model, [path], fai, out_path, pass_sites=pass_sites, narrow=narrow)
         torch.cuda.synchronize(dev)
+        if os.path.exists(out_path):
+            os.remove(out_path)                      # (truncating the previous run's half gigabyte of tmpfs pages is not part of a run)
         st = {}
         c0 = bc.cgroup_cpu_stat()
         t0 = time.perf_counter()
@@ -116,7 +118,7 @@ def _run(args, rank, world, local_rank, emit, created):
                 "stage_busy_s_per_step": {names[k]: round(v, 4) for k, v in per.items()}, "bound_by": names[max(per, key=per.get)],
                 "h2d_GB_per_s": st.get("bytes_h2d", 0.0) / max(st.get("h2d_s", 0.0), 1e-9) / 1e9, "bytes_over_pcie_per_site": bps,
                 "pcie_bound_sites_per_s_at_the_measured_h2d_rate": st.get("bytes_h2d", 0.0) / max(st.get("h2d_s", 0.0), 1e-9) / bps,
-                "main_thread_s_per_step": {k: round(st.get(k, 0.0) / steps, 4) for k in ("wait_stage_s", "issue_s", "drain_s")},
+                "main_thread_s_per_step": {k: round(st.get(k, 0.0) / steps, 4) for k in ("setup_s", "wait_stage_s", "issue_s", "drain_s", "account_s")},
                 "staging_thread_s_per_step": {k: round(st.get(k, 0.0) / steps, 4) for k in ("stage_values_s", "stage_coverage_s", "stage_fields_s")},
                 "compute_stream_idle_between_passes_s_per_step": round(st.get("gpu_idle_s", 0.0) / steps, 4), "host_cpu_over_the_timed_region": st.get("host_cpu")}
 

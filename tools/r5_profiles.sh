@@ -52,6 +52,7 @@ python bench.py --workload two-stage --steps 3 --warmup 1 > gpurun_out/r05_profi
 python bench.py --workload deep60 --steps 8 --warmup 2 > gpurun_out/r05_profiles/r05_deep60_line.json 2> gpurun_out/r05_deep60_line.err; echo deep rc=$?
 python bench.py --workload e2e --steps 8 --warmup 2 > gpurun_out/r05_profiles/r05_e2e_line.json 2> gpurun_out/r05_e2e_line.err; echo e2e rc=$?
 python bench.py --workload hap-e2e --steps 8 --warmup 1 > gpurun_out/r05_profiles/r05_hap_e2e_line.json 2> gpurun_out/r05_hap_e2e_line.err; echo hape2e rc=$?
+python bench.py --workload pd-e2e --steps 16 --warmup 1 > gpurun_out/r05_profiles/r05_pd_e2e_line.json 2> gpurun_out/r05_pd_e2e_line.err; echo pde2e rc=$?
 fi
 rm -rf gpurun_out/prof_r05*           # raw rocprof output stays on the box (the summaries travel)
 ls gpurun_out/r05_profiles
