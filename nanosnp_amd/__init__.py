@@ -7,6 +7,8 @@ this package holds only the host-side mirror of the reference's interface for th
     haplotype_model.LSTMNetwork  HaplotypeModel/model_dev.py LSTMNetwork (predict only)
     pipeline                     mpileup text -> column encode -> windows -> PileupModel -> pileup.vcf in one pass
                                  (dna_sv_tensor make_candidate_snp_tensor + make_predict_data + predict.py)
+                                 and .pd.bin window files -> pinned staging / H2D / PileupModel -> pileup.vcf, streamed
+                                 (PileupModel/predict.py + dataset.py PredictDataset behind a DataLoader)
     hap_pipeline                 haplotype site files -> pinned staging / H2D / features + HaplotypeModel -> haplotype.csv, streamed
                                  (HaplotypeModel/predict_dev.py + dataset_dev.py TestDataset behind a DataLoader)
     predict                      PileupModel/predict.py / HaplotypeModel/predict_dev.py loops on arrays
