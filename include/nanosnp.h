@@ -174,7 +174,10 @@ int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts, const int6
 /* nsnp_pileup_forward_windows and predict.py:54-57 (np.argmax / np.max of both heads) in one call: the fp32 heads kernel writes
  * gt_arg / zy_arg (uint8) and gt_max / zy_max (fp32) from the registers that hold the probabilities, one launch less per batch than
  * forward + nsnp_pileup_postprocess; every other arithmetic mode / kernel generation runs the two back to back on `stream`.
- * Same values as the two-call sequence, bit for bit (first maximum wins, as np.argmax). */
+ * Same values as the two-call sequence, bit for bit (first maximum wins, as np.argmax).  gt_arg, zy_arg, gt_max, zy_max may be device
+ * pointers or pointers into PINNED HOST memory (hipHostMalloc / hipHostRegister: mapped on the device): the kernel then writes the 10
+ * bytes per site straight into host memory and a streamed caller needs no D2H copy - the values are valid on the host once an event
+ * recorded on `stream` behind the call has completed (nanosnp_amd/pipeline.py predict_pileup_bins). */
 int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, int64_t N,
                                       float* gt_prob, float* zy_prob, uint8_t* gt_arg, uint8_t* zy_arg,
                                       float* gt_max, float* zy_max, void* stream);

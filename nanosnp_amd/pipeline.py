@@ -467,12 +467,12 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     else:
         paths = [str(p) for p in testing_paths]
     files = []
-    for p in paths:
+    for p in paths:                                    # every header is checked before a descriptor is opened or a row is written
         idx = sitefile.array_index(p)
         if ("position_matrix" not in idx or "position" not in idx or idx["position_matrix"][0] not in (np.dtype(np.int32), np.dtype(np.int16))
                 or idx["position_matrix"][1][1:] != (33, 18)):
             raise sitefile.SiteFileError(f"{p}: not a pileup site file (position_matrix int16 / int32 [N,33,18] + position)")
-        files.append(dict(path=p, n=idx["position_matrix"][1][0], x_off=idx["position_matrix"][2], fd=os.open(p, os.O_RDONLY),
+        files.append(dict(path=p, n=idx["position_matrix"][1][0], x_off=idx["position_matrix"][2], fd=-1,
                           elem=idx["position_matrix"][0].itemsize,
                           position=sitefile.read_arrays(p, mmap=True)["position"]))
     P = int(max(1, pass_sites))
@@ -490,6 +490,8 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     total_rows = 0
     out = open(output_file, "wb")
     try:
+        for f in files:
+            f["fd"] = os.open(f["path"], os.O_RDONLY)
         out.write(host.vcf_header(fai_text).encode())
         if passes:
             n_sets = min(3, len(passes))
@@ -641,5 +643,6 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     finally:
         out.close()
         for f in files:
-            os.close(f["fd"])
+            if f["fd"] >= 0:
+                os.close(f["fd"])
     return total_rows

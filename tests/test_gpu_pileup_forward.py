@@ -440,6 +440,15 @@ def test_fused_forward_and_argmax_equals_the_two_calls(pileup_weights, opts):
     assert torch.equal(gt, gt2) and torch.equal(zy, zy2)
     assert torch.equal(ga, ga2) and torch.equal(za, za2) and torch.equal(gm, gm2) and torch.equal(zm, zm2)
     assert torch.equal(ga2.long(), gt2.argmax(1)) and torch.equal(gm2, gt2.max(1).values)
+    # the same call with the four call arrays in PINNED HOST memory (slices at odd offsets): the kernel writes them over PCIe, no copy
+    pin = [torch.full((n + 7,), 99, dtype=dt, pin_memory=True) for dt in (torch.uint8, torch.uint8, torch.float32, torch.float32)]
+    gt3, zy3, *_ = c.pileup_forward_windows_calls(counts, centers, calls_out=tuple(t[3:3 + n] for t in pin))
+    torch.cuda.synchronize()
+    assert torch.equal(gt3, gt2) and torch.equal(zy3, zy2)
+    for t, want in zip(pin, (ga2, za2, gm2, zm2)):
+        assert torch.equal(t[3:3 + n], want.cpu()) and (t[:3] == 99).all() and (t[3 + n:] == 99).all()
+    with pytest.raises(_lib.NanoSNPError):
+        c.pileup_forward_windows_calls(counts, centers, calls_out=(torch.empty(n, dtype=torch.uint8),) * 2 + (torch.empty(n),) * 2)   # pageable host memory
     c.close()
 
 
