@@ -92,8 +92,11 @@ def run(args, rank, world, local_rank, emit=None):
         dist.barrier()
     stats = {}
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(K):
+        t_s = time.perf_counter()
         rows_text, n_sites, n_rows = one_pass(stats)
+        step_ms.append(round((time.perf_counter() - t_s) * 1e3, 2))
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -194,6 +197,9 @@ def run(args, rank, world, local_rank, emit=None):
                                 "round trip in the loop); wall < sum when they overlap.  main_thread_s_per_step: where the issuing thread spends the step "
                                 "(issue_s includes wait_counts_s)"},
             "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "vcf_s", "write_s")},
+            "step_ms_each": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms), "all": step_ms,
+                             "note": "a step well above the median early in a process is the HIP runtime opening a further SDMA copy engine (6-8 ms inside "
+                                     "hipMemcpyAsync on its first use: docs/rounds/r05.md), or the CPU quota"},
             **({"bf16x3": second} if second else {}),
             **({"per_rank_s_per_step": per_rank} if per_rank else {}),
             "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,
