@@ -48,6 +48,10 @@ __device__ __forceinline__ int nt4(int b)            // cpp_aux.cpp:85-102 (only
 // Iterator over the counted indels of a column (those with length <= 60), following exactly
 // the scan of tensor_maker.cpp:83-114: '^' swallows the next byte; '+'/'-' read decimal digits,
 // then skip `advance` bytes (advance == 0 re-examines the byte after the sign/digits).
+// An allele the end of the column cuts short (advance > the bytes left; only the last construct of a column can be) is an allele
+// of its own in the reference: tensor_maker.cpp:101 appends `advance` characters from c_str() whatever the string still holds, so
+// the key carries the string's terminating NUL and can equal no complete allele.  Such an indel comes back with bit 8 of `sign`
+// set, which keeps it apart from every other in the comparisons below.
 template <typename P>
 struct IndelIterT {
     P base; int64_t i, end;
@@ -63,7 +67,7 @@ struct IndelIterT {
                 const int64_t l = adv < avail ? adv : avail;
                 const int64_t o = i;
                 i += adv;           // (advance-1) + the loop's ++; past-the-end is clamped by the while
-                if (adv <= MAX_INDEL) { off = o; len = (int)l; sign = b; return true; }
+                if (adv <= MAX_INDEL) { off = o; len = (int)l; sign = b | (adv > avail ? 0x100 : 0); return true; }
             } else if (b == '^') {
                 i += 2;
             } else {
@@ -95,7 +99,7 @@ __device__ __forceinline__ Quad rescan_maxima(P base, int64_t begin, int64_t end
     IndelIterT<P> a{base, begin, end};
     int64_t ao; int al, as;
     while (a.next(ao, al, as)) {
-        const int kind = (as == '-' ? 2 : 0) + (al > 0 && is_fwd_char(base[ao]) ? 0 : 1);
+        const int kind = ((as & 0xff) == '-' ? 2 : 0) + (al > 0 && is_fwd_char(base[ao]) ? 0 : 1);
         IndelIterT<P> b2{base, begin, end};
         int64_t bo; int bl, bs; int same = 0;
         while (b2.next(bo, bl, bs)) {
@@ -484,8 +488,9 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
                         }
                         atomicAdd(&cacc[0][owner], nx); atomicAdd(&cacc[1][owner], ny);
                         if (nz & 0xffffffu) atomicAdd(&cacc[2][owner], nz & 0xffffffu);
-                        // a flagged byte inside the bytes a construct consumes is not an opener (pass 1 cannot know): exact path
-                        if (mybad || inner) atomicOr(&cacc[2][owner], 0x80000000u);                   // (bit 31 of word 2)
+                        // a flagged byte inside the bytes a construct consumes is not an opener (pass 1 cannot know): exact path; so is a
+                        // counted allele the end of its column cuts short (an allele of its own in the reference: IndelIterT)
+                        if (mybad || inner || (counted && adv > nskip)) atomicOr(&cacc[2][owner], 0x80000000u);   // (bit 31 of word 2)
                     }
                     // the counted indels move to the front of the list, order kept (slot c <= j: every slot of this trip has been read)
                     const unsigned long long cm = __ballot(counted);

@@ -53,7 +53,14 @@ static int base_channel(int c)
     }
 }
 
-typedef struct { const char* p; int len; int count; } key_t_;
+/* One counted indel: the `len` allele characters the column still holds behind the digits, the declared length `adv`.
+ * tensor_maker.cpp:101 appends `advance` characters starting at c_str() + base_idx WHATEVER the column still holds: an allele the
+ * end of the column cuts short (adv > len; only the last construct of a column can be) gets a key of adv characters = the visible
+ * ones, the string's terminating NUL, and adv - len - 1 bytes of whatever follows the buffer.  The NUL alone makes that key differ
+ * from every complete allele of the column (whose characters are all inside the string), so a cut allele is ALWAYS an allele of its
+ * own - never merged with a complete "+2AC" that shows the same visible characters - and in std::map order it comes right behind the
+ * key that equals its visible part.  (Pinned by the reference's binaries: tests/test_oracle_golden.py, the fuzzed contig.) */
+typedef struct { const char* p; int len; int adv; int count; } key_t_;
 
 static int key_cmp(const void* a, const void* b)
 {
@@ -61,7 +68,9 @@ static int key_cmp(const void* a, const void* b)
     int n = x->len < y->len ? x->len : y->len;
     int c = memcmp(x->p, y->p, (size_t)n);
     if (c) return c;
-    return (x->len > y->len) - (x->len < y->len);
+    if (x->len != y->len) return (x->len > y->len) - (x->len < y->len);
+    const int xc = x->adv > x->len, yc = y->adv > y->len;            /* cut short: behind the complete allele with the same characters */
+    return xc - yc;
 }
 
 /* owned-string variant for alt_dict keys */
@@ -114,6 +123,7 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
                 int l = (int)(advance < avail ? advance : avail);
                 indel[n_indel].p = bases + i;
                 indel[n_indel].len = l;
+                indel[n_indel].adv = (int)advance;
                 indel[n_indel].count = (b == '+') ? 1 : -1; /* sign kept in count for now */
                 ++n_indel;
             }
@@ -167,16 +177,19 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
         else               { t[ORC_CH_i] += cnt; if (cnt > max_ins_1) max_ins_1 = cnt; }
         if (alts) { /* "I" + chr_base + upper(seq)  (tensor_maker.cpp:131-136) */
             alt_t_* a = &alts[n_alt++];
-            a->len = 2 + ins[k].len; a->s = (char*)malloc((size_t)a->len + 1);
+            const int cut_short = ins[k].adv > ins[k].len;          /* the key then holds the column string's NUL behind the visible part */
+            a->len = 2 + ins[k].len + cut_short; a->s = (char*)malloc((size_t)a->len + 1);
             a->s[0] = 'I'; a->s[1] = chr_base;
             for (int q = 0; q < ins[k].len; ++q) a->s[2 + q] = (char)toupper((unsigned char)ins[k].p[q]);
+            if (cut_short) a->s[2 + ins[k].len] = '\0';
             a->count = cnt;
         }
     }
     for (int k = 0; k < n_del; ++k) {
         int cnt = del[k].count;
         have_D = 1; pile_D += cnt;
-        if (del[k].len > max_del_length) max_del_length = del[k].len;
+        const int dlen = del[k].adv;                                /* key.size() - 1: the DECLARED length, also for an allele cut short */
+        if (dlen > max_del_length) max_del_length = dlen;
         int first = del[k].len ? (unsigned char)del[k].p[0] : 0;
         if (is_fwd(first)) { t[ORC_CH_D] += cnt; if (cnt > max_del_0) max_del_0 = cnt; }
         else               { t[ORC_CH_d] += cnt; if (cnt > max_del_1) max_del_1 = cnt; }
@@ -184,9 +197,9 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
                      * contig the reference reads the NUL that terminates its sequence buffer; the key keeps that byte
                      * (it sorts before every base) and the C-string output of alt_info stops there (see below). */
             alt_t_* a = &alts[n_alt++];
-            a->len = 1 + del[k].len; a->s = (char*)malloc((size_t)a->len + 1);
+            a->len = 1 + dlen; a->s = (char*)malloc((size_t)a->len + 1);
             a->s[0] = 'D';
-            for (int q = 0; q < del[k].len; ++q)
+            for (int q = 0; q < dlen; ++q)
                 a->s[1 + q] = (next_ref && q < n_next) ? next_ref[q] : '\0';
             a->count = cnt;
         }

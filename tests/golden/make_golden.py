@@ -65,6 +65,43 @@ def run_ref_encode(workdir, contig, fasta, mpileup_bytes):
         return f.read()
 
 
+def cut_allele_columns(rng, n_cols, ref_seq):
+    """bytes per column: (1) read stacks over a two-letter allele alphabet that end in an indel whose declared length exceeds what is
+    left of the column, beside complete alleles with the same visible characters, in both cases and signs; (2) printable bytes drawn
+    at random: every symbol class of the scanner, +n / -n with allele text shorter than n, digits, punctuation"""
+    sets = [b"ACGTNacgtn", b"*#", b"^", b"$", b"+-", b"0123456789", b".,<>!?@~;:=/\\|%&()[]{}'`_", bytes(range(33, 127))]
+    cols = []
+    for c in range(n_cols):
+        r = chr(ref_seq[c]).upper()
+        r = r if r in "ACGT" else "A"
+        out = bytearray()
+        if c % 2 == 0:
+            depth = int(rng.choice([6, 8, 12, 30]))
+            alph = rng.choice(["AC", "ac", "AG", "aC", "N*", "#a"])
+            for _ in range(depth):
+                out += (r if rng.random() < 0.5 else r.lower()).encode()
+                if rng.random() < 0.45:
+                    n = int(rng.choice([1, 2, 2, 3]))
+                    out += (rng.choice(["+", "-"]) + str(n) + "".join(rng.choice(list(alph), n))).encode()
+            n = int(rng.choice([1, 2, 3, 4, 9, 59, 60, 61]))
+            vis = int(rng.integers(0, n))                                     # 0 .. n - 1 characters of the allele are left
+            out += (rng.choice(["+", "-"]) + str(n) + "".join(rng.choice(list(alph), vis))).encode()
+        else:
+            w = rng.dirichlet(np.ones(len(sets)) * 0.7); w[0] += 1.0; w /= w.sum()
+            for _ in range(int(rng.integers(1, 90))):
+                a = sets[rng.choice(len(sets), p=w)]
+                ch = a[rng.integers(0, len(a))]
+                out.append(ch)
+                if ch in b"+-" and rng.random() < 0.9:
+                    n = int(rng.choice([0, 1, 2, 3, 5, 9, 10, 30, 59, 60, 61, 99, 100]))
+                    out += str(n).encode() if rng.random() < 0.95 else b""
+                    ln = n if rng.random() < 0.75 else int(rng.integers(0, n + 3))
+                    out += (bytes(rng.choice(np.frombuffer(b"ACGTNacgtn*#", np.uint8), size=ln)) if rng.random() < 0.85
+                            else bytes(rng.integers(33, 127, size=ln, dtype=np.uint8)))
+        cols.append(bytes(out))
+    return cols
+
+
 def adversarial_columns(rng, n_cols, ref_seq):
     """Columns that exercise every branch of tensor_maker.cpp:83-114,127-188: long indels
     (> 60 are skipped but not counted), multi-digit lengths, '^' swallowing a base-like
@@ -150,7 +187,15 @@ def group_encode():
         if i % 3 == 0:
             ecols[i] += "".join(f"-{L}{'ACGTN' * 12}"[:len(str(L)) + 1 + L] for L in (int(rng.choice([30, 59, 60])), 45)) * 3
     text_c = b"".join(b"chrE\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c.encode(), b"I") for i, c in enumerate(ecols) if c)
-    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b), ("end", "chrE", seq3, text_c)):
+    # (d) alleles the END OF THE COLUMN cuts short (declared length > the characters left): tensor_maker.cpp:101 appends `advance`
+    #     characters from c_str() regardless, so the key holds the string's NUL - an allele of its own, never merged with a complete
+    #     allele that shows the same characters (channels I1 / i1 / D1 / d1), a deletion's length is the declared one, and the alt_info
+    #     text stops behind the visible part of a cut insertion; plus columns of printable bytes drawn at random under a loose grammar
+    M4 = 1400
+    seq4 = rng.choice(list(b"ACGTacgtN"), M4 + 100, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
+    dcols = cut_allele_columns(rng, M4, seq4)
+    text_d = b"".join(b"chrC\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c, b"I") for i, c in enumerate(dcols) if c)
+    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b), ("end", "chrE", seq3, text_c), ("cut", "chrC", seq4, text_d)):
         with tempfile.TemporaryDirectory() as d:
             fa = os.path.join(d, "ref.fa")
             host.write_fasta(fa, contig, sq)

@@ -20,7 +20,7 @@ def _enc(ctx, bases, col_off, ref, **kw):
     return c, d, f
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut"])
 def test_reference_fixture_end_to_end(gpu_ctx, tag):
     """mpileup text -> encode -> select -> gather == the tensors the reference programs wrote"""
     import torch

@@ -21,7 +21,7 @@ def _load_encode_fixture(tag):
     return text, seq, pd
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut"])
 def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
     text, seq, pd = _load_encode_fixture(tag)
     mp = tmp_path / "x.mpileup"
@@ -31,7 +31,7 @@ def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
     assert (tmp_path / "o.pd").read_bytes() == pd
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut"])
 def test_array_path_matches_the_reference_tensors(tag):
     """encode_columns -> select_sites -> gather_windows == the [N,33,18] matrices in the .pd"""
     text, seq, pd = _load_encode_fixture(tag)
@@ -182,6 +182,37 @@ def test_oracle_vs_reference_binaries_on_a_fresh_contig(tmp_path):
     want = (tmp_path / "pd" / "chrQ.pd").read_bytes()
     n = oracle.mpileup_to_pd(str(pile / "chrQ.mpileup"), bytes(seq), str(tmp_path / "o.pd"))
     assert n == want.count(b"\n") and n > 500
+    assert (tmp_path / "o.pd").read_bytes() == want
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref not built (no reference tree)")
+@pytest.mark.parametrize("seed", [31, 32])
+def test_oracle_vs_reference_binaries_on_cut_alleles_and_random_bytes(tmp_path, seed):
+    """Fresh columns of the kind behind tests/golden/encode_cut.*: indels the end of the column cuts short beside complete alleles with
+    the same visible characters (tensor_maker.cpp:101 reads `advance` characters whatever the string holds), and printable bytes drawn
+    at random under a loose grammar - the .pd of the compiled reference against the oracle's, byte for byte (alt_info included)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", golden("make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    rng = np.random.default_rng(seed)
+    M = 3000
+    seq = rng.choice(list(b"ACGTacgtN"), M + 100, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
+    cols = mg.cut_allele_columns(rng, M, seq)
+    fa = str(tmp_path / "ref.fa")
+    host.write_fasta(fa, "chrC", seq)
+    pile = tmp_path / "pile"; pile.mkdir()
+    (pile / "chrC.mpileup").write_bytes(b"".join(b"chrC\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c, b"I") for i, c in enumerate(cols) if c))
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    subprocess.run([os.path.join(refdir, "DNA_CreateCanSnpTensor"), "-reference", fa, "-chr_pileup_dir", str(pile),
+                    "-output_dir", str(tmp_path / "tensor"), "-min_af", "0.12", "-snp_min_af", "0.12",
+                    "-indel_min_af", "0.12", "-min_coverage", "6", "-flanking_base", "16", "-num_threads", "1", "chrC"],
+                   check=True, capture_output=True)
+    subprocess.run([os.path.join(refdir, "DNA_CreatePredictData"), "-chr_tensor_dir", str(tmp_path / "tensor"),
+                    "-reference", fa, "-output_dir", str(tmp_path / "pd"), "-num_threads", "1", "chrC"],
+                   check=True, capture_output=True)
+    want = (tmp_path / "pd" / "chrC.pd").read_bytes()
+    n = oracle.mpileup_to_pd(str(pile / "chrC.mpileup"), bytes(seq), str(tmp_path / "o.pd"))
+    assert n == want.count(b"\n") and n > 1500
     assert (tmp_path / "o.pd").read_bytes() == want
 
 
