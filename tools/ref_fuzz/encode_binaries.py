@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""DEVELOPMENT CONTAINER ONLY (runs oracle/_ref, reads tests/golden/make_golden.py): the reference's compiled DNA_CreateCanSnpTensor +
+DNA_CreatePredictData against oracle.mpileup_to_pd on adversarial and cut-allele contigs, three threshold sets, .pd byte for byte.
+    python tools/ref_fuzz/encode_binaries.py FIRST_SEED END_SEED"""
+import os, sys, subprocess, tempfile, importlib.util
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from nanosnp_amd import host
+from oracle import oracle
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+spec = importlib.util.spec_from_file_location("make_golden", ROOT+"/tests/golden/make_golden.py")
+mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+bad=0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(seed)
+    M = 4000
+    seq = rng.choice(list(b"ACGTacgtN"), M + 100, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
+    cols = mg.cut_allele_columns(rng, M, seq) if seed % 2 else [c.encode() for c in mg.adversarial_columns(rng, M, seq)]
+    tmp = tempfile.mkdtemp()
+    fa = os.path.join(tmp, "ref.fa"); host.write_fasta(fa, "chrC", seq)
+    pile = os.path.join(tmp, "pile"); os.mkdir(pile)
+    open(os.path.join(pile, "chrC.mpileup"), "wb").write(b"".join(b"chrC\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c, b"I") for i, c in enumerate(cols) if c))
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    for mc, af in ((6, "0.12"), (0, "0.0"), (3, "0.3")):
+        out_t = os.path.join(tmp, f"tensor{mc}"); out_p = os.path.join(tmp, f"pd{mc}")
+        subprocess.run([os.path.join(refdir, "DNA_CreateCanSnpTensor"), "-reference", fa, "-chr_pileup_dir", pile, "-output_dir", out_t, "-min_af", af, "-snp_min_af", af,
+                        "-indel_min_af", af, "-min_coverage", str(mc), "-flanking_base", "16", "-num_threads", "1", "chrC"], check=True, capture_output=True)
+        subprocess.run([os.path.join(refdir, "DNA_CreatePredictData"), "-chr_tensor_dir", out_t, "-reference", fa, "-output_dir", out_p, "-num_threads", "1", "chrC"], check=True, capture_output=True)
+        want = open(os.path.join(out_p, "chrC.pd"), "rb").read()
+        try:
+            n = oracle.mpileup_to_pd(os.path.join(pile, "chrC.mpileup"), bytes(seq), os.path.join(tmp, "o.pd"), min_af=float(af), min_coverage=mc)
+        except TypeError:
+            if mc != 6: continue
+            n = oracle.mpileup_to_pd(os.path.join(pile, "chrC.mpileup"), bytes(seq), os.path.join(tmp, "o.pd"))
+        got = open(os.path.join(tmp, "o.pd"), "rb").read()
+        ok = got == want
+        bad += not ok
+        print(seed, mc, af, "sites", n, want.count(b"\n"), "identical" if ok else "DIFFER", flush=True)
+print("bad", bad)
