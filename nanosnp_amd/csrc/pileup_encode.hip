@@ -655,7 +655,13 @@ __device__ __forceinline__ bool site_ok(const int64_t* pos, const uint8_t* flags
 {
     if (!(flags[c] & NSNP_FLAG_CANDIDATE)) return false;
     if (c < PCENTER || c + PCENTER >= M) return false;
-    return pos[c + PCENTER] - pos[c] == PCENTER && pos[c] - pos[c - PCENTER] == PCENTER;
+    if (!(pos[c + PCENTER] - pos[c] == PCENTER && pos[c] - pos[c - PCENTER] == PCENTER)) return false;
+    // main.cpp:174-178 resets its window at EVERY position that is not the previous one + 1.  For ascending positions the two end
+    // differences say it all; a text whose positions repeat or step back (concatenated or damaged input) can have a gap of two and a
+    // repeated position cancel inside the window, so a candidate that passed is confirmed step by step (2 % of the columns get here)
+    for (int k = -PCENTER; k < PCENTER; ++k)
+        if (pos[c + k + 1] - pos[c + k] != 1) return false;
+    return true;
 }
 
 constexpr int SEL_BLOCK = 256, SEL_PER_THREAD = 8, SEL_TILE = SEL_BLOCK * SEL_PER_THREAD;

@@ -195,7 +195,27 @@ def group_encode():
     seq4 = rng.choice(list(b"ACGTacgtN"), M4 + 100, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
     dcols = cut_allele_columns(rng, M4, seq4)
     text_d = b"".join(b"chrC\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c, b"I") for i, c in enumerate(dcols) if c)
-    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b), ("end", "chrE", seq3, text_c), ("cut", "chrC", seq4, text_d)):
+    # (e) positions that repeat or step back, zero-depth placeholder lines, extra columns (concatenated / damaged text): main.cpp:174-178
+    #     resets the window at every position that is not the previous one + 1 - a gap of two and a repeated position must not cancel
+    M5 = 3000
+    cols5 = host.synth_columns(20260005, M5, coverage=20, het_rate=0.2)
+    seq5 = np.concatenate([cols5.ref, np.frombuffer(b"ACGT" * 25, np.uint8)]).copy()
+    seq5[rng.random(seq5.size) < 0.04] |= 0x20
+    lines5 = cols5.mpileup_text("chrP").split(b"\n")[:-1]
+    out5, i = [], 0
+    while i < M5:
+        u = rng.random()
+        if u < 0.01: i += int(rng.integers(1, 40)); continue
+        if u < 0.02 and i > 50: i -= int(rng.integers(1, 40)); continue
+        if u < 0.035: out5.append(lines5[i])                                       # the same line twice
+        if u < 0.045:
+            f = lines5[i].split(b"\t"); out5.append(b"\t".join([f[0], f[1], b"N", b"0", b"*", b"*"])); i += 1; continue
+        if u < 0.055: out5.append(lines5[i] + b"\textra\tcolumns"); i += 1; continue
+        if u < 0.065 and i + 3 < M5: out5.append(lines5[i]); out5.append(lines5[i + 2]); i += 3; continue   # a gap of two shortly before / behind a repeat
+        out5.append(lines5[i]); i += 1
+    text_e = b"\n".join(out5) + b"\n"
+    for tag, contig, sq, text in (("g1", "chrS", seq, text_a), ("adv", "chrT", seq2, text_b), ("end", "chrE", seq3, text_c), ("cut", "chrC", seq4, text_d),
+                                  ("pos", "chrP", seq5, text_e)):
         with tempfile.TemporaryDirectory() as d:
             fa = os.path.join(d, "ref.fa")
             host.write_fasta(fa, contig, sq)

@@ -20,7 +20,7 @@ def _enc(ctx, bases, col_off, ref, **kw):
     return c, d, f
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos"])
 def test_reference_fixture_end_to_end(gpu_ctx, tag):
     """mpileup text -> encode -> select -> gather == the tensors the reference programs wrote"""
     import torch
@@ -168,6 +168,14 @@ def test_select_sites_vs_oracle(gpu_ctx, m):
     if len(want) > 3:       # capacity smaller than the result: count still exact, prefix written
         got2, n2 = gpu_ctx.pileup_select_sites(torch.from_numpy(pos).cuda(), torch.from_numpy(flags).cuda(), cap=3)
         assert n2 == len(want) and np.array_equal(got2.cpu().numpy(), want[:3])
+    # positions that repeat or step back: every step inside the window counts, a gap of two and a repeat must not cancel (main.cpp:174-178)
+    u = rng.random(m)
+    step2 = np.where(u < 0.01, 0, np.where(u < 0.02, -rng.integers(1, 20, m), np.where(u < 0.04, 2, 1)))
+    pos2 = (np.cumsum(step2) + 1000).astype(np.int64)
+    flags2 = np.where(rng.random(m) < 0.5, 8, 0).astype(np.uint8)
+    want2 = oracle.select_sites(pos2, flags2)
+    got3, n3 = gpu_ctx.pileup_select_sites(torch.from_numpy(pos2).cuda(), torch.from_numpy(flags2).cuda())
+    assert n3 == len(want2) and np.array_equal(got3.cpu().numpy(), want2)
 
 
 def test_full_size_invariants_1m_columns(gpu_ctx):

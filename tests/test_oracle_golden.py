@@ -21,7 +21,7 @@ def _load_encode_fixture(tag):
     return text, seq, pd
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos"])
 def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
     text, seq, pd = _load_encode_fixture(tag)
     mp = tmp_path / "x.mpileup"
@@ -31,7 +31,7 @@ def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
     assert (tmp_path / "o.pd").read_bytes() == pd
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos"])
 def test_array_path_matches_the_reference_tensors(tag):
     """encode_columns -> select_sites -> gather_windows == the [N,33,18] matrices in the .pd"""
     text, seq, pd = _load_encode_fixture(tag)

@@ -23,13 +23,16 @@ for r in range(rounds):
     rng = np.random.default_rng(7700 + r)
     seq = rng.choice(np.frombuffer(b"ACGTacgtNn", np.uint8), n_cols + 5000, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).astype(np.uint8)
     step = np.where(rng.random(n_cols) < 0.01, rng.integers(2, 40, n_cols), 1)
-    pos = np.cumsum(step); pos = pos[pos < seq.size]
-    cols = mg.adversarial_columns(rng, len(pos), seq[pos - 1])
+    if r % 2:                                      # odd rounds: positions that step BACK or repeat (main.cpp:174-178 resets its window at
+        u = rng.random(n_cols)                     # every position that is not the previous one + 1), and indel alleles cut short by the
+        step = np.where(u < 0.004, -rng.integers(1, 30, n_cols), np.where(u < 0.008, 0, step))     # end of their column
+    pos = np.cumsum(step); pos = pos[(pos < seq.size) & (pos >= 1)]
+    cols = [c.decode("latin-1") for c in mg.cut_allele_columns(rng, len(pos), seq[pos - 1])] if r % 2 else mg.adversarial_columns(rng, len(pos), seq[pos - 1])
     lines = []
     for p, c in zip(pos, cols):
         if not c:
             c = "*"
-        lines.append(b"chrA\t%d\t%c\t%d\t%s\t%s\n" % (p, seq[p - 1], len(c), c.encode(), b"I" * max(1, len(c) // 2)))
+        lines.append(b"chrA\t%d\t%c\t%d\t%s\t%s\n" % (p, seq[p - 1], len(c), c.encode("latin-1"), b"I" * max(1, len(c) // 2)))
     text = b"".join(lines)
     want = call_contig(m, text, "chrA", seq, chunk_bytes=1 << 40)
     for cb in (len(text) // 3, len(text) // 7, 50_000, 9_000):
