@@ -22,31 +22,32 @@ __global__ __launch_bounds__(ARR_BLOCK) void k_hap_arrange(
     int32_t* __restrict__ depth_out)
 {
     extern __shared__ int32_t arr_lds[];
-    int32_t* key = arr_lds;            // [R] HP at the centre column, INT_MAX for dropped rows
+    int32_t* key = arr_lds;            // [R] HP at the centre column (any int32: an HP tag is whatever the BAM holds)
     int32_t* src = arr_lds + R;        // [D_out] source row of each output row, -1 = padding
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x;
     const int rows = n_reads ? min(n_reads[n], R) : R;
     const size_t ibase = (size_t)n * R * L;
     const int mid = L / 2;
+    // rank_acc[r]: -1 for a row that is dropped (beyond n_reads, or no base at the centre column), else its rank
+    int32_t* rank_acc = src + D_out;                      // [R]
     for (int r = tid; r < R; r += ARR_BLOCK) {
-        int32_t k = 0x7fffffff;
-        if (r < rows && seq[ibase + (size_t)r * L + mid] != 0) k = hap[ibase + (size_t)r * L + mid];
-        key[r] = k;
+        const bool keep = r < rows && seq[ibase + (size_t)r * L + mid] != 0;
+        key[r] = keep ? hap[ibase + (size_t)r * L + mid] : 0;
+        rank_acc[r] = keep ? 0 : -1;
     }
     for (int d = tid; d < D_out; d += ARR_BLOCK) src[d] = -1;
     __syncthreads();
     // stable rank of every kept row among the kept rows; with R <= 64 the four waves split the comparisons of a row (row r = lane,
-    // wave w compares with rows q = w mod 4) and add their partial ranks in LDS
-    int32_t* rank_acc = src + D_out;                      // [R]
-    for (int r = tid; r < R; r += ARR_BLOCK) rank_acc[r] = 0;
-    __syncthreads();
+    // wave w compares with rows q = w mod 4) and add their partial ranks in LDS.  (Dropped rows keep -1: nobody adds to them, and the
+    // partial ranks of a kept row are added to its 0.)
     const int nsplit = R <= 64 ? ARR_BLOCK / 64 : 1;
     for (int r = nsplit > 1 ? (tid & 63) : tid; r < R; r += nsplit > 1 ? R : ARR_BLOCK) {
+        if (rank_acc[r] < 0) continue;
         const int32_t k = key[r];
-        if (k == 0x7fffffff) continue;
         int rank = 0;
         for (int q = nsplit > 1 ? (tid >> 6) : 0; q < R; q += nsplit) {
+            if (rank_acc[q] < 0) continue;                 // (a mark is -1, or >= 0 and only ever grows while the ranks are added: never mistaken)
             const int32_t kq = key[q];
             rank += (kq < k) || (kq == k && q < r);
         }
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(ARR_BLOCK) void k_hap_arrange(
     }
     __syncthreads();
     for (int r = tid; r < R; r += ARR_BLOCK)
-        if (key[r] != 0x7fffffff && rank_acc[r] < D_out) src[rank_acc[r]] = r;
+        if (rank_acc[r] >= 0 && rank_acc[r] < D_out) src[rank_acc[r]] = r;
     if (depth_out && tid < 64) {
         int kept = 0;
-        for (int r = tid; r < R; r += 64) kept += key[r] != 0x7fffffff;
+        for (int r = tid; r < R; r += 64) kept += rank_acc[r] >= 0;
         for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
         if (tid == 0) depth_out[n] = kept < D_out ? kept : D_out;
     }

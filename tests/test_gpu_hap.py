@@ -306,6 +306,16 @@ def test_hap_arrange_reads_vs_oracle(gpu_ctx):
             for k in range(4):
                 assert np.array_equal(outs[k][n].cpu().numpy(), want[k]), (n, k)
             assert int(outs[4][n]) == want[4]
+    # an HP tag is whatever integer the BAM holds: every int32 value sorts, INT_MAX included (once the kernel's mark of a dropped row),
+    # for the two rank paths (R <= 64: four waves share a row's comparisons; R > 64)
+    for R2 in (40, 64, 65):
+        seq = rng.integers(-1, 5, (7, R2, 11)).astype(np.int32)
+        hap = rng.choice([1, 2, 2 ** 31 - 1, -2 ** 31, 0, -5], (7, R2, 11)).astype(np.int32)
+        bq = rng.integers(0, 60, (7, R2, 11)).astype(np.int32); mq = rng.integers(0, 61, (7, R2, 11)).astype(np.int32)
+        outs = gpu_ctx.hap_arrange_reads(*[torch.from_numpy(a).cuda() for a in (seq, bq, mq, hap)], 50)
+        for n in range(7):
+            want = oracle.hap_arrange(seq[n], bq[n], mq[n], hap[n], 50)
+            assert all(np.array_equal(outs[k][n].cpu().numpy(), want[k]) for k in range(4)) and int(outs[4][n]) == want[4], (R2, n)
 
 
 def test_hap_forward_f16x3_mode(gpu_ctx):
