@@ -59,6 +59,18 @@ def test_coverage_filter_and_foreign_bases():
     k = next(i for i, r in enumerate(bad) if r["a"] <= 260 <= r["b"] and r["ops"][260 - r["a"]] != "D")
     bad[k]["ops"] = list(bad[k]["ops"]); bad[k]["ops"][260 - bad[k]["a"]] = "N"
     assert readmatrix.read_matrices(FakeSamfile(bad), groups, max_coverage=10000) is None
+    # an HP tag other than 1 / 2 (3 = untagged): the reference's assert (:104) lands in the same bare except - nothing, not an exception
+    odd = [dict(r) for r in reads]
+    odd[0]["hp"] = 7
+    assert readmatrix.read_matrices(FakeSamfile(odd), groups, max_coverage=10000) is None
+    # a WINDOW column (not a group position) deeper than max_coverage: the first pass keeps the group, the assert of :98 then ends the chunk
+    gpos = {p for g in groups for _, p in g}
+    centre = groups[0][5][1]
+    wcol = next(p for p in range(centre - 16, centre + 17) if p not in gpos)
+    lim = max(cov.values())                                         # no column of the plain reads is deeper
+    extra = [dict(name=f"x{k}", a=wcol, b=wcol, ops=["A"], hp=1, quals=[30], mapq=60) for k in range(lim - cov[wcol] + 1)]   # reads that cover only that column
+    assert readmatrix.read_matrices(FakeSamfile(reads + extra), groups, max_coverage=lim) is None
+    assert readmatrix.read_matrices(FakeSamfile(reads + extra[:-1]), groups, max_coverage=lim) is not None
 
 
 @pytest.mark.gpu
