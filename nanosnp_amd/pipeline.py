@@ -348,8 +348,71 @@ def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False):
                                    batch_size=batch_size, score_mode=score_mode, as_view=as_view)
 
 
+def _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats):
+    """call_contig for one process with the rows of finished chunks formatted on a writer thread while later chunks compute: every
+    chunk's call rows travel to a pinned buffer of their own behind the chunk's forward; the writer formats the COMPLETE batches of
+    `batch_size` sites that have arrived (the reference's rows depend on the batch a site falls into: predict.py:102-125) with a
+    quarter of the host threads and carries the rest over; what is left when the last chunk is back is formatted on all threads.
+    Byte-identical to formatting all rows at the end (tests/test_gpu_predict.py)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    pins = getattr(model, "_rows_pins", None)
+    if pins is None:
+        pins = model._rows_pins = []
+    events, sizes, pieces = [], [], []
+    state = dict(carry=np.empty((0, 13), np.float64), rows=0, busy=0.0)
+    few = max(1, host.lib().nsnp_host_threads() // 4)
+
+    def fmt(r, nthreads):
+        t0 = time.perf_counter()
+        site_pos = r[:, 0].astype(np.int64)
+        text, n_rows = host.vcf_format_batches(host.ContigTable([contig]), np.zeros(len(r), np.int32), site_pos, chr_seq[site_pos - 1] & 0xDF,
+                                               r[:, 1].astype(np.uint8), r[:, 2].astype(np.uint8), r[:, 3].astype(np.float32), r[:, 4].astype(np.float32),
+                                               r[:, 5:13].astype(np.float32), batch_size=batch_size, score_mode=score_mode, nthreads=nthreads)
+        pieces.append(text); state["rows"] += n_rows; state["busy"] += time.perf_counter() - t0
+
+    def work(k):
+        events[k].synchronize()
+        got = pins[k][:sizes[k]].numpy()
+        c = np.concatenate([state["carry"], got]) if len(state["carry"]) else got
+        full = len(c) // batch_size * batch_size
+        if full:
+            fmt(c[:full], few)
+        state["carry"] = c[full:].copy()
+
+    with ThreadPoolExecutor(max_workers=1) as writer:
+        futs = []
+
+        def on_rows(rows_k):
+            k, n = len(events), int(rows_k.shape[0])
+            if k >= len(pins):
+                pins.append(torch.empty((max(n + n // 4, 4096), 13), dtype=torch.float64, pin_memory=True))
+            elif pins[k].shape[0] < n:
+                pins[k] = torch.empty((n + n // 4, 13), dtype=torch.float64, pin_memory=True)
+            pins[k][:n].copy_(rows_k, non_blocking=True)
+            ev = torch.cuda.Event(blocking=True); ev.record()
+            events.append(ev); sizes.append(n)
+            futs.append(writer.submit(work, k))
+
+        stream_contig(model, mpileup_text, contig, chr_seq, 0, None, chunk_bytes, min_af, min_coverage, stats, on_rows=on_rows)
+        t0 = time.perf_counter()
+        for f in futs:
+            f.result()
+        if len(state["carry"]):
+            fmt(state["carry"], 0)
+        n_sites = int(sum(sizes))
+        text = b"".join(pieces)
+        if stats is not None:
+            stats["vcf_s"] = stats.get("vcf_s", 0.0) + time.perf_counter() - t0          # what the caller still waits for behind the last chunk
+            stats["vcf_beside_s"] = stats.get("vcf_beside_s", 0.0) + state["busy"]
+            stats["sites"] = stats.get("sites", 0) + n_sites
+            stats["vcf_rows"] = stats.get("vcf_rows", 0) + state["rows"]
+    return text, n_sites, state["rows"]
+
+
 def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.12, min_coverage=6,
-                batch_size=1000, score_mode=host.SCORE_FLOAT64, chunk_bytes=64 << 20, stats=None):
+                batch_size=1000, score_mode=host.SCORE_FLOAT64, chunk_bytes=64 << 20, stats=None, rows_beside=None):
     """One contig: returns (vcf_rows: bytes-like - a memoryview of the formatter's buffer, no copy; bytes(...) it to keep it -, n_sites, n_rows).  model: pileup_model.LSTMNetwork; mpileup_text: bytes, mmap or a
     numpy uint8 array holding the contig's samtools-mpileup text.
 
@@ -367,6 +430,10 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
     finder, arr = _as_bytes_like(mpileup_text)
     sharded = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
+    if rows_beside is None:
+        rows_beside = os.environ.get("NSNP_ROWS_BESIDE", "0") == "1"
+    if rows_beside and not sharded:
+        return _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats)
     cuts = line_cuts(finder, world, 0, arr.size)
     rows = stream_contig(model, mpileup_text, contig, chr_seq, cuts[rank], cuts[rank + 1], chunk_bytes, min_af, min_coverage, stats)
     if sharded:
@@ -377,9 +444,11 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
             tdist.broadcast(n_tot, src=0)
             return b"", int(n_tot.item()), 0
         tdist.broadcast(torch.tensor([rows.shape[0]], dtype=torch.int64, device=backend_dev), src=0)
-    # (formatting the rows of finished chunks on a worker thread while later chunks are parsed was measured: parse and formatter are
-    # both OpenMP-parallel host work on the same cores - 24 + 34 ms per 6 M-column contig on 16 cores - and run slower side by side
-    # than one after the other: 162 against 75 ms per contig)
+    # (formatting the rows of finished chunks on a worker thread while later chunks compute - rows_beside=True,
+    # _call_contig_rows_beside - is built, byte-identical and SLOWER: round 3 with the 34 ms formatter 162 against 75 ms per 6 M-column
+    # contig; round 5 with the 2.4 ms formatter on a quarter of the threads 27.6-28.4 against 22.5 ms (median of 30 steps, A/B/A/B on
+    # one box): the per-chunk D2H copies and the writer's numpy passes cost the issuing thread 5 ms (GIL, copy-engine calls) to save
+    # 2.4 ms behind the last chunk.  Off by default.)
     n_sites = int(rows.shape[0])
     if n_sites == 0:
         return b"", 0, 0

@@ -153,6 +153,13 @@ def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_wei
     want = call_contig(m, big, "chrB", seqb, chunk_bytes=1 << 30)
     got = call_contig(m, big, "chrB", seqb, chunk_bytes=256 << 10)
     assert got == want and want[1] > 500
+    # the opt-in form that formats the complete batches of finished chunks on a writer thread (measured slower, kept off): same bytes
+    for cb in (256 << 10, 90_000, 1 << 30):
+        for bs in (1000, 64, 7):
+            a = call_contig(m, big, "chrB", seqb, chunk_bytes=cb, batch_size=bs, rows_beside=True)
+            b = call_contig(m, big, "chrB", seqb, chunk_bytes=1 << 30, batch_size=bs)
+            assert bytes(a[0]) == bytes(b[0]) and a[1:] == b[1:], (cb, bs)
+    assert call_contig(m, b"", "chrB", seqb, rows_beside=True) == (b"", 0, 0)
 
 
 def test_streamed_pipeline_edge_inputs(pileup_weights):
