@@ -125,6 +125,26 @@ int nsnp_stage_values(int fd, const void* src, int64_t src_off, int elem_src, in
     return err;
 }
 
+/* Python's int(text) for a decimal position field: surrounding blanks, one sign, digits with single underscores BETWEEN digits
+ * ("1_000" is 1000: PEP 515), at most 18 digits.  Returns 0 where int() raises ValueError (or the value would not fit). */
+static int py_int(const uint8_t* p, const uint8_t* e, int64_t* out)
+{
+    while (p < e && (*p == ' ' || (*p >= 9 && *p <= 13))) ++p;
+    while (e > p && (e[-1] == ' ' || (e[-1] >= 9 && e[-1] <= 13))) --e;
+    int neg = 0;
+    if (p < e && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+    if (p >= e) return 0;
+    int64_t v = 0; int digits = 0, last_us = 1;                     /* last_us: an underscore may not come first */
+    for (; p < e; ++p) {
+        if (*p == '_') { if (last_us) return 0; last_us = 1; continue; }
+        if (*p < '0' || *p > '9' || ++digits > 18) return 0;
+        v = v * 10 + (*p - '0'); last_us = 0;
+    }
+    if (last_us) return 0;                                           /* ... nor last */
+    *out = neg ? -v : v;
+    return 1;
+}
+
 /* "ctg:pos" in a zero-padded field of `width` bytes: exactly one ':' (str.split(":") into two names, dataset_dev.py:109,153), the
  * position an optionally signed decimal integer (int(pos); surrounding blanks are accepted as int() accepts them).  The contig is
  * looked up among `n_names` names (blob + offsets); one that is not there gets id -1 - the reference's lookup then fails inside its
@@ -146,16 +166,7 @@ int nsnp_parse_ctg_pos(const uint8_t* rows, int64_t n, int width, const char* na
         if (!colon || memchr(colon + 1, ':', (size_t)(r + len - colon - 1))) { BAD(); continue; }
         const int cl = (int)(colon - r);
         /* position */
-        const uint8_t* p = colon + 1; const uint8_t* e = r + len;
-        while (p < e && (*p == ' ' || (*p >= 9 && *p <= 13))) ++p;
-        while (e > p && (e[-1] == ' ' || (e[-1] >= 9 && e[-1] <= 13))) --e;
-        int neg = 0;
-        if (p < e && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
-        if (p >= e || e - p > 18) { BAD(); continue; }
-        int64_t v = 0; int ok = 1;
-        for (; p < e; ++p) { if (*p < '0' || *p > '9') { ok = 0; break; } v = v * 10 + (*p - '0'); }
-        if (!ok) { BAD(); continue; }
-        pos[i] = neg ? -v : v;
+        if (!py_int(colon + 1, r + len, &pos[i])) { BAD(); continue; }
         /* contig (the table is short: a bin holds one contig, a run a few dozen) */
         int id = -1;
         for (int k = 0; k < n_names; ++k) {
@@ -189,16 +200,7 @@ int nsnp_parse_ctg_pos_ref(const uint8_t* rows, int64_t n, int width, const char
         const uint8_t* c1 = (const uint8_t*)memchr(r, ':', (size_t)(e - r));
         const uint8_t* c2 = c1 ? (const uint8_t*)memchr(c1 + 1, ':', (size_t)(e - c1 - 1)) : NULL;
         if (!c2 || memchr(c2 + 1, ':', (size_t)(e - c2 - 1)) || e - (c2 + 1) < 17) { BAD(); continue; }
-        const uint8_t* p = c1 + 1; const uint8_t* q = c2;
-        while (p < q && (*p == ' ' || (*p >= 9 && *p <= 13))) ++p;
-        while (q > p && (q[-1] == ' ' || (q[-1] >= 9 && q[-1] <= 13))) --q;
-        int neg = 0;
-        if (p < q && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
-        if (p >= q || q - p > 18) { BAD(); continue; }
-        int64_t v = 0; int ok = 1;
-        for (; p < q; ++p) { if (*p < '0' || *p > '9') { ok = 0; break; } v = v * 10 + (*p - '0'); }
-        if (!ok) { BAD(); continue; }
-        pos[i] = neg ? -v : v;
+        if (!py_int(c1 + 1, c2, &pos[i])) { BAD(); continue; }
         ref_base[i] = c2[1 + 16];
         const int cl = (int)(c1 - r);
         int id = -1;

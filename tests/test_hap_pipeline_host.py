@@ -55,7 +55,9 @@ def test_position_fields():
     assert pos.shape == (2, 2) and pos.tolist() == [[1, 2], [3, 4]] and ctg.tolist() == [[0, 1], [2, -1]]
     wide = np.zeros((3, 300), np.uint8); wide[:, :7] = np.frombuffer(b"chr1:42", np.uint8)       # StringAtom(300) fields
     assert host.parse_ctg_pos(wide, tbl)[0].tolist() == [42, 42, 42]
-    for bad in ("chr1", "chr1:", "chr1:1:2", "chr1:12a", "chr1:1.5", ":", "chr1:--1"):
+    f3 = _as_fields(["chr1:1_000", "chr1: +1_2_3 ", "chr1:-0_0"])                          # int() takes single underscores between digits (PEP 515)
+    assert host.parse_ctg_pos(f3, tbl)[0].tolist() == [int(s.split(":")[1]) for s in ("chr1:1_000", "chr1: +1_2_3 ", "chr1:-0_0")] == [1000, 123, 0]
+    for bad in ("chr1", "chr1:", "chr1:1:2", "chr1:12a", "chr1:1.5", ":", "chr1:--1", "chr1:_1", "chr1:1_", "chr1:1__0", "chr1:+_1", "chr1:1 0"):
         with pytest.raises(host.HostError):
             host.parse_ctg_pos(_as_fields(["chr1:5", bad]), tbl)
     assert host.parse_ctg_pos(np.zeros((0, 9), np.uint8), tbl)[0].shape == (0,)
