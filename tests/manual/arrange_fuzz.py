@@ -3,7 +3,7 @@
 int32 HP value (negative, huge, INT_MAX: the kernel's own sentinel for a dropped row), many ties, zero centre bases, n_reads below /
 at / above R, R from 1 to 200, D_out below and above the kept depth, L in {33, 11, 1, 7}; bit for bit.  Test infrastructure."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

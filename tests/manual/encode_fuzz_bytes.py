@@ -2,9 +2,9 @@
 """Fuzz: columns built from random BYTES under a loose grammar (every symbol class of tensor_maker.cpp:83-114 - bases in both cases,
 * #, ^x, $, +n / -n with n up to 3 digits and allele text that may be shorter than n or run into the next column's boundary, digits and
 punctuation the scanner ignores) - the HIP column encode against oracle/liboracle.so, bit for bit (counts, depth, flags), seed after
-seed.  Test infrastructure (loads oracle/): `python tools/encode_fuzz.py [seeds] [columns]`."""
+seed.  Test infrastructure (loads oracle/): `python tests/manual/encode_fuzz_bytes.py [seeds] [columns]`."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

@@ -4,7 +4,7 @@ dataset_dev.get_frequency_feature on the same kinds of planes: docs/rounds/r05.m
 reference ignores, negative and huge qualities (the packed 8- / 16-bit running sums must fall back), all padding / all deletions, a
 read set present through ONE element, D from 1 to 200, L in {33, 11, 1, 5, 40}; bit for bit.  Test infrastructure (loads oracle/)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """DEVELOPMENT CONTAINER ONLY (runs oracle/_ref, reads tests/golden/make_golden.py): the reference's compiled DNA_CreateCanSnpTensor +
 DNA_CreatePredictData against oracle.mpileup_to_pd on adversarial and cut-allele contigs, three threshold sets, .pd byte for byte.
-    python tools/ref_fuzz/encode_binaries.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/encode_binaries.py FIRST_SEED END_SEED"""
 import os, sys, subprocess, tempfile, importlib.util
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from nanosnp_amd import host
 from oracle import oracle
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 spec = importlib.util.spec_from_file_location("make_golden", ROOT+"/tests/golden/make_golden.py")
 mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
 bad=0

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """DEVELOPMENT CONTAINER ONLY (runs oracle/_ref): position gaps, backward steps, duplicate lines, zero-depth lines, extra columns in the
 mpileup text - the compiled reference against oracle.mpileup_to_pd and against the product's host parser + the oracle's array path.
-    python tools/ref_fuzz/encode_positions.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/encode_positions.py FIRST_SEED END_SEED"""
 import os, sys, subprocess, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from nanosnp_amd import host
 from oracle import oracle
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 bad=0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(seed)

@@ -4,9 +4,9 @@
 tabs, leading / trailing tabs, an empty field in front of the bases (every later field moves up), no quality column, \\r\\n, a lone \\r
 inside a field, "+12" / "12abc" / " 12" positions (atoll), no final newline - the compiled reference against oracle.mpileup_to_pd and
 against the product's parsers (nsnp_mpileup_parse and nsnp_mpileup_parse_into, the chunked AVX2 one) + the oracle's array path.
-    python tools/ref_fuzz/encode_text.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/encode_text.py FIRST_SEED END_SEED"""
 import os, sys, subprocess, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from nanosnp_amd import host

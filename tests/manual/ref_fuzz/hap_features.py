@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """DEVELOPMENT CONTAINER ONLY (imports /root/reference): dataset_dev.get_frequency_feature against oracle.hap_features on planes outside
 the generator's range (codes the reference ignores, huge and negative qualities, all padding, one-element read sets), float64 bit for bit.
-    python tools/ref_fuzz/hap_features.py"""
+    python tests/manual/ref_fuzz/hap_features.py"""
 import os, sys, types
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 for name, attrs in (("ranger", {"Ranger": object}), ("ranger21", {"Ranger21": object}), ("tables", {"Filters": lambda **k: None})):
     m = types.ModuleType(name); [setattr(m, k, v) for k, v in attrs.items()]; sys.modules[name] = m

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """DEVELOPMENT CONTAINER ONLY (imports /root/reference): scripts/merge.py Run and select_hetesnp_homosnp.find_adjacent_sites on random
-call sets (VCF rows from tools/ref_fuzz/vcf_rows.py's sites, haplotype rows over all 21 labels, positions the VCF lacks) against
+call sets (VCF rows from tests/manual/ref_fuzz/vcf_rows.py's sites, haplotype rows over all 21 labels, positions the VCF lacks) against
 nanosnp_amd.merge.merge_calls / select_groups.
-    python tools/ref_fuzz/merge_select.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/merge_select.py FIRST_SEED END_SEED"""
 import os, sys, tempfile, types, argparse, io, contextlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from nanosnp_amd import host
 from nanosnp_amd.merge import merge_calls, select_groups

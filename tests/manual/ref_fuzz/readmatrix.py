@@ -3,9 +3,9 @@
 stand-in alignment file of tests/helpers.py on random read sets (few / many reads, short reads that leave group columns uncovered,
 other HP values, refskips, every read untagged, groups at the contig's start) against nanosnp_amd.readmatrix + the oracle's arrangement:
 candidates, position lists, depths, the HP-sorted centre column, the rows of every HP group as multisets.
-    python tools/ref_fuzz/readmatrix.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/readmatrix.py FIRST_SEED END_SEED"""
 import os, sys, types, io, contextlib
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 for name, attrs in (("ranger", {"Ranger": object}), ("ranger21", {"Ranger21": object}), ("tables", {"Filters": lambda **k: None}), ("pysam", {})):

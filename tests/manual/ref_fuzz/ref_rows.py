@@ -2,9 +2,9 @@
 """DEVELOPMENT CONTAINER ONLY (imports /root/reference): dataset_dev.PileupFeature / HaplotypeFeature reference rows on a stand-in table
 file - positions that are negative, zero, past the contig's end, contigs the reference dictionary lacks, lower-case / N / IUPAC
 sequence - against host.haplotype_ref_rows and hap_pipeline.DeviceReference.rows (torch on the CPU).
-    python tools/ref_fuzz/ref_rows.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/ref_rows.py FIRST_SEED END_SEED"""
 import os, sys, types
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 for name, attrs in (("ranger", {"Ranger": object}), ("ranger21", {"Ranger21": object}), ("tables", {"Filters": lambda **k: None})):

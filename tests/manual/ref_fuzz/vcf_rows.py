@@ -2,9 +2,9 @@
 """DEVELOPMENT CONTAINER ONLY (imports /root/reference): the reference's own predict() loop (PileupModel/predict.py:37-195) driven by a
 stand-in model that returns prepared probabilities - every genotype / zygosity class, ties, exact ones, depth 0, odd reference bases -
 against nsnp_vcf_format_batches, byte for byte, batch sizes 1000 / 64 / 7, both NumPy promotion generations.
-    python tools/ref_fuzz/vcf_rows.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/vcf_rows.py FIRST_SEED END_SEED"""
 import os, sys, tempfile, types
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np, torch
 from torch.utils.data import Dataset
 from nanosnp_amd import host

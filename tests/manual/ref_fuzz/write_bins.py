@@ -2,9 +2,9 @@
 """DEVELOPMENT CONTAINER ONLY (imports /root/reference): HaplotypeModel/write_to_bins.py with a recording stand-in for PyTables (what is
 appended to which EArray) against sitefile.write_haplotype_bin + read_haplotype_bin on random chunks - ragged depths padded to the
 chunk maximum, depth limits below / at / above it, unsorted (distinct) positions, one site, int8 and int32 storage.
-    python tools/ref_fuzz/write_bins.py FIRST_SEED END_SEED"""
+    python tests/manual/ref_fuzz/write_bins.py FIRST_SEED END_SEED"""
 import os, sys, types, tempfile, argparse, io, contextlib
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 import numpy as np
 rec = {}
