@@ -506,7 +506,7 @@ class _SiteSet:
 
 
 def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=1000, score_mode=host.SCORE_FLOAT64, pass_sites=65536,
-                        narrow=True, stats=None):
+                        narrow=True, stats=None, distributed=True):
     """The reference's ``predict(model, testing_paths, reference_index_file, batch_size, output_file, device)`` (PileupModel/predict.py:
     37-195) over this repository's ``.pd.bin`` site files (sitefile.write_pileup_bin / pd_to_bin: the arrays of make_bin_predict_data.py:
     90-100): every file's windows are STREAMED - a worker thread `pread`s passes of `pass_sites` windows from the page cache into one of
@@ -516,14 +516,21 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     slice of predict.py:63 is taken from the staged pass on the host: the H2D copy of a pass is the only copy-engine work); the
     files are one pipeline, and the rows of a file are formatted (one native call over the reference's batches of `batch_size` sites,
     which restart with every file as its DataLoader does) and appended on a writer thread while the next file computes.
-    testing_paths: a list of paths, or a directory (its ``*.bin`` files in os.listdir order: predict.py:215).  Returns rows written."""
+    testing_paths: a list of paths, or a directory (its ``*.bin`` files in os.listdir order: predict.py:215).  Returns rows written.
+    Under torch.distributed (one process per GPU) every rank works on its shard_range of every file's windows, the calls travel to
+    rank 0 in one rooted gather and rank 0 formats (the reference's batches run over the whole file) and writes; the other ranks
+    return 0.  distributed=False: this process alone does the whole job even inside a process group."""
     import threading
     import time
     from concurrent.futures import ThreadPoolExecutor
     import torch
+    import torch.distributed as tdist
     from . import sitefile
+    from .dist import gather_varlen, shard_range
     from .hap_pipeline import _LocalNames
     t_begin = time.perf_counter()
+    sharded = bool(distributed) and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+    rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
     ctx = model.ctx
     dev = torch.device("cuda", ctx.device)
     st = stats if stats is not None else {}
@@ -541,27 +548,31 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
         if ("position_matrix" not in idx or "position" not in idx or idx["position_matrix"][0] not in (np.dtype(np.int32), np.dtype(np.int16))
                 or idx["position_matrix"][1][1:] != (33, 18)):
             raise sitefile.SiteFileError(f"{p}: not a pileup site file (position_matrix int16 / int32 [N,33,18] + position)")
-        files.append(dict(path=p, n=idx["position_matrix"][1][0], x_off=idx["position_matrix"][2], fd=-1,
+        n_file = int(idx["position_matrix"][1][0])
+        lo, hi = shard_range(n_file, rank, world)              # this rank's windows of the file: [lo, hi) (everything without a process group)
+        files.append(dict(path=p, n_file=n_file, lo=lo, n=hi - lo, x_off=idx["position_matrix"][2], fd=-1,
                           elem=idx["position_matrix"][0].itemsize,
                           position=sitefile.read_arrays(p, mmap=True)["position"]))
     P = int(max(1, pass_sites))
     seg_off = np.concatenate([[0], np.cumsum([f["n"] for f in files])]).astype(np.int64)
     n_total = int(seg_off[-1])
-    passes = []
+    passes = []                                                # (file, first window, end - ABSOLUTE indices in the file -, offset among this rank's sites)
     for fi, f in enumerate(files):
-        a = 0
-        while a < f["n"]:
-            b = min(f["n"], a + (max(1, P // 4) if not passes and f["n"] > P else P))       # the very first pass: a quarter (the pipeline's fill)
-            passes.append((fi, a, b, int(seg_off[fi]) + a))
+        a = f["lo"]
+        while a < f["lo"] + f["n"]:
+            b = min(f["lo"] + f["n"], a + (max(1, P // 4) if not passes and f["n"] > P else P))   # the very first pass: a quarter (the pipeline's fill)
+            passes.append((fi, a, b, int(seg_off[fi]) + a - f["lo"]))
             a = b
     last_pass_of = {fi: k for k, (fi, _, _, _) in enumerate(passes)}
     names = _LocalNames()
     total_rows = 0
-    out = open(output_file, "wb")
+    kept = {}                                                  # sharded: the calls of every file stay on this rank until the gather
+    out = open(output_file, "wb") if rank == 0 else None
     try:
         for f in files:
             f["fd"] = os.open(f["path"], os.O_RDONLY)
-        out.write(host.vcf_header(fai_text).encode())
+        if out:
+            out.write(host.vcf_header(fai_text).encode())
         if passes:
             n_sets = min(3, len(passes))
             hsets = getattr(model, "_site_host_sets", None)
@@ -632,7 +643,12 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                 o0, o1 = int(seg_off[fi]), int(seg_off[fi + 1])
                 r0 = (fi % n_slots) * max_n
                 r1 = r0 + (o1 - o0)
-                if o1 > o0:
+                if sharded:
+                    if o1 > o0:                        # the result slot is about to be reused: this rank's calls of the file as one float64 block (all exact)
+                        kept[fi] = np.concatenate([ctg_all[o0:o1, None], pos_all[o0:o1, None], refb_all[o0:o1, None], res["ga"][r0:r1].numpy()[:, None],
+                                                   res["za"][r0:r1].numpy()[:, None], res["gm"][r0:r1].numpy()[:, None], res["zm"][r0:r1].numpy()[:, None],
+                                                   cov_all[o0:o1]], axis=1, dtype=np.float64)
+                elif o1 > o0:
                     text, rows = host.vcf_format_batches(names.table, ctg_all[o0:o1], pos_all[o0:o1], refb_all[o0:o1], res["ga"][r0:r1].numpy(),
                                                          res["za"][r0:r1].numpy(), res["gm"][r0:r1].numpy(), res["zm"][r0:r1].numpy(),
                                                          cov_all[o0:o1], batch_size=batch_size, score_mode=score_mode, as_view=True,
@@ -682,7 +698,7 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                     # the H2D copy of a pass is the only copy-engine work of the run
                     if a == 0 and fi >= n_slots and fi - n_slots < len(seg_futs):
                         seg_futs[fi - n_slots].result()                                # the rows of the file that had this result slot are written
-                    r = (fi % n_slots) * max_n + a
+                    r = (fi % n_slots) * max_n + a - files[fi]["lo"]
                     ctx.pileup_forward_windows_calls(x.view(m * 33, 18), centers[:m],
                                                      calls_out=(res["ga"][r:r + m], res["za"][r:r + m], res["gm"][r:r + m], res["zm"][r:r + m]))
                     ev[k]["c1"].record(main)
@@ -709,8 +725,42 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                     if "gaps" in st and gap > 5e-4:
                         st["gaps"].append((k, round(gap * 1e3, 2), round(ev[k - 1]["c1"].elapsed_time(e_["h1"]), 2), round(e_["h0"].elapsed_time(e_["h1"]), 2)))
             st["account_s"] += time.perf_counter() - t_a
+        if sharded:
+            # contig ids index every rank's OWN name table: the tables are merged, every rank renumbers its ids, then the calls of all files
+            # travel as ONE [n, 15] float64 block to rank 0, which cuts it back into files (every rank knows every shard size) and formats
+            t0 = time.perf_counter()
+            lists = [None] * world
+            tdist.all_gather_object(lists, list(names.names))
+            merged = list(dict.fromkeys(n_ for lst in lists for n_ in lst))
+            remap = np.array([merged.index(n_) for n_ in names.names], np.float64)
+            blks = []
+            for fi in range(len(files)):
+                if fi in kept:
+                    b = kept[fi]
+                    b[:, 0] = remap[b[:, 0].astype(np.int64)]
+                    blks.append(b)
+            blk = np.concatenate(blks) if blks else np.zeros((0, 15))
+            backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
+            allb = gather_varlen(torch.from_numpy(blk).to(backend_dev))
+            if rank == 0:
+                allb = allb.cpu().numpy()
+                tbl = host.ContigTable(merged)
+                sizes = [[shard_range(f["n_file"], r, world)[1] - shard_range(f["n_file"], r, world)[0] for f in files] for r in range(world)]
+                start = np.concatenate([[0], np.cumsum([sum(sz) for sz in sizes])])
+                within = [np.concatenate([[0], np.cumsum(sz)]) for sz in sizes]
+                for i in range(len(files)):
+                    rows = np.concatenate([allb[start[r] + within[r][i]:start[r] + within[r][i + 1]] for r in range(world)])
+                    if len(rows):
+                        text, n_rows = host.vcf_format_batches(tbl, rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int64), rows[:, 2].astype(np.uint8),
+                                                               rows[:, 3].astype(np.uint8), rows[:, 4].astype(np.uint8), rows[:, 5].astype(np.float32),
+                                                               rows[:, 6].astype(np.float32), np.ascontiguousarray(rows[:, 7:15], np.float32),
+                                                               batch_size=batch_size, score_mode=score_mode, as_view=True)
+                        out.write(text)
+                        total_rows += n_rows
+            st["vcf_s"] += time.perf_counter() - t0
     finally:
-        out.close()
+        if out:
+            out.close()
         for f in files:
             if f["fd"] >= 0:
                 os.close(f["fd"])

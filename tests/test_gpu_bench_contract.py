@@ -211,6 +211,22 @@ def test_two_ranks_through_the_launcher_on_one_gpu(workload):
         assert d["scaling"] == "strong" and d["config"]["stage2_sites"] == 2 * 12288 and d["config"]["stage5_sites"] == 3001     # whole batches per rank
 
 
+def test_two_ranks_pd_e2e_on_one_gpu():
+    """--workload pd-e2e under two ranks sharing the GPU (gloo): every rank streams its shard of every file, rank 0 formats and writes;
+    the line's parity sample compares the sharded, streamed VCF with the one-pass run and the oracle"""
+    env = dict(os.environ, NSNP_PDE2E_SITES="100000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo", "--share-gpu",
+                          "--no-cpu-baseline", "--workload", "pd-e2e"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["sites"] == 100000 and d["parity_sample"]["ok"]
+    assert all(v["vcf_equals_the_int16_run"] for v in d["second_values"].values())
+
+
 def test_bench_with_the_library_gather_entry():
     """--gather rccl-abi: the final merge through nsnp_comm_init + nsnp_gather_results (one rank here)"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "65536", "--gather", "rccl-abi",

@@ -1,4 +1,5 @@
 """End-to-end predict loops on the GPU vs what the reference's predict() wrote."""
+import os
 import re
 
 import numpy as np
@@ -299,3 +300,66 @@ def test_streamed_pd_bin_files_write_the_array_path_vcf(tmp_path, pileup_weights
     with pytest.raises(host.HostError):
         predict_pileup_bins(m, [str(pb)], fai, str(o1))
     assert predict_pileup_bins(m, files, fai, str(o1), batch_size=100) == want.count(b"\n") - header.count(b"\n")      # the model is usable afterwards
+
+
+def _pd_rank_worker(rank, world, port, tmp, q):
+    import torch.distributed as dist
+    from nanosnp_amd.fixtures import load_pileup_weights
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import predict_pileup_bins
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = LSTMNetwork().load_weight_list(load_pileup_weights())
+        out = os.path.join(tmp, f"sharded_{rank}.vcf")
+        files = [os.path.join(tmp, f"part{i}.pd.bin") for i in range(4)]
+        rows = predict_pileup_bins(m, files, open(os.path.join(tmp, "fai.txt")).read(), out, batch_size=100, pass_sites=64)
+        alone = os.path.join(tmp, f"alone_{rank}.vcf")                      # distributed=False inside the group: the whole job by this process
+        rows_alone = predict_pileup_bins(m, files, open(os.path.join(tmp, "fai.txt")).read(), alone, batch_size=100, distributed=False)
+        q.put((rank, rows, os.path.exists(out), rows_alone))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_site_sharded_window_files_write_the_single_process_vcf(tmp_path, pileup_weights, world):
+    """pipeline.predict_pileup_bins under a process group: every rank takes its shard_range of every file's windows (all on cuda:0 of
+    the one-GPU box, the gather over gloo), rank 0 formats over the whole file - the rows depend on the batch a site falls into - and
+    writes the single-process VCF; an empty file and a file smaller than the number of ranks among them; contigs met in different
+    orders by different ranks"""
+    import socket
+    import torch.multiprocessing as mp
+    from nanosnp_amd import sitefile
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import predict_pileup_bins
+    z = np.load(golden("pileup_vcf_modes.npz"))
+    x = z["x"].astype(np.int32)
+    names, pos, refb = list(z["names"]), z["pos"], z["refb"]
+    fai = bytes(z["fai"]).decode()
+    position = [f"{c}:{int(p)}:{'N' * 16}{chr(int(r))}{'N' * 16}" for c, p, r in zip(names, pos, refb)]
+    n = x.shape[0]
+    cuts = [0, n // 3, n // 3, n - 2, n]                                   # a third, an empty file, most of the rest, two sites
+    files = []
+    for i in range(4):
+        a, b = cuts[i], cuts[i + 1]
+        sitefile.write_pileup_bin(tmp_path / f"part{i}.pd.bin", x[a:b], position[a:b], matrix_dtype="int32" if i == 2 else "int16")
+        files.append(str(tmp_path / f"part{i}.pd.bin"))
+    (tmp_path / "fai.txt").write_text(fai)
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    want = tmp_path / "single.vcf"
+    n_rows = predict_pileup_bins(m, files, fai, str(want), batch_size=100, pass_sites=64)
+    assert n_rows > 100
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pd_rank_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][:3] == (0, n_rows, True) and all(r[1] == 0 and not r[2] for r in res[1:]) and all(r[3] == n_rows for r in res)
+    assert (tmp_path / "sharded_0.vcf").read_bytes() == want.read_bytes()
+    for r in range(world):
+        assert (tmp_path / f"alone_{r}.vcf").read_bytes() == want.read_bytes()

@@ -32,6 +32,14 @@ def run(args, rank, world, local_rank, emit=None):
     try:
         return _run(args, rank, world, local_rank, emit, created)
     finally:
+        if world > 1 and emit is None:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                try:
+                    dist.barrier()                       # nobody removes a file another rank still reads
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
         for pth in created:
             try:
                 if os.path.exists(pth):
@@ -43,9 +51,16 @@ def run(args, rank, world, local_rank, emit=None):
 def _run(args, rank, world, local_rank, emit, created):
     import numpy as np
     import torch
-    if world != 1:
-        print("bench.py: --workload pd-e2e is a one-rank measurement (the text path e2e and the stage-5 path hap-e2e shard over ranks)", file=sys.stderr)
-        return 2
+    import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0                               # TEST configuration: every rank on GPU 0 (one-GPU boxes), collectives over gloo
+    if world > 1 and emit is None and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    cdev = torch.device("cuda", local_rank) if (world > 1 and args.dist_backend == "nccl") else torch.device("cpu")
     from nanosnp_amd import host, sitefile
     from nanosnp_amd.fixtures import load_pileup_weights
     from nanosnp_amd.pileup_model import LSTMNetwork
@@ -61,15 +76,31 @@ def _run(args, rank, world, local_rank, emit, created):
     ctx = model.ctx
     tmp = scratch_dir(n * (2376 + 1188) * 2)
     path = os.path.join(tmp, f"nsnp_pde2e_{n}.pd.bin")
-    out_path = os.path.join(tmp, "nsnp_pde2e.vcf")
-    created += [path, out_path]
-    # ---- the site file: G2 windows encoded + gathered on the device, chunk by chunk ----
+    path32 = os.path.join(tmp, f"nsnp_pde2e_{n}_int32.pd.bin")
+    if rank == 0:
+        created += [path, path32]
+    # ---- the site file: G2 windows encoded + gathered on the device, chunk by chunk (rank 0 writes, every rank reads the page cache) ----
     t_gen = time.perf_counter()
+    cols_keep = None
+    if rank == 0:
+        cols_keep = _make_files(args, ctx, dev, n, path, path32)
+    if world > 1:
+        dist.barrier()
+    t_gen = time.perf_counter() - t_gen
+    fai = "chrP\t%d\t6\t60\t61\n" % (n * 40 + 100)
+    out_path = os.path.join(tmp, f"nsnp_pde2e_{rank}.vcf")
+    created.append(out_path)
+    W, K = max(1, args.warmup), max(1, args.steps)
+    return _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev, n, P, path, path32, out_path, fai, weights, cols_keep, t_gen, tmp, W, K)
+
+
+def _make_files(args, ctx, dev, n, path, path32):
+    import numpy as np
+    import torch
+    from nanosnp_amd import host, sitefile
     chunk = 65536
     position = np.char.add(np.char.add("chrP:", (np.arange(n) * 40 + 17).astype(str)), ":" + "N" * 16 + "A" + "N" * 16).astype("S83")
     pf = np.frombuffer(position.tobytes(), np.uint8).reshape(n, 83)
-    path32 = os.path.join(tmp, f"nsnp_pde2e_{n}_int32.pd.bin")
-    created.append(path32)
     maps = sitefile.create_arrays(path, {"position_matrix": (np.int16, (n, 33, 18)), "position": (np.uint8, (n, 83))})
     maps32 = sitefile.create_arrays(path32, {"position_matrix": (np.int32, (n, 33, 18)), "position": (np.uint8, (n, 83))})
     cols_keep = None
@@ -88,9 +119,20 @@ def _run(args, rank, world, local_rank, emit, created):
     for a in list(maps.values()) + list(maps32.values()):
         a.flush()
     del maps, maps32
-    t_gen = time.perf_counter() - t_gen
-    fai = "chrP\t%d\t6\t60\t61\n" % (n * 40 + 100)
-    W, K = max(1, args.warmup), max(1, args.steps)
+    return cols_keep
+
+
+def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev, n, P, path, path32, out_path, fai, weights, cols_keep, t_gen, tmp, W, K):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from nanosnp_amd import host, sitefile
+    from nanosnp_amd.pipeline import predict_pileup_bins
+    from tools import bench_common as bc
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
     def timed(steps, narrow=True, pass_sites=P, path=path):
         for _ in range(W):
@@ -98,12 +140,17 @@ def _run(args, rank, world, local_rank, emit, created):
         torch.cuda.synchronize(dev)
         if os.path.exists(out_path):
             os.remove(out_path)                      # (truncating the previous run's half gigabyte of tmpfs pages is not part of a run)
+        barrier()
         st = {}
         c0 = bc.cgroup_cpu_stat()
         t0 = time.perf_counter()
         predict_pileup_bins(model, [path] * steps, fai, out_path, pass_sites=pass_sites, narrow=narrow, stats=st)
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev); barrier()
         dt = time.perf_counter() - t0
+        if world > 1:
+            tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt = float(tm.item())
         c1 = bc.cgroup_cpu_stat()
         if c0 and c1:
             st["host_cpu"] = {"core_seconds_used": round((c1[2] - c0[2]) * 1e-6, 3), "average_cores_busy": round((c1[2] - c0[2]) * 1e-6 / dt, 1),
@@ -123,21 +170,30 @@ def _run(args, rank, world, local_rank, emit, created):
                 "compute_stream_idle_between_passes_s_per_step": round(st.get("gpu_idle_s", 0.0) / steps, 4), "host_cpu_over_the_timed_region": st.get("host_cpu")}
 
     dt, st = timed(K)
-    vcf_all = open(out_path, "rb").read()
     header = host.vcf_header(fai).encode()
-    body = vcf_all[len(header):]
-    vcf_one_file = body[:len(body) // K]
-    files_equal = body == vcf_one_file * K
+    vcf_one_file, files_equal = b"", True
+    if rank == 0:
+        body = open(out_path, "rb").read()[len(header):]
+        vcf_one_file = body[:len(body) // K]
+        files_equal = body == vcf_one_file * K
     head = describe(dt, st, K, 594 * 2)
     K2 = max(1, min(K, 4))
     second = {}
     if not args.no_second_precision:
         for key, nrw, bps in (("int32_counts_on_disk_narrowed_while_staged", True, 594 * 2), ("int32_counts_on_disk_sent_as_int32", False, 594 * 4)):
             d2, s2 = timed(K2, narrow=nrw, path=path32)
-            b2 = open(out_path, "rb").read()[len(header):]
             second[key] = describe(d2, s2, K2, bps)
-            second[key]["vcf_equals_the_int16_run"] = bool(b2[:len(b2) // K2] == vcf_one_file)
-    # ---- HBM-resident rate of the same forward + calls ----
+            if rank == 0:
+                b2 = open(out_path, "rb").read()[len(header):]
+                second[key]["vcf_equals_the_int16_run"] = bool(b2[:len(b2) // K2] == vcf_one_file)
+    one = os.path.join(tmp, f"nsnp_pde2e_one_{rank}.vcf")
+    if not args.no_parity_sample:
+        created.append(one)
+        predict_pileup_bins(model, [path], fai, one, pass_sites=n)          # (every rank: its shard of the file as ONE pass)
+    if rank != 0:
+        barrier()
+        return 0
+    # ---- HBM-resident rate of the same forward + calls (rank 0) ----
     m = min(P, n)
     xr = torch.from_numpy(np.asarray(sitefile.read_arrays(path)["position_matrix"][:m], np.int32)).to(dev)
     centers = (torch.arange(m, dtype=torch.int64, device=dev) * 33 + 16).contiguous()
@@ -153,9 +209,6 @@ def _run(args, rank, world, local_rank, emit, created):
 
     parity = None
     if not args.no_parity_sample:
-        one = os.path.join(tmp, "nsnp_pde2e_one.vcf")
-        created.append(one)
-        predict_pileup_bins(model, [path], fai, one, pass_sites=n)
         v1 = open(one, "rb").read()[len(header):]
         # and the first windows against the oracle: encode -> forward on the same columns
         from oracle import oracle
@@ -175,12 +228,13 @@ def _run(args, rank, world, local_rank, emit, created):
                             all(v.get("vcf_equals_the_int16_run", True) for v in second.values()))
     out = {
         "metric": "candidate SNP sites/sec, .pd.bin site file to pileup.vcf (windows on the page cache: staging + H2D + PileupModel fwd + VCF)",
-        "value": head["value"], "unit": "sites/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"],
+        "value": head["value"], "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "stage 2 from site files: %d G2 windows (30x) as a .pd.bin site file (%.2f GB, int16 counts, page cache) -> passes of %d: "
                                "pread into pinned buffers beside H2D beside PileupModel fwd (fp32) + calls written to pinned memory -> pileup.vcf; NOT the headline "
                                "configuration (BASELINE configs[1] has its inputs in HBM)" % (n, os.path.getsize(path) / 1e9, P),
-                   "sites": n, "sites_per_pass": P, "file_bytes": os.path.getsize(path)},
+                   "sites": n, "sites_per_pass": P, "file_bytes": os.path.getsize(path), "world_size_observed": world,
+                   **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: device time is serialised, not a scaling number"} if args.share_gpu else {})},
         **{k: head[k] for k in ("stage_busy_s_per_step", "bound_by", "h2d_GB_per_s", "bytes_over_pcie_per_site", "pcie_bound_sites_per_s_at_the_measured_h2d_rate",
                                 "main_thread_s_per_step", "staging_thread_s_per_step", "compute_stream_idle_between_passes_s_per_step", "host_cpu_over_the_timed_region")},
         "hbm_resident_sites_per_s": resident, "fraction_of_hbm_resident_rate": head["value"] / resident,
@@ -204,6 +258,7 @@ def _run(args, rank, world, local_rank, emit, created):
         out["cpu_baseline"] = {"value": kk / t2, "unit": "sites/s", "cores": cores, "kind": "port",
                                "sample": f"{kk} of the file's windows through the oracle's blocked full-schedule fp32 forward, OpenMP over {cores} threads ({t2:.1f} s); "
                                          "no file I/O, no row formatting; oracle/liboracle.so", "host_cpu": bc.host_cpu_name(), "logical_cpus": os.cpu_count()}
+    barrier()                                        # (the other ranks wait here while rank 0 measured the resident rate and checked)
     if emit is not None:
         emit(out)
     else:
