@@ -11,7 +11,7 @@ out = {"what": "ranks SHARE one GPU (gloo collectives): device time is serialise
        "rows": []}
 print("| workload | ranks | value (sites/s, TEST configuration) | wall ms/step | host work per rank: max (s/step) | wait for host work: max | device busy per rank: max | formatting (rank 0) |")
 print("|---|---|---|---|---|---|---|---|")
-for wl, hostk, waitk, fmtk in (("e2e", "parse_s", "wait_parse_s", "vcf_s"), ("hap-e2e", "stage_s", "wait_stage_s", "csv_s")):
+for wl, hostk, waitk, fmtk in (("e2e", "parse_s", "wait_parse_s", "vcf_s"), ("hap-e2e", "stage_s", "wait_stage_s", "csv_s"), ("pd-e2e", "stage_s", "wait_stage_s", "vcf_s")):
     for n in (1, 2, 4, 8):
         f = os.path.join(d, f"{wl}_{n}.json")
         try:

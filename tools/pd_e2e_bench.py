@@ -151,6 +151,12 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
             tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
+        if world > 1:
+            mine = {k: round(st.get(k, 0.0) / steps, 4) for k in ("stage_s", "wait_stage_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "vcf_s")}
+            mine["rank"] = rank
+            per = [None] * world
+            dist.all_gather_object(per, mine)
+            st["per_rank"] = per
         c1 = bc.cgroup_cpu_stat()
         if c0 and c1:
             st["host_cpu"] = {"core_seconds_used": round((c1[2] - c0[2]) * 1e-6, 3), "average_cores_busy": round((c1[2] - c0[2]) * 1e-6 / dt, 1),
@@ -167,7 +173,8 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
                 "pcie_bound_sites_per_s_at_the_measured_h2d_rate": st.get("bytes_h2d", 0.0) / max(st.get("h2d_s", 0.0), 1e-9) / bps,
                 "main_thread_s_per_step": {k: round(st.get(k, 0.0) / steps, 4) for k in ("setup_s", "wait_stage_s", "issue_s", "drain_s", "account_s")},
                 "staging_thread_s_per_step": {k: round(st.get(k, 0.0) / steps, 4) for k in ("stage_values_s", "stage_coverage_s", "stage_fields_s")},
-                "compute_stream_idle_between_passes_s_per_step": round(st.get("gpu_idle_s", 0.0) / steps, 4), "host_cpu_over_the_timed_region": st.get("host_cpu")}
+                "compute_stream_idle_between_passes_s_per_step": round(st.get("gpu_idle_s", 0.0) / steps, 4), "host_cpu_over_the_timed_region": st.get("host_cpu"),
+                **({"per_rank_s_per_step": st["per_rank"]} if "per_rank" in st else {})}
 
     dt, st = timed(K)
     header = host.vcf_header(fai).encode()
@@ -237,6 +244,7 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
                    **({"TEST_CONFIGURATION": "ranks share GPU 0, gather over gloo: device time is serialised, not a scaling number"} if args.share_gpu else {})},
         **{k: head[k] for k in ("stage_busy_s_per_step", "bound_by", "h2d_GB_per_s", "bytes_over_pcie_per_site", "pcie_bound_sites_per_s_at_the_measured_h2d_rate",
                                 "main_thread_s_per_step", "staging_thread_s_per_step", "compute_stream_idle_between_passes_s_per_step", "host_cpu_over_the_timed_region")},
+        **({"per_rank_s_per_step": head["per_rank_s_per_step"]} if "per_rank_s_per_step" in head else {}),
         "hbm_resident_sites_per_s": resident, "fraction_of_hbm_resident_rate": head["value"] / resident,
         "second_values": second, "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,
         "file_generation_s": round(t_gen, 1), "cpu_baseline": None,
