@@ -92,10 +92,20 @@ def test_all_workloads_have_a_line():
 def test_host_scaling_table_is_committed():
     t = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_host_scaling.json")))
     rows = {(r["workload"], r["ranks"]) for r in t["rows"]}
-    assert rows == {(w, n) for w in ("e2e", "hap-e2e") for n in (1, 2, 4, 8)} and "not a scaling number" in t["what"]
+    assert rows == {(w, n) for w in ("e2e", "hap-e2e", "pd-e2e") for n in (1, 2, 4, 8)} and "not a scaling number" in t["what"]
 
 
 def test_fetch_calibration_is_committed():
     c = json.load(open(os.path.join(ROOT, "profiles", "r04_fetch_calibration.json")))["shapes"]
     assert abs(c["k_calib_b128"]["factor_bytes_per_counted_byte"] - 2.0) < 0.02                # the documented wide-read case reproduces
     assert 1.3 < c["k_calib_rows33<unsigned int>"]["factor_bytes_per_counted_byte"] < 2.0      # k_hap_features' shape does not follow it
+
+
+def test_pd_e2e_line_is_committed():
+    """the streamed window-file path's line: parity against the one-pass run and the oracle, both on-disk layouts, >= 0.75 of the
+    HBM-resident rate with int16 counts on disk, the compute stream idle < 2 ms per file between passes"""
+    h = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_pd_e2e_line.json")))
+    assert h["parity_sample"]["ok"] and h["parity_sample"]["timed_run_equals_the_one_pass_run"] and h["parity_sample"]["file_windows_equal_the_oracle_encode"]
+    assert h["fraction_of_hbm_resident_rate"] >= 0.75 and h["compute_stream_idle_between_passes_s_per_step"] < 0.002
+    assert set(h["second_values"]) == {"int32_counts_on_disk_narrowed_while_staged", "int32_counts_on_disk_sent_as_int32"}
+    assert all(v["vcf_equals_the_int16_run"] for v in h["second_values"].values())
