@@ -197,8 +197,10 @@ int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, const int64_
                                const uint8_t* ref, int64_t M, double min_af, int min_coverage,
                                int32_t* counts, int32_t* depth, uint8_t* flags, void* stream);
 
-/* pos: device int64 [M], strictly increasing inside a contig (fold the contig index into the
- * high bits when several contigs share a call).  center_idx: device int64 [cap] receives the
+/* pos: device int64 [M], the positions in line order (fold the contig index into the high bits
+ * when several contigs share a call).  A site is emitted when its 33 columns are 33 consecutive
+ * positions - every step + 1, as main.cpp:174-178 resets its window at any other step: positions
+ * that repeat or step back (concatenated text) are taken as they come.  center_idx: device int64 [cap] receives the
  * column indices of emitted sites in ascending order; *n_sites (device int64) their number
  * (may exceed cap: then only the first cap were written). */
 int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M,
