@@ -197,6 +197,12 @@ int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, const int64_
                                const uint8_t* ref, int64_t M, double min_af, int min_coverage,
                                int32_t* counts, int32_t* depth, uint8_t* flags, void* stream);
 
+/* The same with the reference program's two thresholds apart (DNA_CreateCanSnpTensor -snp_min_af / -indel_min_af, main.cpp:79-88;
+ * tensor_maker.cpp:205-212: an indel allele - the I and D totals - is tested against indel_min_af, a base against snp_min_af). */
+int nsnp_pileup_encode_columns2(nsnp_ctx* ctx, const uint8_t* bases, const int64_t* col_off,
+                                const uint8_t* ref, int64_t M, double snp_min_af, double indel_min_af, int min_coverage,
+                                int32_t* counts, int32_t* depth, uint8_t* flags, void* stream);
+
 /* pos: device int64 [M], the positions in line order (fold the contig index into the high bits
  * when several contigs share a call).  A site is emitted when its 33 columns are 33 consecutive
  * positions - every step + 1, as main.cpp:174-178 resets its window at any other step: positions

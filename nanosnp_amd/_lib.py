@@ -44,6 +44,9 @@ _SIGNATURES = {
     "nsnp_pileup_encode_columns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                              C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
+    "nsnp_pileup_encode_columns2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
     "nsnp_pileup_select_sites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_gather_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -269,7 +272,9 @@ class Context:
         return gt_arg, zy_arg, gt_max, zy_max, depth
 
     # ---- pileup encode -----------------------------------------------------------------------
-    def pileup_encode_columns(self, bases, col_off, ref, min_af=0.12, min_coverage=6, stream=None):
+    def pileup_encode_columns(self, bases, col_off, ref, min_af=0.12, min_coverage=6, stream=None, indel_min_af=None):
+        """min_af: the SNP threshold and, unless indel_min_af is given, the indel threshold too (DNA_CreateCanSnpTensor -snp_min_af /
+        -indel_min_af; make_predict_data.sh passes 0.12 for both)"""
         import torch
         assert bases.is_cuda and bases.dtype == torch.uint8 and col_off.dtype == torch.int64 and ref.dtype == torch.uint8
         m = ref.shape[0]
@@ -277,10 +282,10 @@ class Context:
         counts = torch.empty((m, 18), dtype=torch.int32, device=dev)
         depth = torch.empty(m, dtype=torch.int32, device=dev)
         flags = torch.empty(m, dtype=torch.uint8, device=dev)
-        check(self.lib.nsnp_pileup_encode_columns(self.handle, _dptr(bases), _dptr(col_off), _dptr(ref), m,
-                                                  float(min_af), int(min_coverage), _dptr(counts), _dptr(depth),
-                                                  _dptr(flags), _stream_ptr(stream)),
-              self.handle, "nsnp_pileup_encode_columns")
+        check(self.lib.nsnp_pileup_encode_columns2(self.handle, _dptr(bases), _dptr(col_off), _dptr(ref), m,
+                                                   float(min_af), float(min_af if indel_min_af is None else indel_min_af), int(min_coverage),
+                                                   _dptr(counts), _dptr(depth), _dptr(flags), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_encode_columns2")
         return counts, depth, flags
 
     def pileup_select_sites(self, pos, flags, cap=None, stream=None):

@@ -127,6 +127,7 @@ struct nsnp_ctx {
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
     bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
+    bool af2_cached; uint64_t af2_bits, af2_t; int af2_k, af2_mode; uint32_t af2_table_words[128];     // the indel threshold when it differs
     KernelTimer* timer;
     void* comm; int comm_rank, comm_world;    // optional RCCL communicator of nsnp_comm_init / nsnp_comm_attach (nsnp_comm.hip)
     bool comm_borrowed;                        // attached by the caller: never destroyed here

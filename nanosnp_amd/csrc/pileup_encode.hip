@@ -230,7 +230,7 @@ constexpr int P3_STEP = NSNP_ENC_P3STEP;             // records one trip of the 
 constexpr int ENC_NBLK = 8;                          // 32-byte blocks of a column the fast path covers (8-bit counters: at most 253 bytes)
 static_assert(STAGE_BYTES >= 64 * NCH * 4, "the stage buffer doubles as the 64 x 18 output transposition buffer");
 static_assert(STAGE_BYTES <= 8192, "staged positions are kept in 13 bits");
-static_assert(4 * (ENC_WAVES * (STAGE_BYTES + (ENC_ECAP + P3_STEP) * 8 + 64 * 32) + 4096 + 512) <= 160 * 1024, "four blocks per CU (LDS)");
+static_assert(4 * (ENC_WAVES * (STAGE_BYTES + (ENC_ECAP + P3_STEP) * 8 + 64 * 32) + 4096 + 2 * 512) <= 160 * 1024, "four blocks per CU (LDS)");
 
 // inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (no LDS)
 __device__ __forceinline__ int wave_scan_incl(int v)
@@ -250,10 +250,12 @@ __device__ __forceinline__ int wave_scan_incl(int v)
 #endif
 __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     const uint8_t* __restrict__ bases, const int64_t* __restrict__ col_off, const uint8_t* __restrict__ ref,
-    int64_t M, AfThreshold af, const AfTable aft, int min_cov, int32_t* __restrict__ counts, int32_t* __restrict__ depth_out,
+    int64_t M, AfThreshold af, const AfTable aft, AfThreshold afi, const AfTable afti, int min_cov, int32_t* __restrict__ counts,
+    int32_t* __restrict__ depth_out,
     uint8_t* __restrict__ flags)
 {
-    __shared__ uint32_t af_min[128];          // 256 x uint16: smallest passing count by depth (make_af_table)
+    __shared__ uint32_t af_min[128];          // 256 x uint16: smallest passing count by depth (make_af_table): the SNP threshold
+    __shared__ uint32_t afi_min[128];         // the same for the indel threshold (-indel_min_af; the same table when the two are equal)
     __shared__ __attribute__((aligned(16))) uint8_t stage_b[ENC_WAVES][STAGE_BYTES];
     // opener j of the segment sits behind P3_STEP end records (bit 31: no column; the walk of an indel over the earlier ones of its
     // column ends there): { position | column << 16, end of the column }, written by the column.  The lanes that decode the openers compact the
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
         // 1 9 3 11 7 15 0 8), '.' ',' of real pileups (6, 4), and the construct bytes + - ^ $ 1 2 3 mostly beside them: 1.41 LDS cycles
         // per lane group on generator G2's bytes, 1.09 on '.'/','-dominated ones, against 1.57 / 1.24 with only the case bit folded
         tab[tid ^ ((tid >> 2) & 12)] = r;
-        if (tid < 128) af_min[tid] = aft.w[tid];
+        if (tid < 128) { af_min[tid] = aft.w[tid]; afi_min[tid] = afti.w[tid]; }
         if (tid < ENC_WAVES * P3_STEP) ents[tid / P3_STEP][tid % P3_STEP] = uint2{0x80000000u, 0u};
     }
     __syncthreads();
@@ -603,19 +605,20 @@ __global__ __launch_bounds__(ENC_BLOCK, NSNP_ENC_MINW) void k_encode_columns(
     if (__ballot(depth > 255) == 0ull) {
         // every column of the wave inside the table (always, unless a column went through the exact path with more than 255 reads)
         const int thr = (int)((af_min[depth >> 1] >> (16 * (depth & 1))) & 0xffffu);
+        const int thri = (int)((afi_min[depth >> 1] >> (16 * (depth & 1))) & 0xffffu);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const bool ok = lc[k] > 0 && lk[k] != chr_idx && lc[k] >= thr;
-            if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
+            const bool cand = lc[k] > 0 && lk[k] != chr_idx;
+            if (lk[k] >= 4) pass_indel = pass_indel || (cand && lc[k] >= thri); else pass_snp = pass_snp || (cand && lc[k] >= thr);
         }
     } else {
         const uint32_t den = (uint32_t)(depth ? depth : 1);
-        const unsigned __int128 rhs = (unsigned __int128)af.t * den;
+        const unsigned __int128 rhs = (unsigned __int128)af.t * den, rhsi = (unsigned __int128)afi.t * den;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             if (lc[k] <= 0 || lk[k] == chr_idx) continue;
-            const bool ok = af.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << af.k) >= rhs) : af.mode == 1;
-            if (lk[k] >= 4) pass_indel = pass_indel || ok; else pass_snp = pass_snp || ok;
+            if (lk[k] >= 4) pass_indel = pass_indel || (afi.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << afi.k) >= rhsi) : afi.mode == 1);
+            else pass_snp = pass_snp || (af.mode == 0 ? (((unsigned __int128)(uint32_t)lc[k] << af.k) >= rhs) : af.mode == 1);
         }
     }
     const bool pass_af = (top >= 0 && top != chr_idx) || pass_snp || pass_indel;
@@ -734,30 +737,45 @@ __global__ void k_gather_windows(const int32_t* __restrict__ counts, const int64
 
 }  // namespace
 
-extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, const int64_t* col_off,
-                                          const uint8_t* ref, int64_t M, double min_af, int min_coverage,
-                                          int32_t* counts, int32_t* depth, uint8_t* flags, void* stream)
+extern "C" int nsnp_pileup_encode_columns2(nsnp_ctx* ctx, const uint8_t* bases, const int64_t* col_off,
+                                           const uint8_t* ref, int64_t M, double snp_min_af, double indel_min_af, int min_coverage,
+                                           int32_t* counts, int32_t* depth, uint8_t* flags, void* stream)
 {
     if (!ctx || M < 0 || (M > 0 && (!bases || !col_off || !ref || !counts || !depth || !flags))) return NSNP_EINVAL;
     if (M == 0) return NSNP_OK;
     const unsigned grid = (unsigned)NSNP_CDIV(M, ENC_BLOCK);
     ScopedKernelTimer tm(ctx, NSNP_K_ENCODE, (hipStream_t)stream);
-    // threshold + table of the last min_af are kept in the context (a caller passes the same value call after call)
+    // threshold + table of the last thresholds are kept in the context (a caller passes the same values call after call)
     static_assert(sizeof(AfTable) == sizeof(ctx->af_table_words), "AfTable is 128 words");
-    uint64_t af_bits; memcpy(&af_bits, &min_af, 8);
+    uint64_t af_bits; memcpy(&af_bits, &snp_min_af, 8);
     if (!ctx->af_cached || ctx->af_bits != af_bits) {
-        const AfThreshold a0 = make_af_threshold(min_af);
+        const AfThreshold a0 = make_af_threshold(snp_min_af);
         const AfTable t0 = make_af_table(a0);
         ctx->af_t = a0.t; ctx->af_k = a0.k; ctx->af_mode = a0.mode;
         memcpy(ctx->af_table_words, t0.w, sizeof(t0.w));
         ctx->af_bits = af_bits; ctx->af_cached = true;
     }
-    AfThreshold af{ctx->af_t, ctx->af_k, ctx->af_mode};
-    AfTable aft; memcpy(aft.w, ctx->af_table_words, sizeof(aft.w));
+    uint64_t af2_bits; memcpy(&af2_bits, &indel_min_af, 8);
+    if (!ctx->af2_cached || ctx->af2_bits != af2_bits) {
+        const AfThreshold a0 = make_af_threshold(indel_min_af);
+        const AfTable t0 = make_af_table(a0);
+        ctx->af2_t = a0.t; ctx->af2_k = a0.k; ctx->af2_mode = a0.mode;
+        memcpy(ctx->af2_table_words, t0.w, sizeof(t0.w));
+        ctx->af2_bits = af2_bits; ctx->af2_cached = true;
+    }
+    AfThreshold af{ctx->af_t, ctx->af_k, ctx->af_mode}, afi{ctx->af2_t, ctx->af2_k, ctx->af2_mode};
+    AfTable aft, afti; memcpy(aft.w, ctx->af_table_words, sizeof(aft.w)); memcpy(afti.w, ctx->af2_table_words, sizeof(afti.w));
     hipLaunchKernelGGL(k_encode_columns, dim3(grid), dim3(ENC_BLOCK), 0, (hipStream_t)stream,
-                       bases, col_off, ref, M, af, aft, min_coverage, counts, depth, flags);
+                       bases, col_off, ref, M, af, aft, afi, afti, min_coverage, counts, depth, flags);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
+}
+
+extern "C" int nsnp_pileup_encode_columns(nsnp_ctx* ctx, const uint8_t* bases, const int64_t* col_off,
+                                          const uint8_t* ref, int64_t M, double min_af, int min_coverage,
+                                          int32_t* counts, int32_t* depth, uint8_t* flags, void* stream)
+{
+    return nsnp_pileup_encode_columns2(ctx, bases, col_off, ref, M, min_af, min_af, min_coverage, counts, depth, flags, stream);
 }
 
 extern "C" int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M,

@@ -69,6 +69,11 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
  * strings, col_off[M+1] byte offsets, ref[M] raw reference byte per column.
  * counts[M*18], depth[M], flags[M] (ORC_FLAG_*).  min_af is applied to both the SNP and
  * the indel test, as the pipeline does (make_predict_data.sh:184-194). */
+void orc_encode_columns2(const uint8_t* bases, const int64_t* col_off, const uint8_t* ref,
+                         int64_t M, double snp_min_af, double indel_min_af, int min_coverage,
+                         int32_t* counts, int32_t* depth, uint8_t* flags);
+int64_t orc_mpileup_to_pd2(const char* mpileup_path, const char* chr_seq, int64_t chr_len,
+                           double snp_min_af, double indel_min_af, int min_coverage, int flank, const char* pd_path);
 void orc_encode_columns(const uint8_t* bases, const int64_t* col_off, const uint8_t* ref,
                         int64_t M, double min_af, int min_coverage,
                         int32_t* counts, int32_t* depth, uint8_t* flags);

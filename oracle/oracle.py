@@ -28,6 +28,10 @@ def _load():
     p = C.c_void_p
     lib.orc_encode_columns.restype = None
     lib.orc_encode_columns.argtypes = [p, p, p, C.c_int64, C.c_double, C.c_int, p, p, p]
+    lib.orc_encode_columns2.restype = None
+    lib.orc_encode_columns2.argtypes = [p, p, p, C.c_int64, C.c_double, C.c_double, C.c_int, p, p, p]
+    lib.orc_mpileup_to_pd2.restype = C.c_int64
+    lib.orc_mpileup_to_pd2.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char_p]
     lib.orc_select_sites.restype = C.c_int64
     lib.orc_select_sites.argtypes = [p, p, C.c_int64, C.c_int, p, C.c_int64]
     lib.orc_gather_windows.restype = None
@@ -74,14 +78,14 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
-def encode_columns(bases, col_off, ref, min_af=0.12, min_coverage=6):
+def encode_columns(bases, col_off, ref, min_af=0.12, min_coverage=6, indel_min_af=None):
     bases = _c(bases, np.uint8); col_off = _c(col_off, np.int64); ref = _c(ref, np.uint8)
     M = ref.shape[0]
     counts = np.empty((M, NCH), np.int32); depth = np.empty(M, np.int32); flags = np.empty(M, np.uint8)
     if bases.size == 0:
         bases = np.zeros(1, np.uint8)
-    lib().orc_encode_columns(_p(bases), _p(col_off), _p(ref), M, min_af, min_coverage,
-                             _p(counts), _p(depth), _p(flags))
+    lib().orc_encode_columns2(_p(bases), _p(col_off), _p(ref), M, min_af, min_af if indel_min_af is None else indel_min_af, min_coverage,
+                              _p(counts), _p(depth), _p(flags))
     return counts, depth, flags
 
 
@@ -102,8 +106,8 @@ def gather_windows(counts, center_idx, flank=16):
     return x
 
 
-def mpileup_to_pd(mpileup_path, chr_seq: bytes, pd_path, min_af=0.12, min_coverage=6, flank=16):
-    n = lib().orc_mpileup_to_pd(os.fsencode(mpileup_path), chr_seq, len(chr_seq), min_af,
+def mpileup_to_pd(mpileup_path, chr_seq: bytes, pd_path, min_af=0.12, min_coverage=6, flank=16, indel_min_af=None):
+    n = lib().orc_mpileup_to_pd2(os.fsencode(mpileup_path), chr_seq, len(chr_seq), min_af, min_af if indel_min_af is None else indel_min_af,
                                 min_coverage, flank, os.fsencode(pd_path))
     if n < 0:
         raise RuntimeError(f"orc_mpileup_to_pd failed: {n}")

@@ -312,15 +312,27 @@ size_t orc_make_tensor(const char* bases, int64_t len, char ref_raw,
     return need;
 }
 
+void orc_encode_columns2(const uint8_t* bases, const int64_t* col_off, const uint8_t* ref,
+                         int64_t M, double snp_min_af, double indel_min_af, int min_coverage,
+                         int32_t* counts, int32_t* depth, uint8_t* flags);
+
 void orc_encode_columns(const uint8_t* bases, const int64_t* col_off, const uint8_t* ref,
                         int64_t M, double min_af, int min_coverage,
                         int32_t* counts, int32_t* depth, uint8_t* flags)
+{
+    orc_encode_columns2(bases, col_off, ref, M, min_af, min_af, min_coverage, counts, depth, flags);
+}
+
+/* the reference program's two thresholds apart (main.cpp:79-88: -snp_min_af, -indel_min_af) */
+void orc_encode_columns2(const uint8_t* bases, const int64_t* col_off, const uint8_t* ref,
+                         int64_t M, double snp_min_af, double indel_min_af, int min_coverage,
+                         int32_t* counts, int32_t* depth, uint8_t* flags)
 {
     #pragma omp parallel for schedule(dynamic, 1024)
     for (int64_t c = 0; c < M; ++c) {
         orc_column_t col;
         orc_make_tensor((const char*)bases + col_off[c], col_off[c + 1] - col_off[c], (char)ref[c],
-                        NULL, 0, min_af, min_af, &col, NULL, 0);
+                        NULL, 0, snp_min_af, indel_min_af, &col, NULL, 0);
         memcpy(counts + c * ORC_NCH, col.counts, sizeof(int32_t) * ORC_NCH);
         depth[c] = col.depth;
         uint8_t f = 0;
@@ -395,8 +407,17 @@ static int split_tabs(char* line, char** tok, int max_tok)
     return n;
 }
 
+int64_t orc_mpileup_to_pd2(const char* mpileup_path, const char* chr_seq, int64_t chr_len,
+                           double snp_min_af, double indel_min_af, int min_coverage, int flank, const char* pd_path);
+
 int64_t orc_mpileup_to_pd(const char* mpileup_path, const char* chr_seq, int64_t chr_len,
                           double min_af, int min_coverage, int flank, const char* pd_path)
+{
+    return orc_mpileup_to_pd2(mpileup_path, chr_seq, chr_len, min_af, min_af, min_coverage, flank, pd_path);
+}
+
+int64_t orc_mpileup_to_pd2(const char* mpileup_path, const char* chr_seq, int64_t chr_len,
+                           double snp_min_af, double indel_min_af, int min_coverage, int flank, const char* pd_path)
 {
     FILE* in = fopen(mpileup_path, "r");
     if (!in) return -1;
@@ -436,13 +457,13 @@ int64_t orc_mpileup_to_pd(const char* mpileup_path, const char* chr_seq, int64_t
         size_t blen = strlen(bases);
         char small[256]; char* alt = small;
         size_t need = orc_make_tensor(bases, (int64_t)blen, chr_seq[ref_off - 1],
-                                      chr_seq + ref_off, chr_len - ref_off, min_af, min_af,
+                                      chr_seq + ref_off, chr_len - ref_off, snp_min_af, indel_min_af,
                                       &col, small, sizeof small);
         if (nt4((unsigned char)ref_base) < 4 && col.pass_af && col.depth >= min_coverage) {
             if (need + 1 > sizeof small) {
                 alt = malloc(need + 1);
                 orc_make_tensor(bases, (int64_t)blen, chr_seq[ref_off - 1], chr_seq + ref_off,
-                                chr_len - ref_off, min_af, min_af, &col, alt, need + 1);
+                                chr_len - ref_off, snp_min_af, indel_min_af, &col, alt, need + 1);
             }
             int slot = (head + cnt) % (W + 2);
             ppos[slot] = ref_off; pdepth[slot] = col.depth;

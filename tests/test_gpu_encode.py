@@ -63,6 +63,17 @@ def test_thresholds_are_parameters(gpu_ctx):
         c, d, f = _enc(gpu_ctx, cols.bases, cols.col_off, cols.ref, min_af=af, min_coverage=mc)
         oc, od, of = oracle.encode_columns(cols.bases, cols.col_off, cols.ref, af, mc)
         assert np.array_equal(f.cpu().numpy(), of), (af, mc)
+    # the reference program's two thresholds apart (-snp_min_af / -indel_min_af): nsnp_pileup_encode_columns2; deep columns (beyond the
+    # threshold table: the exact 128-bit test) among them
+    deep = host.synth_columns(10, 3000, coverage=400, max_depth=1200)
+    for cset in (cols, deep):
+        for snp, ind in ((0.12, 0.3), (0.3, 0.05), (0.0, 1.0), (1.0, 0.0), (0.12, 0.12)):
+            c, d, f = _enc(gpu_ctx, cset.bases, cset.col_off, cset.ref, min_af=snp, indel_min_af=ind, min_coverage=6)
+            oc, od, of = oracle.encode_columns(cset.bases, cset.col_off, cset.ref, snp, 6, indel_min_af=ind)
+            assert np.array_equal(f.cpu().numpy(), of) and np.array_equal(c.cpu().numpy(), oc), (snp, ind)
+    _, _, f1 = _enc(gpu_ctx, cols.bases, cols.col_off, cols.ref, min_af=0.12, indel_min_af=0.5)
+    _, _, f2 = _enc(gpu_ctx, cols.bases, cols.col_off, cols.ref, min_af=0.12)
+    assert not np.array_equal(f1.cpu().numpy(), f2.cpu().numpy())                      # (the second threshold does something on this data)
 
 
 def test_handwritten_edge_columns(gpu_ctx):

@@ -203,17 +203,19 @@ def test_oracle_vs_reference_binaries_on_cut_alleles_and_random_bytes(tmp_path, 
     pile = tmp_path / "pile"; pile.mkdir()
     (pile / "chrC.mpileup").write_bytes(b"".join(b"chrC\t%d\tN\t%d\t%s\t%s\n" % (i + 1, 1, c, b"I") for i, c in enumerate(cols) if c))
     refdir = os.path.join(ROOT, "oracle", "_ref")
-    subprocess.run([os.path.join(refdir, "DNA_CreateCanSnpTensor"), "-reference", fa, "-chr_pileup_dir", str(pile),
-                    "-output_dir", str(tmp_path / "tensor"), "-min_af", "0.12", "-snp_min_af", "0.12",
-                    "-indel_min_af", "0.12", "-min_coverage", "6", "-flanking_base", "16", "-num_threads", "1", "chrC"],
-                   check=True, capture_output=True)
-    subprocess.run([os.path.join(refdir, "DNA_CreatePredictData"), "-chr_tensor_dir", str(tmp_path / "tensor"),
-                    "-reference", fa, "-output_dir", str(tmp_path / "pd"), "-num_threads", "1", "chrC"],
-                   check=True, capture_output=True)
-    want = (tmp_path / "pd" / "chrC.pd").read_bytes()
-    n = oracle.mpileup_to_pd(str(pile / "chrC.mpileup"), bytes(seq), str(tmp_path / "o.pd"))
-    assert n == want.count(b"\n") and n > 1500
-    assert (tmp_path / "o.pd").read_bytes() == want
+    for snp, ind, mc in (("0.12", "0.12", 6), ("0.3", "0.05", 6), ("0.05", "0.4", 3)):     # (-snp_min_af and -indel_min_af apart: main.cpp:79-88)
+        out_t, out_p = tmp_path / f"tensor{snp}{ind}", tmp_path / f"pd{snp}{ind}"
+        subprocess.run([os.path.join(refdir, "DNA_CreateCanSnpTensor"), "-reference", fa, "-chr_pileup_dir", str(pile),
+                        "-output_dir", str(out_t), "-min_af", "0.12", "-snp_min_af", snp,
+                        "-indel_min_af", ind, "-min_coverage", str(mc), "-flanking_base", "16", "-num_threads", "1", "chrC"],
+                       check=True, capture_output=True)
+        subprocess.run([os.path.join(refdir, "DNA_CreatePredictData"), "-chr_tensor_dir", str(out_t),
+                        "-reference", fa, "-output_dir", str(out_p), "-num_threads", "1", "chrC"],
+                       check=True, capture_output=True)
+        want = (out_p / "chrC.pd").read_bytes()
+        n = oracle.mpileup_to_pd(str(pile / "chrC.mpileup"), bytes(seq), str(tmp_path / "o.pd"), min_af=float(snp), indel_min_af=float(ind), min_coverage=mc)
+        assert n == want.count(b"\n") and n > 1000, (snp, ind)
+        assert (tmp_path / "o.pd").read_bytes() == want, (snp, ind)
 
 
 def _check_arranged_against_reference(arrange, z):
