@@ -33,6 +33,18 @@ for r in range(rounds):
         if not c:
             c = "*"
         lines.append(b"chrA\t%d\t%c\t%d\t%s\t%s\n" % (p, seq[p - 1], len(c), c.encode("latin-1"), b"I" * max(1, len(c) // 2)))
+    if r % 3 == 2:                                 # every third round: the line reader's and split_line's corner cases (cpp_aux.cpp:44-59,
+        for i in range(len(lines)):                # line_reader.cpp:95-127): runs of tabs, \r\n, no quality column, atoll-style positions
+            u = rng.random()
+            l = lines[i][:-1]
+            f = l.split(b"\t")
+            if u < 0.02: l = l.replace(b"\t", b"\t\t", int(rng.integers(1, 6)))
+            elif u < 0.03: l = b"\t" + l + b"\t"
+            elif u < 0.04: l = b"\t".join(f[:5])
+            elif u < 0.05: l = l + b"\r"
+            elif u < 0.06: f[1] = b"+000" + f[1] + b"xyz"; l = b"\t".join(f)
+            elif u < 0.07: f[0] = b"another_name"; l = b"\t".join(f)
+            lines[i] = l + b"\n"
     text = b"".join(lines)
     want = call_contig(m, text, "chrA", seq, chunk_bytes=1 << 40)
     for cb in (len(text) // 3, len(text) // 7, 50_000, 9_000):
