@@ -90,6 +90,21 @@ def test_handwritten_edge_columns(gpu_ctx):
     oc, od, of = oracle.encode_columns(bases, off, ref)
     assert np.array_equal(c.cpu().numpy(), oc), (c.cpu().numpy(), oc)
     assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(f.cpu().numpy(), of)
+    # an allele the END OF THE COLUMN cuts short is an allele of its own (tensor_maker.cpp:101 reads the declared length past the string:
+    # the key holds the NUL) - values as the reference's binaries give them (tests/golden/encode_cut.*): I1 / D1 / i1 / d1 = largest count of ONE allele
+    cut = [(b"AAAAAAAAAAAA+2AC+2AC+3AC", {"I": 3, "I1": 2}), (b"AAAAAAAAAAAAaaaaaa-2ac-2ac-3ac", {"d": 3, "d1": 2}),
+           (b"AAAAAAAAAAAA+2AC+2AC+2AC+3AC", {"I": 4, "I1": 3}), (b"AAAAAAAAAAAA+1A+2A", {"I": 2, "I1": 1}), (b"AAAAAAAAAAAA+3", {"i": 1, "i1": 1}),
+           (b"AAAAAAAAAAAA+2ac+2ac+3ac", {"i": 3, "i1": 2}), (b"AAAA+2AC+2AC+2AC", {"I": 3, "I1": 3})]
+    ch = {"I": 4, "I1": 5, "D": 6, "D1": 7, "i": 13, "i1": 14, "d": 15, "d1": 16}
+    bases = np.frombuffer(b"".join(c for c, _ in cut), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(c) for c, _ in cut])]).astype(np.int64)
+    ref = np.frombuffer(b"A" * len(cut), np.uint8)
+    c, d, f = _enc(gpu_ctx, bases, off, ref)
+    oc, od, of = oracle.encode_columns(bases, off, ref)
+    assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(f.cpu().numpy(), of)
+    for k, (_, want) in enumerate(cut):
+        got = {name: int(oc[k, i]) for name, i in ch.items()}
+        assert all(got[n] == v for n, v in want.items()) and sum(got.values()) == sum(want.values()), (k, got, want)
 
 
 def test_opener_dense_columns(gpu_ctx):
