@@ -240,6 +240,11 @@ def stream_haplotype(ctx, source, reference=None, lo=0, hi=None, pass_sites=1638
 
 
 def stream_segments(ctx, segments, reference=None, pass_sites=16384, narrow=True, stats=None, keep_probabilities=False, on_segment=None):
+    with host.gc_paused():
+        return _stream_segments(ctx, segments, reference, pass_sites, narrow, stats, keep_probabilities, on_segment)
+
+
+def _stream_segments(ctx, segments, reference, pass_sites, narrow, stats, keep_probabilities, on_segment):
     """stream_haplotype over several (source, lo, hi) segments - the bins of a directory - as ONE pipeline: the first pass of segment
     f + 1 is staged and copied while the last passes of segment f compute, so a directory of bins pays the pipeline's fill and drain
     once, not once per file.  on_segment(index, HapCalls), when given, is called on a writer thread as soon as the calls of a segment
@@ -447,6 +452,9 @@ def stream_segments(ctx, segments, reference=None, pass_sites=16384, narrow=True
         st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
         st["gpu_s"] += e["c0"].elapsed_time(e["c1"]) * 1e-3
     return out
+
+
+stream_segments.__doc__ = _stream_segments.__doc__
 
 
 def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16384, narrow=True, score_mode=host.SCORE_FLOAT64, stats=None,

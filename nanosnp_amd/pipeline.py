@@ -116,6 +116,11 @@ class _DevSet:
 
 
 def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None, on_rows=None):
+    with host.gc_paused():
+        return _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows)
+
+
+def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows):
     """The device part of stages s1 + s2 over the lines of text[lo:hi], chunk by chunk, three things at a time:
 
         worker thread   parses chunks k + 1 and k + 2 (libnanosnp_host.so, OpenMP, straight into one of three pinned buffer sets)
@@ -327,6 +332,9 @@ def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 <<
     return torch.cat(rows_all) if rows_all else torch.zeros((0, 13), dtype=torch.float64, device=dev)
 
 
+stream_contig.__doc__ = _stream_contig.__doc__
+
+
 def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False):
     """call rows [n, 13] float64 (a device tensor, a host tensor or a numpy array) -> (VCF text, rows written) of the reference's
     predict loop over consecutive batches.  Device rows are cut into their typed columns ON the device (six small kernels, 41 B per
@@ -528,7 +536,9 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     from . import sitefile
     from .dist import gather_varlen, shard_range
     from .hap_pipeline import _LocalNames
+    import gc
     t_begin = time.perf_counter()
+    gc_was_on = gc.isenabled()
     sharded = bool(distributed) and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
     ctx = model.ctx
@@ -569,6 +579,8 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     kept = {}                                                  # sharded: the calls of every file stay on this rank until the gather
     out = open(output_file, "wb") if rank == 0 else None
     try:
+        gc.disable()                                   # (a generation-2 pass of the interpreter's collector in the middle of the set-up was measured
+                                                       # at 38 ms - twelve passes of device work; nothing here makes reference cycles; restored below)
         for f in files:
             f["fd"] = os.open(f["path"], os.O_RDONLY)
         if out:
@@ -759,6 +771,8 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                         total_rows += n_rows
             st["vcf_s"] += time.perf_counter() - t0
     finally:
+        if gc_was_on:
+            gc.enable()
         if out:
             out.close()
         for f in files:

@@ -93,6 +93,8 @@ def run(args, rank, world, local_rank, emit=None):
     stats = {}
     t0 = time.perf_counter()
     step_ms = []
+    ms0 = torch.cuda.memory_stats(dev)
+    cg0 = bc.cgroup_cpu_stat()
     for _ in range(K):
         t_s = time.perf_counter()
         rows_text, n_sites, n_rows = one_pass(stats)
@@ -101,6 +103,14 @@ def run(args, rank, world, local_rank, emit=None):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    cg1 = bc.cgroup_cpu_stat()
+    ms1 = torch.cuda.memory_stats(dev)
+    allocator = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")}
+    host_cpu = None
+    if cg0 and cg1:
+        host_cpu = {"core_seconds_used": round((cg1[2] - cg0[2]) * 1e-6, 3), "average_cores_busy": round((cg1[2] - cg0[2]) * 1e-6 / dt, 1),
+                    "quota_throttled_periods": cg1[0] - cg0[0], "quota_throttled_thread_ms": round((cg1[1] - cg0[1]) * 1e-3, 1),
+                    "note": "a throttled period freezes every thread of the cgroup until the next 100 ms period starts: the steps far above the median"}
     if world > 1:
         tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -197,6 +207,7 @@ def run(args, rank, world, local_rank, emit=None):
                                 "round trip in the loop); wall < sum when they overlap.  main_thread_s_per_step: where the issuing thread spends the step "
                                 "(issue_s includes wait_counts_s)"},
             "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "vcf_s", "write_s")},
+            "host_cpu_over_the_timed_region": host_cpu, "torch_allocator_over_the_timed_region": allocator,
             "step_ms_each": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms), "all": step_ms,
                              "note": "a step well above the median early in a process is the HIP runtime opening a further SDMA copy engine (6-8 ms inside "
                                      "hipMemcpyAsync on its first use: docs/rounds/r05.md), or the CPU quota"},

@@ -135,8 +135,9 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
             dist.barrier()
 
     def timed(steps, narrow=True, pass_sites=P, path=path):
-        for _ in range(W):
-            predict_pileup_bins(model, [path], fai, out_path, pass_sites=pass_sites, narrow=narrow)
+        for _ in range(W):                           # a warm-up run is a few files long: the HIP runtime opens its SDMA copy engines one by one on
+            # first use (6-8 ms each inside hipMemcpyAsync: docs/rounds/r05.md), a once-per-process cost that a one-file run does not reach
+            predict_pileup_bins(model, [path] * min(4, steps), fai, out_path, pass_sites=pass_sites, narrow=narrow)
         torch.cuda.synchronize(dev)
         if os.path.exists(out_path):
             os.remove(out_path)                      # (truncating the previous run's half gigabyte of tmpfs pages is not part of a run)
