@@ -326,7 +326,7 @@ def main():
         for prec, label, text in ((2, "bf16x3", "bf16x3 (every fp32 operand as three bf16 terms = its full 24-bit significand and exponent range, "
                                                 "six bf16 MFMAs per product, fp32 accumulate)"),
                                   (1, "f16x3", "f16x3 (every fp32 operand split into two fp16, 3 fp16 MFMAs per product, fp32 accumulate; opt-in)")):
-            stage.set_precision(prec, fwd_group=4 if prec == 2 else 1)     # bf16x3: 16,384 sites per forward launch (its kernels fill the chip there)
+            stage.set_precision(prec, fwd_group=int(os.environ.get("NSNP_B3_FWD_GROUP", "4")) if prec == 2 else 1)     # bf16x3: 16,384 sites per forward launch (its kernels fill the chip there)
             dt2, _, _, tot2 = timed_pass()
             d = max((stage.gt_all[:n_done] - ref_gt).abs().max().item(), (stage.zy_all[:n_done] - ref_zy).abs().max().item())
             sv = {"value": sites_timed / dt2, "unit": "sites/s", "ms_per_step": dt2 / K * 1e3, "dtype": text, "sites_per_forward_launch": stage.batch * stage.F,

@@ -515,6 +515,11 @@ class _SiteSet:
 
 def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=1000, score_mode=host.SCORE_FLOAT64, pass_sites=65536,
                         narrow=True, stats=None, distributed=True):
+    with host.gc_paused():                             # (a generation-2 pass of the interpreter's collector sat in the set-up of a run: 38 ms)
+        return _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size, score_mode, pass_sites, narrow, stats, distributed)
+
+
+def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size, score_mode, pass_sites, narrow, stats, distributed):
     """The reference's ``predict(model, testing_paths, reference_index_file, batch_size, output_file, device)`` (PileupModel/predict.py:
     37-195) over this repository's ``.pd.bin`` site files (sitefile.write_pileup_bin / pd_to_bin: the arrays of make_bin_predict_data.py:
     90-100): every file's windows are STREAMED - a worker thread `pread`s passes of `pass_sites` windows from the page cache into one of
@@ -536,9 +541,7 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     from . import sitefile
     from .dist import gather_varlen, shard_range
     from .hap_pipeline import _LocalNames
-    import gc
     t_begin = time.perf_counter()
-    gc_was_on = gc.isenabled()
     sharded = bool(distributed) and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)
     ctx = model.ctx
@@ -579,8 +582,6 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
     kept = {}                                                  # sharded: the calls of every file stay on this rank until the gather
     out = open(output_file, "wb") if rank == 0 else None
     try:
-        gc.disable()                                   # (a generation-2 pass of the interpreter's collector in the middle of the set-up was measured
-                                                       # at 38 ms - twelve passes of device work; nothing here makes reference cycles; restored below)
         for f in files:
             f["fd"] = os.open(f["path"], os.O_RDONLY)
         if out:
@@ -771,11 +772,12 @@ def predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size=
                         total_rows += n_rows
             st["vcf_s"] += time.perf_counter() - t0
     finally:
-        if gc_was_on:
-            gc.enable()
         if out:
             out.close()
         for f in files:
             if f["fd"] >= 0:
                 os.close(f["fd"])
     return total_rows
+
+
+predict_pileup_bins.__doc__ = _predict_pileup_bins.__doc__
