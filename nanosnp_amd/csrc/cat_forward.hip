@@ -229,7 +229,7 @@ struct ConvArgs {
 };
 
 constexpr int CONV_HALO = 12;                          // W + 1 for the widths of this network (W = 11)
-constexpr int CONV_ROWS = TS + 2 * CONV_HALO + 1;      // staged pixels + the zero row (one pixel tile per workgroup)
+// (a workgroup stages PIX + 2 * CONV_HALO + 1 rows: its pixels, the halo on either side and the zero row - ROWS inside k_cat_conv)
 
 // NPT = pixel tiles (of 128) per workgroup.  2 for the blocks with <= 64 output channels (round 5): their waves had 8 / 16 MFMAs
 // between two barriers at 128 pixels (0.47 / 0.65 of the peak against 0.75-0.78 for the wide blocks); with 256 pixels a wave owns 64
@@ -806,11 +806,11 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
                 // (fp32 only: the bf16x3 form needs 92 KB of LDS at 256 pixels - one workgroup per CU - and measured 2 % slower)
                 const bool pix2 = AR == 0 && ctx->cat_conv_pix2 && b.cout <= 64;
                 const unsigned gx = pix2 ? (unsigned)((n_ptiles + 1) / 2) : (unsigned)n_ptiles;
-                if (pix2) hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);
+                if (pix2) hipLaunchKernelGGL((k_cat_conv<0, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);        // (pix2 implies AR == 0)
                 else hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
                 c.w = wm(b.w2); c.bias = b.b2; c.x = Y; c.sc = X; c.cc_in = b.cc_out; c.cc_sc = b.cc_in; c.nk_img = 9 * b.cc_out + b.cc_in;
                 c.out = O;
-                if (pix2) hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);
+                if (pix2) hipLaunchKernelGGL((k_cat_conv<0, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);        // (pix2 implies AR == 0)
                 else hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
             } else {
             StepLaunch L; StepArgs& a = L.z[0];
