@@ -84,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true", help="test configuration: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--workloads", default="all", help="pileup workload only: after the headline's timed region, short runs of the other BASELINE "
                     "configurations in the same process, reported under \"workloads\" in the same line (tools/workloads.py): 'all' (default), 'none', or a "
-                    "comma-separated subset of haplotype,two_stage,deep60,hap_e2e,e2e")
+                    "comma-separated subset of haplotype,two_stage,deep60,hap_e2e,e2e,pd_e2e")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU/gloo dry run of the multi-rank plumbing (spawn, barrier, "
                     "max-over-ranks timing, rooted gather, one JSON line); no kernels, value is null -- tests/test_dist.py")
     return ap.parse_args(argv)

@@ -36,7 +36,7 @@ def _run(*argv, env=None, timeout=900):
 
 
 SMALL_POOLS = dict(NSNP_TWO_STAGE_N2="40960", NSNP_TWO_STAGE_N5="4096", NSNP_HAP_N="4096", NSNP_CAT_N="2048", NSNP_DEEP_WINDOWS="40960",
-                   NSNP_HAPE2E_SITES="6000", NSNP_E2E_COLS="400000", NSNP_E2E_CHUNK_MB="4")
+                   NSNP_HAPE2E_SITES="6000", NSNP_E2E_COLS="400000", NSNP_E2E_CHUNK_MB="4", NSNP_PDE2E_SITES="70000")
 
 
 def test_bench_line_schema():
@@ -44,7 +44,7 @@ def test_bench_line_schema():
     # the other BASELINE configurations ride in the same line (tools/workloads.py): every one with a value, a parity sample that holds, a CPU
     # baseline, and - where a device kernel dominates - a roofline fraction
     w = d["workloads"]
-    assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e"}
+    assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e", "pd_e2e"}
     for name, line in w.items():
         assert "error" not in line, (name, line.get("error"))
         sm = line["summary"]

@@ -58,7 +58,7 @@ def test_pileup_line_is_the_headline_configuration():
     d = _load(os.path.join(ROOT, "profiles", f"{ROUND}_default_line.json"))
     # the default command carries every other configuration as a sub-line (tools/workloads.py)
     w = d["workloads"]
-    assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e"}
+    assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e", "pd_e2e"}
     for name, line in w.items():
         sm = line["summary"]
         assert "error" not in line and sm["value"] > 0 and sm["parity_ok"] is True and sm["cpu_baseline_value"] > 0, name

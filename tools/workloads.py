@@ -5,7 +5,7 @@
 headline; after its timed region, in the same process, short runs of the existing workload tools on reduced resident pools fill
 
     "workloads": {"haplotype": configs[2], "two_stage": configs[3], "deep60": configs[4], "hap_e2e": stage 5 from host memory,
-                  "e2e": mpileup text to VCF}
+                  "e2e": mpileup text to VCF, "pd_e2e": window files to VCF}
 
 each with its own value / ms_per_step / dominant-kernel roofline fraction / parity_sample / cpu_baseline, so that whoever runs
 the one command witnesses every configuration.  A sub-line is the tool's own full line (run it alone with `--workload NAME` for
@@ -18,13 +18,14 @@ import sys
 import time
 import traceback
 
-# (name, tool, overrides): sizes chosen so that all five finish in about a minute on one MI355X + 16 host cores
+# (name, tool, overrides): sizes chosen so that all six finish in about a minute on one MI355X + 16 host cores
 PLAN = (
     ("haplotype", "hap", dict(hap_sites=32768, steps=4, warmup=1, cpu_seconds=3.0)),
     ("two_stage", "two_stage", dict(two_stage_n2=327_680, two_stage_n5=32_768, steps=3, warmup=1, cpu_seconds=3.0)),
     ("deep60", "deep60", dict(hap_sites=16384, cat_sites=16384, deep_windows=163_840, steps=3, warmup=1, cpu_seconds=3.0)),
     ("hap_e2e", "hap_e2e", dict(hap_sites=32768, steps=4, warmup=1, cpu_seconds=3.0)),
     ("e2e", "e2e", dict(e2e_cols=1_500_000, steps=4, warmup=1, cpu_seconds=3.0)),
+    ("pd_e2e", "pd_e2e", dict(pd_sites=262_144, steps=6, warmup=1, cpu_seconds=3.0)),
 )
 
 
@@ -65,6 +66,9 @@ def run_all(args, rank, world, local_rank, only=None):
                 rc = run(a, rank, world, local_rank, emit=got.append)
             elif tool == "hap_e2e":
                 from tools.hap_e2e_bench import run
+                rc = run(a, rank, world, local_rank, emit=got.append)
+            elif tool == "pd_e2e":
+                from tools.pd_e2e_bench import run
                 rc = run(a, rank, world, local_rank, emit=got.append)
             else:
                 from tools.e2e_bench import run
