@@ -238,18 +238,18 @@ def test_bench_with_the_library_gather_entry():
 
 def test_two_ranks_with_the_other_configurations_in_the_same_line():
     """the default line's "workloads" under two ranks (sharing GPU 0, collectives over gloo): the sub-runs reuse the process group of the
-    headline, every rank takes part in their gathers, rank 0 reports them; hap_e2e shards the sites of the FILE over the ranks"""
+    headline, every rank takes part in their gathers, rank 0 reports them; hap_e2e and pd_e2e shard the sites of every FILE over the ranks"""
     env = dict(os.environ, **SMALL_POOLS)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "65536",
                           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--hap-batch", "2048",
-                          "--workloads", "two_stage,hap_e2e,haplotype"], capture_output=True, text=True, timeout=900, env=env)
+                          "--workloads", "two_stage,hap_e2e,haplotype,pd_e2e"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and set(d["workloads"]) == {"two_stage", "hap_e2e", "haplotype"}
+    assert d["n_gpus"] == 2 and set(d["workloads"]) == {"two_stage", "hap_e2e", "haplotype", "pd_e2e"}
     for name, line in d["workloads"].items():
         assert "error" not in line and line["n_gpus"] == 2 and line["config"]["world_size_observed"] == 2 and line["summary"]["parity_ok"] is True, name
     assert d["workloads"]["hap_e2e"]["parity_sample"]["rows"] == 6000
