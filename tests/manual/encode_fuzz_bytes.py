@@ -41,7 +41,7 @@ def main():
     ctx = _lib.Context(0)
     bad = 0
     for s in range(seeds):
-        bases, off, ref = make(9000 + s, m)
+        bases, off, ref = make(9000 + s + int(os.environ.get("NSNP_STRESS_SEED", "0")), m)
         for af, mc in ((0.12, 6), (0.0, 0), (0.5, 20)):
             oc, od, of = oracle.encode_columns(bases, off, ref, af, mc)
             c, d, f = ctx.pileup_encode_columns(torch.from_numpy(bases).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(ref).cuda(), af, mc)

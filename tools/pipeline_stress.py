@@ -20,7 +20,7 @@ w = load_pileup_weights()
 m = LSTMNetwork().load_weight_list(w)
 bad = 0
 for r in range(rounds):
-    rng = np.random.default_rng(7700 + r)
+    rng = np.random.default_rng(7700 + r + int(os.environ.get("NSNP_STRESS_SEED", "0")))
     seq = rng.choice(np.frombuffer(b"ACGTacgtNn", np.uint8), n_cols + 5000, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).astype(np.uint8)
     step = np.where(rng.random(n_cols) < 0.01, rng.integers(2, 40, n_cols), 1)
     if r % 2:                                      # odd rounds: positions that step BACK or repeat (main.cpp:174-178 resets its window at
