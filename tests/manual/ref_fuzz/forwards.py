@@ -3,7 +3,7 @@
 LSTMNetwork.predict (torch CPU) and, in a second process, HaplotypeModel/model_dev.py LSTMNetwork.predict - against the fp32 oracle on
 the same weights and inputs: the oracle is pinned by the three shipped checkpoints and seeded HaplotypeModel weights; this checks that
 nothing in it leans on how those weights look (scales 0.1 .. 3 times torch's default initialisation, large biases, a dominating channel).
-    python tests/manual/ref_fuzz/forwards.py pileup|haplotype [N_SEEDS]"""
+    python tests/manual/ref_fuzz/forwards.py pileup|haplotype|cat [N_SEEDS]"""
 import os, sys, types
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
@@ -42,6 +42,30 @@ if which == "pileup":
             ok = d <= max(1e-5, 3 * dr)
             bad += not ok
             print(f"pileup seed {seed} scale {scale} input {kind}: |oracle - reference| {d:.1e} (reference vs float64 {dr:.1e}) {'ok' if ok else 'LOOK'}", flush=True)
+elif which == "cat":
+    # the legacy CatModel (HaplotypeModel/model.py:332-358) with torch's OWN random initialisation (BatchNorm statistics randomised: a fresh
+    # module has mean 0 / variance 1) against oracle.cat_forward on the module's state dict
+    sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
+    from model import CatModel
+    from nanosnp_amd.fixtures import cat_weight_names, synth_cat_groups
+    for seed in range(seeds):
+        torch.manual_seed(500 + seed)
+        m = CatModel(nc0=5, nc1=5, nc2=2, nclass=10, nh=256); m.eval()
+        sd = m.state_dict()
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for k in sd:
+                if k.endswith("running_var"): sd[k].copy_(torch.rand(sd[k].shape, generator=g) + 0.5)
+                elif k.endswith("running_mean"): sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.2)
+        ws = [sd[k].numpy().astype(np.float32) for k in cat_weight_names()]
+        g0, g1 = synth_cat_groups(900 + seed, 48)
+        with torch.no_grad():
+            gt = m.predict(torch.from_numpy(g0), torch.from_numpy(g1), None, None).numpy()
+        og = oracle.cat_forward(ws, g0, g1, nthreads=8)
+        d = float(np.abs(og - gt).max())
+        ok = d <= 2e-5
+        bad += not ok
+        print(f"cat seed {seed}: |oracle - reference| {d:.1e} {'ok' if ok else 'LOOK'}", flush=True)
 else:
     sys.path.insert(0, os.path.join(REF, "HaplotypeModel"))
     from model_dev import LSTMNetwork
