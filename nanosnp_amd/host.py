@@ -464,10 +464,18 @@ VCF_HEADER = ('##fileformat=VCFv4.3\n'
 
 
 def vcf_header(fai_text: str):
-    """write_head of PileupModel/predict.py:13-27 from the text of a .fai"""
-    contigs = "".join('##contig=<ID={},length={}>\n'.format(*line.strip().split()[:2])
-                      for line in fai_text.splitlines() if line.strip())
-    return VCF_HEADER.format(contigs=contigs)
+    """write_head of PileupModel/predict.py:13-27 from the text of a .fai.  As there, a line that does not hold two fields - a blank
+    line among them - raises IndexError (`line.strip().split()[1]`): a .fai written by samtools has neither."""
+    lines = fai_text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()                                                  # (iterating a file yields no line behind the last newline)
+    contigs = []
+    for line in lines:
+        f = line.strip().split()
+        if len(f) < 2:
+            raise IndexError(f"fai line without a length field: {line!r} (PileupModel/predict.py:19-20 indexes [1])")
+        contigs.append('##contig=<ID={},length={}>\n'.format(f[0], f[1]))
+    return VCF_HEADER.format(contigs="".join(contigs))
 
 
 # ---- reference rows of the haplotype features (H3) ---------------------------------------------------
