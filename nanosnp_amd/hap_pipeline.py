@@ -463,7 +463,8 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
     bin_paths (a directory - os.listdir order, as the reference iterates it - or a list of paths) go through ONE pipeline
     (stream_segments: the first pass of the next file is staged while the last passes of this one compute) and the rows
     ``ctg \t pos \t GT \t qual`` of every file are formatted and appended to output_file on a writer thread as soon as the file's calls
-    are back, while later files compute.  reference: a DeviceReference or a dict {contig: sequence} (uploaded once).
+    are back, while later files compute.  reference: a DeviceReference, a dict {contig: sequence} (uploaded once) or the path of a FASTA
+    file (read as get_truth.load_reference_file reads it: host.load_reference_file).
     Under torch.distributed every rank works on its shard_range of every file, the calls travel to rank 0 in one rooted gather and
     rank 0 writes (distributed=False: this process alone does the whole job even inside a process group).  Returns the number of rows
     written (on rank 0; 0 elsewhere)."""
@@ -476,6 +477,8 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
         paths = [os.path.join(d, f) for f in os.listdir(d)] if os.path.isdir(d) else [d]
     else:
         paths = [str(p) for p in bin_paths]
+    if isinstance(reference, (str, os.PathLike)):      # predict_dev.py:28: references = load_reference_file(reference_path)
+        reference = host.load_reference_file(reference)
     ref = reference if isinstance(reference, DeviceReference) else DeviceReference(reference, ctx.device)
     sharded = bool(distributed) and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
     rank, world = (tdist.get_rank(), tdist.get_world_size()) if sharded else (0, 1)

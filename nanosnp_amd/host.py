@@ -321,6 +321,29 @@ def fasta_load_contig(path, contig):
     return seq[:n2]
 
 
+def load_reference_file(ref_fn):
+    """get_truth.load_reference_file (HaplotypeModel/get_truth.py:88-104), what predict_dev.py:28 hands to TestDataset: {contig:
+    sequence} with the contig name = the header line up to its first BLANK (not tab), every '>' of that token removed; the stripped
+    sequence lines joined as they are (case kept: BASE2INT then maps lower case to 0); a header without sequence lines leaves no entry;
+    the later of two equal names wins; lines in front of the first header land under the name "".  Values are bytes (the reference's
+    are str: same characters)."""
+    references, ctg, parts = {}, "", []
+    with open(ref_fn, "rb") as fin:
+        for line in fin.read().replace(b"\r\n", b"\n").replace(b"\r", b"\n").split(b"\n"):      # (text mode there: universal newlines)
+            if line.startswith(b">"):
+                if parts and any(parts):
+                    references[ctg] = b"".join(parts)
+                parts = []
+                ctg = line.decode().strip().split(" ")[0].replace(">", "")
+            else:
+                t = line.decode().strip().encode() if line else b""
+                if t:
+                    parts.append(t)
+    if parts:
+        references[ctg] = b"".join(parts)
+    return references
+
+
 def pd_parse(text: bytes):
     """.pd text -> (x int32[N,33,18], contig names list[str], pos int64[N], ref_base uint8[N])."""
     n = _check(lib().nsnp_pd_parse(text, len(text), None, None, None, None, None, 0),

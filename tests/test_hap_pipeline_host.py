@@ -185,3 +185,18 @@ def test_sources_hand_out_the_same_bytes(tmp_path):
     (tmp_path / "nope.bin").write_bytes(b"NSNPBIN1" + bytes(8))            # a valid container without the arrays
     with pytest.raises(sitefile.SiteFileError):
         HapBinSource(tmp_path / "nope.bin")
+
+
+def test_load_reference_file_reads_a_fasta_as_get_truth_does(tmp_path):
+    """get_truth.py:88-104 (checked against the reference's function in the development container): the name ends at the first blank,
+    every '>' of it is dropped, sequence lines are stripped and joined with their case, a header without sequence leaves no entry, the
+    later of two equal names wins, text in front of the first header lands under ''"""
+    cases = {">chr1 desc\nACGT\nacgtN\n>chr2\tx\nAAAA\n": {"chr1": b"ACGTacgtN", "chr2\tx": b"AAAA"},
+             "ACGT\n>c1\nAA\n>c1\nCC\n": {"": b"ACGT", "c1": b"CC"},
+             ">c1\n\n>c2\nGG \n  TT\n": {"c2": b"GGTT"},
+             ">c>1 a\nAC\r\nGT\r\n": {"c1": b"ACGT"},
+             "": {}, ">only\n": {}, ">a\nAC\n>b\n>c\nGG": {"a": b"AC", "c": b"GG"}, "\n\n>x\nA\n\nC\n": {"x": b"AC"}}
+    for k, (text, want) in enumerate(cases.items()):
+        p = tmp_path / f"r{k}.fa"
+        p.write_bytes(text.encode())
+        assert host.load_reference_file(p) == want, text
