@@ -52,6 +52,11 @@ def test_streamed_stage5_equals_the_per_site_restatement_and_the_oracle(tmp_path
     assert predict_haplotype_bins(hctx, [path], ref, str(out), stats=st) == n
     assert st["passes"] == 1 and st["passes_int8"] == 1 and st["sites"] == n
     rows = out.read_text().splitlines()
+    # the reference's call shape: predict(model, test_data, reference_path, ...) - a FASTA path (predict_dev.py:28 load_reference_file)
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b"".join(b">" + k.encode() + b" some description\n" + b"\n".join(bytes(v[i:i + 70]) for i in range(0, len(v), 70)) + b"\n" for k, v in refs.items()))
+    out_fa = tmp_path / "from_fasta.csv"
+    assert predict_haplotype_bins(hctx, [path], str(fa), str(out_fa)) == n and out_fa.read_bytes() == out.read_bytes()
     # (a) the array entry with reference rows made by the per-site host restatement of dataset_dev.py:106-120,150-162
     rp = host.haplotype_ref_rows(refs, cands, 33)
     rh = host.haplotype_ref_rows(refs, cands, 11, position_lists=hpos)
