@@ -487,8 +487,11 @@ VCF_HEADER = ('##fileformat=VCFv4.3\n'
 
 
 def vcf_header(fai_text: str):
-    """write_head of PileupModel/predict.py:13-27 from the text of a .fai.  As there, a line that does not hold two fields - a blank
+    """write_head of PileupModel/predict.py:13-27 from the text of a .fai (or its path).  As there, a line that does not hold two fields - a blank
     line among them - raises IndexError (`line.strip().split()[1]`): a .fai written by samtools has neither."""
+    if isinstance(fai_text, os.PathLike) or (isinstance(fai_text, str) and "\n" not in fai_text and "\t" not in fai_text and os.path.isfile(fai_text)):
+        with open(fai_text) as f:                                    # the reference's argument is the PATH of the index (predict.py:37,216)
+            fai_text = f.read()
     lines = fai_text.split("\n")
     if lines and lines[-1] == "":
         lines.pop()                                                  # (iterating a file yields no line behind the last newline)
