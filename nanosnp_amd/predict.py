@@ -2,6 +2,8 @@
 
     predict_pileup     PileupModel/predict.py:37-195     position_matrix -> pileup.vcf
     predict_haplotype  HaplotypeModel/predict_dev.py:27-48  read planes -> haplotype.csv
+    predict            PileupModel/predict.py:37           the reference's call shape over window files (streamed)
+    predict_dev        HaplotypeModel/predict_dev.py:27    the reference's call shape over haplotype bins (streamed)
 
 The loops keep the reference's batch structure (its VCF rows depend on the batch boundary, see
 nanosnp_amd/csrc/nsnp_vcf.c) but every per-site Python statement is gone: forward, argmax/max and
@@ -72,3 +74,36 @@ def predict_haplotype(ctx, planes_pileup, planes_haplotype, candidate_positions,
         if n:
             f.write(host.hap_csv_format(calls.table, calls.contig_id, calls.pos, calls.gt_arg, calls.gt_max, score_mode))
     return n
+
+
+# ---- the reference's own call shapes ------------------------------------------------------------------------------------------------
+def predict(model, testing_paths, reference_index_file, batch_size, output_file, device=None, **kw):
+    """PileupModel/predict.py:37 `predict(model, testing_paths, reference_index_file, batch_size, output_file, device)`, argument for
+    argument, over this repository's window files: model = nanosnp_amd.pileup_model.LSTMNetwork (it carries its device: `device` is
+    accepted and ignored unless it names another GPU than the model's), testing_paths a list of `.pd.bin` files or a directory,
+    reference_index_file the path of the .fai.  Streams through pipeline.predict_pileup_bins; returns the rows written."""
+    from .pipeline import predict_pileup_bins
+    _same_device(model.ctx, device)
+    return predict_pileup_bins(model, testing_paths, reference_index_file, output_file, batch_size=batch_size, **kw)
+
+
+def predict_dev(model, test_data, reference_path, batch_size, pileup_length, haplotype_length, output_file, device=None, **kw):
+    """HaplotypeModel/predict_dev.py:27 `predict(model, test_data, reference_path, batch_size, pileup_length, haplotype_length,
+    output_file, device)`, argument for argument, over this repository's haplotype site files: model =
+    nanosnp_amd.haplotype_model.LSTMNetwork, test_data the directory of bins, reference_path the FASTA.  batch_size only sized the
+    reference's DataLoader batches (its rows do not depend on it): accepted, unused.  Streams through
+    hap_pipeline.predict_haplotype_bins; returns the rows written."""
+    from .hap_pipeline import predict_haplotype_bins
+    if (int(pileup_length), int(haplotype_length)) != (33, 11):
+        raise ValueError("the HaplotypeModel of this path takes windows of 33 and groups of 11 columns (config/ont_haplotype.yaml)")
+    _same_device(model.ctx, device)
+    return predict_haplotype_bins(model.ctx, test_data, reference_path, output_file, **kw)
+
+
+def _same_device(ctx, device):
+    if device is None:
+        return
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda" or (d.index is not None and d.index != ctx.device):
+        raise ValueError(f"the model lives on cuda:{ctx.device}; predict(..., device={device!r}) names another device (there is no CPU path)")

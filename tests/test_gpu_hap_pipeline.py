@@ -3,6 +3,7 @@
 The csv must not depend on the pass size, the on-disk dtype, the narrowing or the number of ranks, and must equal the rows made from
 the per-site host restatement of the reference rows + the oracle chain."""
 import os
+import types
 import re
 
 import numpy as np
@@ -57,6 +58,15 @@ def test_streamed_stage5_equals_the_per_site_restatement_and_the_oracle(tmp_path
     fa.write_bytes(b"".join(b">" + k.encode() + b" some description\n" + b"\n".join(bytes(v[i:i + 70]) for i in range(0, len(v), 70)) + b"\n" for k, v in refs.items()))
     out_fa = tmp_path / "from_fasta.csv"
     assert predict_haplotype_bins(hctx, [path], str(fa), str(out_fa)) == n and out_fa.read_bytes() == out.read_bytes()
+    # ... and predict_dev.py:27 argument for argument: predict(model, test_data, reference_path, batch_size, pileup_length, haplotype_length, output_file, device)
+    from nanosnp_amd import predict as nsnp_predict
+    bins = tmp_path / "bins_dir"; bins.mkdir()
+    (bins / path.name).write_bytes(path.read_bytes())
+    model = types.SimpleNamespace(ctx=hctx)
+    out_pd = tmp_path / "predict_dev.csv"
+    assert nsnp_predict.predict_dev(model, str(bins), str(fa), 1000, 33, 11, str(out_pd), "cuda:0") == n and out_pd.read_bytes() == out.read_bytes()
+    with pytest.raises(ValueError):
+        nsnp_predict.predict_dev(model, str(bins), str(fa), 1000, 33, 21, str(out_pd))
     # (a) the array entry with reference rows made by the per-site host restatement of dataset_dev.py:106-120,150-162
     rp = host.haplotype_ref_rows(refs, cands, 33)
     rh = host.haplotype_ref_rows(refs, cands, 11, position_lists=hpos)

@@ -279,6 +279,13 @@ def test_streamed_pd_bin_files_write_the_array_path_vcf(tmp_path, pileup_weights
         assert st["passes_int16"] == st["passes"]                                            # int16 files travel as they are
         mixed = [files[0], files32[1], files32[2], files[3]]
         assert predict_pileup_bins(m, mixed, fai, str(o), batch_size=100, **kw) == rows and o.read_bytes() == want, kw
+    # the reference's own call shape (PileupModel/predict.py:37): predict(model, testing_paths, reference_index_file, batch_size, output_file, device)
+    from nanosnp_amd import predict as nsnp_predict
+    fai_path = tmp_path / "ref.fa.fai"; fai_path.write_text(fai)
+    o = tmp_path / "shape.vcf"
+    assert nsnp_predict.predict(m, files, str(fai_path), 100, str(o), "cuda") == rows and o.read_bytes() == want
+    with pytest.raises(ValueError):
+        nsnp_predict.predict(m, files, str(fai_path), 100, str(o), "cpu")
     # a directory: the reference takes os.listdir order and only names ending in .bin (predict.py:215)
     (d / "notes.txt").write_text("not a bin")
     order = [os.path.join(str(d), f) for f in os.listdir(d) if f.endswith(".bin")]
