@@ -5,6 +5,7 @@ this package holds only the host-side mirror of the reference's interface for th
 
     pileup_model.LSTMNetwork     PileupModel/model.py LSTMNetwork (predict only)
     haplotype_model.LSTMNetwork  HaplotypeModel/model_dev.py LSTMNetwork (predict only)
+    cat_model.CatModel           HaplotypeModel/model.py CatModel, the legacy path (predict only)
     pipeline                     mpileup text -> column encode -> windows -> PileupModel -> pileup.vcf in one pass
                                  (dna_sv_tensor make_candidate_snp_tensor + make_predict_data + predict.py)
                                  and .pd.bin window files -> pinned staging / H2D / PileupModel -> pileup.vcf, streamed

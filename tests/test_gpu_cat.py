@@ -158,3 +158,29 @@ def test_cat_conv_kernels_agree(prec):
     print("cat conv kernels, precision", prec, "max difference", d)
     assert d < 1e-5
     c.close()
+
+
+def test_reference_style_cat_model_interface():
+    """nanosnp_amd.cat_model.CatModel mirrors the legacy CatModel as HaplotypeModel/predict.py uses it: CatModel(nc0, nc1, nc2, nclass, nh),
+    load_state_dict, eval, to, predict(g0, g1, g2, g3) -> [N, 10]; the golden written by the reference module"""
+    import torch
+    from nanosnp_amd import _lib
+    from nanosnp_amd.cat_model import CatModel
+    from nanosnp_amd.fixtures import cat_weight_names, seeded_cat_weights
+    z = np.load(golden("cat_fwd.npz"))
+    m = CatModel(nc0=5, nc1=5, nc2=2, nclass=10, nh=256).to("cuda")
+    g0 = torch.from_numpy(z["g0"].astype(np.float32)).cuda(); g1 = torch.from_numpy(z["g1"].astype(np.float32)).cuda()
+    with pytest.raises(_lib.NanoSNPError):
+        m.predict(g0, g1, None, None)                                                   # weights not loaded
+    sd = {k: torch.from_numpy(w) for k, w in zip(cat_weight_names(), seeded_cat_weights(int(z["seed"])))}
+    sd["haplotype_base.cnn.0.bn1.num_batches_tracked"] = torch.tensor(0)              # (extra buffers of a real state dict are ignored)
+    m.load_state_dict(sd)
+    m.eval()
+    got = m.predict(g0, g1, None, None).cpu().numpy()
+    assert np.abs(got - z["gt"]).max() < PROB_ATOL and np.array_equal(got.argmax(1), z["gt"].argmax(1))
+    with pytest.raises(KeyError):
+        CatModel().load_state_dict({k: v for k, v in list(sd.items())[:10]})
+    with pytest.raises(_lib.NanoSNPError):
+        CatModel(nh=128)
+    with pytest.raises(_lib.NanoSNPError):
+        m.predict(g0.cpu(), g1.cpu(), None, None)
