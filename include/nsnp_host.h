@@ -140,6 +140,19 @@ int64_t nsnp_vcf_format_batches(int64_t N, int64_t batch_size, const char* names
                                 const float* gt_prob, const float* zy_prob, const float* cov,
                                 int score_mode, char* out, int64_t cap, int64_t* n_rows, int nthreads);
 
+/* One rank's share of a sharded run: the rows [first, first + N) of a list of n_total sites whose batches run over the WHOLE list
+ * (PileupModel/predict.py:45-47: the DataLoader cuts the whole dataset).  All a row takes from its batch is the batch's length and
+ * its first ten argmax values (the gt_output[ti] quirk, predict.py:102-125): heads[10 k .. 10 k + 10) holds them for global batch k
+ * (nanosnp_amd/dist.py::batch_heads exchanges them); heads NULL: first must be a multiple of batch_size and the values are read from
+ * gt_arg.  The arrays hold the N local rows.  The outputs of consecutive parts, concatenated, are the bytes of
+ * nsnp_vcf_format_batches over the whole list. */
+int64_t nsnp_vcf_format_batches_part(int64_t N, int64_t batch_size, int64_t first, int64_t n_total, const uint8_t* heads,
+                                     const char* names_blob, const int64_t* name_off,
+                                     const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                                     const uint8_t* gt_arg, const uint8_t* zy_arg,
+                                     const float* gt_prob, const float* zy_prob, const float* cov,
+                                     int score_mode, char* out, int64_t cap, int64_t* n_rows, int nthreads);
+
 /* haplotype.csv rows (HaplotypeModel/predict_dev.py:40-47) */
 int64_t nsnp_hap_csv_format(int64_t N, const char* names_blob, const int64_t* name_off,
                             const int32_t* contig_id, const int64_t* pos, const uint8_t* gt_arg,

@@ -172,16 +172,17 @@ static void emit(sbuf* b, const char* ctg, int ctg_len, int64_t pos, char sref, 
     if (line != stack) free(line);
 }
 
-int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* name_off,
-                              const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
-                              const uint8_t* gt_arg, const uint8_t* zy_arg,
-                              const float* gt_prob, const float* zy_prob, const float* cov,
-                              int score_mode, char* out, int64_t cap, int64_t* n_rows)
+/* J consecutive rows of ONE batch of B sites whose first ten argmax values are head[0 .. min(B, 10)): all a row takes from its batch
+ * (the gt_output[ti] quirk and its IndexError).  The arrays point at the first of the J rows. */
+static int64_t format_rows(int64_t J, int64_t B, const uint8_t* head, const char* names_blob, const int64_t* name_off,
+                           const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                           const uint8_t* gt_arg, const uint8_t* zy_arg,
+                           const float* gt_prob, const float* zy_prob, const float* cov,
+                           int score_mode, char* out, int64_t cap, int64_t* n_rows)
 {
-    if (B < 0 || !name_off || !n_rows) return NSNP_HOST_EINVAL;
     sbuf sb = { out, 0, out ? cap : 0, 0, 0 };
     int64_t rows = 0;
-    for (int64_t j = 0; j < B; ++j) {
+    for (int64_t j = 0; j < J; ++j) {
         const int g = gt_arg[j];
         if (g >= 10) continue;                                   /* predict.py:68-69 */
         if (zy_arg[j] > 2) continue;
@@ -227,7 +228,7 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
                     const int ti = TI[q];
                     if (GT_LABELS[ti][0] == sref) continue;
                     if (ti >= B) { err = 1; break; }             /* IndexError */
-                    if ((int)gt_arg[ti] > max_v) { max_v = gt_arg[ti]; max_ti = ti; }
+                    if ((int)head[ti] > max_v) { max_v = head[ti]; max_ti = ti; }
                 }
                 if (err) continue;
                 /* max_ti == -1 would index labels[-1] = 'ID' in Python */
@@ -239,7 +240,7 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
                 for (int q = 0; q < 6; ++q) {
                     const int ti = TI[q];
                     if (ti >= B) { err = 1; break; }
-                    if ((int)gt_arg[ti] > max_v) { max_v = gt_arg[ti]; max_ti = ti; }
+                    if ((int)head[ti] > max_v) { max_v = head[ti]; max_ti = ti; }
                 }
                 if (err) continue;
                 const char* l2 = max_ti < 0 ? "ID" : GT_LABELS[max_ti];
@@ -266,6 +267,16 @@ int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* 
     return sb.len;
 }
 
+int64_t nsnp_vcf_format_batch(int64_t B, const char* names_blob, const int64_t* name_off,
+                              const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                              const uint8_t* gt_arg, const uint8_t* zy_arg,
+                              const float* gt_prob, const float* zy_prob, const float* cov,
+                              int score_mode, char* out, int64_t cap, int64_t* n_rows)
+{
+    if (B < 0 || !name_off || !n_rows) return NSNP_HOST_EINVAL;
+    return format_rows(B, B, gt_arg, names_blob, name_off, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, score_mode, out, cap, n_rows);
+}
+
 /* HaplotypeModel/predict_dev.py:40-47: "ctg \t pos \t GT \t qual" with GT = gt_decoded_labels[argmax] */
 /* Every batch of the predict loop at once: rows of a batch depend only on that batch (the gt_output[ti] quirk indexes
  * the batch's own argmax array), so the batches are formatted independently on `nthreads` OpenMP threads - a sizing pass,
@@ -277,8 +288,26 @@ int64_t nsnp_vcf_format_batches(int64_t N, int64_t batch_size, const char* names
                                 const float* gt_prob, const float* zy_prob, const float* cov,
                                 int score_mode, char* out, int64_t cap, int64_t* n_rows, int nthreads)
 {
-    if (N < 0 || batch_size <= 0 || !name_off || !n_rows) return NSNP_HOST_EINVAL;
-    const int64_t nb = (N + batch_size - 1) / batch_size;
+    return nsnp_vcf_format_batches_part(N, batch_size, 0, N, NULL, names_blob, name_off, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob,
+                                        cov, score_mode, out, cap, n_rows, nthreads);
+}
+
+/* The rows [first, first + N) of a site list of n_total sites whose batches run over the WHOLE list (one rank's share of a sharded
+ * run): batch k holds the global rows [k batch_size, min((k + 1) batch_size, n_total)) and heads[10 k .. 10 k + 10) are its first ten
+ * argmax values (heads NULL: every batch that has rows here must START here - first a multiple of batch_size -, and the values are
+ * read from gt_arg).  The arrays hold the N local rows.  Concatenating the outputs of consecutive parts gives the bytes of
+ * nsnp_vcf_format_batches over the whole list. */
+int64_t nsnp_vcf_format_batches_part(int64_t N, int64_t batch_size, int64_t first, int64_t n_total, const uint8_t* heads,
+                                     const char* names_blob, const int64_t* name_off,
+                                     const int32_t* contig_id, const int64_t* pos, const uint8_t* ref_base,
+                                     const uint8_t* gt_arg, const uint8_t* zy_arg,
+                                     const float* gt_prob, const float* zy_prob, const float* cov,
+                                     int score_mode, char* out, int64_t cap, int64_t* n_rows, int nthreads)
+{
+    if (N < 0 || batch_size <= 0 || first < 0 || n_total < first + N || !name_off || !n_rows) return NSNP_HOST_EINVAL;
+    if (!heads && N > 0 && first % batch_size) return NSNP_HOST_EINVAL;
+    const int64_t kb0 = first / batch_size;                                     /* the first global batch with rows here */
+    const int64_t nb = N > 0 ? (first + N - 1) / batch_size - kb0 + 1 : 0;
     if (nthreads <= 0) nthreads = nsnp_host_threads();        /* 0: as many as this process may use */
     if (nthreads > nb) nthreads = nb > 0 ? (int)nb : 1;
     /* every thread formats a contiguous range of batches ONCE into a buffer of its own (grown when a batch does not fit); the
@@ -296,17 +325,22 @@ int64_t nsnp_vcf_format_batches(int64_t N, int64_t batch_size, const char* names
         for (int tt = t; tt < nthreads; tt += T) {             /* (a team smaller than asked for still covers every piece) */
             piece* me = pc + tt;
             const int64_t b0 = nb * tt / nthreads, b1 = nb * (tt + 1) / nthreads;
-            const int64_t sites = (b1 * batch_size < N ? b1 * batch_size : N) - b0 * batch_size;
-            me->cap = (sites > 0 ? sites : 0) * 72 + 4096;
+            me->cap = (b1 - b0) * batch_size * 72 + 4096;
+            if (me->cap > N * 72 + 4096) me->cap = N * 72 + 4096;
             me->p = (char*)malloc((size_t)me->cap);
             if (!me->p) { me->err = NSNP_HOST_ENOMEM; continue; }
             for (int64_t b = b0; b < b1 && !me->err; ++b) {
-                const int64_t j0 = b * batch_size, B = (N - j0 < batch_size) ? N - j0 : batch_size;
+                const int64_t g0 = (kb0 + b) * batch_size;                              /* the batch in global rows: [g0, g0 + B) */
+                const int64_t B = (n_total - g0 < batch_size) ? n_total - g0 : batch_size;
+                const int64_t lo = g0 > first ? g0 : first, hi = g0 + B < first + N ? g0 + B : first + N;
+                const int64_t j0 = lo - first, J = hi - lo;                             /* its rows here: local [j0, j0 + J) */
+                const uint8_t* head = heads ? heads + 10 * (kb0 + b) : gt_arg + (g0 - first);
+                if (!heads && J < (B < 10 ? B : 10)) { me->err = NSNP_HOST_EINVAL; break; }     /* the ten values are not all here */
                 for (;;) {
                     int64_t r = 0;
-                    const int64_t need = nsnp_vcf_format_batch(B, names_blob, name_off, contig_id + j0, pos + j0, ref_base + j0, gt_arg + j0,
-                                                               zy_arg + j0, gt_prob + j0, zy_prob + j0, cov + j0 * 8, score_mode,
-                                                               me->p + me->len, me->cap - me->len, &r);
+                    const int64_t need = format_rows(J, B, head, names_blob, name_off, contig_id + j0, pos + j0, ref_base + j0, gt_arg + j0,
+                                                     zy_arg + j0, gt_prob + j0, zy_prob + j0, cov + j0 * 8, score_mode,
+                                                     me->p + me->len, me->cap - me->len, &r);
                     if (need >= 0) { me->len += need; me->rows += r; break; }
                     if (need > -16) { me->err = (int)need; break; }             /* a real error code */
                     const int64_t want = me->len + (-need - 16), grown = want + want / 2 + 4096;

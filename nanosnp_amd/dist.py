@@ -17,13 +17,17 @@ def env_rank_world():
         int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def shard_range(n_items, rank, world):
-    """Contiguous, balanced, order-preserving: [lo, hi) of rank; sizes differ by at most one."""
-    if world <= 0 or not (0 <= rank < world) or n_items < 0:
+def shard_range(n_items, rank, world, align=1):
+    """Contiguous, balanced, order-preserving: [lo, hi) of rank; sizes differ by at most one.  align > 1: the cuts fall on
+    multiples of align (the items are dealt in units of align, the last unit may be short) - with align = the predict loop's
+    batch size every rank owns whole batches and formats its rows without knowing anything of the other ranks'."""
+    if world <= 0 or not (0 <= rank < world) or n_items < 0 or align < 1:
         raise ValueError("bad shard arguments")
-    base, rem = divmod(n_items, world)
+    units = -(-n_items // align)
+    base, rem = divmod(units, world)
     lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    hi = lo + base + (1 if rank < rem else 0)
+    return min(lo * align, n_items), min(hi * align, n_items)
 
 
 def shard_columns(n_cols, rank, world, halo=16):
@@ -93,6 +97,51 @@ def gather_varlen(local, root=0, group=None):
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     return _rooted_gather(local, [int(s.item()) for s in sizes], root, group)
+
+
+def site_offsets(n_local, device="cpu", group=None):
+    """(first, n_total): where this rank's n_local rows start in the rank-ordered list of every rank's rows, and the length of that
+    list (one small all_gather)."""
+    import torch
+    import torch.distributed as dist
+    n = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(sizes, n, group=group)
+    counts = [int(s_.item()) for s_ in sizes]
+    return sum(counts[:dist.get_rank(group)]), sum(counts)
+
+
+def batch_heads(gt_arg, first, n_total, batch_size, device="cpu", group=None):
+    """uint8 [ceil(n_total / batch_size), 10]: the first ten genotype argmax values of every batch of `batch_size` rows of the
+    rank-ordered list - all a pileup.vcf row takes from the other rows of its batch (PileupModel/predict.py:102-125 index
+    gt_output[ti], ti < 10).  gt_arg: this rank's values, rows [first, first + len) of the list.  Every rank fills in the
+    entries it owns (10 of every batch_size rows) and one small all_reduce (10 B per batch) adds the tables up; with it a
+    rank formats its rows exactly as the single process would (host.vcf_format_batches(first=, n_total=, heads=)) and the
+    TEXT travels to the root instead of the calls."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    nb = -(-int(n_total) // int(batch_size))
+    heads = np.zeros((nb, 10), np.uint8)
+    n = len(gt_arg)
+    if n:
+        g = np.arange(first, first + n, dtype=np.int64)
+        ti = g % batch_size
+        own = ti < 10
+        heads[g[own] // batch_size, ti[own]] = np.asarray(gt_arg, np.uint8)[own]
+    t = torch.from_numpy(heads).to(device)
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy()
+
+
+def gather_text(text, device="cpu", root=0, group=None):
+    """Rooted gather of every rank's bytes in rank order (gather_varlen over uint8): a memoryview of the concatenation on root,
+    None elsewhere."""
+    import numpy as np
+    import torch
+    arr = np.frombuffer(text, np.uint8) if len(text) else np.zeros(0, np.uint8)
+    out = gather_varlen(torch.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(device), root, group)
+    return None if out is None else memoryview(out.cpu().numpy())
 
 
 def gather_results_abi(ctx, local, n_total, root=0, stream=None):

@@ -465,13 +465,13 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
     ``ctg \t pos \t GT \t qual`` of every file are formatted and appended to output_file on a writer thread as soon as the file's calls
     are back, while later files compute.  reference: a DeviceReference, a dict {contig: sequence} (uploaded once) or the path of a FASTA
     file (read as get_truth.load_reference_file reads it: host.load_reference_file).
-    Under torch.distributed every rank works on its shard_range of every file, the calls travel to rank 0 in one rooted gather and
-    rank 0 writes (distributed=False: this process alone does the whole job even inside a process group).  Returns the number of rows
+    Under torch.distributed every rank works on its shard_range of every file and formats its own rows, the text travels to rank 0 in
+    one rooted gather and rank 0 writes (distributed=False: this process alone does the whole job even inside a process group).  Returns the number of rows
     written (on rank 0; 0 elsewhere)."""
     import time
     import torch
     import torch.distributed as tdist
-    from .dist import gather_varlen, shard_range
+    from .dist import gather_text, shard_range
     if isinstance(bin_paths, (str, os.PathLike)):
         d = str(bin_paths)
         paths = [os.path.join(d, f) for f in os.listdir(d)] if os.path.isdir(d) else [d]
@@ -492,39 +492,47 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
             sources.append(HapBinSource(p))
         segments = [(s_,) + shard_range(s_.n, rank, world) for s_ in sources]
 
-        def write_rows(tbl, ctg, pos, ga, gm):
+        texts = {}                                      # sharded: this rank's rows of every file (final text) until the gather
+
+        def write_rows(i, tbl, ctg, pos, ga, gm):
             nonlocal total
             t0 = time.perf_counter()
             if pos.size:
-                f.write(host.hap_csv_format(tbl, ctg, pos, ga, gm, score_mode))
-                total += int(pos.size)
+                text = host.hap_csv_format(tbl, ctg, pos, ga, gm, score_mode)
+                if sharded:
+                    texts[i] = text
+                else:
+                    f.write(text)
+                    total += int(pos.size)
             st["csv_s"] += time.perf_counter() - t0
 
         if not sharded:
-            stream_segments(ctx, segments, ref, pass_sites, narrow, st, on_segment=lambda i, c: write_rows(*c[:5]))
+            stream_segments(ctx, segments, ref, pass_sites, narrow, st, on_segment=lambda i, c: write_rows(i, *c[:5]))
         else:
-            calls = stream_segments(ctx, segments, ref, pass_sites, narrow, st)
-            # contig ids index every rank's OWN name table (ranks can meet unknown contigs in different orders): the tables are merged
-            # first, every rank renumbers its ids, then the numbers of all files travel as ONE [n, 4] float64 block (all exact);
-            # the root cuts it back into files (every rank knows every shard size: shard_range)
-            lists = [None] * world
-            tdist.all_gather_object(lists, list(ref.names))
-            merged = list(dict.fromkeys(n_ for lst in lists for n_ in lst))
-            remap = np.array([merged.index(n_) for n_ in ref.names] + [0], np.float64)
+            # a csv row depends on its own site alone (predict_dev.py:40-47): every rank formats its rows beside its compute, as the
+            # single process does, and the TEXT of all files travels to rank 0 in one rooted gather (the sizes first, as one small
+            # object; a rank whose rows cannot be written - calculate_score on p == 1 under score_mode 0 - fails every rank)
+            err = None
+            try:
+                stream_segments(ctx, segments, ref, pass_sites, narrow, st, on_segment=lambda i, c: write_rows(i, *c[:5]))
+            except (host.HostError, ValueError, ArithmeticError) as e_:
+                err = f"rank {rank}: {e_}"
+            mine = [len(texts.get(i, b"")) for i in range(len(sources))]
+            sizes = [None] * world
+            tdist.all_gather_object(sizes, (mine, err))
+            errs = [e_ for _, e_ in sizes if e_]
+            if errs:
+                raise host.HostError("; ".join(errs))
             backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
-            blks = [np.stack([remap[c.contig_id], c.pos.astype(np.float64), c.gt_arg.astype(np.float64), c.gt_max.astype(np.float64)], 1)
-                    for c in calls if c.pos.size]
-            blk = np.concatenate(blks) if blks else np.zeros((0, 4))
-            allb = gather_varlen(torch.from_numpy(blk).to(backend_dev))
+            allt = gather_text(b"".join(texts[i] for i in sorted(texts)), backend_dev)
             if rank == 0:
-                allb = allb.cpu().numpy()
-                tbl = host.ContigTable(merged)
-                sizes = [[hi - lo for lo, hi in (shard_range(s_.n, r, world) for s_ in sources)] for r in range(world)]
-                start = np.concatenate([[0], np.cumsum([sum(sz) for sz in sizes])])
-                within = [np.concatenate([[0], np.cumsum(sz)]) for sz in sizes]
+                start = np.concatenate([[0], np.cumsum([sum(sz) for sz, _ in sizes])])
+                within = [np.concatenate([[0], np.cumsum(sz)]) for sz, _ in sizes]
                 for i in range(len(sources)):
-                    rows = np.concatenate([allb[start[r] + within[r][i]:start[r] + within[r][i + 1]] for r in range(world)])
-                    write_rows(tbl, rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int64), rows[:, 2].astype(np.uint8), rows[:, 3].astype(np.float32))
+                    for r in range(world):
+                        f.write(allt[int(start[r] + within[r][i]):int(start[r] + within[r][i + 1])])
+                        lo_, hi_ = shard_range(sources[i].n, r, world)
+                        total += hi_ - lo_
     finally:
         for s_ in sources:
             s_.close()

@@ -380,6 +380,9 @@ def _bind_vcf():
     l.nsnp_vcf_format_batch.restype = C.c_int64
     l.nsnp_vcf_format_batch.argtypes = [C.c_int64, C.c_char_p, p, p, p, p, p, p, p, p, p, C.c_int, p, C.c_int64,
                                         C.POINTER(C.c_int64)]
+    l.nsnp_vcf_format_batches_part.restype = C.c_int64
+    l.nsnp_vcf_format_batches_part.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, p, C.c_char_p, p, p, p, p, p, p, p, p, p, C.c_int, p,
+                                               C.c_int64, C.POINTER(C.c_int64), C.c_int]
     l.nsnp_vcf_format_batches.restype = C.c_int64
     l.nsnp_vcf_format_batches.argtypes = [C.c_int64, C.c_int64, C.c_char_p, p, p, p, p, p, p, p, p, p, C.c_int, p, C.c_int64,
                                           C.POINTER(C.c_int64), C.c_int]
@@ -427,12 +430,20 @@ def vcf_format_batch(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, z
 
 
 def vcf_format_batches(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob, zy_prob, cov, batch_size=1000,
-                       score_mode=SCORE_FLOAT64, nthreads=None, as_view=False):
+                       score_mode=SCORE_FLOAT64, nthreads=None, as_view=False, first=0, n_total=None, heads=None):
     """All batches of the predict loop in one native call (OpenMP over batches) -> (bytes, n_rows); byte-identical to
     concatenating vcf_format_batch over consecutive slices of batch_size sites.  as_view: a memoryview of the output buffer instead
-    of a bytes copy of it (12 MB per 200 k rows)."""
+    of a bytes copy of it (12 MB per 200 k rows).
+    first / n_total / heads: the arrays are the rows [first, first + N) of a list of n_total sites whose batches run over the whole
+    list (one rank's share; nsnp_vcf_format_batches_part): heads = uint8 [ceil(n_total / batch_size), 10], the first ten argmax values
+    of every batch (dist.batch_heads), or None when first is a multiple of batch_size.  The parts' texts concatenate to the whole."""
     l = _bind_vcf()
     N = len(pos)
+    n_total = first + N if n_total is None else int(n_total)
+    if heads is not None:
+        heads = np.ascontiguousarray(heads, np.uint8)
+        if heads.size < 10 * (-(-n_total // int(batch_size))):
+            raise ValueError("heads holds fewer than ten values per batch of the whole list")
     args = [np.ascontiguousarray(contig_id, np.int32), np.ascontiguousarray(pos, np.int64),
             np.ascontiguousarray(ref_base, np.uint8), np.ascontiguousarray(gt_arg, np.uint8),
             np.ascontiguousarray(zy_arg, np.uint8), np.ascontiguousarray(gt_prob, np.float32),
@@ -442,8 +453,9 @@ def vcf_format_batches(table, contig_id, pos, ref_base, gt_arg, zy_arg, gt_prob,
     rows = C.c_int64(0)
     while True:
         buf = np.empty(cap, np.uint8)
-        n = l.nsnp_vcf_format_batches(N, int(batch_size), table.blob, _ptr(table.off), *[_ptr(a) for a in args], int(score_mode),
-                                      _ptr(buf), cap, C.byref(rows), nthreads)
+        n = l.nsnp_vcf_format_batches_part(N, int(batch_size), int(first), n_total, _ptr(heads) if heads is not None else None,
+                                           table.blob, _ptr(table.off), *[_ptr(a) for a in args], int(score_mode),
+                                           _ptr(buf), cap, C.byref(rows), nthreads)
         if n >= 0:
             return (memoryview(buf)[:n] if as_view else buf[:n].tobytes()), rows.value
         if n > -16:

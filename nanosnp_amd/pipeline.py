@@ -335,9 +335,10 @@ def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, mi
 stream_contig.__doc__ = _stream_contig.__doc__
 
 
-def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False):
+def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False, shard_dev=None):
     """call rows [n, 13] float64 (a device tensor, a host tensor or a numpy array) -> (VCF text, rows written) of the reference's
-    predict loop over consecutive batches.  Device rows are cut into their typed columns ON the device (six small kernels, 41 B per
+    predict loop over consecutive batches.  shard_dev (the device the process group's collectives take their tensors on): the rows are
+    one rank's share of the contig -> (this rank's text, its rows, sites of all ranks); every rank must call.  Device rows are cut into their typed columns ON the device (six small kernels, 41 B per
     site over the bus instead of 104 B and nine numpy passes)."""
     import torch
     if isinstance(r, torch.Tensor):
@@ -351,9 +352,17 @@ def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False):
         cov = r[:, 5:13].astype(np.float32)
     n = site_pos.shape[0]
     site_ref = chr_seq[site_pos - 1] & 0xDF                                  # make_predict_data/main.cpp:91 upper-cases
+    first, n_total, heads = 0, n, None
+    if shard_dev is not None:
+        # one rank's rows of a sharded contig: the batches run over the site list of ALL ranks - where this rank's rows start in it
+        # and the ten argmax values its rows may read from a batch that starts on another rank (two small collectives)
+        from .dist import batch_heads, site_offsets
+        first, n_total = site_offsets(n, shard_dev)
+        heads = batch_heads(ga, first, n_total, batch_size, shard_dev)
     # the VCF rows depend on the batch boundary: one native call formats every batch (OpenMP over the batches)
-    return host.vcf_format_batches(host.ContigTable([contig]), np.zeros(n, np.int32), site_pos, site_ref, ga, za, gm, zm, cov,
-                                   batch_size=batch_size, score_mode=score_mode, as_view=as_view)
+    text, n_rows = host.vcf_format_batches(host.ContigTable([contig]), np.zeros(n, np.int32), site_pos, site_ref, ga, za, gm, zm, cov,
+                                           batch_size=batch_size, score_mode=score_mode, as_view=as_view, first=first, n_total=n_total, heads=heads)
+    return (text, n_rows) if shard_dev is None else (text, n_rows, n_total)
 
 
 def _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats):
@@ -426,14 +435,14 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
 
     The text is worked off in chunks of whole lines (stream_contig: parse of chunk k + 1 on the host beside the device work of
     chunk k).  Under an initialised torch.distributed process group (one process per GPU, torchrun) the TEXT is statically sharded:
-    rank r parses and calls only the lines of its byte range (cut at line boundaries; 16 lines of halo re-parsed, not exchanged), and
-    the per-site calls are gathered to rank 0 in rank = position order, where the rows are formatted exactly as a single process
-    would format them (the reference's batches of `batch_size` sites run over the whole site list).  Ranks other than 0 return
-    (b"", n_sites_total, 0)."""
+    rank r parses and calls only the lines of its byte range (cut at line boundaries; 16 lines of halo re-parsed, not exchanged) and
+    formats the rows of ITS sites exactly as a single process would format them (the reference's batches of `batch_size` sites run
+    over the whole site list: dist.site_offsets + dist.batch_heads hand a rank the little it needs of the others); the text is
+    gathered to rank 0 in rank = position order.  Ranks other than 0 return (b"", n_sites_total, 0)."""
     import time
     import torch
     import torch.distributed as tdist
-    from .dist import gather_varlen
+    from .dist import gather_text
     ctx = model.ctx
     finder, arr = _as_bytes_like(mpileup_text)
     sharded = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
@@ -445,13 +454,21 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
     cuts = line_cuts(finder, world, 0, arr.size)
     rows = stream_contig(model, mpileup_text, contig, chr_seq, cuts[rank], cuts[rank + 1], chunk_bytes, min_af, min_coverage, stats)
     if sharded:
+        # every rank formats ITS rows (on its own host cores, exactly as the single process would format them: _format_rows), the text
+        # - about 60 B per row, half of what the calls take - travels to rank 0 in one rooted gather
         backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
-        rows = gather_varlen(rows.to(backend_dev))
-        if rank != 0:
-            n_tot = torch.zeros(1, dtype=torch.int64, device=backend_dev)
-            tdist.broadcast(n_tot, src=0)
-            return b"", int(n_tot.item()), 0
-        tdist.broadcast(torch.tensor([rows.shape[0]], dtype=torch.int64, device=backend_dev), src=0)
+        t0 = time.perf_counter()
+        text, n_rows, n_sites = _format_rows(rows, contig, chr_seq, batch_size, score_mode, as_view=True, shard_dev=backend_dev)
+        t1 = time.perf_counter()
+        cnt = torch.tensor([n_rows], dtype=torch.int64, device=backend_dev)
+        tdist.all_reduce(cnt)
+        text = gather_text(text, backend_dev)
+        if stats is not None:
+            stats["vcf_s"] = stats.get("vcf_s", 0.0) + t1 - t0
+            stats["gather_s"] = stats.get("gather_s", 0.0) + time.perf_counter() - t1
+            stats["sites"] = stats.get("sites", 0) + int(rows.shape[0])
+            stats["vcf_rows"] = stats.get("vcf_rows", 0) + n_rows
+        return (text, n_sites, int(cnt.item())) if rank == 0 else (b"", n_sites, 0)
     # (formatting the rows of finished chunks on a worker thread while later chunks compute - rows_beside=True,
     # _call_contig_rows_beside - is built, byte-identical and SLOWER: round 3 with the 34 ms formatter 162 against 75 ms per 6 M-column
     # contig; round 5 with the 2.4 ms formatter on a quarter of the threads 27.6-28.4 against 22.5 ms (median of 30 steps, A/B/A/B on
@@ -530,16 +547,17 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
     files are one pipeline, and the rows of a file are formatted (one native call over the reference's batches of `batch_size` sites,
     which restart with every file as its DataLoader does) and appended on a writer thread while the next file computes.
     testing_paths: a list of paths, or a directory (its ``*.bin`` files in os.listdir order: predict.py:215).  Returns rows written.
-    Under torch.distributed (one process per GPU) every rank works on its shard_range of every file's windows, the calls travel to
-    rank 0 in one rooted gather and rank 0 formats (the reference's batches run over the whole file) and writes; the other ranks
-    return 0.  distributed=False: this process alone does the whole job even inside a process group."""
+    Under torch.distributed (one process per GPU) every rank works on its shard_range of every file's windows, cut at multiples of
+    batch_size: the reference's batches run over the whole file, so a rank owns whole batches and formats its rows beside its compute as
+    the single process does; the TEXT travels to rank 0 in one rooted gather behind the last file and rank 0 writes it in file, rank
+    order (the other ranks return 0).  distributed=False: this process alone does the whole job even inside a process group."""
     import threading
     import time
     from concurrent.futures import ThreadPoolExecutor
     import torch
     import torch.distributed as tdist
     from . import sitefile
-    from .dist import gather_varlen, shard_range
+    from .dist import gather_text, shard_range
     from .hap_pipeline import _LocalNames
     t_begin = time.perf_counter()
     sharded = bool(distributed) and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
@@ -562,7 +580,9 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
                 or idx["position_matrix"][1][1:] != (33, 18)):
             raise sitefile.SiteFileError(f"{p}: not a pileup site file (position_matrix int16 / int32 [N,33,18] + position)")
         n_file = int(idx["position_matrix"][1][0])
-        lo, hi = shard_range(n_file, rank, world)              # this rank's windows of the file: [lo, hi) (everything without a process group)
+        # this rank's windows of the file: [lo, hi) (everything without a process group), cut at multiples of batch_size: the reference's batches
+        # run over the whole file, so every rank owns WHOLE batches and formats its rows without a word from the others
+        lo, hi = shard_range(n_file, rank, world, align=int(batch_size))
         files.append(dict(path=p, n_file=n_file, lo=lo, n=hi - lo, x_off=idx["position_matrix"][2], fd=-1,
                           elem=idx["position_matrix"][0].itemsize,
                           position=sitefile.read_arrays(p, mmap=True)["position"]))
@@ -579,7 +599,7 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
     last_pass_of = {fi: k for k, (fi, _, _, _) in enumerate(passes)}
     names = _LocalNames()
     total_rows = 0
-    kept = {}                                                  # sharded: the calls of every file stay on this rank until the gather
+    kept = {}                                                  # sharded: the rows (text) of every file stay on this rank until the gather
     out = open(output_file, "wb") if rank == 0 else None
     try:
         for f in files:
@@ -656,18 +676,17 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
                 o0, o1 = int(seg_off[fi]), int(seg_off[fi + 1])
                 r0 = (fi % n_slots) * max_n
                 r1 = r0 + (o1 - o0)
-                if sharded:
-                    if o1 > o0:                        # the result slot is about to be reused: this rank's calls of the file as one float64 block (all exact)
-                        kept[fi] = np.concatenate([ctg_all[o0:o1, None], pos_all[o0:o1, None], refb_all[o0:o1, None], res["ga"][r0:r1].numpy()[:, None],
-                                                   res["za"][r0:r1].numpy()[:, None], res["gm"][r0:r1].numpy()[:, None], res["zm"][r0:r1].numpy()[:, None],
-                                                   cov_all[o0:o1]], axis=1, dtype=np.float64)
-                elif o1 > o0:
+                if o1 > o0:
                     text, rows = host.vcf_format_batches(names.table, ctg_all[o0:o1], pos_all[o0:o1], refb_all[o0:o1], res["ga"][r0:r1].numpy(),
                                                          res["za"][r0:r1].numpy(), res["gm"][r0:r1].numpy(), res["zm"][r0:r1].numpy(),
                                                          cov_all[o0:o1], batch_size=batch_size, score_mode=score_mode, as_view=True,
-                                                         nthreads=writer_threads if fi + 1 < len(files) else 0)   # the last file: nothing else runs
-                    out.write(text)
-                    total_rows += rows
+                                                         nthreads=writer_threads if fi + 1 < len(files) else 0,   # the last file: nothing else runs
+                                                         first=files[fi]["lo"], n_total=files[fi]["n_file"])
+                    if sharded:
+                        kept[fi] = (text, rows)        # this rank's rows of the file, final: they travel as text behind the last file
+                    else:
+                        out.write(text)
+                        total_rows += rows
                 st["vcf_s"] += time.perf_counter() - t0
 
             tev = lambda: torch.cuda.Event(enable_timing=True)
@@ -739,38 +758,22 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
                         st["gaps"].append((k, round(gap * 1e3, 2), round(ev[k - 1]["c1"].elapsed_time(e_["h1"]), 2), round(e_["h0"].elapsed_time(e_["h1"]), 2)))
             st["account_s"] += time.perf_counter() - t_a
         if sharded:
-            # contig ids index every rank's OWN name table: the tables are merged, every rank renumbers its ids, then the calls of all files
-            # travel as ONE [n, 15] float64 block to rank 0, which cuts it back into files (every rank knows every shard size) and formats
+            # every rank's rows are final text (whole batches of every file): the sizes travel as one small object, the text in ONE rooted
+            # gather; rank 0 puts the pieces in file-major, rank-minor order
             t0 = time.perf_counter()
-            lists = [None] * world
-            tdist.all_gather_object(lists, list(names.names))
-            merged = list(dict.fromkeys(n_ for lst in lists for n_ in lst))
-            remap = np.array([merged.index(n_) for n_ in names.names], np.float64)
-            blks = []
-            for fi in range(len(files)):
-                if fi in kept:
-                    b = kept[fi]
-                    b[:, 0] = remap[b[:, 0].astype(np.int64)]
-                    blks.append(b)
-            blk = np.concatenate(blks) if blks else np.zeros((0, 15))
+            mine = [(len(kept[fi][0]), kept[fi][1]) if fi in kept else (0, 0) for fi in range(len(files))]
+            sizes = [None] * world
+            tdist.all_gather_object(sizes, mine)
             backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
-            allb = gather_varlen(torch.from_numpy(blk).to(backend_dev))
+            allt = gather_text(b"".join(bytes(kept[fi][0]) for fi in range(len(files)) if fi in kept), backend_dev)
             if rank == 0:
-                allb = allb.cpu().numpy()
-                tbl = host.ContigTable(merged)
-                sizes = [[shard_range(f["n_file"], r, world)[1] - shard_range(f["n_file"], r, world)[0] for f in files] for r in range(world)]
-                start = np.concatenate([[0], np.cumsum([sum(sz) for sz in sizes])])
-                within = [np.concatenate([[0], np.cumsum(sz)]) for sz in sizes]
+                start = np.concatenate([[0], np.cumsum([sum(l for l, _ in sz) for sz in sizes])])
+                within = [np.concatenate([[0], np.cumsum([l for l, _ in sz])]) for sz in sizes]
                 for i in range(len(files)):
-                    rows = np.concatenate([allb[start[r] + within[r][i]:start[r] + within[r][i + 1]] for r in range(world)])
-                    if len(rows):
-                        text, n_rows = host.vcf_format_batches(tbl, rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int64), rows[:, 2].astype(np.uint8),
-                                                               rows[:, 3].astype(np.uint8), rows[:, 4].astype(np.uint8), rows[:, 5].astype(np.float32),
-                                                               rows[:, 6].astype(np.float32), np.ascontiguousarray(rows[:, 7:15], np.float32),
-                                                               batch_size=batch_size, score_mode=score_mode, as_view=True)
-                        out.write(text)
-                        total_rows += n_rows
-            st["vcf_s"] += time.perf_counter() - t0
+                    for r in range(world):
+                        out.write(allt[int(start[r] + within[r][i]):int(start[r] + within[r][i + 1])])
+                        total_rows += sizes[r][i][1]
+            st["gather_s"] = st.get("gather_s", 0.0) + time.perf_counter() - t0
     finally:
         if out:
             out.close()

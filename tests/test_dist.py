@@ -238,3 +238,47 @@ def test_gather_varlen_world3_gloo():
     merged = next(o for o in outs if o is not None)
     assert merged.shape == (8, 2)
     assert merged[:, 0].tolist() == [0.0] * 5 + [2.0] * 3 and merged[:, 1].tolist() == [0, 1, 2, 3, 4, 0, 1, 2]
+
+
+def _text_worker(rank, world, port, sizes, bs, q):
+    import torch.distributed as dist
+    from nanosnp_amd import host
+    from nanosnp_amd.dist import batch_heads, gather_text, site_offsets
+    from tests.test_vcf import _random_calls
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        table, a = _random_calls(77, sum(sizes))
+        lo = sum(sizes[:rank])
+        mine = [x[lo:lo + sizes[rank]] for x in a]
+        first, n_total = site_offsets(sizes[rank])
+        assert (first, n_total) == (lo, sum(sizes))
+        heads = batch_heads(mine[3], first, n_total, bs)
+        text, rows = host.vcf_format_batches(table, *mine, batch_size=bs, first=first, n_total=n_total, heads=heads, as_view=True)
+        out = gather_text(text)
+        q.put(bytes(out) if rank == 0 else None)
+        assert (out is None) == (rank != 0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes,bs", [((1204, 0, 803), 1000), ((7, 2, 1300), 64), ((995, 8, 4), 1000)])
+def test_rows_formatted_per_rank_equal_the_single_process_text(sizes, bs):
+    """every rank formats ITS rows (site_offsets + batch_heads: the ten argmax values a batch's rows read from one another), the text
+    is gathered: the bytes of one process formatting the whole list - with an empty rank, a rank inside another's first ten rows
+    and a last batch shorter than ten rows"""
+    import torch.multiprocessing as mp
+    from nanosnp_amd import host
+    from tests.test_vcf import _random_calls
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_text_worker, args=(r, 3, port, sizes, bs, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table, a = _random_calls(77, sum(sizes))
+    assert next(o for o in outs if o is not None) == host.vcf_format_batches(table, *a, batch_size=bs)[0]

@@ -331,8 +331,8 @@ def _pd_rank_worker(rank, world, port, tmp, q):
 @pytest.mark.parametrize("world", [2, 3])
 def test_site_sharded_window_files_write_the_single_process_vcf(tmp_path, pileup_weights, world):
     """pipeline.predict_pileup_bins under a process group: every rank takes its shard_range of every file's windows (all on cuda:0 of
-    the one-GPU box, the gather over gloo), rank 0 formats over the whole file - the rows depend on the batch a site falls into - and
-    writes the single-process VCF; an empty file and a file smaller than the number of ranks among them; contigs met in different
+    the one-GPU box, the gather over gloo) cut at batch boundaries and formats its own rows - they depend on the batch a site falls into -,
+    rank 0 writes the gathered text: the single-process VCF; an empty file and a file smaller than the number of ranks among them; contigs met in different
     orders by different ranks"""
     import socket
     import torch.multiprocessing as mp
