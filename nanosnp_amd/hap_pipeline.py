@@ -16,7 +16,7 @@ Here the read planes of a pass of sites (default 16,384) move through three stat
                     nsnp_hap_forward -> argmax / max of pass k - 1, the calls (5 bytes per site) on their way back to a pinned array
 
 and the csv rows of all sites are written by one native call (``nsnp_hap_csv_format``) at the end.  Under torch.distributed every
-rank takes the contiguous ``shard_range`` of the sites and the calls are gathered to rank 0 (rank order = position order).
+rank takes the contiguous ``shard_range`` of the sites formats its own rows, and the text is gathered to rank 0 (rank order = position order).
 There is no CPU path: a missing HIP library or GPU raises.
 """
 from __future__ import annotations
@@ -517,6 +517,7 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
                 stream_segments(ctx, segments, ref, pass_sites, narrow, st, on_segment=lambda i, c: write_rows(i, *c[:5]))
             except (host.HostError, ValueError, ArithmeticError) as e_:
                 err = f"rank {rank}: {e_}"
+            t_g = time.perf_counter()
             mine = [len(texts.get(i, b"")) for i in range(len(sources))]
             sizes = [None] * world
             tdist.all_gather_object(sizes, (mine, err))
@@ -533,6 +534,7 @@ def predict_haplotype_bins(ctx, bin_paths, reference, output_file, pass_sites=16
                         f.write(allt[int(start[r] + within[r][i]):int(start[r] + within[r][i + 1])])
                         lo_, hi_ = shard_range(sources[i].n, r, world)
                         total += hi_ - lo_
+            st["gather_s"] = st.get("gather_s", 0.0) + time.perf_counter() - t_g
     finally:
         for s_ in sources:
             s_.close()

@@ -117,7 +117,7 @@ def run(args, rank, world, local_rank, emit=None):
         dt = float(tm.item())
     per_rank = None
     if world > 1:
-        mine = {k: round(stats.get(k, 0.0) / K, 4) for k in ("parse_s", "wait_parse_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "vcf_s")}
+        mine = {k: round(stats.get(k, 0.0) / K, 4) for k in ("parse_s", "wait_parse_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "vcf_s", "gather_s")}
         mine["rank"] = rank
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)

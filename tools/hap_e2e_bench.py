@@ -235,7 +235,7 @@ def _run(args, rank, world, local_rank, emit, created):
     dt, st = timed(p8, K)
     per_rank = None
     if world > 1:
-        mine = {k: round(st.get(k, 0.0) / K, 4) for k in ("stage_s", "wait_stage_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "csv_s")}
+        mine = {k: round(st.get(k, 0.0) / K, 4) for k in ("stage_s", "wait_stage_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "csv_s", "gather_s")}
         mine["rank"] = rank
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)

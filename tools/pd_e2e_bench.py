@@ -153,7 +153,7 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dt = float(tm.item())
         if world > 1:
-            mine = {k: round(st.get(k, 0.0) / steps, 4) for k in ("stage_s", "wait_stage_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "vcf_s")}
+            mine = {k: round(st.get(k, 0.0) / steps, 4) for k in ("stage_s", "wait_stage_s", "h2d_s", "gpu_s", "issue_s", "drain_s", "vcf_s", "gather_s")}
             mine["rank"] = rank
             per = [None] * world
             dist.all_gather_object(per, mine)
