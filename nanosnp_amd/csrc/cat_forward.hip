@@ -234,16 +234,18 @@ constexpr int CONV_HALO = 12;                          // W + 1 for the widths o
 // NPT = pixel tiles (of 128) per workgroup.  2 for the blocks with <= 64 output channels (round 5): their waves had 8 / 16 MFMAs
 // between two barriers at 128 pixels (0.47 / 0.65 of the peak against 0.75-0.78 for the wide blocks); with 256 pixels a wave owns 64
 // pixels x all rows = 16 / 32.  Same products in the same order per accumulator: bit-identical.
-template <int AR, int NPT>     // AR: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 2 bf16x3 (six v_mfma_f32_32x32x16_bf16 per product)
+template <int AR, int NPT>     // AR: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 f16x3 (images of (hi, lo) fp16 pairs, three v_mfma_f32_32x32x16_f16 per
+                               // product: hap_gemm.hpp), 2 bf16x3 (six v_mfma_f32_32x32x16_bf16 per product)
 __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
 {
-    constexpr bool B3 = AR == 2;
+    constexpr bool B3 = AR == 2, F16 = AR == 1;
     constexpr int PIX = NPT * TS;                       // pixels of the workgroup
     constexpr int ROWS = PIX + 2 * CONV_HALO + 1;       // staged pixels + halo + the zero row
     constexpr int NHT = (2 * (PIX + 2 * CONV_HALO) + 255) / 256;     // staging tasks (row, half) per thread
     constexpr int ROWF = B3 ? 28 : LDK;                 // floats per LDS row: 112 B (3 planes x 16 bf16 + pad) / 80 B (16 floats + pad)
     constexpr int TILE_W = B3 ? TILE_F * 3 / 2 : TILE_F;
-    constexpr int NPL = B3 ? 3 : 2;                     // 16-byte fragments per row half: three planes / two groups of four K-steps
+    constexpr int NPL = B3 ? 3 : 2;                     // 16-byte fragments per row half: three planes / two groups of four K-steps / hi and lo halves
+    auto frag_at = [](int p, int lh_) { return B3 ? (2 * p + lh_) * 4 : F16 ? lh_ * 4 + p * 8 : lh_ * 8 + p * 4; };   // float offset in an LDS row
     __shared__ float As[2][TR][ROWF];
     __shared__ float Hb[2][ROWS][ROWF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -372,13 +374,13 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
             const int row = ((vmask[ct] >> t_eff) & 1u) ? srow[ct] + off : ROWS - 1;
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                bf[ct][p] = *reinterpret_cast<const f32x4*>(&Hb[hb][row][B3 ? (2 * p + lh) * 4 : lh * 8 + p * 4]);
+                bf[ct][p] = *reinterpret_cast<const f32x4*>(&Hb[hb][row][frag_at(p, lh)]);
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][B3 ? (2 * p + lh) * 4 : lh * 8 + p * 4]);
+                af[rt][p] = *reinterpret_cast<const f32x4*>(&As[cur][64 * wr + 32 * rt + li][frag_at(p, lh)]);
         __builtin_amdgcn_sched_barrier(0);
         if (B3) {
             constexpr int WP[6] = {0, 1, 2, 0, 1, 0}, XP[6] = {2, 1, 0, 1, 0, 0};
@@ -402,6 +404,30 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
                         if (ct >= nct || rt >= nrt) continue;
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, af[rt][WP[g]]), __builtin_bit_cast(b8_t, bf[ct][XP[g]]),
                                                                                acc[rt][ct], 0, 0, 0);
+                    }
+            }
+        } else if (F16) {
+            // af[rt][0] / [1]: the lane's 8 hi / 8 lo halves of its weight row, bf likewise for its pixel: hi.hi + lo.hi + hi.lo (k_hap_gemm's order)
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+                if (term == 1 && have_next) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    lstore_a(cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (term == 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 2 < n_chunks) gload_a(chunk_kc(j + 2));
+                    if (stage_next_block) gload_h(nblk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        if (ct >= nct || rt >= nrt) continue;
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[rt][term == 1 ? 1 : 0]),
+                                                                              __builtin_bit_cast(h8, bf[ct][term == 2 ? 1 : 0]), acc[rt][ct], 0, 0, 0);
                     }
             }
         } else {
@@ -451,7 +477,16 @@ __global__ __launch_bounds__(256, 2) void k_cat_conv(const ConvArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) v[g] = fmaxf(acc[rt][ct][4 * r4 + g], 0.f);
                 float* o = a.out + (size_t)((size_t)bx * NPT + (site >> 7)) * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + (site & 127) * BK;
-                *reinterpret_cast<f32x4*>(o + (f & 15)) = v;
+                if (F16) {                                             // the image row: 16 hi halves, then 16 lo halves
+                    h4 vh, vl;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { _Float16 x, y; split_h(v[g], x, y); vh[g] = x; vl[g] = y; }
+                    _Float16* orow = reinterpret_cast<_Float16*>(o);
+                    *reinterpret_cast<h4*>(orow + (f & 15)) = vh;
+                    *reinterpret_cast<h4*>(orow + 16 + (f & 15)) = vl;
+                } else {
+                    *reinterpret_cast<f32x4*>(o + (f & 15)) = v;
+                }
             }
     }
 }
@@ -796,22 +831,22 @@ int cat_forward_impl(nsnp_ctx* ctx, const float* g0, const float* g1, int64_t N,
             const CatBlock& b = cw.blk[i];
             const int rt = NSNP_CDIV(b.cout, TR);
             float* X = map[cur]; float* Y = map[(cur + 1) % 3]; float* O = map[(cur + 2) % 3];
-            if (AR != 1 && ctx->cat_conv_lds) {
-                // the LDS-staged convolution kernel (fp32 and bf16x3; the f16x3 mode keeps the gathering GEMM)
+            if (ctx->cat_conv_lds) {
+                // the LDS-staged convolution kernel (all three arithmetics; option "cat_conv_lds" 0: the gathering GEMM)
                 ConvArgs c;
                 c.conv_h = Hc; c.conv_w = CAT_L; c.n_pix = n_pix; c.n_pix_alloc = n_ptiles * TS; c.n_rows = b.cout;
                 c.w = wm(b.w1); c.bias = b.b1; c.x = X; c.sc = nullptr; c.cc_in = b.cc_in; c.cc_sc = 0; c.nk_img = 9 * b.cc_in;
                 c.out = Y; c.out_tile_stride = b.cc_out * TILE_F;
                 // blocks of <= 64 output channels: two pixel tiles per workgroup (option "cat_conv_pix2", default 1)
                 // (fp32 only: the bf16x3 form needs 92 KB of LDS at 256 pixels - one workgroup per CU - and measured 2 % slower)
-                const bool pix2 = AR == 0 && ctx->cat_conv_pix2 && b.cout <= 64;
+                const bool pix2 = AR != 2 && ctx->cat_conv_pix2 && b.cout <= 64;
                 const unsigned gx = pix2 ? (unsigned)((n_ptiles + 1) / 2) : (unsigned)n_ptiles;
-                if (pix2) hipLaunchKernelGGL((k_cat_conv<0, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);        // (pix2 implies AR == 0)
-                else hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
+                if (pix2) hipLaunchKernelGGL((k_cat_conv<AR == 2 ? 0 : AR, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);   // (pix2 implies AR != 2)
+                else hipLaunchKernelGGL((k_cat_conv<AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
                 c.w = wm(b.w2); c.bias = b.b2; c.x = Y; c.sc = X; c.cc_in = b.cc_out; c.cc_sc = b.cc_in; c.nk_img = 9 * b.cc_out + b.cc_in;
                 c.out = O;
-                if (pix2) hipLaunchKernelGGL((k_cat_conv<0, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);        // (pix2 implies AR == 0)
-                else hipLaunchKernelGGL((k_cat_conv<AR == 1 ? 0 : AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
+                if (pix2) hipLaunchKernelGGL((k_cat_conv<AR == 2 ? 0 : AR, 2>), dim3(gx, rt, 1), dim3(256), 0, s, c);   // (pix2 implies AR != 2)
+                else hipLaunchKernelGGL((k_cat_conv<AR, 1>), dim3(gx, rt, 1), dim3(256), 0, s, c);
             } else {
             StepLaunch L; StepArgs& a = L.z[0];
             memset(&a, 0, sizeof(a));

@@ -94,7 +94,7 @@ struct nsnp_ctx {
     bool attr_set_b3;
     int hap_b3x;        // bf16x3 LSTM steps of the tile GEMM: 1 = 256 x 256 workgroup tiles where they fill the chip (default), 0 = always 128 x 128
     int cat_conv_pix2;  // k_cat_conv: 1 = blocks of <= 64 output channels on 256-pixel workgroups (default), 0 = 128 pixels everywhere
-    int cat_conv_lds;   // legacy CatModel convolutions: 1 = the LDS-staged kernel k_cat_conv (default; fp32 and bf16x3), 0 = the gathering CONV mode of k_hap_gemm
+    int cat_conv_lds;   // legacy CatModel convolutions: 1 = the LDS-staged kernel k_cat_conv (default; all three arithmetics), 0 = the gathering CONV mode of k_hap_gemm
     int cat_precision;  // legacy CatModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
     int hap_precision;  // HaplotypeModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in)
     int precision;      // PileupModel forward: 0 = exact fp32 MFMA (default), 1 = f16x3 split (opt-in), 2 = bf16x3 (three bf16 terms per operand, six bf16 MFMAs per product)

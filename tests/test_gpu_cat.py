@@ -136,7 +136,7 @@ def test_cat_groups_vs_oracle(gpu_ctx):
         gpu_ctx.cat_groups(short, [torch.from_numpy(a).cuda() for a in t2])
 
 
-@pytest.mark.parametrize("prec", [0, 2], ids=["fp32", "bf16x3"])
+@pytest.mark.parametrize("prec", [0, 1, 2], ids=["fp32", "f16x3", "bf16x3"])
 def test_cat_conv_kernels_agree(prec):
     """the two convolution kernels of the ResCRNN - k_cat_conv (block + halo staged in LDS once; option cat_conv_lds = 1, the default)
     and the gathering implicit GEMM (cat_conv_lds = 0) - sum the same products in a different K order: both inside the tolerance of

@@ -594,7 +594,7 @@ def cat_report(cs, n_sites, seconds, ctim, bc):
         mult = {0: 1, 1: 3, 2: 6}[cs.precision]         # fp16 / bf16 MFMAs executed per fp32 product
         peak = bc.PEAK_F16_MFMA_TFLOPS if mult > 1 else bc.PEAK_F32_MFMA_TFLOPS
         out["roofline"] = bc.roofline_mfma(
-            "k_hap_gemm<LINEAR_RELU, CONV> (implicit-GEMM 3x3 convolution)", bc.cat_conv_exec_flop() * mult * sites_per_pass / 12, conv_ms / conv_n / 12,
+            "k_cat_conv (3x3 convolution + 1x1 shortcut as a GEMM, pixel block + halo staged in LDS once per channel chunk)", bc.cat_conv_exec_flop() * mult * sites_per_pass / 12, conv_ms / conv_n / 12,
             conv_n * 12, alg_flop_per_launch=bc.cat_conv_alg_flop() * sites_per_pass / 12, peak=peak,
             how="one HIP event pair around the 12 convolution launches (+ 4 pooling launches) of a pass of %d sites, divided by 12" % sites_per_pass,
             launches_per_pass=12, sites_per_pass=sites_per_pass)
