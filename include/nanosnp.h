@@ -98,9 +98,8 @@ int nsnp_ctx_reserve(nsnp_ctx* ctx, int64_t max_sites);
  *   "cat_conv_pix2"           1 (default) | 0                  k_cat_conv: the blocks with <= 64 output channels on 256-pixel workgroups (16 / 32 MFMAs
  *                                                              per wave between two barriers instead of 8 / 16); 0 = 128 pixels everywhere.  Same bits.
  *   "cat_conv_lds"            1 (default) | 0                  legacy CatModel 3x3 convolutions: the pixel block + halo of a channel chunk staged in
- *                                                              LDS once and read by all nine taps (fp32 and bf16x3), or the round-3 GEMM that gathers
- *                                                              every tap from the image (the f16x3 mode always does); the two sum the same products in a
- *                                                              different order
+ *                                                              LDS once and read by all nine taps, or the round-3 GEMM that gathers every tap from the
+ *                                                              image; the two sum the same products in a different order
  *   "hap_b3x"                 1 (default) | 0                  bf16x3 HaplotypeModel / CatModel LSTM steps: 256 x 256 workgroup tiles where the launch fills
  *                                                              the chip with them, or always the 128 x 128 tiles of the other modes (bit-identical)
  *   "hap_pass_sites"          128..131072, multiple of 128     sites per internal pass of the HaplotypeModel forward (default 16384;
