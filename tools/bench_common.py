@@ -99,6 +99,16 @@ def cat_conv_alg_flop(rows=40, L=11):
     return total
 
 
+def settle_collector():
+    """Called right BEFORE a timed region starts (outside it): one full pass of the interpreter's cyclic collector over the garbage of
+    the set-up and the warm-up runs.  The streamed pipelines pause the collector while they run (host.gc_paused); what was pending
+    when they were entered runs at the first allocation after they return - measured at 26 + 35 ms right behind a 16-file window-file
+    run, inside `torch.cuda.synchronize`'s Python wrapper, i.e. inside the clock - although none of it is the timed run's garbage.
+    Collections that the timed run's own allocations cause stay inside the region."""
+    import gc
+    gc.collect()
+
+
 def cgroup_cpu_stat():
     """(throttled periods, throttled thread-microseconds, cpu microseconds used) of this cgroup so far, or None outside cgroup v2: the
     difference around a timed region says whether a CPU quota stalled it (a streamed pipeline that keeps 16 host threads spinning is

@@ -88,6 +88,7 @@ def run(args, rank, world, local_rank, emit=None):
     for _ in range(W):
         one_pass()
     torch.cuda.synchronize(dev)
+    bc.settle_collector()
     if world > 1:
         dist.barrier()
     stats = {}
@@ -127,6 +128,7 @@ def run(args, rank, world, local_rank, emit=None):
         model.ctx.set_option("pileup_precision", 2)
         one_pass()
         torch.cuda.synchronize(dev)
+        bc.settle_collector()
         if world > 1:
             dist.barrier()
         st2 = {}

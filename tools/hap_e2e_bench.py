@@ -203,7 +203,7 @@ def _run(args, rank, world, local_rank, emit, created):
         """W warm-up files, then exactly `steps` files between barrier + synchronize on both sides; max over ranks -> (seconds, stats)"""
         for _ in range(W):
             predict_haplotype_bins(ctx, [path], ref, out_path, pass_sites=pass_sites, narrow=narrow)
-        torch.cuda.synchronize(dev); barrier()
+        torch.cuda.synchronize(dev); bc.settle_collector(); barrier()
         st = {}
         t0 = time.perf_counter()
         # the K steps = K files of one run (a directory of bins): ONE pipeline over all of them, as predict_dev.py's loop over

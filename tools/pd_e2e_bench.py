@@ -141,13 +141,26 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
         torch.cuda.synchronize(dev)
         if os.path.exists(out_path):
             os.remove(out_path)                      # (truncating the previous run's half gigabyte of tmpfs pages is not part of a run)
+        bc.settle_collector()
         barrier()
         st = {}
         c0 = bc.cgroup_cpu_stat()
+        prof = None
+        if os.environ.get("NSNP_PD_CPROFILE") == "1":      # development aid: where the main thread spends the run (stderr)
+            import cProfile
+            prof = cProfile.Profile()
         t0 = time.perf_counter()
+        if prof:
+            prof.enable()
         predict_pileup_bins(model, [path] * steps, fai, out_path, pass_sites=pass_sites, narrow=narrow, stats=st)
+        t_ret = time.perf_counter()
         torch.cuda.synchronize(dev); barrier()
         dt = time.perf_counter() - t0
+        if prof:
+            import pstats
+            prof.disable()
+            sys.stderr.write("predict_pileup_bins returned after %.1f ms, timed region %.1f ms\n" % ((t_ret - t0) * 1e3, dt * 1e3))
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)
         if world > 1:
             tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
