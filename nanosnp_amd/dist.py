@@ -125,10 +125,10 @@ def batch_heads(gt_arg, first, n_total, batch_size, device="cpu", group=None):
     heads = np.zeros((nb, 10), np.uint8)
     n = len(gt_arg)
     if n:
-        g = np.arange(first, first + n, dtype=np.int64)
-        ti = g % batch_size
-        own = ti < 10
-        heads[g[own] // batch_size, ti[own]] = np.asarray(gt_arg, np.uint8)[own]
+        kb = np.arange(first // batch_size, (first + n - 1) // batch_size + 1, dtype=np.int64)       # the batches with rows here
+        g = kb[:, None] * batch_size + np.arange(min(10, int(batch_size)), dtype=np.int64)[None, :]  # their first ten rows, global
+        own = (g >= first) & (g < first + n)
+        heads[(g // batch_size)[own], (g % batch_size)[own]] = np.asarray(gt_arg, np.uint8)[g[own] - first]
     t = torch.from_numpy(heads).to(device)
     dist.all_reduce(t, group=group)
     return t.cpu().numpy()

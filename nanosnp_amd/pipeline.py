@@ -765,7 +765,7 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
             sizes = [None] * world
             tdist.all_gather_object(sizes, mine)
             backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
-            allt = gather_text(b"".join(bytes(kept[fi][0]) for fi in range(len(files)) if fi in kept), backend_dev)
+            allt = gather_text(b"".join(kept[fi][0] for fi in range(len(files)) if fi in kept), backend_dev)
             if rank == 0:
                 start = np.concatenate([[0], np.cumsum([sum(l for l, _ in sz) for sz in sizes])])
                 within = [np.concatenate([[0], np.cumsum([l for l, _ in sz])]) for sz in sizes]
