@@ -121,7 +121,7 @@ def batch_heads(gt_arg, first, n_total, batch_size, device="cpu", group=None):
     import numpy as np
     import torch
     import torch.distributed as dist
-    nb = -(-int(n_total) // int(batch_size))
+    nb = max(1, -(-int(n_total) // int(batch_size)))            # (never an empty collective)
     heads = np.zeros((nb, 10), np.uint8)
     n = len(gt_arg)
     if n:
