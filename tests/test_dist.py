@@ -262,7 +262,7 @@ def _text_worker(rank, world, port, sizes, bs, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sizes,bs", [((1204, 0, 803), 1000), ((7, 2, 1300), 64), ((995, 8, 4), 1000), ((40, 3, 25), 7)])
+@pytest.mark.parametrize("sizes,bs", [((1204, 0, 803), 1000), ((7, 2, 1300), 64), ((995, 8, 4), 1000), ((40, 3, 25), 7), ((0, 0, 0), 1000)])
 def test_rows_formatted_per_rank_equal_the_single_process_text(sizes, bs):
     """every rank formats ITS rows (site_offsets + batch_heads: the ten argmax values a batch's rows read from one another), the text
     is gathered: the bytes of one process formatting the whole list - with an empty rank, a rank inside another's first ten rows
