@@ -181,6 +181,14 @@ int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* counts, cons
                                       float* gt_prob, float* zy_prob, uint8_t* gt_arg, uint8_t* zy_arg,
                                       float* gt_max, float* zy_max, void* stream);
 
+/* The call rows a streamed text run keeps on the device - rows: device float64 [N,13] = position, gt argmax, zy argmax, gt max, zy max,
+ * the eight coverage channels x[n,16,{0,1,2,3,9,10,11,12}] of predict.py:63 (all exact in float64) - cut into the typed arrays the row
+ * formatter (nsnp_vcf_format_batches, include/nsnp_host.h) takes.  The outputs may be device pointers or pointers into PINNED HOST memory
+ * (as for nsnp_pileup_forward_windows_calls): the kernel then writes the 41 bytes per site straight into host memory and the run needs no
+ * device-to-host copy at all (nanosnp_amd/pipeline.py call_contigs: its only copy-engine work is the text's way in). */
+int nsnp_pileup_rows_unpack(nsnp_ctx* ctx, const double* rows, int64_t N, int64_t* pos, uint8_t* gt_arg, uint8_t* zy_arg,
+                            float* gt_max, float* zy_max, float* cov8, void* stream);
+
 /* predict.py:54-65: gt_arg/zy_arg = argmax, gt_max/zy_max = max probability,
  * depth = -(sum of the negative entries of x[n,16,{0,1,2,3,9,10,11,12}]).  All device. */
 int nsnp_pileup_postprocess(nsnp_ctx* ctx, const float* gt_prob, const float* zy_prob,

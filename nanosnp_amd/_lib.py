@@ -38,6 +38,7 @@ _SIGNATURES = {
     "nsnp_pileup_forward_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_forward_windows_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7),
+    "nsnp_pileup_rows_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7),
     "nsnp_pileup_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
@@ -255,6 +256,20 @@ class Context:
                                                          _dptr(za), _dptr(gm), _dptr(zm), _stream_ptr(stream)),
               self.handle, "nsnp_pileup_forward_windows_calls")
         return gt, zy, ga, za, gm, zm
+
+    def pileup_rows_unpack(self, rows, outs, stream=None):
+        """rows: device float64 [n,13] (pipeline.stream_contig); outs = (pos int64 [n], gt_arg uint8, zy_arg uint8, gt_max float32, zy_max
+        float32, cov float32 [n,8]): device or PINNED host tensors of at least n elements - written by the kernel itself, no D2H copy; valid
+        on the host once the stream has been synchronised."""
+        import torch
+        n = int(rows.shape[0])
+        if rows.dtype != torch.float64 or rows.dim() != 2 or rows.shape[1] != 13 or not rows.is_contiguous() or not rows.is_cuda:
+            raise NanoSNPError("rows: a contiguous device float64 [n,13] tensor")
+        for t, dt, k in zip(outs, (torch.int64, torch.uint8, torch.uint8, torch.float32, torch.float32, torch.float32), (1, 1, 1, 1, 1, 8)):
+            if t.dtype != dt or t.numel() < n * k or not t.is_contiguous() or not (t.is_cuda or t.is_pinned()):
+                raise NanoSNPError("outs: contiguous int64 / uint8 / uint8 / float32 / float32 / float32 [n,8] tensors, on the device or pinned")
+        check(self.lib.nsnp_pileup_rows_unpack(self.handle, _dptr(rows), n, *[_dptr(t) for t in outs], _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_rows_unpack")
 
     def pileup_postprocess(self, gt, zy, x=None, stream=None):
         import torch

@@ -325,6 +325,32 @@ extern "C" int nsnp_pileup_forward_windows(nsnp_ctx* ctx, const int32_t* counts,
     return pileup_forward_any(ctx, counts, center_idx, N, gt_prob, zy_prob, nullptr, nullptr, (hipStream_t)stream);
 }
 
+// call rows [n][13] float64 (position, gt argmax, zy argmax, gt max, zy max, the eight coverage channels of predict.py:63) -> the typed
+// arrays the row formatter takes; one thread per site, 104 bytes read, 41 written - to the device or straight into pinned host memory
+__global__ void k_rows_unpack(const double* __restrict__ rows, int64_t n, int64_t* __restrict__ pos, uint8_t* __restrict__ ga, uint8_t* __restrict__ za,
+                              float* __restrict__ gm, float* __restrict__ zm, float* __restrict__ cov)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rows + i * 13;
+    pos[i] = (int64_t)r[0];
+    ga[i] = (uint8_t)r[1]; za[i] = (uint8_t)r[2];
+    gm[i] = (float)r[3]; zm[i] = (float)r[4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cov[i * 8 + c] = (float)r[5 + c];
+}
+
+extern "C" int nsnp_pileup_rows_unpack(nsnp_ctx* ctx, const double* rows, int64_t N, int64_t* pos, uint8_t* gt_arg, uint8_t* zy_arg,
+                                       float* gt_max, float* zy_max, float* cov8, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!rows || !pos || !gt_arg || !zy_arg || !gt_max || !zy_max || !cov8))) return NSNP_EINVAL;
+    if (N == 0) return NSNP_OK;
+    hipLaunchKernelGGL(k_rows_unpack, dim3((unsigned)NSNP_CDIV(N, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, rows, N, pos, gt_arg, zy_arg, gt_max,
+                       zy_max, cov8);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
 extern "C" int nsnp_pileup_forward_windows_calls(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, int64_t N,
                                                  float* gt_prob, float* zy_prob, uint8_t* gt_arg, uint8_t* zy_arg,
                                                  float* gt_max, float* zy_max, void* stream)

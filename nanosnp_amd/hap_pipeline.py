@@ -302,7 +302,7 @@ def _stream_segments(ctx, segments, reference, pass_sites, narrow, stats, keep_p
         dsets = [_Set(Pmax, Dp, Dh, elem, dev) for _ in range(n_sets)]
         ctx._hap_dev_sets = dsets
     if getattr(ctx, "_hap_copy_stream", None) is None:
-        ctx._hap_copy_stream = torch.cuda.Stream(dev)
+        ctx._hap_copy_stream = host.copy_stream(dev)
     copy_stream = ctx._hap_copy_stream
     main = torch.cuda.current_stream(dev)
     for s_ in hsets:

@@ -175,7 +175,7 @@ def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, mi
     if not dsets or len(dsets) < min(3, len(ranges)) or dsets[0].bases.device != dev or min(d_.bases.numel() for d_ in dsets) < cap:
         dsets = [_DevSet(cap, dev) for _ in range(min(3, len(ranges)))]
         model._dev_sets = dsets
-        model._copy_stream = torch.cuda.Stream(dev)
+        model._copy_stream = host.copy_stream(dev)
     if len(getattr(model, "_meta_pin", ())) < len(ranges):
         model._meta_pin = torch.zeros((len(ranges), 4), dtype=torch.int64, pin_memory=True)
     meta_pin = model._meta_pin
@@ -335,13 +335,29 @@ def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, mi
 stream_contig.__doc__ = _stream_contig.__doc__
 
 
-def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False, shard_dev=None):
+def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False, shard_dev=None, nthreads=None, ctx=None):
     """call rows [n, 13] float64 (a device tensor, a host tensor or a numpy array) -> (VCF text, rows written) of the reference's
     predict loop over consecutive batches.  shard_dev (the device the process group's collectives take their tensors on): the rows are
     one rank's share of the contig -> (this rank's text, its rows, sites of all ranks); every rank must call.  Device rows are cut into their typed columns ON the device (six small kernels, 41 B per
     site over the bus instead of 104 B and nine numpy passes)."""
     import torch
-    if isinstance(r, torch.Tensor):
+    if isinstance(r, torch.Tensor) and r.is_cuda and ctx is not None:
+        # one kernel cuts the rows into their typed columns and writes them (41 B per site) straight into pinned host memory: no
+        # device-to-host copy, so a text run keeps the copy engines to the text's way in (a D2H copy beside the H2D stream makes the HIP
+        # runtime open further SDMA engines - 6-8 ms each - and was seen to leave later H2D traffic of the process on a slower one)
+        n = int(r.shape[0])
+        hb = getattr(ctx, "_rows_host", None)
+        if hb is None or hb[0].numel() < n:
+            cap = max(n + n // 4, 65536)
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+            hb = ctx._rows_host = (mk(cap, torch.int64), mk(cap, torch.uint8), mk(cap, torch.uint8), mk(cap, torch.float32), mk(cap, torch.float32),
+                                   mk((cap, 8), torch.float32))
+        s_ = torch.cuda.current_stream(r.device)
+        ctx.pileup_rows_unpack(r.contiguous(), hb, stream=s_)
+        s_.synchronize()
+        site_pos, ga, za, gm, zm = (t[:n].numpy() for t in hb[:5])
+        cov = hb[5][:n].numpy()
+    elif isinstance(r, torch.Tensor):
         site_pos = r[:, 0].to(torch.int64).cpu().numpy()
         ga, za = r[:, 1].to(torch.uint8).cpu().numpy(), r[:, 2].to(torch.uint8).cpu().numpy()
         gm, zm = r[:, 3].to(torch.float32).cpu().numpy(), r[:, 4].to(torch.float32).cpu().numpy()
@@ -361,7 +377,8 @@ def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False, shar
         heads = batch_heads(ga, first, n_total, batch_size, shard_dev)
     # the VCF rows depend on the batch boundary: one native call formats every batch (OpenMP over the batches)
     text, n_rows = host.vcf_format_batches(host.ContigTable([contig]), np.zeros(n, np.int32), site_pos, site_ref, ga, za, gm, zm, cov,
-                                           batch_size=batch_size, score_mode=score_mode, as_view=as_view, first=first, n_total=n_total, heads=heads)
+                                           batch_size=batch_size, score_mode=score_mode, as_view=as_view, first=first, n_total=n_total, heads=heads,
+                                           nthreads=nthreads)
     return (text, n_rows) if shard_dev is None else (text, n_rows, n_total)
 
 
@@ -458,7 +475,7 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
         # - about 60 B per row, half of what the calls take - travels to rank 0 in one rooted gather
         backend_dev = torch.device("cuda", ctx.device) if tdist.get_backend() == "nccl" else "cpu"
         t0 = time.perf_counter()
-        text, n_rows, n_sites = _format_rows(rows, contig, chr_seq, batch_size, score_mode, as_view=True, shard_dev=backend_dev)
+        text, n_rows, n_sites = _format_rows(rows, contig, chr_seq, batch_size, score_mode, as_view=True, shard_dev=backend_dev, ctx=ctx)
         t1 = time.perf_counter()
         cnt = torch.tensor([n_rows], dtype=torch.int64, device=backend_dev)
         tdist.all_reduce(cnt)
@@ -478,7 +495,7 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
     if n_sites == 0:
         return b"", 0, 0
     t0 = time.perf_counter()
-    text, n_rows = _format_rows(rows, contig, chr_seq, batch_size, score_mode, as_view=True)
+    text, n_rows = _format_rows(rows, contig, chr_seq, batch_size, score_mode, as_view=True, ctx=ctx)
     if stats is not None:
         stats["vcf_s"] = stats.get("vcf_s", 0.0) + time.perf_counter() - t0
         stats["sites"] = stats.get("sites", 0) + n_sites
@@ -486,36 +503,96 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
     return text, n_sites, n_rows
 
 
+def call_contigs(model, items, out, min_af=0.12, min_coverage=6, batch_size=1000, score_mode=host.SCORE_FLOAT64, chunk_bytes=64 << 20, stats=None):
+    """A run over several contigs.  items: iterable of (name, mpileup text - bytes / mmap / uint8 array -, reference sequence uint8); out:
+    a binary file object the rows are appended to (None on ranks other than 0).  Returns (sites, rows).
+    One process: the rows of contig c are cut, brought to the host (on a stream of their own), formatted and written on a WRITER thread
+    while contig c + 1 streams - formatting + writing is 4-5 ms behind every 6 M-column contig otherwise, a fifth of its time - on a
+    quarter of the host threads (the parser keeps the rest busy; the last contig's rows get them all).  Under a process group the
+    contigs run one after the other through call_contig (its collectives stay on the issuing thread)."""
+    import time
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    import torch.distributed as tdist
+    sharded = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+    st = stats if stats is not None else {}
+    n_sites = n_rows = 0
+    if sharded:
+        for name, text, seq in items:
+            rows_text, ns, nr = call_contig(model, text, name, seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats)
+            if out is not None:
+                out.write(rows_text)
+            n_sites += ns; n_rows += nr
+        return n_sites, n_rows
+    dev = torch.device("cuda", model.ctx.device)
+    side = getattr(model, "_rows_stream", None)
+    if side is None:
+        side = model._rows_stream = torch.cuda.Stream(dev)
+    few = max(1, host.lib().nsnp_host_threads() // 4)
+
+    def finish(rows, name, seq, last):
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):                       # (stream_contig returned behind a device synchronize: the rows are complete)
+            text, nr = _format_rows(rows, name, seq, batch_size, score_mode, as_view=True, nthreads=0 if last else few, ctx=model.ctx)
+        t1 = time.perf_counter()
+        if out is not None:
+            out.write(text)
+        st["vcf_s"] = st.get("vcf_s", 0.0) + t1 - t0
+        st["write_s"] = st.get("write_s", 0.0) + time.perf_counter() - t1
+        return nr
+
+    it = iter(items)
+    nxt = next(it, None)
+    pending = deque()
+    with host.gc_paused(), ThreadPoolExecutor(max_workers=1) as writer:
+        while nxt is not None:
+            name, text, seq = nxt
+            rows = stream_contig(model, text, name, seq, 0, None, chunk_bytes, min_af, min_coverage, stats)
+            nxt = next(it, None)
+            n_sites += int(rows.shape[0])
+            st["sites"] = st.get("sites", 0) + int(rows.shape[0])
+            if rows.shape[0]:
+                pending.append(writer.submit(finish, rows, name, seq, nxt is None))
+            while len(pending) > 1 or (nxt is None and pending):          # at most one contig's rows behind the streaming one
+                t_w = time.perf_counter()
+                n_rows += pending.popleft().result()
+                st["wait_rows_s"] = st.get("wait_rows_s", 0.0) + time.perf_counter() - t_w
+    st["vcf_rows"] = st.get("vcf_rows", 0) + n_rows
+    return n_sites, n_rows
+
+
 def call_variants(model, contigs, fasta_path, fai_text, output_file, **kw):
     """contigs: iterable of (name, path to <name>.mpileup).  Writes pileup.vcf (rank 0 only under torch.distributed: see
-    call_contig); returns total rows."""
+    call_contig); returns total rows.  The contigs are one run (call_contigs): the rows of one are written while the next streams."""
     import torch.distributed as tdist
     root = not (tdist.is_available() and tdist.is_initialized()) or tdist.get_rank() == 0
-    total = 0
+    maps = []
+
+    def items():
+        for name, path in contigs:
+            seq = host.fasta_load_contig(fasta_path, name)
+            g = open(path, "rb")
+            size = os.fstat(g.fileno()).st_size
+            text = mmap.mmap(g.fileno(), 0, access=mmap.ACCESS_READ) if size else b""       # parsed in place, never copied
+            maps.append((g, text if size else None))
+            yield name, text, seq
+
     f = open(output_file, "wb") if root else None
     try:
         if root:
             f.write(host.vcf_header(fai_text).encode())
-        for name, path in contigs:
-            seq = host.fasta_load_contig(fasta_path, name)
-            with open(path, "rb") as g:
-                size = os.fstat(g.fileno()).st_size
-                text = mmap.mmap(g.fileno(), 0, access=mmap.ACCESS_READ) if size else b""    # parsed in place, never copied
-                try:
-                    rows_text, _, rows = call_contig(model, text, name, seq, **kw)
-                finally:
-                    if size:
-                        try:
-                            text.close()
-                        except BufferError:          # (an exception on its way up still holds views of the mapping)
-                            pass
-            if root:
-                f.write(rows_text)
-            total += rows
+        return call_contigs(model, items(), f, **kw)[1]
     finally:
         if f:
             f.close()
-    return total
+        for g, text in maps:
+            if text is not None:
+                try:
+                    text.close()
+                except BufferError:                  # (an exception on its way up still holds views of the mapping)
+                    pass
+            g.close()
 
 
 # ---- .pd.bin site files -> pileup.vcf, streamed (PileupModel/predict.py:37-195 over PredictDataset files) ------------------------------
@@ -613,7 +690,7 @@ def _predict_pileup_bins(model, testing_paths, fai_text, output_file, batch_size
                 hsets = [_SiteSet(P) for _ in range(n_sets)]
                 model._site_host_sets = hsets
                 model._site_dev_sets = [_SiteSet(P, dev) for _ in range(n_sets)]
-                model._site_copy_stream = torch.cuda.Stream(dev)
+                model._site_copy_stream = host.copy_stream(dev)
             dsets, copy_stream = model._site_dev_sets, model._site_copy_stream
             main = torch.cuda.current_stream(dev)
             for s_ in hsets:

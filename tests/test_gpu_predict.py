@@ -163,6 +163,43 @@ def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_wei
     assert call_contig(m, b"", "chrB", seqb, rows_beside=True) == (b"", 0, 0)
 
 
+def test_a_run_over_several_contigs_writes_each_contigs_rows_in_order(tmp_path, pileup_weights):
+    """pipeline.call_variants / call_contigs: the rows of contig c are formatted and written on a writer thread (own stream) while contig
+    c + 1 streams - the file is the header + the rows call_contig gives for every contig on its own, in order; an empty contig and a
+    contig without a site among them; per batch size"""
+    from nanosnp_amd import host
+    from nanosnp_amd.pileup_model import LSTMNetwork
+    from nanosnp_amd.pipeline import call_contig, call_contigs, call_variants
+    m = LSTMNetwork().load_weight_list(pileup_weights)
+    contigs, fasta, fai = [], b"", ""
+    for i, (n, cov) in enumerate(((4000, 30), (0, 30), (2500, 60), (40, 30), (6000, 12))):
+        name = f"ctg{i}"
+        cols = host.synth_columns(20261300 + i, max(n, 1), coverage=cov, het_rate=0.05)
+        text = bytes(cols.mpileup_text_native(name)) if n else b""
+        seq = cols.ref.copy()
+        (tmp_path / f"{name}.mpileup").write_bytes(text)
+        fasta += b">" + name.encode() + b"\n" + b"\n".join(bytes(seq[a:a + 60]) for a in range(0, seq.size, 60)) + b"\n"
+        fai += f"{name}\t{seq.size}\t0\t60\t61\n"
+        contigs.append((name, text, seq))
+    (tmp_path / "ref.fa").write_bytes(fasta)
+    for bs in (1000, 64):
+        want, want_rows, want_sites = host.vcf_header(fai).encode(), 0, 0
+        for name, text, seq in contigs:
+            t, ns, nr = call_contig(m, text, name, seq, batch_size=bs, chunk_bytes=100_000)
+            want += bytes(t); want_rows += nr; want_sites += ns
+        assert want_rows > 300
+        out = tmp_path / f"run{bs}.vcf"
+        rows = call_variants(m, [(name, str(tmp_path / f"{name}.mpileup")) for name, _, _ in contigs], str(tmp_path / "ref.fa"), fai, str(out),
+                             batch_size=bs, chunk_bytes=100_000)
+        assert rows == want_rows and out.read_bytes() == want
+        st = {}
+        with open(tmp_path / "again.vcf", "wb") as f:
+            assert call_contigs(m, contigs, f, batch_size=bs, chunk_bytes=1 << 30, stats=st) == (want_sites, want_rows)
+        assert host.vcf_header(fai).encode() + (tmp_path / "again.vcf").read_bytes() == want and st["vcf_rows"] == want_rows
+    with open(tmp_path / "none.vcf", "wb") as f:
+        assert call_contigs(m, [], f) == (0, 0)
+
+
 def test_streamed_pipeline_edge_inputs(pileup_weights):
     """call_contig on the inputs a real run meets at its edges: no text, one line, fewer columns than a window, a last line without
     its newline, CRLF line ends, a chunk size below one line (every line its own chunk), and the same contig again on the same model

@@ -41,7 +41,7 @@ def run(args, rank, world, local_rank, emit=None):
     from nanosnp_amd import host
     from nanosnp_amd.fixtures import load_pileup_weights
     from nanosnp_amd.pileup_model import LSTMNetwork
-    from nanosnp_amd.pipeline import call_contig
+    from nanosnp_amd.pipeline import call_contig, call_contigs
     from tools import bench_common as bc
     if world > 1 and emit is None:                      # (embedded in the default bench line: the process group exists already)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -74,36 +74,43 @@ def run(args, rank, world, local_rank, emit=None):
     W, K = max(1, args.warmup), max(1, args.steps)
     out_path = os.path.join(tempfile.gettempdir(), f"nsnp_e2e_{rank}.vcf")
 
-    def one_pass(stats=None, cb=chunk):
-        rows_text, n_sites, n_rows = call_contig(model, text, "chr20s", seq, chunk_bytes=cb, stats=stats)
-        t_w = time.perf_counter()
-        if rank == 0:
-            with open(out_path, "wb") as g:
-                g.write(host.vcf_header("chr20s\t%d\t8\t60\t61\n" % n_cols).encode())
-                g.write(rows_text)
-        if stats is not None:
-            stats["write_s"] = stats.get("write_s", 0.0) + time.perf_counter() - t_w
-        return rows_text, n_sites, n_rows
+    header = host.vcf_header("chr20s\t%d\t8\t60\t61\n" % n_cols).encode()
 
-    for _ in range(W):
-        one_pass()
+    def run(k, stats=None):
+        """k contigs = ONE run (pipeline.call_contigs, what call_variants does with a genome's contigs: the rows of contig c are formatted
+        and written on a writer thread while contig c + 1 streams) -> pileup.vcf = header + the k contigs' rows.  (sites, rows) per contig."""
+        if rank == 0 and os.path.exists(out_path):
+            os.remove(out_path)
+        g = open(out_path, "wb") if rank == 0 else None
+        try:
+            if g:
+                g.write(header)
+            ns, nr = call_contigs(model, [("chr20s", text, seq)] * k, g, chunk_bytes=chunk, stats=stats)
+        finally:
+            if g:
+                g.close()
+        return ns // k, nr // k
+
+    def rows_of_first_contig(k):
+        body = open(out_path, "rb").read()[len(header):]
+        assert len(body) % k == 0 and body[:len(body) // k] * k == body, "the contigs of one run gave different rows"
+        return body[:len(body) // k]
+
+    run(max(W, min(3, K)))
     torch.cuda.synchronize(dev)
     bc.settle_collector()
     if world > 1:
         dist.barrier()
     stats = {}
     t0 = time.perf_counter()
-    step_ms = []
     ms0 = torch.cuda.memory_stats(dev)
     cg0 = bc.cgroup_cpu_stat()
-    for _ in range(K):
-        t_s = time.perf_counter()
-        rows_text, n_sites, n_rows = one_pass(stats)
-        step_ms.append(round((time.perf_counter() - t_s) * 1e3, 2))
+    n_sites, n_rows = run(K, stats)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rows_text = rows_of_first_contig(K) if rank == 0 else b""
     cg1 = bc.cgroup_cpu_stat()
     ms1 = torch.cuda.memory_stats(dev)
     allocator = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")}
@@ -126,19 +133,19 @@ def run(args, rank, world, local_rank, emit=None):
     second = None
     if not args.no_second_precision:
         model.ctx.set_option("pileup_precision", 2)
-        one_pass()
+        run(min(2, K))
         torch.cuda.synchronize(dev)
         bc.settle_collector()
         if world > 1:
             dist.barrier()
         st2 = {}
         t0 = time.perf_counter()
-        for _ in range(K):
-            rows2, n_sites2, n_rows2 = one_pass(st2)
+        n_sites2, n_rows2 = run(K, st2)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         dt2 = time.perf_counter() - t0
+        rows2 = rows_of_first_contig(K) if rank == 0 else b""
         if world > 1:
             tm = torch.tensor([dt2], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -177,7 +184,7 @@ def run(args, rank, world, local_rank, emit=None):
         parity = None
         if not args.no_parity_sample and world == 1:
             whole, ns1, nr1 = call_contig(model, text, "chr20s", seq, chunk_bytes=1 << 40)
-            parity = {"ok": bool(whole == rows_text and ns1 == n_sites), "vcf_bytes": len(rows_text), "sites": n_sites,
+            parity = {"ok": bool(bytes(whole) == rows_text and ns1 == n_sites), "vcf_bytes": len(rows_text), "sites": n_sites,
                       "what": "pileup.vcf rows of the chunked, double-buffered run byte-identical to the one-chunk run of the same text "
                               "(nanosnp_amd.pipeline.call_contig; against the reference's own rows: tests/test_gpu_predict.py)"}
         per = {k: stats.get(k, 0.0) / K for k in ("parse_s", "h2d_s", "gpu_s", "vcf_s")}
@@ -208,11 +215,11 @@ def run(args, rank, world, local_rank, emit=None):
                                 "stream runs encode + select of chunk k and the forward of chunk k - 1 (site counts are read one chunk late: no host "
                                 "round trip in the loop); wall < sum when they overlap.  main_thread_s_per_step: where the issuing thread spends the step "
                                 "(issue_s includes wait_counts_s)"},
-            "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "vcf_s", "write_s")},
+            "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "wait_rows_s")},
+            "writer_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("vcf_s", "write_s")},
             "host_cpu_over_the_timed_region": host_cpu, "torch_allocator_over_the_timed_region": allocator,
-            "step_ms_each": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms), "all": step_ms,
-                             "note": "a step well above the median early in a process is the HIP runtime opening a further SDMA copy engine (6-8 ms inside "
-                                     "hipMemcpyAsync on its first use: docs/rounds/r05.md), or the CPU quota"},
+            "step": "one contig of a run of `steps` contigs (pipeline.call_contigs: the rows of contig c are formatted and written on a writer thread "
+                    "while contig c + 1 streams); ms_per_step = the run / steps",
             **({"bf16x3": second} if second else {}),
             **({"per_rank_s_per_step": per_rank} if per_rank else {}),
             "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,

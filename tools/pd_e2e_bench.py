@@ -143,7 +143,7 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
             os.remove(out_path)                      # (truncating the previous run's half gigabyte of tmpfs pages is not part of a run)
         bc.settle_collector()
         barrier()
-        st = {}
+        st = {"trace": []} if os.environ.get("NSNP_PD_TRACE") == "1" else {}
         c0 = bc.cgroup_cpu_stat()
         prof = None
         if os.environ.get("NSNP_PD_CPROFILE") == "1":      # development aid: where the main thread spends the run (stderr)
@@ -156,6 +156,13 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
         t_ret = time.perf_counter()
         torch.cuda.synchronize(dev); barrier()
         dt = time.perf_counter() - t0
+        if "trace" in st:                                    # development aid: where the issuing thread spends a pass (stderr)
+            tr = st.pop("trace")
+            sys.stderr.write("pd trace, ms per pass: wait for staging %.2f, H2D issue %.2f, wait for the set two ahead + submit %.2f, compute issue %.2f (%d passes)\n" % (
+                sum(t[3] - t[2] for t in tr) / len(tr) * 1e3, sum(t[4] - t[3] for t in tr) / len(tr) * 1e3, sum(t[5] - t[4] for t in tr) / len(tr) * 1e3,
+                sum(t[6] - t[5] for t in tr) / len(tr) * 1e3, len(tr)))
+            sys.stderr.write("  per pass compute issue ms: " + " ".join("%.1f" % ((t[6] - t[5]) * 1e3) for t in tr[:40]) + "\n")
+            sys.stderr.write("  per pass H2D issue ms: " + " ".join("%.1f" % ((t[4] - t[3]) * 1e3) for t in tr[:40]) + "\n")
         if prof:
             import pstats
             prof.disable()
