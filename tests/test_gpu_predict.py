@@ -163,6 +163,39 @@ def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_wei
     assert call_contig(m, b"", "chrB", seqb, rows_beside=True) == (b"", 0, 0)
 
 
+def test_rows_unpack_writes_device_and_pinned_outputs(gpu_ctx):
+    """nsnp_pileup_rows_unpack: the float64 call rows of a streamed text run -> the formatter's typed arrays, written by the kernel into
+    device tensors or straight into pinned host memory (no copy); 0 rows, 1 row, a ragged count; wrong shapes / pageable outputs refused"""
+    import torch
+    from nanosnp_amd import _lib
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 70001):
+        rows = np.concatenate([rng.integers(1, 2 ** 40, (n, 1)).astype(np.float64), rng.integers(0, 21, (n, 1)).astype(np.float64),
+                               rng.integers(0, 3, (n, 1)).astype(np.float64), rng.random((n, 2)).astype(np.float32).astype(np.float64),
+                               rng.integers(-3000, 3000, (n, 8)).astype(np.float64)], axis=1)
+        r = torch.from_numpy(rows).cuda()
+        for pinned in (False, True):
+            kw = dict(pin_memory=True) if pinned else dict(device="cuda")
+            outs = (torch.zeros(n + 3, dtype=torch.int64, **kw), torch.zeros(n + 3, dtype=torch.uint8, **kw), torch.zeros(n + 3, dtype=torch.uint8, **kw),
+                    torch.zeros(n + 3, dtype=torch.float32, **kw), torch.zeros(n + 3, dtype=torch.float32, **kw), torch.zeros((n + 3, 8), dtype=torch.float32, **kw))
+            gpu_ctx.pileup_rows_unpack(r, outs)
+            torch.cuda.synchronize()
+            got = [t.cpu().numpy() for t in outs]
+            assert np.array_equal(got[0][:n], rows[:, 0].astype(np.int64)) and np.array_equal(got[1][:n], rows[:, 1].astype(np.uint8))
+            assert np.array_equal(got[2][:n], rows[:, 2].astype(np.uint8)) and np.array_equal(got[3][:n], rows[:, 3].astype(np.float32))
+            assert np.array_equal(got[4][:n], rows[:, 4].astype(np.float32)) and np.array_equal(got[5][:n], rows[:, 5:].astype(np.float32))
+            assert all(not g[n:].any() for g in got)                               # nothing written behind the last row
+    r = torch.zeros((4, 13), dtype=torch.float64, device="cuda")
+    good = (torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4, dtype=torch.uint8, device="cuda"), torch.zeros(4, dtype=torch.uint8, device="cuda"),
+            torch.zeros(4, dtype=torch.float32, device="cuda"), torch.zeros(4, dtype=torch.float32, device="cuda"), torch.zeros((4, 8), dtype=torch.float32, device="cuda"))
+    with pytest.raises(_lib.NanoSNPError):
+        gpu_ctx.pileup_rows_unpack(r[:, :12].contiguous(), good)
+    with pytest.raises(_lib.NanoSNPError):
+        gpu_ctx.pileup_rows_unpack(r, good[:5] + (torch.zeros((4, 8), dtype=torch.float32),))          # pageable host memory
+    with pytest.raises(_lib.NanoSNPError):
+        gpu_ctx.pileup_rows_unpack(r, (good[0][:3],) + good[1:])
+
+
 def test_a_run_over_several_contigs_writes_each_contigs_rows_in_order(tmp_path, pileup_weights):
     """pipeline.call_variants / call_contigs: the rows of contig c are formatted and written on a writer thread (own stream) while contig
     c + 1 streams - the file is the header + the rows call_contig gives for every contig on its own, in order; an empty contig and a
