@@ -2,7 +2,7 @@
 """Stress of the SHARDED runs: `world` processes in one gloo group share GPU 0 (as the 2- / 3-rank tests do) and work through random
 inputs - mpileup text of 150 to 20,000 adversarial columns (so that ranks end up with no site, with fewer than the ten rows the
 gt_output[ti] quirk reads, with batches that straddle two or three ranks), runs of window files of 0 to 3,000 windows - at batch sizes
-1000 / 64 / 7; rank 0 compares what the group wrote (every rank formats its own rows, the text is gathered) with what it computes
+1000 / 64 / 7 -, runs of haplotype site files of 0 to 400 sites; rank 0 compares what the group wrote (every rank formats its own rows, the text is gathered) with what it computes
 alone (the same pipeline outside the group's sharding).  Test infrastructure.
     python tests/manual/sharded_stress.py [ROUNDS] [WORLD]"""
 import os, socket, sys, tempfile
@@ -14,8 +14,9 @@ def worker(rank, world, port, rounds, tmp, q):
     import numpy as np, torch
     import torch.distributed as dist
     import make_golden as mg
-    from nanosnp_amd import host, sitefile
-    from nanosnp_amd.fixtures import load_pileup_weights
+    from nanosnp_amd import _lib, host, sitefile
+    from nanosnp_amd.fixtures import load_pileup_weights, seeded_hap_weights
+    from nanosnp_amd.hap_pipeline import DeviceReference, predict_haplotype_bins
     from nanosnp_amd.pileup_model import LSTMNetwork
     from nanosnp_amd.pipeline import _format_rows, call_contig, predict_pileup_bins, stream_contig
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -24,6 +25,7 @@ def worker(rank, world, port, rounds, tmp, q):
     try:
         m = LSTMNetwork().load_weight_list(load_pileup_weights())
         ctx = m.ctx
+        hctx = _lib.Context(0); hctx.hap_load_weights(seeded_hap_weights(12, H=256))
         fai = "ctgA\t900000\t6\t60\t61\nctgB\t900000\t6\t60\t61\n"
         for r in range(rounds):
             rng = np.random.default_rng(5150 + r + int(os.environ.get("NSNP_STRESS_SEED", "0")))      # the same stream on every rank
@@ -70,10 +72,40 @@ def worker(rank, world, port, rounds, tmp, q):
                 ok2 = open(o, "rb").read() == open(alone, "rb").read() and n_rows == n_alone
             else:
                 ok2 = n_rows == 0 and not os.path.exists(o)
-            bad += not (ok1 and ok2)
+            # ---- haplotype site files -> csv (every rank formats the rows of its shard_range of every file) ----
+            refs = {c: rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), int(rng.integers(300, 5000)), p=[.23, .23, .23, .23, .02, .02, .01, .01, .02]).astype(np.uint8)
+                    for c in ("ctgA", "ctgB")}
+            hfiles = []
+            for fi in range(int(rng.integers(1, 4))):
+                n = int(rng.choice([0, 1, 7, 130, 400]))
+                Dp, Dh = int(rng.choice([1, 30, 90])), int(rng.choice([1, 25, 90]))
+                contig = str(rng.choice(["ctgA", "ctgB", "ctgMissing"], p=[.5, .4, .1]))
+                Lc = len(refs.get(contig, np.zeros(1000)))
+                posn = np.sort(rng.choice(np.arange(-20, Lc + 40), n, replace=False)) if n else np.zeros(0, int)
+                dt = str(rng.choice(["int8", "int32"]))
+                path = os.path.join(tmp, f"r{r}_h{fi}.bin")
+                if rank == 0:
+                    pp = host.synth_hap_planes(100 * r + fi, n, 30, Dp, 33); ph = host.synth_hap_planes(100 * r + fi + 50, n, 30, Dh, 11)
+                    planes = dict(zip(sitefile.HAP_PLANES, (ph[0], ph[3], ph[1], ph[2], pp[0], pp[3], pp[1], pp[2])))
+                    sitefile.write_haplotype_bin(path, [f"{contig}:{p}" for p in posn], [[f"{contig}:{p + 37 * (k - 5)}" for k in range(11)] for p in posn],
+                                                 planes, plane_dtype=dt)
+                hfiles.append(path)
+            dist.barrier()
+            href = DeviceReference(refs, 0)
+            ho = os.path.join(tmp, f"r{r}_hap_{rank}.csv")
+            hps = int(rng.choice([50, 128, 16384]))
+            h_rows = predict_haplotype_bins(hctx, hfiles, href, ho, pass_sites=hps)
+            if rank == 0:
+                h_alone = os.path.join(tmp, f"r{r}_hap_alone.csv")
+                n_h = predict_haplotype_bins(hctx, hfiles, DeviceReference(refs, 0), h_alone, distributed=False)
+                ok3 = open(ho, "rb").read() == open(h_alone, "rb").read() and h_rows == n_h
+            else:
+                ok3 = h_rows == 0
+            bad += not (ok1 and ok2 and ok3)
             if rank == 0:
                 print(f"round {r}: batch size {bs}; text of {len(pos)} columns, {got[1]} sites in chunks of {cb}: {'identical' if ok1 else 'DIFFERS'}; "
-                      f"{len(files)} window files in passes of {ps}, {n_rows} rows: {'identical' if ok2 else 'DIFFER'}", flush=True)
+                      f"{len(files)} window files in passes of {ps}, {n_rows} rows: {'identical' if ok2 else 'DIFFER'}; "
+                      f"{len(hfiles)} haplotype files in passes of {hps}, {h_rows} rows: {'identical' if ok3 else 'DIFFER'}", flush=True)
             dist.barrier()
     finally:
         q.put((rank, bad))
