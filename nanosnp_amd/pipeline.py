@@ -528,13 +528,16 @@ def call_contigs(model, items, out, min_af=0.12, min_coverage=6, batch_size=1000
     dev = torch.device("cuda", model.ctx.device)
     side = getattr(model, "_rows_stream", None)
     if side is None:
+        from . import _lib
         side = model._rows_stream = torch.cuda.Stream(dev)
+        model._rows_ctx = _lib.Context(model.ctx.device)     # the writer thread's OWN context (a context serves one host thread at a time)
+    wctx = model._rows_ctx
     few = max(1, host.lib().nsnp_host_threads() // 4)
 
     def finish(rows, name, seq, last):
         t0 = time.perf_counter()
         with torch.cuda.stream(side):                       # (stream_contig returned behind a device synchronize: the rows are complete)
-            text, nr = _format_rows(rows, name, seq, batch_size, score_mode, as_view=True, nthreads=0 if last else few, ctx=model.ctx)
+            text, nr = _format_rows(rows, name, seq, batch_size, score_mode, as_view=True, nthreads=0 if last else few, ctx=wctx)
         t1 = time.perf_counter()
         if out is not None:
             out.write(text)
