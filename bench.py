@@ -18,7 +18,10 @@ timed passes and outside the clock, the outputs the last fp32 pass left behind a
 `python -m torch.distributed.run`, before anything touches the GPU), relays rank 0's JSON line and exits
 with the children's status.  One process per GPU, every rank owns its own pool (weak scaling, no
 data-path collective); the only exchange is the rooted gather of the compact per-site calls at the end,
-inside the timed region (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+inside the timed region (RCCL over xGMI).  Rank 0 prints ONE JSON line, the LAST line of stdout: a flat object under 4 KB
+(tools/bench_common.py::compact_line - the contract's keys, `roofline`, `cpu_baseline`, numbers per sub-workload; exactly one
+"metric" key, no prose).  Everything else the run knows - per-kernel tables, notes, the full result object of every sub-workload -
+is written to bench_details.json beside this file (path on stderr).
 
 The headline `value` is the exact-fp32 path (the library default, the reference's arithmetic); the bf16x3
 mode (three bf16 terms per operand: the full fp32 significand on the bf16 matrix pipe) and the opt-in f16x3
@@ -119,7 +122,7 @@ def launch_ranks(args):
     return 0
 
 
-from tools.bench_common import usable_cores  # noqa: E402
+from tools.bench_common import emit_line, usable_cores  # noqa: E402
 
 
 def selftest_launcher(args, rank, world):
@@ -404,9 +407,9 @@ def main():
         assert merged is not None and merged.shape[0] == n_done * world
         if sub:
             out["workloads"] = sub
-            out["workloads_note"] = ("short runs of the other BASELINE configurations in this process after the headline's timed region, on reduced resident "
-                                     "pools (tools/workloads.py); each is the full line of `bench.py --workload NAME`; `value` above is configs[1] alone")
-        print(json.dumps(out))
+            out["workloads_note"] = ("short runs of the other BASELINE configurations in this process after the headline's timed region "
+                                     "(tools/workloads.py); each is the full result object of `bench.py --workload NAME`; `value` above is configs[1] alone")
+        emit_line(out)                                # the driver's line (flat, < 4 KB) last on stdout; the whole object -> bench_details.json
         for who in (out, out.get("bf16x3") or {}):
             if who.get("parity_sample") is not None and not who["parity_sample"]["ok"]:
                 print("bench.py: parity_sample FAILED: " + json.dumps(who["parity_sample"]), file=sys.stderr)

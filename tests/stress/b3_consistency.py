@@ -3,7 +3,7 @@
 GEMM's 128 x 128 / 256 x 256 LSTM tiles) - every site's result must not depend on the choice.  PileupModel: forward of N sites against the
 same sites in ragged sub-batches; HaplotypeModel: pass sizes that fall on either side of the 256 x 256 threshold, hap_b3x on / off."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

@@ -2,7 +2,7 @@
 """Stress: a column's counts / depth / flags must not depend on which launch, wave or staging sub-batch it falls into - the encode of a
 block of columns against the same columns encoded in ragged pieces (cuts at arbitrary columns), at 5x / 30x / 60x / 200x coverage."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib, host

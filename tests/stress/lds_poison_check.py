@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """Stress: does any kernel read LDS it never wrote?  Every forward / encode runs once on a fresh chip state, then again after every CU's
 LDS was filled with NaN patterns (fp32 quiet NaN, which is also a pair of bf16 NaNs; then 0xffffffff) - the results must be the same bits.
-(The bf16x3 layer-0 bug of round 4 - stale split planes - is of this class.)  build: hipcc -shared tools/probes/lds_poison.hip ->
-build_tmp/liblds_poison.so"""
+(The bf16x3 layer-0 bug of round 4 - stale split planes - is of this class.)  build: __graft_entry__.build() (hipcc -shared tests/helpers_native/lds_poison.hip ->
+tests/helpers_native/liblds_poison.so)"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib, host
 from nanosnp_amd.fixtures import load_pileup_weights, seeded_hap_weights, seeded_cat_weights, synth_cat_groups
-poison = C.CDLL(os.path.join(ROOT, "build_tmp", "liblds_poison.so")).lds_poison
+poison = C.CDLL(os.path.join(ROOT, "tests", "helpers_native", "liblds_poison.so")).lds_poison
 poison.argtypes = [C.c_void_p, C.c_uint]
 rng = np.random.default_rng(11)
 ctx = _lib.Context(0)

@@ -56,3 +56,40 @@ def test_committed_traffic_lookup(tmp_path, monkeypatch):
 def test_usable_cores_is_positive_and_bounded():
     n = bc.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_the_drivers_line_is_flat_and_small():
+    """the 58 KB default line (six nested full lines, each with its own "metric") could not be read back by the driver.
+    The same result object through compact_line: one flat object under 4 KB, one "metric" key, no prose, the contract's keys all there."""
+    full = json.load(open(os.path.join(bc.ROOT, "profiles", "r05_default_line.json")))
+    assert len(json.dumps(full)) > 50_000
+    line = bc.compact_line(full, "/somewhere/bench_details.json")
+    s = bc.dump_compact(line)
+    assert len(s) < bc.COMPACT_LINE_MAX_BYTES and s.count('"metric"') == 1 and "\n" not in s
+    back = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "timed_region_s", "parity_ok", "workloads"):
+        assert k in back, k
+    assert back["dtype"] == "f32" and back["config"]["workload"].startswith("BASELINE configs[1]") and back["details"] == "bench_details.json"
+    assert abs(back["value"] - full["value"]) < 1 and abs(back["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert set(back["roofline"]) == {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_timed", "chip_frac"}
+    assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "host_cpu"} and len(back["cpu_baseline"]["sample"]) <= 100
+    assert set(back["workloads"]) == set(full["workloads"])
+    for name, w in back["workloads"].items():
+        assert w["parity_ok"] is True and w["cpu"] > 0 and all(not isinstance(v, (dict, list)) for v in w.values()), name
+    # a sub-workload that raised is a short error entry with parity_ok false, not a traceback
+    full["workloads"]["e2e"] = {"error": "RuntimeError: " + "x" * 500}
+    e = bc.compact_line(full)["workloads"]["e2e"]
+    assert e["parity_ok"] is False and len(e["error"]) <= 80
+    # a line that would not fit is refused rather than printed
+    full["config"]["workload"] = "w" * 100
+    big = bc.compact_line(full)
+    big["workloads"] = {f"w{i}": big["workloads"]["haplotype"] for i in range(40)}
+    with pytest.raises(RuntimeError):
+        bc.dump_compact(big)
+
+
+def test_write_details_round_trip(tmp_path, monkeypatch):
+    monkeypatch.setattr(bc, "ROOT", str(tmp_path))
+    p = bc.write_details({"metric": "m", "value": 1.5, "nested": {"metric": "inner"}})
+    assert p == str(tmp_path / "bench_details.json") and json.load(open(p))["nested"]["metric"] == "inner"

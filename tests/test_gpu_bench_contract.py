@@ -27,12 +27,57 @@ def _fractions_are_physical(d):
     return n
 
 
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+             "config", "roofline", "cpu_baseline", "timed_region_s", "parity_ok")
+
+
+def _parse(stdout):
+    """What the driver does with a run: the LAST stdout line is one flat JSON object under 4 KB with exactly one "metric" key (round 5's 58 KB
+    line with six nested full lines could not be read back: BENCH_r05.json parsed null).  -> the run's full result object from the details
+    file the line names, with the line itself under "_line"; every number of the line must be the details' number."""
+    last = stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) < 4096 and last.count('"metric"') == 1, (len(last), last.count('"metric"'))
+    assert [l for l in stdout.splitlines() if l.startswith("{")] == [last]
+    for k in LINE_KEYS:
+        assert k in line, k
+    assert all(not isinstance(v, str) or len(v) <= 160 for k, x in line.items() if k != "metric" for v in _leaves(x)), "prose in the driver's line"
+    d = json.load(open(os.path.join(ROOT, line["details"])))
+    assert abs(line["value"] - d["value"]) <= 1e-6 * d["value"] and abs(line["ms_per_step"] - d["ms_per_step"]) <= 1e-6 * d["ms_per_step"]
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "data"):
+        assert line[k] == d[k], k
+    assert line["config"]["workload"] == d["config"]["workload"][:160]
+    if d.get("roofline"):
+        for k in ("bound", "kernel", "peak", "unit"):
+            assert line["roofline"][k] == d["roofline"][k]
+        for k in ("achieved", "frac", "avg_launch_ms"):
+            assert abs(line["roofline"][k] - d["roofline"][k]) <= 1e-5 * abs(d["roofline"][k])
+    else:
+        assert line["roofline"] is None
+    if d.get("cpu_baseline"):
+        assert abs(line["cpu_baseline"]["value"] - d["cpu_baseline"]["value"]) <= 1e-5 * d["cpu_baseline"]["value"]
+        assert line["cpu_baseline"]["cores"] == d["cpu_baseline"]["cores"] and line["cpu_baseline"]["kind"] == d["cpu_baseline"]["kind"] and line["cpu_baseline"]["sample"]
+    if isinstance(d.get("parity_sample"), dict):
+        assert line["parity_ok"] is d["parity_sample"]["ok"]
+    d["_line"] = line
+    return d
+
+
+def _leaves(v):
+    if isinstance(v, dict):
+        for x in v.values():
+            yield from _leaves(x)
+    elif isinstance(v, list):
+        for x in v:
+            yield from _leaves(x)
+    else:
+        yield v
+
+
 def _run(*argv, env=None, timeout=900):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0])
+    return _parse(out.stdout)
 
 
 SMALL_POOLS = dict(NSNP_TWO_STAGE_N2="40960", NSNP_TWO_STAGE_N5="4096", NSNP_HAP_N="4096", NSNP_CAT_N="2048", NSNP_DEEP_WINDOWS="40960",
@@ -45,6 +90,13 @@ def test_bench_line_schema():
     # baseline, and - where a device kernel dominates - a roofline fraction
     w = d["workloads"]
     assert set(w) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e", "pd_e2e"}
+    lw = d["_line"]["workloads"]                                  # the driver's line: numbers only per sub-workload
+    assert set(lw) == set(w)
+    for name, c in lw.items():
+        assert c["parity_ok"] is True and c["value"] > 0 and c["ms_per_step"] > 0 and c["cpu"] > 0 and "error" not in c, (name, c)
+        assert abs(c["value"] - w[name]["value"]) <= 1e-5 * c["value"] and "metric" not in c
+        assert (0 < c["frac"] <= 1) if name in ("haplotype", "two_stage", "deep60") else c["frac"] is None
+    assert d["_line"]["dtype"] == "f32" and d["_line"]["bf16x3"]["parity_ok"] is True and d["_line"]["roofline_encode"]["bound"] == "hbm"
     for name, line in w.items():
         assert "error" not in line, (name, line.get("error"))
         sm = line["summary"]
@@ -199,9 +251,7 @@ def test_two_ranks_through_the_launcher_on_one_gpu(workload):
                           "--workloads", "none"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _parse(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["value"] > 1e5
     if workload == "haplotype":
         assert d["scaling"] == "weak" and d["config"]["hap_sites_resident_per_gpu"] == 3000 and "TEST_CONFIGURATION" in d["config"]
@@ -222,9 +272,7 @@ def test_two_ranks_pd_e2e_on_one_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo", "--share-gpu",
                           "--no-cpu-baseline", "--workload", "pd-e2e"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _parse(out.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["sites"] == 100000 and d["parity_sample"]["ok"]
     assert all(v["vcf_equals_the_int16_run"] for v in d["second_values"].values())
 
@@ -234,7 +282,7 @@ def test_bench_with_the_library_gather_entry():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "65536", "--gather", "rccl-abi",
                           "--no-cpu-baseline", "--no-second-precision", "--workloads", "none"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    d = _parse(out.stdout)
     assert d["config"]["gather"] == "rccl-abi" and d["value"] > 1e6
 
 
@@ -248,9 +296,7 @@ def test_two_ranks_with_the_other_configurations_in_the_same_line():
                           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--hap-batch", "2048",
                           "--workloads", "two_stage,hap_e2e,haplotype,pd_e2e"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _parse(out.stdout)
     assert d["n_gpus"] == 2 and set(d["workloads"]) == {"two_stage", "hap_e2e", "haplotype", "pd_e2e"}
     for name, line in d["workloads"].items():
         assert "error" not in line and line["n_gpus"] == 2 and line["config"]["world_size_observed"] == 2 and line["summary"]["parity_ok"] is True, name

@@ -1,6 +1,6 @@
-"""Results must not depend on how the work is cut into launches (workgroup shapes are chosen by launch size): the stress tools of
-tools/ as tests.  b3_consistency found the round-4 bug of the bf16x3 layer-0 kernels (stale split planes of a site group below its
-workgroup's level); lds_poison_check runs when its helper library has been built (hipcc -shared tools/probes/lds_poison.hip)."""
+"""Results must not depend on how the work is cut into launches (workgroup shapes are chosen by launch size): the stress scripts of
+tests/stress/ as tests.  b3_consistency found the round-4 bug of the bf16x3 layer-0 kernels (stale split planes of a site group below its
+workgroup's level); lds_poison_check runs when its helper library has been built (tests/helpers_native/lds_poison.hip, by build())."""
 import os
 import subprocess
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(script, *args, timeout=600):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stress", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     return p.stdout
 
@@ -28,7 +28,7 @@ def test_encode_results_do_not_depend_on_the_launch_partition():
 
 
 def test_no_kernel_reads_lds_or_workspace_it_never_wrote():
-    if not os.path.exists(os.path.join(ROOT, "build_tmp", "liblds_poison.so")):
-        pytest.skip("build_tmp/liblds_poison.so not built")
+    if not os.path.exists(os.path.join(ROOT, "tests", "helpers_native", "liblds_poison.so")):
+        pytest.skip("tests/helpers_native/liblds_poison.so not built")
     out = _run("lds_poison_check.py")
     assert out.count("identical") == 2, out

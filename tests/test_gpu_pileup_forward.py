@@ -522,7 +522,7 @@ def test_bf16x3_mode_carries_the_full_fp32_operand_width(pileup_weights):
 def test_bf16x3_split_levels_of_different_site_groups_in_one_workgroup(ckpt):
     """The bf16x3 layer-0 kernels run a step at the split level of the LARGEST count any site group of the WORKGROUP staged for it
     (1 term up to 256, 2 up to 65536, 3 beyond); a group below that level multiplies its own planes 1 and 2 as well, which must then be
-    zeros.  (Round 4, found by tools/b3_consistency.py: they held whatever an earlier step had left there - a workgroup with one
+    zeros.  (Round 4, found by tests/stress/b3_consistency.py: they held whatever an earlier step had left there - a workgroup with one
     large-count site gave wrong probabilities, by up to 0.08, for the sites of its OTHER group.  Coverage beyond 256x only.)
     8192 sites = the skewed two-group kernel, with large counts in the first group of some workgroups, the second group of others,
     both, at single steps and at all steps; every site must equal, bit for bit, its result in a 16-site batch of its own group (one

@@ -239,3 +239,136 @@ def reference_cpu(section):
             except Exception:
                 pass
     return None, None
+
+
+# ---- the line the driver reads ------------------------------------------------------------------------------------------
+# bench.py's LAST stdout line is one flat JSON object of a few KB: the contract's keys, one `roofline`, one `cpu_baseline`, numbers
+# per sub-workload - no nested "metric" key, no prose.  Everything else a run knows (per-kernel tables, notes, every sub-workload's
+# own full line) goes to bench_details.json beside bench.py.  Round 5's single 58 KB line with six nested full lines could not be
+# read back by the driver (BENCH_r05.json: parsed null).
+COMPACT_LINE_MAX_BYTES = 4096
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_timed")
+
+
+def _num(v, digits=6):
+    """numbers of the compact line: 6 significant digits are plenty and keep the line short"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    out = {k: _num(r.get(k)) for k in _ROOF_KEYS}
+    if isinstance(r.get("chip"), dict):
+        out["chip_frac"] = _num(r["chip"].get("frac"))
+    return out
+
+
+def _parity_ok(line):
+    p = line.get("parity_sample") if isinstance(line, dict) else None
+    return p.get("ok") if isinstance(p, dict) else None
+
+
+def compact_workload(line):
+    """one sub-workload of the default run -> numbers only"""
+    if not isinstance(line, dict) or "error" in line:
+        return {"value": None, "ms_per_step": None, "frac": None, "parity_ok": False, "cpu": None,
+                "error": str((line or {}).get("error", "no line"))[:80]}
+    roof = line.get("roofline") or {}
+    cb = line.get("cpu_baseline") or {}
+    out = {"value": _num(line.get("value")), "ms_per_step": _num(line.get("ms_per_step")), "frac": _num(roof.get("frac")),
+           "bound": roof.get("bound"), "parity_ok": _parity_ok(line), "cpu": _num(cb.get("value")),
+           "wall_s": line.get("wall_s_of_this_sub_run")}
+    if line.get("value") and line.get("ms_per_step"):
+        out["sites_per_step"] = int(round(line["value"] * line["ms_per_step"] * 1e-3))      # units one step processed (value x step time)
+    if line.get("bound_by"):
+        out["bound_by"] = str(line["bound_by"]).split(":")[0].split(" (")[0][:16]
+    if line.get("fraction_of_hbm_resident_rate") is not None:
+        out["frac_of_resident_rate"] = _num(line["fraction_of_hbm_resident_rate"])
+    b = line.get("bf16x3")
+    if isinstance(b, dict) and b.get("value"):
+        out["bf16x3"] = _num(b["value"])
+    return out
+
+
+def compact_line(full, details_path=None):
+    """The driver's line from a run's full result object (`full` keeps every key it had; this only selects)."""
+    cfg = full.get("config") or {}
+    cb = full.get("cpu_baseline")
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _num(out["value"], 9), _num(out["ms_per_step"], 9)
+    out["dtype"] = str(out["dtype"]).split(" ")[0]
+    out["config"] = {k: (str(v)[:160] if isinstance(v, str) else v) for k, v in cfg.items()
+                     if k in ("workload", "batch", "windows_resident_per_gpu", "batches_per_step", "sites_per_step", "streams", "coverage", "precision",
+                              "parallelism", "world_size_observed", "gather", "TEST_CONFIGURATION")}
+    out["roofline"] = compact_roofline(full.get("roofline"))
+    for k in sorted(full):
+        if k.startswith("roofline_") and isinstance(full[k], dict):
+            out[k] = compact_roofline(full[k])
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": str(cb.get("sample_short") or cb.get("sample") or "")[:100], "host_cpu": str(cb.get("host_cpu", ""))[:48]}
+    else:
+        out["cpu_baseline"] = None
+    out["timed_region_s"] = _num(full.get("timed_region_s"))
+    out["parity_ok"] = _parity_ok(full)
+    p = full.get("parity_sample")
+    if isinstance(p, dict):
+        out["parity"] = {"sites": p.get("sites"), "max_abs_dp": _num(p.get("max_abs_dp")), "tolerance": p.get("tolerance"),
+                         "encode_bit_exact": p.get("encode_bit_exact")}
+    if isinstance(full.get("repeats"), dict):
+        out["repeats"] = full["repeats"].get("values")
+    if isinstance(full.get("shader_clock_mhz"), dict):
+        out["shader_clock_mhz"] = _num(full["shader_clock_mhz"].get("value"))
+    for label in ("bf16x3", "f16x3"):
+        s = full.get(label)
+        if isinstance(s, dict):
+            out[label] = {"value": _num(s.get("value")), "ms_per_step": _num(s.get("ms_per_step")),
+                          "frac": _num((s.get("roofline") or {}).get("frac")), "max_abs_dp_vs_fp32": _num(s.get("max_abs_dp_vs_fp32_on_the_pool")),
+                          "parity_ok": _parity_ok(s)}
+    if full.get("workloads"):
+        out["workloads"] = {name: compact_workload(line) for name, line in full["workloads"].items()}
+    if details_path:
+        out["details"] = os.path.basename(details_path)
+    return out
+
+
+def dump_compact(line):
+    """-> the text of the line; refuses to print something the driver could not read back"""
+    s = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    if len(s) >= COMPACT_LINE_MAX_BYTES or s.count('"metric"') != 1 or "\n" in s:
+        raise RuntimeError(f"bench line is {len(s)} bytes with {s.count(chr(34) + 'metric' + chr(34))} metric keys: the driver's reader needs one flat line under "
+                           f"{COMPACT_LINE_MAX_BYTES} bytes")
+    return s
+
+
+def write_details(full, name="bench_details.json"):
+    """the run's full result object -> bench_details.json beside bench.py (falls back to the working directory, then to the
+    temporary directory); returns the path written, or None"""
+    import tempfile
+    for d in (ROOT, os.getcwd(), tempfile.gettempdir()):
+        p = os.path.join(d, name)
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+                f.write("\n")
+            return p
+        except OSError:
+            continue
+    return None
+
+
+def emit_line(full, tag=None, file=None):
+    """print the driver's line for a run's full result object and keep the object itself in bench_details[_<tag>].json"""
+    import sys
+    path = write_details(full, "bench_details.json" if not tag else f"bench_details_{tag}.json")
+    if path:
+        print(f"bench.py: full result object -> {path}", file=sys.stderr, flush=True)
+    print(dump_compact(compact_line(full, path)), file=file or sys.stdout, flush=True)

@@ -230,7 +230,7 @@ def run(args, rank, world, local_rank, emit=None):
         if emit is not None:
             emit(out)
         else:
-            print(json.dumps(out))
+            bc.emit_line(out, "e2e")
         if (parity is not None and not parity["ok"]) or (second and not second["parity_sample"]["ok"]):
             print("bench.py: parity_sample FAILED: " + json.dumps([parity, second and second["parity_sample"]]), file=sys.stderr)
             exit_code = 1

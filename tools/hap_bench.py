@@ -571,7 +571,7 @@ def run(args, rank, world, local_rank, deep60=False, emit=None):
         if emit is not None:
             emit(out)
         else:
-            print(json.dumps(out))
+            bc.emit_line(out, "deep60" if deep60 else "haplotype")
         if out["parity_sample"] is not None and not out["parity_sample"]["ok"]:
             print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
             exit_code = 1

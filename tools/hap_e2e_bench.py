@@ -358,7 +358,7 @@ def _run(args, rank, world, local_rank, emit, created):
         if emit is not None:
             emit(out)
         else:
-            print(json.dumps(out))
+            bc.emit_line(out, "hap_e2e")
         if parity is not None and not parity["ok"]:
             print("bench.py: parity_sample FAILED: " + json.dumps(parity), file=sys.stderr)
             exit_code = 1

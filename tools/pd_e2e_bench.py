@@ -291,7 +291,7 @@ def _measure(args, rank, world, local_rank, emit, created, model, ctx, dev, cdev
     if emit is not None:
         emit(out)
     else:
-        print(json.dumps(out))
+        bc.emit_line(out, "pd_e2e")
     if parity is not None and not parity["ok"]:
         print("bench.py: parity_sample FAILED: " + json.dumps(parity), file=sys.stderr)
         return 1

@@ -200,7 +200,7 @@ def run(args, rank, world, local_rank, emit=None):
         if emit is not None:
             emit(out)
         else:
-            print(json.dumps(out))
+            bc.emit_line(out, "two_stage")
         if (out["parity_sample"] is not None and not out["parity_sample"]["ok"]) or (second and second.get("parity_sample") and not second["parity_sample"]["ok"]):
             print("bench.py: parity_sample FAILED: " + json.dumps(out["parity_sample"]), file=sys.stderr)
             exit_code = 1
