@@ -11,6 +11,7 @@
  *   nsnp_pileup_encode_columns   TensorMaker::make_tensor       dna_sv_tensor/src/make_candidate_snp_tensor/tensor_maker.cpp:61-249
  *                                + candidate test               dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:194-201
  *   nsnp_pileup_select_sites     window / pending-queue rule    dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:174-217
+ *   nsnp_mpileup_tokenise        LineReader + split_line + atoll dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:162-172
  *   nsnp_pileup_gather_windows   33-column window emission      dna_sv_tensor/src/make_candidate_snp_tensor/main.cpp:233-244
  *   nsnp_pileup_postprocess      argmax / max / depth           PileupModel/predict.py:52-65
  *   nsnp_hap_features            get_frequency_feature + ref row HaplotypeModel/dataset_dev.py:55-87,337-349
@@ -218,6 +219,27 @@ int nsnp_pileup_encode_columns2(nsnp_ctx* ctx, const uint8_t* bases, const int64
  * (may exceed cap: then only the first cap were written). */
 int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M,
                              int64_t* center_idx, int64_t cap, int64_t* n_sites, void* stream);
+
+/* The reader in front of the column encode, on the device: samtools-mpileup text resident in HBM (whole lines; the end of the
+ * text ends its last line) -> per line the position, the reference byte and the column-5 string, in line order:
+ *   LineReader::getline  dna_sv_tensor/src/common/line_reader.cpp:95-127  ('\n' or "\r\n" ends a line)
+ *   split_line           dna_sv_tensor/src/common/cpp_aux.cpp:43-59       (tokens are maximal runs of non-tab bytes)
+ *   create_pileup_tensor make_candidate_snp_tensor/main.cpp:162-172       (ref_off = atoll(token 1), pileup_bases = token 4)
+ * text: device uint8 [text_len] (any alignment).  chr_seq: device uint8 [chr_len] as stored in the FASTA, with ref: device uint8
+ * [cap_cols] receiving chr_seq[pos - 1] of every line (both may be NULL: no reference bytes).  pos: device int64 [cap_cols];
+ * col_off: device int64 [cap_cols + 1]; bases: device uint8 [cap_bytes] - exactly the arrays nsnp_pileup_encode_columns takes.
+ * meta: int64 [4] in any memory the device can write (device or pinned host memory): { lines, column-5 bytes, status, 0 }, valid when
+ * the stream has passed this call.  status bits: NSNP_TOK_EFORMAT a line with fewer than five fields, NSNP_TOK_BLANK an empty or
+ * CR-only line (the reference aborts on both: cpp_aux.cpp:10-21 via main.cpp:165), NSNP_TOK_EPOS a position outside [1, chr_len]
+ * (main.cpp:170 asserts), NSNP_TOK_ERANGE lines > cap_cols or bytes > cap_bytes (nothing is written out of bounds; meta holds what is
+ * needed).  With any status bit set the outputs must not be used.  One call at a time per context (scratch lives in the context). */
+#define NSNP_TOK_EFORMAT 1
+#define NSNP_TOK_BLANK   2
+#define NSNP_TOK_EPOS    4
+#define NSNP_TOK_ERANGE  8
+int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t text_len, const uint8_t* chr_seq, int64_t chr_len,
+                          int64_t cap_cols, int64_t cap_bytes, int64_t* pos, int64_t* col_off, uint8_t* bases, uint8_t* ref,
+                          int64_t* meta, void* stream);
 
 /* x[n][t][c] = counts[center_idx[n]-16+t][c]; x: device int32 [N,33,18]. */
 int nsnp_pileup_gather_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,

@@ -52,6 +52,7 @@ _SIGNATURES = {
                                            C.c_int64, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_gather_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p]),
+    "nsnp_mpileup_tokenise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 6),
     "nsnp_hap_features": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nsnp_hap_features_i8": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nsnp_hap_arrange_reads": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
@@ -71,6 +72,18 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+
+
+def tokenise_status_check(status, what="mpileup text"):
+    """status word of nsnp_mpileup_tokenise -> ValueError for text the reference's reader aborts on"""
+    if status & 1:
+        raise ValueError(f"{what}: a line with fewer than five tab-separated fields")
+    if status & 2:
+        raise ValueError(f"{what}: an empty line")
+    if status & 4:
+        raise ValueError(f"{what}: position outside the reference sequence")
+    if status & 8:
+        raise NanoSNPError(f"{what}: tokeniser output buffers too small")
 
 _lib = None
 
@@ -326,6 +339,39 @@ class Context:
                                                 _dptr(n_sites), _stream_ptr(stream)),
               self.handle, "nsnp_pileup_select_sites")
         return center, n_sites
+
+    TOK_EFORMAT, TOK_BLANK, TOK_EPOS, TOK_ERANGE = 1, 2, 4, 8
+
+    def mpileup_tokenise_into(self, text, chr_seq, pos, col_off, bases, ref, meta, stream=None):
+        """nsnp_mpileup_tokenise into the caller's buffers, asynchronously: text uint8 [T] on the device; chr_seq uint8 on the device (or
+        None, with ref None); pos int64 [cap], col_off int64 [cap + 1], bases uint8 [cap_bytes], ref uint8 [cap] on the device; meta int64 [4]
+        on the device or in pinned host memory ({lines, bytes, status, 0} once the stream has passed the call)."""
+        check(self.lib.nsnp_mpileup_tokenise(self.handle, _dptr(text), int(text.numel()), _dptr(chr_seq) if chr_seq is not None else None,
+                                             int(chr_seq.numel()) if chr_seq is not None else 0, int(pos.numel()), int(bases.numel()),
+                                             _dptr(pos), _dptr(col_off), _dptr(bases), _dptr(ref) if ref is not None else None,
+                                             meta.data_ptr(), _stream_ptr(stream)),
+              self.handle, "nsnp_mpileup_tokenise")
+
+    def mpileup_tokenise(self, text, chr_seq=None, stream=None):
+        """mpileup text (uint8 device tensor) -> (pos [M] int64, col_off [M + 1] int64, bases uint8, ref uint8 [M] or None) on the device.
+        Synchronous (the sizes come back from the device); raises on text the reference's reader could not read."""
+        import torch
+        t = int(text.numel())
+        cap, cap_b = t // 10 + 2, max(t, 1)
+        while True:
+            pos = torch.empty(cap, dtype=torch.int64, device=text.device)
+            off = torch.empty(cap + 1, dtype=torch.int64, device=text.device)
+            bases = torch.empty(cap_b, dtype=torch.uint8, device=text.device)
+            ref = torch.empty(cap, dtype=torch.uint8, device=text.device) if chr_seq is not None else None
+            meta = torch.zeros(4, dtype=torch.int64, device=text.device)
+            self.mpileup_tokenise_into(text, chr_seq, pos, off, bases, ref, meta, stream)
+            m, nb, status, _ = meta.tolist()
+            if status & self.TOK_ERANGE and not status & (self.TOK_EFORMAT | self.TOK_BLANK):
+                cap, cap_b = max(cap, m + 1), max(cap_b, nb)
+                continue
+            break
+        tokenise_status_check(status)
+        return pos[:m], off[:m + 1], bases[:nb], (ref[:m] if ref is not None else None)
 
     def pileup_gather_windows(self, counts, center_idx, stream=None):
         import torch

@@ -67,6 +67,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
 void nsnp_hap_free(nsnp_ctx* ctx);   // hap_forward.hip
 int  nsnp_hap_reserve(nsnp_ctx* ctx);
 void nsnp_cat_free(nsnp_ctx* ctx);   // cat_forward.hip
+void nsnp_tok_free(nsnp_ctx* ctx);   // mpileup_tokenise.hip
 
 // ---- per-kernel timing ----------------------------------------------------------------------------
 constexpr size_t TIMER_MAX_PAIRS = 8192;
@@ -247,6 +248,7 @@ extern "C" int nsnp_ctx_destroy(nsnp_ctx* ctx)
     if (ctx->pw16.l1f_bias) (void)hipFree(ctx->pw16.l1f_bias);
     if (ctx->pwb3.arena) (void)hipFree(ctx->pwb3.arena);
     if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
+    nsnp_tok_free(ctx);
     (void)nsnp_comm_destroy(ctx);
     nsnp_hap_free(ctx);
     nsnp_cat_free(ctx);

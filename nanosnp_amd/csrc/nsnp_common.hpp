@@ -125,6 +125,7 @@ struct nsnp_ctx {
     CatWeightsDev* cw;
     void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
+    void* tok_ws; size_t tok_ws_bytes;        // mpileup tokeniser scratch: tile summaries + one bit per text byte (mpileup_tokenise.hip)
     // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
     bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
     bool af2_cached; uint64_t af2_bits, af2_t; int af2_k, af2_mode; uint32_t af2_table_words[128];     // the indel threshold when it differs

@@ -96,6 +96,11 @@ void orc_gather_windows(const int32_t* counts, const int64_t* center_idx, int64_
 int64_t orc_mpileup_to_pd(const char* mpileup_path, const char* chr_seq, int64_t chr_len,
                           double min_af, int min_coverage, int flank, const char* pd_path);
 
+/* mpileup text in memory -> per line the position (atoll of token 1) and the byte range of token 4 (the pileup bases), read the
+ * way the reference reads the file: line_reader.cpp:95-127, cpp_aux.cpp:43-59, make_candidate_snp_tensor/main.cpp:162-172.
+ * Returns the number of lines, or -(k + 1) when line k has fewer than five tokens (the reference cannot survive such a line). */
+int64_t orc_mpileup_tokenise(const char* text, int64_t len, int64_t cap, int64_t* pos, int64_t* beg, int64_t* end);
+
 /* ---- LSTM building block (torch.nn.LSTM semantics, gate order i,f,g,o) --------------- */
 /* One bidirectional layer over a [T][I] sequence -> out [T][2H] (fwd in [:H], rev in [H:]).
  * Restates what nn.LSTM(batch_first, bidirectional, h0=c0=0) computes in eval mode:

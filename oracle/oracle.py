@@ -39,6 +39,8 @@ def _load():
     lib.orc_mpileup_to_pd.restype = C.c_int64
     lib.orc_mpileup_to_pd.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_double, C.c_int,
                                       C.c_int, C.c_char_p]
+    lib.orc_mpileup_tokenise.restype = C.c_int64
+    lib.orc_mpileup_tokenise.argtypes = [p, C.c_int64, C.c_int64, p, p, p]
     lib.orc_pileup_forward.restype = None
     lib.orc_pileup_forward.argtypes = [p, p, C.c_int64, p, p, C.c_int]
     lib.orc_pileup_forward_blocked.restype = None
@@ -112,6 +114,22 @@ def mpileup_to_pd(mpileup_path, chr_seq: bytes, pd_path, min_af=0.12, min_covera
     if n < 0:
         raise RuntimeError(f"orc_mpileup_to_pd failed: {n}")
     return n
+
+
+def mpileup_tokenise(text):
+    """mpileup text (bytes / uint8 array) -> (pos [M] int64, col_off [M + 1] int64, bases uint8): what the reference's reader makes of every
+    line (position, column 5), the column-5 strings laid end to end.  ValueError when a line has fewer than five fields."""
+    t = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+    cap = int((t == 10).sum()) + 1
+    pos, beg, end = (np.zeros(cap, np.int64) for _ in range(3))
+    m = lib().orc_mpileup_tokenise(_p(t), t.size, cap, _p(pos), _p(beg), _p(end))
+    if m < 0:
+        raise ValueError(f"line {-m - 1}: fewer than five fields")
+    pos, beg, end = pos[:m], beg[:m], end[:m]
+    off = np.zeros(m + 1, np.int64)
+    np.cumsum(end - beg, out=off[1:])
+    bases = np.concatenate([t[b:e] for b, e in zip(beg, end)]) if m else np.zeros(0, np.uint8)
+    return pos, off, bases
 
 
 def _wptrs(weights):

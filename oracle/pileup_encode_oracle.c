@@ -501,3 +501,50 @@ int64_t orc_mpileup_to_pd2(const char* mpileup_path, const char* chr_seq, int64_
     if (fclose(out) != 0) return -4;
     return n_sites;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * mpileup text in memory -> (position, column-5 token) per line, byte at a time.
+ *
+ * Restates how the reference reads a <chr>.mpileup:
+ *   LineReader::getline   common/line_reader.cpp:95-127   a line ends at '\n' (or at the end of the text); the '\n' and ONE
+ *                                                          '\r' in front of it are dropped; a '\r' elsewhere stays in the line
+ *   split_line(.., "\t")  common/cpp_aux.cpp:43-59         tokens = maximal runs of non-tab characters
+ *   main.cpp:162-172                                       ref_off = atoll(token 1), pileup_bases = token 4
+ * A line with fewer than five tokens (an empty line included) makes the reference index a vector out of range (it aborts or
+ * worse): reported here as -(line number + 1), nothing the callers may accept.
+ * Returns the number of lines; beg/end are offsets into text.  Used as the checker of the device tokeniser
+ * (nanosnp_amd/csrc/mpileup_tokenise.hip) and of the host one (nsnp_textio.c).
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_mpileup_tokenise(const char* text, int64_t len, int64_t cap, int64_t* pos, int64_t* beg, int64_t* end)
+{
+    int64_t m = 0, p = 0;
+    while (p < len) {
+        int64_t le = p;
+        while (le < len && text[le] != '\n') ++le;
+        const int64_t next = le < len ? le + 1 : len;
+        if (le > p && text[le - 1] == '\r') --le;
+        /* tokens of text[p, le) */
+        int ntok = 0; int64_t q = p, t1 = -1, t1e = -1, t4 = -1, t4e = -1;
+        while (q < le) {
+            while (q < le && text[q] == '\t') ++q;
+            if (q >= le) break;
+            const int64_t s = q;
+            while (q < le && text[q] != '\t') ++q;
+            if (ntok == 1) { t1 = s; t1e = q; } else if (ntok == 4) { t4 = s; t4e = q; }
+            ++ntok;
+        }
+        if (ntok < 5) return -(m + 1);
+        if (m < cap) {
+            /* atoll on the token: white space, one sign, digits (the token holds no tab / newline) */
+            int64_t s = t1; uint64_t v = 0; int neg = 0;
+            while (s < t1e && isspace((unsigned char)text[s])) ++s;
+            if (s < t1e && (text[s] == '-' || text[s] == '+')) { neg = text[s] == '-'; ++s; }
+            while (s < t1e && text[s] >= '0' && text[s] <= '9') { v = v * 10u + (uint64_t)(text[s] - '0'); ++s; }
+            pos[m] = neg ? (int64_t)(0u - v) : (int64_t)v;
+            beg[m] = t4; end[m] = t4e;
+        }
+        ++m;
+        p = next;
+    }
+    return m;
+}
