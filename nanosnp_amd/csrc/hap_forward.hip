@@ -20,6 +20,15 @@
 
 #include "hap_gemm.hpp"
 
+#ifndef NSNP_HAP_BS
+// bf16x3: 1 = activation images as three bf16 planes, written by the producing epilogue (hap_gemm.hpp BS / OS); 0 (default) = fp32 images,
+// split by every consumer on their way into LDS.  Built and measured in round 6: bit-identical results (crc 24ae9da2
+// both ways on 16,384 sites), and SLOWER - 21.09 against 20.41 ms per 16,384-site forward: the split's vector instructions sit in the
+// shadow of the MFMAs of the other wave, what the 1.5 x larger activation images cost in L2 / HBM traffic does not.  Kept as an A/B build
+// (tools/build_variant.sh bs -DNSNP_HAP_BS=1).
+#define NSNP_HAP_BS 0
+#endif
+
 namespace {
 
 // x [N][F][L] (predict_dev.py hands [N,105,L]; model_dev.py:136-137 permutes to [N,L,F]) ->
@@ -30,10 +39,12 @@ namespace {
 // lane 4 bytes out of a different 128-byte line: 3.9 GB of HBM reads per 16384-site launch for 0.23 GB of input, 0.53 ms.)
 constexpr int PK_SITES = 16;                    // sites per workgroup
 constexpr int PK_MAXL = 33;
-template <bool F16>
+template <int AR>                  // element format of the images: 0 fp32, 1 (hi, lo) fp16 pairs, 2 three bf16 planes (rows of 96 bytes)
 __global__ __launch_bounds__(256) void k_hap_pack_input(const float* __restrict__ x, int64_t N, int F, int L, int n_tiles, int nkc,
                                                         float* __restrict__ xT)
 {
+    constexpr bool F16 = AR == 1, B3 = AR == 2;
+    constexpr int TILE_X = B3 ? TILE_F3 : TILE_F, ROW_X = B3 ? ROW_F3 : BK;
     __shared__ float buf[PK_SITES][16 * PK_MAXL + 1];
     const int tid = threadIdx.x;
     const int sub = blockIdx.x % (TS / PK_SITES);
@@ -53,8 +64,15 @@ __global__ __launch_bounds__(256) void k_hap_pack_input(const float* __restrict_
         const int t = i / (PK_SITES * 4), j = i - t * (PK_SITES * 4);
         const int s = j >> 2, p4 = (j & 3) * 4;
         const f32x4 v = f32x4{buf[s][(p4 + 0) * L + t], buf[s][(p4 + 1) * L + t], buf[s][(p4 + 2) * L + t], buf[s][(p4 + 3) * L + t]};
-        float* row = xT + (((size_t)t * n_tiles + tile) * nkc + kc) * TILE_F + (size_t)(sub * PK_SITES + s) * BK;
-        if (F16) {
+        float* row = xT + (((size_t)t * n_tiles + tile) * nkc + kc) * TILE_X + (size_t)(sub * PK_SITES + s) * ROW_X;
+        if (B3) {
+            b4_t p0, p1, p2;
+            split3_b4(v, p0, p1, p2);
+            __bf16* br = reinterpret_cast<__bf16*>(row);
+            *reinterpret_cast<b4_t*>(br + p4) = p0;
+            *reinterpret_cast<b4_t*>(br + 16 + p4) = p1;
+            *reinterpret_cast<b4_t*>(br + 32 + p4) = p2;
+        } else if (F16) {
             h4 vh, vl;
 #pragma unroll
             for (int g = 0; g < 4; ++g) { _Float16 hi, lo; split_sat(v[g], hi, lo); vh[g] = hi; vl[g] = lo; }
@@ -131,15 +149,18 @@ struct HapWeightsDev {
 
 // workspace of one pass of `chunk` sites (floats): packed inputs of both encoders, h of all steps / both directions for two
 // layers per encoder (ping-pong), c for up to 4 z-slices, the concatenated projections, the dense output.  ~195 KB per site.
+// planes3: the activation images that feed a GEMM (packed inputs, h, the concatenated projections) hold three bf16 planes per element
+// (the bf16x3 mode: 6 bytes instead of 4); the cell state and the dense output stay fp32
 struct HapWsLayout { size_t xT_f, hbuf_f, c_f, cat_f, inner_f, bytes; };
-static HapWsLayout hap_ws_layout(int64_t chunk, int nk_in0)
+static HapWsLayout hap_ws_layout(int64_t chunk, int nk_in0, bool planes3)
 {
     const size_t max_tiles = (size_t)(chunk / TS);
+    const size_t tile_act = planes3 ? TILE_F3 : TILE_F;
     HapWsLayout w;
-    w.xT_f = (size_t)33 * max_tiles * nk_in0 * TILE_F;
-    w.hbuf_f = (size_t)33 * max_tiles * 2 * 16 * TILE_F;
+    w.xT_f = (size_t)33 * max_tiles * nk_in0 * tile_act;
+    w.hbuf_f = (size_t)33 * max_tiles * 2 * 16 * tile_act;
     w.c_f = (size_t)4 * max_tiles * 16 * TILE_F;
-    w.cat_f = max_tiles * 32 * TILE_F;
+    w.cat_f = max_tiles * 32 * tile_act;
     w.inner_f = max_tiles * 16 * TILE_F;
     w.bytes = (2 * w.xT_f + 4 * w.hbuf_f + w.c_f + w.cat_f + w.inner_f) * sizeof(float);
     return w;
@@ -150,14 +171,16 @@ static HapWsLayout hap_ws_layout(int64_t chunk, int nk_in0)
 int nsnp_hap_reserve(nsnp_ctx* ctx)
 {
     if (!ctx->hw) return NSNP_OK;                       // sized when the weights arrive
-    const HapWsLayout w = hap_ws_layout(ctx->hap_chunk, ctx->hw->nk_in0);
-    if (ctx->hap_ws && ctx->hap_ws_bytes == w.bytes) return NSNP_OK;
+    // sized for the arithmetic selected now; the larger bf16x3 images only when that mode is (or has been) chosen: the workspace never
+    // shrinks for a change of arithmetic alone (callers switch back and forth), it is re-made when the pass size changes
+    const HapWsLayout w = hap_ws_layout(ctx->hap_chunk, ctx->hw->nk_in0, ctx->hap_precision == 2 && NSNP_HAP_BS);
+    if (ctx->hap_ws && ctx->hap_ws_chunk == ctx->hap_chunk && ctx->hap_ws_bytes >= w.bytes) return NSNP_OK;
     NSNP_HIP(ctx, hipSetDevice(ctx->device));
     NSNP_HIP(ctx, hipDeviceSynchronize());
     if (ctx->hap_ws) (void)hipFree(ctx->hap_ws);
     ctx->hap_ws = nullptr; ctx->hap_ws_bytes = 0;
     if (hipMalloc(&ctx->hap_ws, w.bytes) != hipSuccess) { ctx->hap_ws = nullptr; ctx->last_err = hipErrorOutOfMemory; return NSNP_ENOMEM; }
-    ctx->hap_ws_bytes = w.bytes;
+    ctx->hap_ws_bytes = w.bytes; ctx->hap_ws_chunk = ctx->hap_chunk;
     return NSNP_OK;
 }
 
@@ -318,21 +341,23 @@ extern "C" int nsnp_hap_load_weights(nsnp_ctx* ctx, const float* const* t, int n
     return nsnp_hap_reserve(ctx);                      // the forward itself never allocates (graph capture, no stream stalls)
 }
 
-// AR: 0 exact fp32, 1 f16x3 (activation images hold (hi, lo) fp16 pairs), 2 bf16x3 (activation images stay fp32, weights as three bf16 planes)
+// AR: 0 exact fp32, 1 f16x3 (activation images hold (hi, lo) fp16 pairs), 2 bf16x3 (weights AND activation images as three bf16 planes)
 template <int AR>
 static int hap_forward_t(nsnp_ctx* ctx, const float* xp, const float* xh, int64_t N, float* gt_prob, float* zy_prob, hipStream_t s)
 {
     const HapWeightsDev& hw = *ctx->hw;
     const int H = hw.H, F = hw.F;
-    constexpr bool F16 = AR == 1;                              // element format of the activation images
+    constexpr bool F16 = AR == 1;                              // element format of the activation images: (hi, lo) fp16 pairs ...
+    constexpr bool BS = AR == 2 && NSNP_HAP_BS;                // ... or three bf16 planes (written by the producing epilogue: hap_gemm.hpp)
+    constexpr size_t TILE_A = BS ? TILE_F3 : TILE_F;           // floats of one [128][16] activation tile image
     const WeightMap wm{hw.arena, AR == 1 ? (const void*)hw.arena16 : (const void*)hw.arena_b3, AR};
     const int Lp = 33, Lh = 11;                       // ont_haplotype.yaml:10-11
     // sites per pass: every time step of a layer is one launch over all sites of the pass, so the pass size sets how long
     // each of the 83 dependent launches is (16384 sites: 2048-4096 workgroups, 2-4 rounds of the chip; ramp + tail of a launch
     // ~5 % instead of ~18 % at 4096).  Option "hap_pass_sites"; workspace ~195 KB per site, allocated at load time.
     const int64_t chunk = ctx->hap_chunk;
-    const HapWsLayout wl = hap_ws_layout(chunk, hw.nk_in0);
-    if (!ctx->hap_ws || ctx->hap_ws_bytes < wl.bytes) return NSNP_ENOMEM;      // nsnp_hap_load_weights reserves it
+    const HapWsLayout wl = hap_ws_layout(chunk, hw.nk_in0, BS);
+    if (!ctx->hap_ws || ctx->hap_ws_bytes < wl.bytes) return NSNP_ENOMEM;      // nsnp_hap_load_weights / nsnp_ctx_set_option reserve it
     const size_t xT_f = wl.xT_f, hbuf_f = wl.hbuf_f, c_f = wl.c_f, cat_f = wl.cat_f;
     float* base = (float*)ctx->hap_ws;
     float* xT[2] = {base, base + xT_f};
@@ -348,11 +373,12 @@ static int hap_forward_t(nsnp_ctx* ctx, const float* xp, const float* xh, int64_
         const float* xin[2] = {xp + n0 * F * Lp, xh + n0 * F * Lh};
         for (int e = 0; e < 2; ++e) {
             const unsigned blocks = (unsigned)n_tiles * hw.nk_in0 * (TS / PK_SITES);
-            hipLaunchKernelGGL(k_hap_pack_input<F16>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
+            hipLaunchKernelGGL(k_hap_pack_input<(AR == 2 ? (BS ? 2 : 0) : AR)>, dim3(blocks), dim3(256), 0, s, xin[e], n, F, Ls[e], n_tiles, hw.nk_in0, xT[e]);
         }
         // h of one layer: [t][site tile][dir][16 chunks][128][16] -> the 32 chunks [h_fwd ; h_bwd] of a site
         // tile at time t are contiguous (what the next layer and output_proj consume)
-        const size_t tile_h = (size_t)16 * TILE_F;                 // one direction of one site tile at one step
+        const size_t tile_h = (size_t)16 * TILE_A;                 // one direction of one site tile at one step
+        const size_t tile_c = (size_t)16 * TILE_F;                 // its cell state (always fp32)
         const size_t step_h = (size_t)n_tiles * 2 * tile_h;
         ScopedKernelTimer tm_lstm(ctx, NSNP_K_HAPLSTM, s);         // one event pair around the 83 fused step launches of this pass
         for (int l = 0; l < 3; ++l) {
@@ -369,8 +395,8 @@ static int hap_forward_t(nsnp_ctx* ctx, const float* xp, const float* xh, int64_
                         StepArgs& a = L.z[nz];
                         a.w = wm(hw.w[e][l][d]); a.bias = hw.b[e][l][d];
                         if (l == 0) {
-                            a.in0 = xT[e] + (size_t)t * n_tiles * hw.nk_in0 * TILE_F;
-                            a.nk0 = hw.nk_in0; a.in0_tile_stride = hw.nk_in0 * TILE_F;
+                            a.in0 = xT[e] + (size_t)t * n_tiles * hw.nk_in0 * TILE_A;
+                            a.nk0 = hw.nk_in0; a.in0_tile_stride = (int)(hw.nk_in0 * TILE_A);
                         } else {
                             a.in0 = hb[e][(l - 1) & 1] + (size_t)t * step_h;
                             a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(2 * tile_h);
@@ -380,13 +406,13 @@ static int hap_forward_t(nsnp_ctx* ctx, const float* xp, const float* xh, int64_
                         a.nk_img = a.nk0 + H / BK;
                         a.out = hb[e][l & 1] + (size_t)t * step_h + (size_t)d * tile_h;
                         a.out_tile_stride = (int)(2 * tile_h);
-                        a.cstate = cst + (size_t)(e * 2 + d) * n_tiles * tile_h;
-                        a.c_tile_stride = (int)tile_h;
+                        a.cstate = cst + (size_t)(e * 2 + d) * n_tiles * tile_c;
+                        a.c_tile_stride = (int)tile_c;
                         a.first = st == 0;
                         ++nz;
                     }
                 }
-                launch_hap_gemm<MODE_LSTM, AR>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
+                launch_hap_gemm<MODE_LSTM, AR, false, BS, BS>(ctx, s, L, (int)(n_tiles), 4 * H / TR, nz);
             }
         }
         tm_lstm.stop();
@@ -400,17 +426,17 @@ static int hap_forward_t(nsnp_ctx* ctx, const float* xp, const float* xh, int64_
                 a.in0 = hb[e][0] + (size_t)(Ls[e] / 2) * step_h;
                 a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(2 * tile_h);
                 a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0;
-                a.out = cat + (size_t)e * 16 * TILE_F; a.out_tile_stride = 32 * TILE_F;
+                a.out = cat + (size_t)e * 16 * TILE_A; a.out_tile_stride = (int)(32 * TILE_A);
                 a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
             }
-            launch_hap_gemm<MODE_LINEAR, AR>(ctx, s, L, (int)(n_tiles), H / TR, 2);
+            launch_hap_gemm<MODE_LINEAR, AR, false, BS, BS>(ctx, s, L, (int)(n_tiles), H / TR, 2);
         }
         {
             StepLaunch L; StepArgs& a = L.z[0];
-            a.w = wm(hw.dense_w); a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = 32 * TILE_F;
+            a.w = wm(hw.dense_w); a.bias = hw.dense_b; a.in0 = cat; a.nk0 = 2 * H / BK; a.in0_tile_stride = (int)(32 * TILE_A);
             a.in1 = nullptr; a.nk1 = 0; a.in1_tile_stride = 0; a.nk_img = a.nk0; a.out = inner; a.out_tile_stride = 16 * TILE_F;
             a.cstate = nullptr; a.c_tile_stride = 0; a.first = 0;
-            launch_hap_gemm<MODE_LINEAR_TANH, AR>(ctx, s, L, (int)(n_tiles), H / TR, 1);
+            launch_hap_gemm<MODE_LINEAR_TANH, AR, false, BS, false>(ctx, s, L, (int)(n_tiles), H / TR, 1);      // (its output feeds the heads kernel: fp32)
         }
         hipLaunchKernelGGL(k_hap_heads<F16>, dim3((unsigned)NSNP_CDIV(n, 4)), dim3(256), 0, s, inner, n, hw.head_w, hw.head_b,
                            hw.n_gt, hw.n_zy, gt_prob + n0 * hw.n_gt, zy_prob + n0 * hw.n_zy);

@@ -113,8 +113,9 @@ __device__ __forceinline__ void split_sat(float v, _Float16& hi, _Float16& lo)
 
 // AR = 2 : "bf16x3" - weights are stored as three bf16 planes per element (a row of a weight tile image = 16 p0 | 16 p1 | 16 p2 bf16 =
 //          96 bytes, v = p0 + p1 + p2 with p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1): the full 24-bit significand and the
-//          fp32 exponent range), ACTIVATIONS STAY fp32 in memory exactly as in the fp32 mode and are split the same way on their way
-//          into LDS; a product is the six v_mfma_f32_32x32x16_bf16 whose dropped terms are below 2^-24 of it, fp32 accumulation.
+//          fp32 exponent range); activations are fp32 in memory and split the same way on their way into LDS (the CatModel's launches),
+//          or arrive as the same three planes, written by the epilogue that produced them (BS / OS below: the HaplotypeModel's launches);
+//          a product is the six v_mfma_f32_32x32x16_bf16 whose dropped terms are below 2^-24 of it, fp32 accumulation.
 //          Same launch sequence, activation images and epilogues as AR = 0; weight tile images are 12 KB instead of 8.
 typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
 constexpr int LDB3 = 48;          // bf16 per LDS row in the bf16x3 mode: 3 planes x 16, NO padding (96 B = 6 slots of 16 B; 48 KB per workgroup, three
@@ -133,12 +134,35 @@ __device__ __forceinline__ void split3_b8(const f32x4& lo, const f32x4& hi, b8_t
     }
 }
 
-template <int MODE, int AR, bool CONV = false>
+typedef __bf16 b4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_b4(const f32x4& v, b4_t& p0, b4_t& p1, b4_t& p2)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        p0[j] = a; p1[j] = b; p2[j] = (__bf16)(r1 - (float)b);
+    }
+}
+constexpr int TILE_F3 = TILE_F * 3 / 2;       // floats of a [128][16] tile image whose elements are three bf16 planes (rows of 96 bytes)
+constexpr int ROW_F3 = BK * 3 / 2;            // floats of one of its rows
+
+// BS (bf16x3 only): the ACTIVATION images hold three bf16 planes per element as well - a row of an activation tile image is 16 p0 | 16 p1 |
+//      16 p2 like a weight row, written that way by the epilogue that produced it (OS: this launch writes its output so) - and a K chunk
+//      is loads + MFMAs only.  Before, every workgroup that consumed an activation split it again on its way into LDS: the h_t of a step
+//      was split by each of the 4-8 row-tile workgroups of the next step and of the next layer, 2.7 vector instructions per MFMA
+//      (profiles/r05_hap_forward_bf16x3_sq_counters.json).  Same planes (the split is a function of the fp32 value), same products, same
+//      order: bit-identical results.  6 instead of 4 bytes per activation element in memory.
+template <int MODE, int AR, bool CONV = false, bool BS = false, bool OS = false>
 __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaunch L)
 {
     constexpr bool F16 = AR == 1, B3 = AR == 2;
+    static_assert(!(BS || OS) || (B3 && !CONV), "pre-split activations exist in the bf16x3 mode of the plain GEMM only");
     constexpr int LDS_ROW_F = B3 ? LDB3 / 2 : LDK;            // floats per LDS row
     constexpr int TILE_W = B3 ? TILE_F * 3 / 2 : TILE_F;      // floats per weight tile image
+    constexpr int TILE_B = BS ? TILE_F3 : TILE_F;             // floats per input activation tile image
+    constexpr int TILE_O = OS ? TILE_F3 : TILE_F;             // floats per output activation tile image
     __shared__ float As[2][TR][LDS_ROW_F];
     __shared__ float Bs[2][TS][LDS_ROW_F];
     NSNP_DEVCLK_START
@@ -172,6 +196,7 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
         py = rem / a.conv_w; px = rem - py * a.conv_w;
     }
     f32x4 ga2;                                     // bf16x3: the third 16-byte piece of the thread's half of a 96-byte weight row
+    f32x4 gb2;                                     // BS: likewise of an activation row
     auto gload = [&](int kc, f32x4& a0, f32x4& a1, f32x4& bb0, f32x4& bb1) {
         if (B3) {
             const f32x4* pa = reinterpret_cast<const f32x4*>(wt + (size_t)kc * TILE_W) + crow * 6 + (tid & 1) * 3;
@@ -194,7 +219,12 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
             }
             return;
         }
-        const float* src = kc < a.nk0 ? b0 + (size_t)kc * TILE_F : b1 + (size_t)(kc - a.nk0) * TILE_F;
+        const float* src = kc < a.nk0 ? b0 + (size_t)kc * TILE_B : b1 + (size_t)(kc - a.nk0) * TILE_B;
+        if (BS) {
+            const f32x4* pb = reinterpret_cast<const f32x4*>(src) + crow * 6 + (tid & 1) * 3;
+            bb0 = pb[0]; bb1 = pb[1]; gb2 = pb[2];
+            return;
+        }
         const f32x4* pb = reinterpret_cast<const f32x4*>(src) + crow * 4 + cq;
         bb0 = pb[0]; bb1 = pb[1];
     };
@@ -203,6 +233,11 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
             const int sw = (crow >> 3) & 1, h3 = (tid & 1) * 3;
             f32x4* ra = reinterpret_cast<f32x4*>(&As[buf][crow][0]);
             ra[(h3 + 0) ^ sw] = a0; ra[(h3 + 1) ^ sw] = a1; ra[(h3 + 2) ^ sw] = ga2;
+            if (BS) {                              // the activation row arrives as its three planes: a plain copy, like the weights
+                f32x4* rbs = reinterpret_cast<f32x4*>(&Bs[buf][crow][0]);
+                rbs[(h3 + 0) ^ sw] = bb0; rbs[(h3 + 1) ^ sw] = bb1; rbs[(h3 + 2) ^ sw] = gb2;
+                return;
+            }
             // the thread's 8 activations (K positions 8 (tid & 1) ..) -> its 16-byte piece of each of the three planes
             b8_t p0, p1, p2;
             split3_b8(bb0, bb1, p0, p1, p2);
@@ -388,7 +423,13 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
                     cv[rt][r4] = cn;
                 }
             *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
-            if (F16) {
+            if (OS) {
+                // the lane's 8 positions lh*8.. are 8 consecutive bf16 of each of the row's three planes
+                b8_t p0, p1, p2;
+                split3_b8(hv[0], hv[1], p0, p1, p2);
+                b8_t* hrow = reinterpret_cast<b8_t*>(a.out + (size_t)bx * a.out_tile_stride + (size_t)(2 * by + wr) * TILE_O + site * ROW_F3);
+                hrow[lh] = p0; hrow[2 + lh] = p1; hrow[4 + lh] = p2;
+            } else if (F16) {
                 // the lane's 8 positions lh*8.. are 8 consecutive halves of the hi block and of the lo block
                 h8 hh, hl;
 #pragma unroll
@@ -418,6 +459,15 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
                         const float t = acc[rt][ct][4 * r4 + g] + (NSNP_GEMM_BIASINIT ? 0.f : a.bias[f + g]);
                         v[g] = MODE == MODE_LINEAR_TANH ? tanh_f(t) : MODE == MODE_LINEAR_RELU ? fmaxf(t, 0.f) : t;
                     }
+                    if (OS) {
+                        b4_t p0, p1, p2;
+                        split3_b4(v, p0, p1, p2);
+                        __bf16* orow = reinterpret_cast<__bf16*>(a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_O + site * ROW_F3);
+                        *reinterpret_cast<b4_t*>(orow + (f & 15)) = p0;
+                        *reinterpret_cast<b4_t*>(orow + 16 + (f & 15)) = p1;
+                        *reinterpret_cast<b4_t*>(orow + 32 + (f & 15)) = p2;
+                        continue;
+                    }
                     float* o = a.out + (size_t)bx * a.out_tile_stride + (size_t)(f >> 4) * TILE_F + site * BK;
                     if (F16) {
                         h4 vh, vl;
@@ -445,8 +495,10 @@ __global__ __launch_bounds__(256, NSNP_GEMM_MINW) void k_hap_gemm(const StepLaun
 // barrier, 32 instead of 40 KB from L2 per 2 x 2 tiles, one split of an activation per 256 instead of 128 rows.  Same images, same
 // k order and product order per accumulator: bit-identical to k_hap_gemm<MODE_LSTM, 2>.  One workgroup per CU (96 KB of LDS).
 constexpr int BT = 256;
+template <bool BS>                 // BS: activations in and out as three bf16 planes (see k_hap_gemm)
 __global__ __launch_bounds__(512, 1) void k_hap_lstm_b3x(const StepLaunch L)
 {
+    constexpr int TILE_B = BS ? TILE_F3 : TILE_F;
     constexpr int TILE_W = TILE_F * 3 / 2;
     __shared__ float As[2][BT][LDB3 / 2];
     __shared__ float Bs[2][BT][LDB3 / 2];
@@ -469,16 +521,40 @@ __global__ __launch_bounds__(512, 1) void k_hap_lstm_b3x(const StepLaunch L)
     const int bsite = tid >> 1, bhalf = tid & 1;
     const float* __restrict__ b0 = a.in0 ? a.in0 + (size_t)(2 * bx + (bsite >> 7)) * a.in0_tile_stride + (bsite & 127) * BK + bhalf * 8 : nullptr;
     const float* __restrict__ b1 = a.in1 ? a.in1 + (size_t)(2 * bx + (bsite >> 7)) * a.in1_tile_stride + (bsite & 127) * BK + bhalf * 8 : nullptr;
-    f32x4 ga[3], gb0, gb1;
+    // BS: the 256 x 96 B of the two activation tile images are 1536 pieces as well, three per thread, the same rows and slots as the weights'
+    const float* __restrict__ bs0[3]; const float* __restrict__ bs1[3];
+    if (BS) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int p = tid + 512 * i, r = p / 6, sl = p - 6 * r;
+            bs0[i] = a.in0 ? a.in0 + (size_t)(2 * bx + (r >> 7)) * a.in0_tile_stride + (size_t)(r & 127) * ROW_F3 + sl * 4 : nullptr;
+            bs1[i] = a.in1 ? a.in1 + (size_t)(2 * bx + (r >> 7)) * a.in1_tile_stride + (size_t)(r & 127) * ROW_F3 + sl * 4 : nullptr;
+        }
+    }
+    f32x4 ga[3], gb0, gb1, gb2;
     auto gload = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) ga[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + (size_t)kc * TILE_W);
+        if (BS) {
+            const bool first = kc < a.nk0;
+            const size_t o = (size_t)(first ? kc : kc - a.nk0) * TILE_B;
+            gb0 = *reinterpret_cast<const f32x4*>((first ? bs0[0] : bs1[0]) + o);
+            gb1 = *reinterpret_cast<const f32x4*>((first ? bs0[1] : bs1[1]) + o);
+            gb2 = *reinterpret_cast<const f32x4*>((first ? bs0[2] : bs1[2]) + o);
+            return;
+        }
         const float* src = kc < a.nk0 ? b0 + (size_t)kc * TILE_F : b1 + (size_t)(kc - a.nk0) * TILE_F;
         gb0 = *reinterpret_cast<const f32x4*>(src); gb1 = *reinterpret_cast<const f32x4*>(src + 4);
     };
     auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(&As[buf][arow[i]][aslot[i]]) = ga[i];
+        if (BS) {
+            *reinterpret_cast<f32x4*>(&Bs[buf][arow[0]][aslot[0]]) = gb0;
+            *reinterpret_cast<f32x4*>(&Bs[buf][arow[1]][aslot[1]]) = gb1;
+            *reinterpret_cast<f32x4*>(&Bs[buf][arow[2]][aslot[2]]) = gb2;
+            return;
+        }
         b8_t p0, p1, p2;
         split3_b8(gb0, gb1, p0, p1, p2);
         b8_t* rb = reinterpret_cast<b8_t*>(&Bs[buf][bsite][0]);
@@ -562,24 +638,32 @@ __global__ __launch_bounds__(512, 1) void k_hap_lstm_b3x(const StepLaunch L)
                 cv[rt][r4] = cn;
             }
         *reinterpret_cast<f32x4*>(cptr) = cv[0]; *reinterpret_cast<f32x4*>(cptr + 4) = cv[1];
-        *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
+        if (BS) {
+            b8_t p0, p1, p2;
+            split3_b8(hv[0], hv[1], p0, p1, p2);
+            b8_t* hrow = reinterpret_cast<b8_t*>(a.out + tile * a.out_tile_stride + (size_t)(4 * by + wr) * TILE_B + site * ROW_F3);
+            hrow[lh] = p0; hrow[2 + lh] = p1; hrow[4 + lh] = p2;
+        } else {
+            *reinterpret_cast<f32x4*>(hptr) = hv[0]; *reinterpret_cast<f32x4*>(hptr + 4) = hv[1];
+        }
     }
 }
 
 // launch of the tile GEMM over n_tiles site tiles x n_rt row tiles x nz slices
 // AR: 0 exact fp32, 1 f16x3, 2 bf16x3 (k_hap_gemm); `true` / `false` of the round-2 callers still mean f16x3 / fp32
-template <int MODE, int AR, bool CONV = false>
+template <int MODE, int AR, bool CONV = false, bool BS = false, bool OS = false>
 inline void launch_hap_gemm(nsnp_ctx* ctx, hipStream_t s, StepLaunch& L, int n_tiles, int n_rt, int nz)
 {
     if constexpr (MODE == MODE_LSTM && AR == 2 && !CONV && NSNP_GEMM_B3X) {
+        static_assert(BS == OS, "an LSTM step reads and writes one kind of activation image");
         // two row tiles x two site tiles per workgroup where the launch still fills the chip with them (one workgroup per CU)
         if (ctx->hap_b3x && n_tiles % 2 == 0 && n_rt % 2 == 0 && (long long)(n_tiles / 2) * (n_rt / 2) * nz >= ctx->n_cu) {
-            hipLaunchKernelGGL(k_hap_lstm_b3x, dim3(n_tiles / 2, n_rt / 2, nz), dim3(512), 0, s, L);
+            hipLaunchKernelGGL(k_hap_lstm_b3x<BS>, dim3(n_tiles / 2, n_rt / 2, nz), dim3(512), 0, s, L);
             return;
         }
     }
     // (the bf16x3 mode holds 48 KB of LDS per workgroup: three per CU, no ballast)
-    hipLaunchKernelGGL((k_hap_gemm<MODE, AR, CONV>), dim3(n_tiles, n_rt, nz), dim3(256),
+    hipLaunchKernelGGL((k_hap_gemm<MODE, AR, CONV, BS, OS>), dim3(n_tiles, n_rt, nz), dim3(256),
 #ifdef NSNP_GEMM_FORCE_BALLAST
                        (unsigned)NSNP_GEMM_FORCE_BALLAST, s, L);       // (A/B build: a fixed dynamic-LDS ballast = fewer workgroups per CU)
 #else

@@ -22,8 +22,9 @@
 //   k_tok_scan2     one workgroup: exclusive scan of the bytes per tile; totals and status -> meta
 //   k_tok_compact   per tile: the token-4 bytes compacted through LDS into `bases` with 16-byte stores, col_off of the columns that
 //                   start in the tile                                                       (reads the text a third time, + the bitmap)
-// Algorithmic bytes per text byte: 3 reads + 1/8 bitmap write + 1/8 read, ~0.37 written as bases: ~3.6 B per text byte; the kernels
-// are HBM-bound scans.  No line-length limit, no slow path: a line may span any number of tiles.
+// Algorithmic bytes per text byte: 3 reads + 1/8 bitmap write + 1/8 read, ~0.37 written as bases: ~3.6 B per text byte.  No line-length
+// limit, no slow path: a line may span any number of tiles.  This five-launch form is the plain statement of the algorithm (option
+// "tok_fused" 0); the default is k_tok_fused below - the same grammar as ONE launch that reads the text once.
 #include "nsnp_common.hpp"
 
 namespace {
@@ -324,12 +325,177 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_compact(TokText t, const int64
     }
 }
 
+
+// ---- the same in ONE launch: a chained scan (decoupled look-back) -------------------------------------------------------------------
+// The five launches above read the text three times and spend two launches on single-workgroup scans: 180 us per 64 MB chunk, of which
+// the text itself is 25 us at HBM speed.  Here a tile keeps its 32 bytes per thread in registers, publishes its (newlines, token-start
+// state) aggregate, looks back over its predecessors' aggregates / prefixes for the line index and the token-start count at its first
+// byte, marks column 5, publishes its byte count, looks back for its output offset and compacts - the text is read once.  Tiles take
+// their index from a counter (a tile's predecessors have always started), descriptors are single 64-bit words:
+//   a: [63:62] 0 empty / 1 aggregate / 2 inclusive prefix, [61:58] token-start state, [57:0] newlines;   b: [63:62] likewise, [61:0] bytes
+struct TokDesc { unsigned long long a, b; };
+constexpr unsigned long long TD_AGG = 1ull << 62, TD_PFX = 2ull << 62;
+__device__ __forceinline__ unsigned long long td_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void td_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one wave: exclusive prefix of tile `tile` over descriptor word `word` (0: a = state + newlines, 1: b = bytes); every lane returns it
+__device__ __forceinline__ void td_lookback(const TokDesc* desc, long long tile, int word, long long& sum_out, int& st_out)
+{
+    const int lane = threadIdx.x & 63;
+    long long run = 0; int run_st = 0;
+    for (long long base = tile - 1; base >= 0; base -= 64) {
+        const long long j = base - lane;
+        unsigned long long d;
+        for (;;) {
+            d = j >= 0 ? td_load(word ? &desc[j].b : &desc[j].a) : TD_PFX;     // (in front of tile 0: an empty prefix)
+            if (!__any((d >> 62) == 0)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const unsigned long long pm = __ballot((d >> 62) == 2);
+        const int P = pm ? __builtin_ctzll(pm) : 64;                            // the nearest tile that knows its inclusive prefix
+        long long v = lane <= P ? (long long)(d & (word ? ((1ull << 62) - 1) : ((1ull << 58) - 1))) : 0;
+        int st = (!word && lane <= P) ? (int)((d >> 58) & 15) : 0;
+        // lane l holds tile base - l: the window's value is  d[P] o ... o d[1] o d[0]  (earlier tiles on the left)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long ov = __shfl_down(v, o); const int os = __shfl_down(st, o);
+            if (lane + o < 64) { v += ov; st = st_combine(os, st); }
+        }
+        v = __shfl(v, 0); st = __shfl(st, 0);
+        run += v; run_st = st_combine(st, run_st);
+        if (pm) break;
+    }
+    sum_out = run; st_out = run_st;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_tiles, TokDesc* __restrict__ desc, unsigned long long* __restrict__ ws_ctr,
+                                                         const uint8_t* __restrict__ chr_seq, int64_t chr_len, int64_t cap_cols, int64_t cap_bytes,
+                                                         int64_t* __restrict__ pos, uint8_t* __restrict__ ref, int64_t* __restrict__ col_off,
+                                                         uint8_t* __restrict__ bases, int64_t* __restrict__ meta)
+{
+    // ws_ctr: [0] next tile index, [1] tiles finished, [2] status bits, [3] lines, [4] bytes
+    __shared__ int sh[TK_BLOCK / 64][2];
+    __shared__ long long sh_b[4];
+    __shared__ __attribute__((aligned(16))) uint8_t cbuf[TK_TILE + 32];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) sh_b[0] = (long long)atomicAdd(&ws_ctr[0], 1ull);
+    __syncthreads();
+    const long long tile = sh_b[0];
+    const int64_t p0 = tile * TK_TILE + tid * TK_CHUNK;
+    uint32_t w[8];
+    const TokMasks m = tk_load(t, p0, w);
+    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);
+    // ---- newlines and token-start state in front of this tile ----
+    if (wave == 0) {
+        if (tid == 0) td_store(&desc[tile].a, (tile == 0 ? TD_PFX : TD_AGG) | ((unsigned long long)s.st_total << 58) | (unsigned long long)s.v_total);
+        long long nl0 = 0; int st0 = 0;
+        if (tile > 0) {
+            td_lookback(desc, tile, 0, nl0, st0);
+            if (tid == 0) td_store(&desc[tile].a, TD_PFX | ((unsigned long long)st_combine(st0, s.st_total) << 58) | (unsigned long long)(nl0 + s.v_total));
+        }
+        if (tid == 0) { sh_b[1] = nl0; sh_b[2] = st0; }
+    }
+    __syncthreads();
+    const int64_t line0 = sh_b[1] + s.v_excl;
+    int cc = st_combine((int)sh_b[2], s.st_excl) & 7;
+    // ---- the grammar over this chunk's events: column-5 bytes, their starts, the position of every line that starts its token 1 here ----
+    uint32_t ev = m.ts | m.nl, m4 = 0, s4 = 0, err = 0;
+    int prevb = 0;
+    while (ev) {
+        const int b = __ffs(ev) - 1;
+        ev &= ev - 1;
+        if (cc == 5) m4 |= (b ? (0xffffffffu >> (32 - b)) : 0u) & (0xffffffffu << prevb);
+        if ((m.nl >> b) & 1u) {
+            if (cc == 0) err |= TOK_BLANK; else if (cc < 5) err |= TOK_EFORMAT;
+            cc = 0;
+        } else {
+            cc = cc < TK_SAT ? cc + 1 : TK_SAT;
+            if (cc == 5) s4 |= 1u << b;
+            if (cc == 2) {
+                const int64_t line = line0 + __popc(m.nl & ((1u << b) - 1u));
+                const int64_t v = tk_atoll(t, p0 + b);
+                if (line < cap_cols) {
+                    pos[line] = v;
+                    if (ref) {
+                        if (v >= 1 && v <= chr_len) ref[line] = chr_seq[v - 1];
+                        else { ref[line] = 'N'; err |= TOK_EPOS; }
+                    }
+                }
+            }
+        }
+        prevb = b;
+    }
+    if (cc == 5) m4 |= 0xffffffffu << prevb;
+    m4 &= ~m.sep;
+    if (err) atomicOr(&ws_ctr[2], (unsigned long long)err);
+    // ---- column-5 bytes in front of this tile ----
+    const BlockScan sb = tk_block_scan(__popc(m4), 0, sh);
+    const int r0 = sb.v_excl, tile_cnt = sb.v_total;
+    if (wave == 0) {
+        if (tid == 0) td_store(&desc[tile].b, (tile == 0 ? TD_PFX : TD_AGG) | (unsigned long long)tile_cnt);
+        long long b0 = 0; int unused = 0;
+        if (tile > 0) {
+            td_lookback(desc, tile, 1, b0, unused);
+            if (tid == 0) td_store(&desc[tile].b, TD_PFX | (unsigned long long)(b0 + tile_cnt));
+        }
+        if (tid == 0) sh_b[3] = b0;
+    }
+    __syncthreads();
+    const int64_t out0 = sh_b[3];
+    const int mis = (int)(out0 & 15);
+    while (s4) {
+        const int b = __ffs(s4) - 1;
+        s4 &= s4 - 1;
+        const uint32_t below = (1u << b) - 1u;
+        const int64_t line = line0 + __popc(m.nl & below);
+        if (line < cap_cols) col_off[line] = out0 + r0 + __popc(m4 & below);
+    }
+    {
+        uint32_t rest = m4; int r = mis + r0;
+        while (rest) {
+            const int b = __ffs(rest) - 1;
+            rest &= rest - 1;
+            cbuf[r++] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+    __syncthreads();
+    const int span = mis + tile_cnt;
+    uint8_t* __restrict__ gb = bases + (out0 - mis);
+    for (int o = tid * 16; o < span; o += TK_BLOCK * 16) {
+        const bool whole = o >= mis && o + 16 <= span && out0 - mis + o + 16 <= cap_bytes && ((uintptr_t)(gb + o) & 15) == 0;
+        if (whole) *reinterpret_cast<uint4*>(gb + o) = *reinterpret_cast<const uint4*>(cbuf + o);
+        else {
+            for (int k = 0; k < 16; ++k) {
+                const int q = o + k;
+                if (q >= mis && q < span && out0 - mis + q < cap_bytes) gb[q] = cbuf[q];
+            }
+        }
+    }
+    // ---- totals and status: the last tile knows the totals, the tile that finishes last knows that every status bit is in ----
+    if (tid == 0) {
+        if (tile == n_tiles - 1) {
+            td_store(&ws_ctr[3], (unsigned long long)(sh_b[1] + s.v_total));
+            td_store(&ws_ctr[4], (unsigned long long)(out0 + tile_cnt));
+        }
+        __threadfence();
+        const unsigned long long done = atomicAdd(&ws_ctr[1], 1ull);
+        if (done == (unsigned long long)(n_tiles - 1)) {
+            __threadfence();
+            const int64_t n_cols = (int64_t)td_load(&ws_ctr[3]), n_bytes = (int64_t)td_load(&ws_ctr[4]);
+            int64_t status = (int64_t)td_load(&ws_ctr[2]);
+            if (n_cols > cap_cols || n_bytes > cap_bytes) status |= TOK_ERANGE;
+            else col_off[n_cols] = n_bytes;
+            meta[0] = n_cols; meta[1] = n_bytes; meta[2] = status; meta[3] = 0;
+        }
+    }
+}
+
 }  // namespace
 
 // workspace of the tokeniser: grows when a longer text than ever before arrives (synchronous, like the selection scratch)
 static int tok_reserve(nsnp_ctx* ctx, int64_t n_tiles, hipStream_t s)
 {
-    const size_t need = (size_t)n_tiles * (8 + 8 + 4 + 4 * TK_BLOCK) + 64 + 256;
+    const size_t need = (size_t)n_tiles * (8 + 8 + 4 + 4 * TK_BLOCK) + 64 + 256;       // (the one-launch form needs 16 bytes per tile + 64: less)
     if (ctx->tok_ws_bytes >= need) return NSNP_OK;
     NSNP_HIP(ctx, hipStreamSynchronize(s));
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
@@ -369,6 +535,16 @@ extern "C" int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t
     if (text_len == 0) {
         NSNP_HIP(ctx, hipMemsetAsync(meta, 0, 4 * sizeof(int64_t), s));
         NSNP_HIP(ctx, hipMemsetAsync(col_off, 0, sizeof(int64_t), s));
+        return NSNP_OK;
+    }
+    if (ctx->tok_fused) {
+        // one launch: descriptors + counters zeroed in front of it (64 bytes + 16 per tile)
+        unsigned long long* ctr = (unsigned long long*)ws;
+        TokDesc* desc = (TokDesc*)(ws + 64);
+        NSNP_HIP(ctx, hipMemsetAsync(ws, 0, 64 + (size_t)n_tiles * sizeof(TokDesc), s));
+        hipLaunchKernelGGL(k_tok_fused, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (long long)n_tiles, desc, ctr, chr_seq, chr_len, cap_cols, cap_bytes,
+                           pos, ref, col_off, bases, meta);
+        NSNP_HIP(ctx, hipGetLastError());
         return NSNP_OK;
     }
     hipLaunchKernelGGL(k_tok_summary, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, tile_nl, tile_st);

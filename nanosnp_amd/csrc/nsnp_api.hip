@@ -47,6 +47,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->cat_conv_lds = 1;
     ctx->cat_conv_pix2 = 1;
     ctx->hap_b3x = 1;
+    ctx->tok_fused = 1;
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
     ctx->l0_rs = 1;
@@ -99,6 +100,11 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
         ctx->cat_precision = (int)value;
         return NSNP_OK;
     }
+    if (strcmp(name, "tok_fused") == 0) {
+        if (value != 0 && value != 1) return NSNP_EINVAL;
+        ctx->tok_fused = (int)value;
+        return NSNP_OK;
+    }
     if (strcmp(name, "hap_b3x") == 0) {
         if (value != 0 && value != 1) return NSNP_EINVAL;
         ctx->hap_b3x = (int)value;
@@ -117,7 +123,7 @@ extern "C" int nsnp_ctx_set_option(nsnp_ctx* ctx, const char* name, int64_t valu
     if (strcmp(name, "hap_precision") == 0) {
         if (value != 0 && value != 1 && value != 2) return NSNP_EINVAL;
         ctx->hap_precision = (int)value;
-        return NSNP_OK;
+        return nsnp_hap_reserve(ctx);           // (bf16x3 activation images are 1.5 x the fp32 ones: the workspace grows here, synchronously, never in the forward)
     }
     if (strcmp(name, "hap_pass_sites") == 0) {
         if (value < 128 || value > 131072 || value % 128) return NSNP_EINVAL;

@@ -120,12 +120,13 @@ struct nsnp_ctx {
     PileupWeightsF16 pw16;
     PileupWeightsB3 pwb3;
     HapWeightsDev* hw;
-    void*  hap_ws; size_t hap_ws_bytes;
+    void*  hap_ws; size_t hap_ws_bytes; int64_t hap_ws_chunk;     // (the pass size the workspace was made for)
     int64_t hap_chunk;  // sites per pass of the HaplotypeModel forward (option "hap_pass_sites", default 16384)
     CatWeightsDev* cw;
     void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
     void* tok_ws; size_t tok_ws_bytes;        // mpileup tokeniser scratch: tile summaries + one bit per text byte (mpileup_tokenise.hip)
+    int tok_fused;      // mpileup tokeniser: 1 = one launch, chained scan (default), 0 = five launches
     // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
     bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
     bool af2_cached; uint64_t af2_bits, af2_t; int af2_k, af2_mode; uint32_t af2_table_words[128];     // the indel threshold when it differs

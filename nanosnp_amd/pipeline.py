@@ -70,6 +70,26 @@ def line_cuts(text, n_parts, lo=0, hi=None):
     return cuts
 
 
+def ramp_cuts(text, lo, hi, chunk_bytes, first=None, growth=1.5):
+    """offsets cutting text[lo:hi] into chunks of whole lines whose sizes grow from `first` bytes (default chunk_bytes / 16, at least 1 MB) by
+    `growth` per chunk up to chunk_bytes: the pipeline's fill - nothing computes before the first chunk has been staged, copied, tokenised
+    and encoded, and the forward of chunk 0 is issued behind the tokeniser of chunk 2 - costs a sixteenth of what it costs with equal
+    chunks (measured on the 6 M-column contig: 4.0 ms of 18.4 before the first forward starts); growth 1.5 keeps the copy of the next,
+    larger chunk shorter than the compute of the current one (H2D 0.018 ms / MB against 0.029 ms / MB of device work)."""
+    chunk_bytes = max(1, int(chunk_bytes))
+    first = int(first) if first else max(min(chunk_bytes, 1 << 20), chunk_bytes // 16)
+    cuts, size = [lo], float(min(first, chunk_bytes))
+    while cuts[-1] < hi:
+        g = cuts[-1] + int(size)
+        if g >= hi or hi - g < size / 2:             # (what is left is smaller than half a chunk: it joins this one)
+            cuts.append(hi)
+            break
+        nl = text.find(b"\n", max(g - 1, cuts[-1]), hi)
+        cuts.append(hi if nl < 0 else nl + 1)
+        size = min(size * growth, float(chunk_bytes))
+    return cuts
+
+
 def halo_range(text, lo, hi, halo=16):
     """[lo, hi) grown by up to `halo` whole lines on either side -> (lo_ext, hi_ext, lines added in front, lines added behind)"""
     n_txt = len(text)
@@ -115,9 +135,243 @@ class _DevSet:
         self.free = None                               # event on the compute stream: the last kernels reading this set are done
 
 
-def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None, on_rows=None):
+def tokenise_mode(tokenise=None):
+    """where the mpileup text is cut into columns: "device" (default: the raw text crosses PCIe and nsnp_mpileup_tokenise cuts it in HBM; the
+    host only copies the text into pinned memory) or "host" (nsnp_mpileup_parse_into on the host cores; NSNP_TOKENISE=host)"""
+    t = tokenise or os.environ.get("NSNP_TOKENISE", "device")
+    if t not in ("device", "host"):
+        raise ValueError(f"tokenise: 'device' or 'host', not {t!r}")
+    return t
+
+
+def stream_contig(model, text, contig, chr_seq, lo=0, hi=None, chunk_bytes=64 << 20, min_af=0.12, min_coverage=6, stats=None, on_rows=None,
+                  tokenise=None):
     with host.gc_paused():
+        if tokenise_mode(tokenise) == "device":
+            return _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows)
         return _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows)
+
+
+class _TextSet:
+    """one chunk of raw mpileup text in flight: pinned on the host (filled by the staging thread, read by the copy engine) or on the device
+    (filled by the copy stream, read by the tokeniser)"""
+    def __init__(self, cap_bytes, dev=None):
+        import torch
+        self.buf = torch.empty(cap_bytes, dtype=torch.uint8, **(dict(pin_memory=True) if dev is None else dict(device=dev)))
+        self.np = self.buf.numpy() if dev is None else None
+        self.h2d_done = None                           # host set: the copy engine has read it
+        self.free = None                               # device set: the tokeniser has read it
+
+
+class _ColSet:
+    """the columns of one chunk on the device, as nsnp_mpileup_tokenise writes them and the encode reads them.  Sized for any text of
+    cap_bytes (a line is at least 10 bytes, its column 5 shorter than the line): no growth path, nothing to re-run."""
+    def __init__(self, cap_bytes, dev):
+        import torch
+        cc = cap_bytes // 10 + 2
+        self.pos = torch.empty(cc, dtype=torch.int64, device=dev)
+        self.off = torch.empty(cc + 1, dtype=torch.int64, device=dev)
+        self.ref = torch.empty(cc, dtype=torch.uint8, device=dev)
+        self.bases = torch.empty(cap_bytes, dtype=torch.uint8, device=dev)
+
+
+def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows):
+    """stream_contig with the text cut into columns ON THE DEVICE (nsnp_mpileup_tokenise).  The host touches every byte of the text once - a
+    multi-threaded copy of the chunk (whole lines, 16 lines of halo either side, found by a few find / rfind calls) from the page cache
+    into pinned memory - and the chunks are worked off four things at a time:
+
+        worker thread   copies chunks k + 1 and k + 2 into two of three pinned text buffers (libnanosnp_host.so: nsnp_stage_values)
+        copy stream     sends the text of chunk k (two device text buffers: chunk k waits for the tokeniser of chunk k - 2)
+        compute stream  tokenise chunk k -> positions, reference bytes, column-5 strings (three column sets on the device)
+                        encode + select chunk k - 1 (its line count came back through pinned memory while chunk k was being issued)
+                        PileupModel forward + argmax / max of chunk k - 2 (its site count likewise)
+
+    so this thread never waits for work it has just issued, and the device never waits for this thread.  Same rows as the host-parsed
+    path (tests/test_gpu_predict.py); text the reference's reader aborts on is refused with the same errors."""
+    import time
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    ctx = model.ctx
+    dev = torch.device("cuda", ctx.device)
+    finder, arr = _as_bytes_like(text)
+    hi = arr.size if hi is None else hi
+    st = stats if stats is not None else {}
+    for k in ("parse_s", "h2d_s", "gpu_s", "tok_s", "text_bytes", "columns", "chunks", "setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s"):
+        st.setdefault(k, 0.0)
+    st["tokenise"] = "device"
+    t_enter = time.perf_counter()
+    if hi <= lo:
+        return torch.zeros((0, 13), dtype=torch.float64, device=dev)
+    cuts = ramp_cuts(finder, lo, hi, int(chunk_bytes))
+    ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k + 1] > cuts[k]]
+    cap = max(b - a for a, b, _, _ in ranges) + 64
+    hsets = getattr(model, "_text_host_sets", None)
+    n_sets = min(3, len(ranges))
+    if not hsets or min(s_.buf.numel() for s_ in hsets) < cap or len(hsets) < n_sets:
+        hsets = model._text_host_sets = [_TextSet(cap) for _ in range(n_sets)]
+        model._text_dev_sets = None
+    tsets = getattr(model, "_text_dev_sets", None)
+    if not tsets or tsets[0].buf.device != dev or min(t_.buf.numel() for t_ in tsets) < cap or len(tsets) < min(2, len(ranges)):
+        tsets = model._text_dev_sets = [_TextSet(cap, dev) for _ in range(min(2, len(ranges)))]
+        model._col_dev_sets = [_ColSet(cap, dev) for _ in range(n_sets)]
+        model._copy_stream = getattr(model, "_copy_stream", None) or host.copy_stream(dev)
+    csets, copy_stream = model._col_dev_sets, model._copy_stream
+    if len(getattr(model, "_meta_pin", ())) < len(ranges):
+        model._meta_pin = torch.zeros((len(ranges), 4), dtype=torch.int64, pin_memory=True)
+    if len(getattr(model, "_tok_meta_pin", ())) < len(ranges):
+        model._tok_meta_pin = torch.zeros((len(ranges), 4), dtype=torch.int64, pin_memory=True)
+    meta_pin, tok_pin = model._meta_pin, model._tok_meta_pin
+    main = torch.cuda.current_stream(dev)
+    for s_ in hsets:
+        s_.h2d_done = None
+    for t_ in tsets:
+        t_.free = None
+    d_seq = torch.from_numpy(np.ascontiguousarray(chr_seq)).to(dev)
+    cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
+    copy_stream.wait_stream(main)
+
+    trace = st.get("trace")
+
+    def stage(k):
+        t0 = time.perf_counter()
+        a, b, _, _ = ranges[k]
+        host.stage_values(hsets[k % len(hsets)].np, b - a, src=arr, src_off=a, src_dtype=np.uint8)
+        t1 = time.perf_counter()
+        if trace is not None:
+            trace.append(("stage", k, t0, t1))
+        return t1 - t0
+
+    rows_all = []
+    ev0 = torch.cuda.Event(enable_timing=True)
+    if trace is not None:
+        torch.cuda.synchronize(dev); ev0.record(main); torch.cuda.synchronize(dev)
+    t_ev0 = time.perf_counter()
+    st["setup_s"] += time.perf_counter() - t_enter
+    tev = lambda: torch.cuda.Event(enable_timing=True)
+    ev = [dict(h0=tev(), h1=tev(), t0=tev(), t1=tev(), a0=tev(), a1=tev(), b0=tev(), b1=tev()) for _ in ranges]
+
+    def encode_of(tk):
+        """the second third of a chunk: its line count is on the host by now"""
+        k, n_lo, n_hi, cs, tok_done = tk
+        t_w = time.perf_counter()
+        tok_done.synchronize()
+        st["wait_counts_s"] += time.perf_counter() - t_w
+        M, nb, status, _ = tok_pin[k].tolist()
+        if status & ctx.TOK_EFORMAT:
+            raise host.HostError(f"{contig}: malformed input (a line with fewer than five tab-separated fields)")
+        if status & ctx.TOK_BLANK:
+            raise host.HostError(f"{contig}: mpileup text holds empty line(s): malformed input (every line must be one pileup column)")
+        if status & ctx.TOK_EPOS:
+            raise ValueError(f"{contig}: position outside the reference sequence")
+        if status:
+            raise host.HostError(f"{contig}: tokeniser status {status}")
+        own = M - n_lo - n_hi
+        st["columns"] += own
+        ev[k]["a0"].record(main)
+        job = None
+        if own > 0:
+            d_pos = cs.pos[:M]
+            counts, depth, flags = ctx.pileup_encode_columns(cs.bases[:max(nb, 1)], cs.off[:M + 1], cs.ref[:M], min_af, min_coverage)
+            center, n_sel = ctx.pileup_select_sites_async(d_pos, flags)
+            meta = torch.stack([n_sel[0], (center < n_lo).sum(), (center < M - n_hi).sum(), n_sel[0]])
+            meta_pin[k].copy_(meta, non_blocking=True)
+            sel_done = torch.cuda.Event(); sel_done.record(main)
+            job = (k, M, cs, counts, center, sel_done)
+        ev[k]["a1"].record(main)
+        return job
+
+    def calls_of(job):
+        """the last third of a chunk: its site count is on the host by now"""
+        k, M, cs, counts, center, sel_done = job
+        t_w = time.perf_counter()
+        sel_done.synchronize()
+        st["wait_counts_s"] += time.perf_counter() - t_w
+        _, c_lo, c_hi, _ = meta_pin[k].tolist()
+        ev[k]["b0"].record(main)
+        if c_hi > c_lo:
+            centers = center[c_lo:c_hi]
+            gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(counts, centers)
+            cov = counts.index_select(0, centers).index_select(1, cov_idx).to(torch.float64)      # predict.py:63
+            f64 = lambda t: t.to(torch.float64)[:, None]
+            rows_k = torch.cat([f64(cs.pos[:M].index_select(0, centers)), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1)
+            if on_rows is not None:
+                on_rows(rows_k)
+            else:
+                rows_all.append(rows_k)
+        ev[k]["b1"].record(main)
+
+    pending, job = deque(), None
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        futs = [pool.submit(stage, j) for j in range(min(2, len(ranges)))]
+        for k, (a, b, n_lo, n_hi) in enumerate(ranges):
+            t_w = time.perf_counter()
+            t_stage = futs[k].result()
+            t_i = time.perf_counter()
+            st["wait_parse_s"] += t_i - t_w
+            if trace is not None:
+                trace.append(("main: wait stage", k, t_w, t_i))
+            hs, ts, cs = hsets[k % len(hsets)], tsets[k % len(tsets)], csets[k % len(csets)]
+            n = b - a
+            st["parse_s"] += t_stage; st["text_bytes"] += n; st["chunks"] += 1
+            # ---- the text of chunk k on its way: copy stream, behind the tokeniser of chunk k - 2 (the last reader of this text buffer) ----
+            if ts.free is not None:
+                copy_stream.wait_event(ts.free)
+            with torch.cuda.stream(copy_stream):
+                ev[k]["h0"].record(copy_stream)
+                ts.buf[:n].copy_(hs.buf[:n], non_blocking=True)
+                ev[k]["h1"].record(copy_stream)
+            hs.h2d_done = ev[k]["h1"]
+            if k + 2 < len(ranges):
+                nxt = hsets[(k + 2) % len(hsets)]
+                if nxt.h2d_done is not None:
+                    nxt.h2d_done.synchronize()          # the copy engine is done with the buffer the staging thread is about to overwrite
+                futs.append(pool.submit(stage, k + 2))
+            # ---- first third of chunk k on the compute stream: the tokeniser; lines / bytes / status land in pinned memory ----
+            main.wait_event(ev[k]["h1"])
+            ev[k]["t0"].record(main)
+            ctx.mpileup_tokenise_into(ts.buf[:n], d_seq, cs.pos, cs.off, cs.bases, cs.ref, tok_pin[k], stream=main)
+            ev[k]["t1"].record(main)
+            ts.free = ev[k]["t1"]
+            tok_done = torch.cuda.Event(); tok_done.record(main)
+            pending.append((k, n_lo, n_hi, cs, tok_done))
+            # ---- second third of chunk k - 1, last third of chunk k - 2 ----
+            nxt_job = encode_of(pending.popleft()) if len(pending) > 1 else None
+            if job is not None:
+                calls_of(job)
+            job = nxt_job
+            st["issue_s"] += time.perf_counter() - t_i
+            if trace is not None:
+                trace.append(("main: issue", k, t_i, time.perf_counter()))
+        t_i = time.perf_counter()
+        while pending or job is not None:
+            nxt_job = encode_of(pending.popleft()) if pending else None
+            if job is not None:
+                calls_of(job)
+            job = nxt_job
+        st["issue_s"] += time.perf_counter() - t_i
+    t_d = time.perf_counter()
+    torch.cuda.synchronize(dev)
+    st["drain_s"] += time.perf_counter() - t_d
+    if trace is not None:
+        for k, e in enumerate(ev):
+            for what, x0, x1 in (("h2d", "h0", "h1"), ("tokenise", "t0", "t1"), ("encode+select", "a0", "a1"), ("forward+rows", "b0", "b1")):
+                try:
+                    trace.append((what, k, t_ev0 + ev0.elapsed_time(e[x0]) * 1e-3, t_ev0 + ev0.elapsed_time(e[x1]) * 1e-3))
+                except RuntimeError:
+                    pass
+    for e in ev:
+        st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
+        tk = e["t0"].elapsed_time(e["t1"]) * 1e-3
+        st["tok_s"] += tk; st["gpu_s"] += tk
+        for x0, x1 in (("a0", "a1"), ("b0", "b1")):
+            try:
+                st["gpu_s"] += e[x0].elapsed_time(e[x1]) * 1e-3
+            except (RuntimeError, ValueError):
+                pass                                   # (a chunk without columns of its own never recorded its last third)
+    if on_rows is not None:
+        return None
+    return torch.cat(rows_all) if rows_all else torch.zeros((0, 13), dtype=torch.float64, device=dev)
 
 
 def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows):
@@ -382,7 +636,7 @@ def _format_rows(r, contig, chr_seq, batch_size, score_mode, as_view=False, shar
     return (text, n_rows) if shard_dev is None else (text, n_rows, n_total)
 
 
-def _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats):
+def _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats, tokenise=None):
     """call_contig for one process with the rows of finished chunks formatted on a writer thread while later chunks compute: every
     chunk's call rows travel to a pinned buffer of their own behind the chunk's forward; the writer formats the COMPLETE batches of
     `batch_size` sites that have arrived (the reference's rows depend on the batch a site falls into: predict.py:102-125) with a
@@ -429,7 +683,7 @@ def _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_c
             events.append(ev); sizes.append(n)
             futs.append(writer.submit(work, k))
 
-        stream_contig(model, mpileup_text, contig, chr_seq, 0, None, chunk_bytes, min_af, min_coverage, stats, on_rows=on_rows)
+        stream_contig(model, mpileup_text, contig, chr_seq, 0, None, chunk_bytes, min_af, min_coverage, stats, on_rows=on_rows, tokenise=tokenise)
         t0 = time.perf_counter()
         for f in futs:
             f.result()
@@ -446,9 +700,9 @@ def _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_c
 
 
 def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.12, min_coverage=6,
-                batch_size=1000, score_mode=host.SCORE_FLOAT64, chunk_bytes=64 << 20, stats=None, rows_beside=None):
+                batch_size=1000, score_mode=host.SCORE_FLOAT64, chunk_bytes=64 << 20, stats=None, rows_beside=None, tokenise=None):
     """One contig: returns (vcf_rows: bytes-like - a memoryview of the formatter's buffer, no copy; bytes(...) it to keep it -, n_sites, n_rows).  model: pileup_model.LSTMNetwork; mpileup_text: bytes, mmap or a
-    numpy uint8 array holding the contig's samtools-mpileup text.
+    numpy uint8 array holding the contig's samtools-mpileup text.  tokenise: "device" (default) / "host" (tokenise_mode).
 
     The text is worked off in chunks of whole lines (stream_contig: parse of chunk k + 1 on the host beside the device work of
     chunk k).  Under an initialised torch.distributed process group (one process per GPU, torchrun) the TEXT is statically sharded:
@@ -467,9 +721,9 @@ def call_contig(model, mpileup_text, contig: str, chr_seq: np.ndarray, min_af=0.
     if rows_beside is None:
         rows_beside = os.environ.get("NSNP_ROWS_BESIDE", "0") == "1"
     if rows_beside and not sharded:
-        return _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats)
+        return _call_contig_rows_beside(model, mpileup_text, contig, chr_seq, min_af, min_coverage, batch_size, score_mode, chunk_bytes, stats, tokenise)
     cuts = line_cuts(finder, world, 0, arr.size)
-    rows = stream_contig(model, mpileup_text, contig, chr_seq, cuts[rank], cuts[rank + 1], chunk_bytes, min_af, min_coverage, stats)
+    rows = stream_contig(model, mpileup_text, contig, chr_seq, cuts[rank], cuts[rank + 1], chunk_bytes, min_af, min_coverage, stats, tokenise=tokenise)
     if sharded:
         # every rank formats ITS rows (on its own host cores, exactly as the single process would format them: _format_rows), the text
         # - about 60 B per row, half of what the calls take - travels to rank 0 in one rooted gather

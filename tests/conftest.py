@@ -33,3 +33,11 @@ def gpu_ctx():
 def pileup_weights():
     from tests.helpers import load_pileup_weights
     return load_pileup_weights()
+
+
+@pytest.fixture(params=["device", "host"])
+def tok_mode(request, monkeypatch):
+    """the text pipelines with the mpileup text cut into columns on the device (nsnp_mpileup_tokenise, the default) and on the host cores
+    (nsnp_mpileup_parse_into): both must give the same bytes"""
+    monkeypatch.setenv("NSNP_TOKENISE", request.param)
+    return request.param

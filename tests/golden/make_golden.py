@@ -229,6 +229,48 @@ def group_encode():
 
 
 # ------------------------------------------------------------------------------------------
+def group_encode_reader():
+    """encode_rdr.*: the corner cases of the reference's READER on otherwise ordinary columns - runs of tabs and a leading / trailing tab
+    (split_line collapses them: cpp_aux.cpp:43-59), "\\r\\n" line ends (line_reader.cpp:95-127), a missing quality column and extra columns
+    (only tokens 0, 1, 4 are read: main.cpp:162-172), positions atoll reads through (white space, a sign, leading zeros, trailing junk),
+    another name in column 0 (the program's contig argument names the output), a last line without its newline.  The device tokeniser
+    (mpileup_tokenise.hip), the host one (nsnp_textio.c) and the oracle's reader must all give the tensors the reference wrote."""
+    from nanosnp_amd import host
+    M = 5000
+    cols = host.synth_columns(20260006, M, coverage=25, het_rate=0.1)
+    rng = np.random.default_rng(11)
+    seq = np.concatenate([cols.ref, np.frombuffer(b"ACGT" * 25, np.uint8)]).copy()
+    seq[rng.random(seq.size) < 0.04] |= 0x20
+    lines = cols.mpileup_text("chrR").split(b"\n")[:-1]
+    out = []
+    for i, l in enumerate(lines):
+        f = l.split(b"\t")
+        u = rng.random()
+        if u < 0.04: f[1] = b"+000" + f[1] + b"xyz"
+        elif u < 0.07: f[1] = b"  " + f[1]
+        elif u < 0.09: f[1] = b"0" + f[1] + b" 7"
+        elif u < 0.11: f[0] = b"some_other_name"
+        l = b"\t".join(f)
+        u = rng.random()
+        if u < 0.05: l = l.replace(b"\t", b"\t\t\t", int(rng.integers(1, 6)))
+        elif u < 0.08: l = b"\t" + l + b"\t"
+        elif u < 0.12: l = b"\t".join(f[:5])
+        elif u < 0.20: l = l + b"\r"
+        elif u < 0.23: l = l + b"\textra\tcolumns"
+        elif u < 0.25: l = b"\t".join(f[:5]) + b"\r"
+        out.append(l)
+    text = b"\n".join(out)                              # (no newline behind the last line)
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "ref.fa")
+        host.write_fasta(fa, "chrR", seq)
+        pd = run_ref_encode(d, "chrR", fa, text)
+        fa_bytes = open(fa, "rb").read()
+    for name, data in (("encode_rdr.mpileup.gz", text), ("encode_rdr.fa.gz", fa_bytes), ("encode_rdr.pd.gz", pd)):
+        with gzip.GzipFile(os.path.join(GOLD, name), "wb", mtime=0) as f:
+            f.write(data)
+    print(f"encode_rdr: {text.count(10) + 1} columns -> {pd.count(10)} sites")
+
+
 def group_pileup():
     import torch
     import yaml
@@ -822,7 +864,7 @@ def group_cat_large():
     print("cat_fwd_large: argmax histogram", np.bincount(gt.argmax(1), minlength=10), "max p %.3f .. %.3f" % (gt.max(1).min(), gt.max(1).max()))
 
 
-GROUPS = {"haparrange": group_haparrange, "twostage": group_twostage, "twostage_s2": group_twostage_s2, "next": group_next, "vcf": group_vcf, "encode": group_encode, "pileup": group_pileup, "pileup_ckpts": group_pileup_ckpts, "hapfeat": group_hapfeat,
+GROUPS = {"haparrange": group_haparrange, "twostage": group_twostage, "twostage_s2": group_twostage_s2, "next": group_next, "vcf": group_vcf, "encode": group_encode, "encode_reader": group_encode_reader, "pileup": group_pileup, "pileup_ckpts": group_pileup_ckpts, "hapfeat": group_hapfeat,
           "hapfwd": group_hapfwd, "cat": group_cat, "hapfwd_large": group_hapfwd_large, "cat_large": group_cat_large}
 
 if __name__ == "__main__":

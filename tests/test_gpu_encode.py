@@ -20,17 +20,24 @@ def _enc(ctx, bases, col_off, ref, **kw):
     return c, d, f
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos"])
-def test_reference_fixture_end_to_end(gpu_ctx, tag):
-    """mpileup text -> encode -> select -> gather == the tensors the reference programs wrote"""
+@pytest.mark.parametrize("reader", ["device", "host"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos", "rdr"])
+def test_reference_fixture_end_to_end(gpu_ctx, tag, reader):
+    """mpileup text -> tokenise -> encode -> select -> gather == the tensors the reference programs wrote from the same text; the text
+    cut into columns by the device tokeniser (nsnp_mpileup_tokenise) or by the host one (nsnp_mpileup_parse)"""
     import torch
     text = gzip.open(golden(f"encode_{tag}.mpileup.gz")).read()
     fa = gzip.open(golden(f"encode_{tag}.fa.gz")).read()
     pd = gzip.open(golden(f"encode_{tag}.pd.gz")).read()
     seq = np.frombuffer(b"".join(fa.split(b"\n")[1:]), np.uint8)
     pos, col_off, bases = host.mpileup_parse(text)
-    ref = seq[pos - 1]
-    c, d, f = _enc(gpu_ctx, bases, col_off, ref)
+    if reader == "device":
+        dpos, doff, dbases, dref = gpu_ctx.mpileup_tokenise(torch.from_numpy(np.frombuffer(text, np.uint8).copy()).cuda(), torch.from_numpy(seq.copy()).cuda())
+        assert np.array_equal(dpos.cpu().numpy(), pos) and np.array_equal(doff.cpu().numpy(), col_off) and np.array_equal(dbases.cpu().numpy(), bases)
+        c, d, f = gpu_ctx.pileup_encode_columns(dbases, doff, dref)
+    else:
+        ref = seq[pos - 1]
+        c, d, f = _enc(gpu_ctx, bases, col_off, ref)
     centers, n = gpu_ctx.pileup_select_sites(torch.from_numpy(pos).cuda(), f)
     x = gpu_ctx.pileup_gather_windows(c, centers)
     gx, names, gpos, gref = host.pd_parse(pd)

@@ -78,7 +78,7 @@ def test_haplotype_csv_end_to_end(tmp_path, gpu_ctx):
     assert out8.read_bytes() == out.read_bytes()
 
 
-def test_mpileup_to_vcf_pipeline(tmp_path, pileup_weights):
+def test_mpileup_to_vcf_pipeline(tmp_path, pileup_weights, tok_mode):
     """s1+s2 in one pass: mpileup text + FASTA -> VCF, against the rows the reference's predict() wrote
     for the same contig's sites (golden pileup_vcf.npz holds the chrS sites first, batch 1000)."""
     import gzip
@@ -128,7 +128,7 @@ def test_mpileup_to_vcf_pipeline(tmp_path, pileup_weights):
         assert qual_reachable(float(wf[5]), zy_gpu[j].max(), gt_gpu[j].max(), refcall=gf[6] == "RefCall", score_mode=host.SCORE_FLOAT64), (g, w)
 
 
-def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_weights):
+def test_streamed_pipeline_is_independent_of_the_chunk_size(tmp_path, pileup_weights, tok_mode):
     """pipeline.call_contig works the text off in chunks of whole lines (parse of chunk k + 1 on the host beside the device work of
     chunk k, 16 lines of halo re-parsed): the VCF is byte-identical whatever the chunk size - one chunk, a few, or chunks shorter
     than a window - on a contig with position gaps and lower-case / N reference bases (encode_g1) and on a 40 k-column G1 contig"""
@@ -196,7 +196,7 @@ def test_rows_unpack_writes_device_and_pinned_outputs(gpu_ctx):
         gpu_ctx.pileup_rows_unpack(r, (good[0][:3],) + good[1:])
 
 
-def test_a_run_over_several_contigs_writes_each_contigs_rows_in_order(tmp_path, pileup_weights):
+def test_a_run_over_several_contigs_writes_each_contigs_rows_in_order(tmp_path, pileup_weights, tok_mode):
     """pipeline.call_variants / call_contigs: the rows of contig c are formatted and written on a writer thread (own stream) while contig
     c + 1 streams - the file is the header + the rows call_contig gives for every contig on its own, in order; an empty contig and a
     contig without a site among them; per batch size"""
@@ -233,7 +233,7 @@ def test_a_run_over_several_contigs_writes_each_contigs_rows_in_order(tmp_path, 
         assert call_contigs(m, [], f) == (0, 0)
 
 
-def test_streamed_pipeline_edge_inputs(pileup_weights):
+def test_streamed_pipeline_edge_inputs(pileup_weights, tok_mode):
     """call_contig on the inputs a real run meets at its edges: no text, one line, fewer columns than a window, a last line without
     its newline, CRLF line ends, a chunk size below one line (every line its own chunk), and the same contig again on the same model
     after a larger one (the pinned / device buffer sets kept on the model are re-used): always the rows of the one-chunk run"""
@@ -267,7 +267,7 @@ def test_streamed_pipeline_edge_inputs(pileup_weights):
         call_contig(m, text, "chrE", seq[:100])                     # positions beyond the reference sequence
 
 
-def test_streamed_pipeline_refuses_blank_lines_and_grows_its_column_buffers(pileup_weights):
+def test_streamed_pipeline_refuses_blank_lines_and_grows_its_column_buffers(pileup_weights, tok_mode):
     """(a) the pipeline's halo bookkeeping takes one line = one column: an empty line (which the tolerant parser steps over) near a
     chunk cut would shift the chunk's own range - the text is refused (the reference aborts on such a line); (b) the pinned / device
     column buffers are budgeted at 24 text bytes per line and grow when a chunk holds more, shorter lines: a shallow contig of 19-byte

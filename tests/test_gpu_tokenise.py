@@ -10,10 +10,13 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[1, 0], ids=["one_launch", "five_launches"])
+def ctx(request):
+    """both forms of the tokeniser: the chained scan in one launch (default) and the five-launch statement of the same grammar"""
     from nanosnp_amd import _lib
-    return _lib.Context(0)
+    c = _lib.Context(0)
+    c.set_option("tok_fused", request.param)
+    return c
 
 
 def _dev(a):
@@ -141,3 +144,16 @@ def test_capacity_is_respected(ctx):
         assert (pos[cap:] == -7).all() and (off[cap + 1:] == -7).all() and (bases[cap_b:] == 255).all()
         if not status:
             assert off[:cap + 1].tolist() == list(range(0, 12001, 4)) and bytes(bases[:cap_b].cpu().numpy()) == b"ACGT" * 3000
+
+
+def test_many_tiles_and_repeated_calls(ctx):
+    """a text of ~3,000 tiles (the chained scan's look-back windows span several rounds of 64 descriptors), tokenised repeatedly into the
+    same buffers (descriptors and counters are re-armed by every call): always the oracle's columns"""
+    import torch
+    cols = host.synth_columns(20260001, 280_000, coverage=30)
+    text = np.frombuffer(bytes(cols.mpileup_text_native("chrS")), np.uint8)
+    opos, ooff, obases = oracle.mpileup_tokenise(text)
+    d = _dev(text)
+    for _ in range(4):
+        pos, off, bases, _ = ctx.mpileup_tokenise(d)
+        assert np.array_equal(pos.cpu().numpy(), opos) and np.array_equal(off.cpu().numpy(), ooff) and np.array_equal(bases.cpu().numpy(), obases)

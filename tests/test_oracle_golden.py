@@ -21,7 +21,7 @@ def _load_encode_fixture(tag):
     return text, seq, pd
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos", "rdr"])
 def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
     text, seq, pd = _load_encode_fixture(tag)
     mp = tmp_path / "x.mpileup"
@@ -31,11 +31,13 @@ def test_mpileup_to_pd_is_byte_identical_to_the_reference_output(tag, tmp_path):
     assert (tmp_path / "o.pd").read_bytes() == pd
 
 
-@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos"])
+@pytest.mark.parametrize("tag", ["g1", "adv", "end", "cut", "pos", "rdr"])
 def test_array_path_matches_the_reference_tensors(tag):
     """encode_columns -> select_sites -> gather_windows == the [N,33,18] matrices in the .pd"""
     text, seq, pd = _load_encode_fixture(tag)
-    pos, col_off, bases = host.mpileup_parse(text)
+    pos, col_off, bases = oracle.mpileup_tokenise(text)           # the oracle's restatement of the reference's reader ...
+    hpos, hoff, hbases = host.mpileup_parse(text)                 # ... and the host library's tokeniser: the same columns
+    assert np.array_equal(hpos, pos) and np.array_equal(hoff, col_off) and np.array_equal(hbases, bases)
     ref = np.frombuffer(seq, np.uint8)[pos - 1]
     counts, depth, flags = oracle.encode_columns(bases, col_off, ref)
     centers = oracle.select_sites(pos, flags)

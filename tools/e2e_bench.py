@@ -41,7 +41,7 @@ def run(args, rank, world, local_rank, emit=None):
     from nanosnp_amd import host
     from nanosnp_amd.fixtures import load_pileup_weights
     from nanosnp_amd.pileup_model import LSTMNetwork
-    from nanosnp_amd.pipeline import call_contig, call_contigs
+    from nanosnp_amd.pipeline import call_contig, call_contigs, tokenise_mode
     from tools import bench_common as bc
     if world > 1 and emit is None:                      # (embedded in the default bench line: the process group exists already)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -178,6 +178,38 @@ def run(args, rank, world, local_rank, emit=None):
                                                                  "decimal - except sites whose two largest probabilities tie within the arithmetic's ~1e-6 (counted; at most 1 in "
                                                                  "20,000 rows); the probabilities themselves: the bf16x3 parity samples of the pileup line"}}
 
+    # ---- labelled second value: the same text cut into columns on the HOST cores (nsnp_mpileup_parse_into), the path of rounds 1-5 ----
+    mode = tokenise_mode()
+    host_parsed = None
+    if mode == "device" and not getattr(args, "no_host_parsed", False):
+        os.environ["NSNP_TOKENISE"] = "host"
+        try:
+            run(min(2, K))
+            torch.cuda.synchronize(dev)
+            bc.settle_collector()
+            if world > 1:
+                dist.barrier()
+            st3 = {}
+            t0 = time.perf_counter()
+            n_sites3, n_rows3 = run(K, st3)
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            dt3 = time.perf_counter() - t0
+            rows3 = rows_of_first_contig(K) if rank == 0 else b""
+        finally:
+            os.environ["NSNP_TOKENISE"] = "device"
+        if world > 1:
+            tm = torch.tensor([dt3], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt3 = float(tm.item())
+        if rank == 0:
+            per3 = {k: st3.get(k, 0.0) / K for k in ("parse_s", "h2d_s", "gpu_s", "vcf_s")}
+            host_parsed = {"value": n_sites3 * K / dt3, "unit": "sites/s", "ms_per_step": dt3 / K * 1e3,
+                           "stage_busy_s_per_step": {k: round(v, 4) for k, v in per3.items()}, "bound_by": max(per3, key=per3.get),
+                           "vcf_equals_the_device_tokenised_run": bool(bytes(rows3) == bytes(rows_text) and n_sites3 == n_sites),
+                           "what": "NSNP_TOKENISE=host: nsnp_mpileup_parse_into on the host cores writes pos / col_off / bases into pinned memory, those cross PCIe"}
+
     exit_code = 0
     if rank == 0:
         # parity: the chunked run against the one-chunk run of the same text, byte for byte (outside the clock)
@@ -189,8 +221,20 @@ def run(args, rank, world, local_rank, emit=None):
                               "(nanosnp_amd.pipeline.call_contig; against the reference's own rows: tests/test_gpu_predict.py)"}
         per = {k: stats.get(k, 0.0) / K for k in ("parse_s", "h2d_s", "gpu_s", "vcf_s")}
         bound = max(per, key=per.get)
-        names = {"parse_s": "host parse (nsnp_mpileup_parse_into, OpenMP)", "h2d_s": "H2D copies", "gpu_s": "device: encode + select + forward + calls",
+        dev_tok = stats.get("tokenise") == "device"
+        names = {"parse_s": "host: text into pinned memory (nsnp_stage_values, OpenMP)" if dev_tok else "host parse (nsnp_mpileup_parse_into, OpenMP)",
+                 "h2d_s": "H2D copies", "gpu_s": ("device: tokenise + " if dev_tok else "device: ") + "encode + select + forward + calls",
                  "vcf_s": "D2H + VCF formatting (nsnp_vcf_format_batches)"}
+        h2d_bytes = text_bytes if dev_tok else int(cols.col_off[-1]) + 16 * n_cols
+        # the tokeniser against HBM: algorithmic bytes = the text read once + what it writes (column-5 bytes, position 8 + offset 8 + reference
+        # byte 1 per line); its five launches read the text three times, so HBM traffic is ~2.6x this figure
+        tok = None
+        if dev_tok and stats.get("tok_s"):
+            chunks_per_step = stats.get("chunks", 0) / K
+            alg = stats.get("text_bytes", 0) / K * (1 + int(cols.col_off[-1]) / text_bytes) + 17 * (stats.get("columns", 0) / K)
+            tok = bc.roofline_hbm("mpileup_tokenise (5 launches)", alg / max(chunks_per_step, 1), stats["tok_s"] / K / max(chunks_per_step, 1) * 1e3,
+                                  int(stats.get("chunks", 0)), how="HIP events around the five launches of every chunk on the compute stream, inside the timed run "
+                                  "(other streams' copies run beside them)", chunk_bytes=chunk, text_bytes_per_step=stats.get("text_bytes", 0) / K)
         cols_per_pass = stats.get("columns", 0) / K * (world if world > 1 else 1)
         out = {
             "metric": "candidate SNP sites/sec, mpileup text to VCF (text on the page cache, parse + H2D + encode + forward + VCF)",
@@ -206,21 +250,24 @@ def run(args, rank, world, local_rank, emit=None):
             "columns_per_s": n_cols * K / dt, "text_MB_per_s": text_bytes * K / dt / 1e6,
             "stage_busy_s_per_step": {names[k]: round(v, 4) for k, v in per.items()},
             "stage_rates": {"parse_MB_per_s": text_bytes / world / max(per["parse_s"], 1e-9) / 1e6,
-                            "h2d_GB_per_s": (int(cols.col_off[-1]) + 16 * n_cols) / world / max(per["h2d_s"], 1e-9) / 1e9,
+                            "h2d_GB_per_s": h2d_bytes / world / max(per["h2d_s"], 1e-9) / 1e9,
                             "device_columns_per_s": n_cols / world / max(per["gpu_s"], 1e-9),
                             "vcf_rows_per_s": n_rows / max(per["vcf_s"], 1e-9)},
             "bound_by": names[bound],
             "overlap": {"sum_of_stage_busy_s": round(sum(per.values()), 4), "wall_s_per_step": round(dt / K, 4),
-                        "note": "three things at a time: the worker thread parses chunk k + 1 / k + 2, the copy stream sends chunk k, the compute "
-                                "stream runs encode + select of chunk k and the forward of chunk k - 1 (site counts are read one chunk late: no host "
-                                "round trip in the loop); wall < sum when they overlap.  main_thread_s_per_step: where the issuing thread spends the step "
-                                "(issue_s includes wait_counts_s)"},
+                        "note": "several things at a time: the worker thread stages (or parses) chunk k + 1 / k + 2, the copy stream sends chunk k, the "
+                                "compute stream tokenises chunk k, encodes + selects chunk k - 1 and runs the forward of chunk k - 2 (line and site counts are "
+                                "read one chunk late: no host round trip in the loop); wall < sum when they overlap.  main_thread_s_per_step: where the "
+                                "issuing thread spends the step (issue_s includes wait_counts_s)"},
             "main_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("setup_s", "wait_parse_s", "issue_s", "wait_counts_s", "drain_s", "wait_rows_s")},
             "writer_thread_s_per_step": {k: round(stats.get(k, 0.0) / K, 4) for k in ("vcf_s", "write_s")},
             "host_cpu_over_the_timed_region": host_cpu, "torch_allocator_over_the_timed_region": allocator,
             "step": "one contig of a run of `steps` contigs (pipeline.call_contigs: the rows of contig c are formatted and written on a writer thread "
                     "while contig c + 1 streams); ms_per_step = the run / steps",
+            "tokenise": stats.get("tokenise", "host"), "tokenise_s_per_step": round(stats.get("tok_s", 0.0) / K, 5),
+            "bytes_over_pcie_per_column": h2d_bytes / n_cols, "roofline_tokenise": tok,
             **({"bf16x3": second} if second else {}),
+            **({"host_parsed": host_parsed} if host_parsed else {}),
             **({"per_rank_s_per_step": per_rank} if per_rank else {}),
             "usable_cores": bc.usable_cores(), "roofline": None, "parity_sample": parity, "timed_region_s": dt,
             "cpu_baseline": None,
@@ -231,6 +278,9 @@ def run(args, rank, world, local_rank, emit=None):
             emit(out)
         else:
             bc.emit_line(out, "e2e")
+        if host_parsed and parity is not None:
+            parity["vcf_equals_the_host_parsed_run"] = host_parsed["vcf_equals_the_device_tokenised_run"]
+            parity["ok"] = bool(parity["ok"] and host_parsed["vcf_equals_the_device_tokenised_run"])
         if (parity is not None and not parity["ok"]) or (second and not second["parity_sample"]["ok"]):
             print("bench.py: parity_sample FAILED: " + json.dumps([parity, second and second["parity_sample"]]), file=sys.stderr)
             exit_code = 1

@@ -24,8 +24,10 @@ call_contig(model, text, "chr20s", cols.ref, chunk_bytes=chunk, stats=st)
 t1 = time.perf_counter()
 base = min(x[2] for x in st["trace"])
 print(f"pass {1e3 * (t1 - t0):.2f} ms; first traced event at {1e3 * (base - t0):.2f} ms")
-for what in ("parse", "h2d", "encode+select", "forward+rows", "main: wait parse", "main: issue"):
+for what in ("parse", "stage", "h2d", "tokenise", "encode+select", "forward+rows", "main: wait parse", "main: wait stage", "main: issue"):
     rows = sorted((x for x in st["trace"] if x[0] == what), key=lambda x: x[1])
+    if not rows:
+        continue
     print(f"{what:<18s}" + "  ".join(f"{k}:{1e3 * (a - base):6.2f}-{1e3 * (b - base):6.2f}" for _, k, a, b in rows))
 print({k: round(v, 4) for k, v in st.items() if k != "trace" and isinstance(v, float)})
 os.remove(path)

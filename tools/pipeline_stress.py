@@ -51,9 +51,17 @@ for r in range(rounds):
         got = call_contig(m, text, "chrA", seq, chunk_bytes=cb)
         if not (bytes(got[0]) == bytes(want[0]) and got[1:] == want[1:]):
             bad += 1; print("round", r, "chunk", cb, "DIFFERS from the one-chunk run")
+    # the text cut into columns on the host cores (nsnp_mpileup_parse_into) instead of on the device (nsnp_mpileup_tokenise): the same bytes
+    for cb in (1 << 40, len(text) // 5):
+        got = call_contig(m, text, "chrA", seq, chunk_bytes=cb, tokenise="host")
+        if not (bytes(got[0]) == bytes(want[0]) and got[1:] == want[1:]):
+            bad += 1; print("round", r, "chunk", cb, "host-parsed run DIFFERS from the device-tokenised one")
     # the one-chunk rows against the oracle chain
     rows = stream_contig(m, text, "chrA", seq, chunk_bytes=1 << 40).cpu().numpy()
-    ppos, poff, pbases = host.mpileup_parse(text)
+    ppos, poff, pbases = oracle.mpileup_tokenise(text)            # the oracle's restatement of the reference's reader
+    hp = host.mpileup_parse(text)
+    if not (np.array_equal(hp[0], ppos) and np.array_equal(hp[1], poff) and np.array_equal(hp[2], pbases)):
+        bad += 1; print("round", r, "the host tokeniser differs from the oracle's reader")
     oc, od, of = oracle.encode_columns(pbases, poff, seq[ppos - 1])
     centers = oracle.select_sites(ppos, of)
     if not (len(centers) == rows.shape[0] and np.array_equal(ppos[centers], rows[:, 0].astype(np.int64))):
