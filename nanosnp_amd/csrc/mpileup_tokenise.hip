@@ -176,19 +176,26 @@ __global__ __launch_bounds__(1024) void k_tok_scan(int64_t* __restrict__ tile_nl
 
 enum { TOK_EFORMAT = NSNP_TOK_EFORMAT, TOK_BLANK = NSNP_TOK_BLANK, TOK_EPOS = NSNP_TOK_EPOS, TOK_ERANGE = NSNP_TOK_ERANGE };
 
-// atoll on the token that starts at p (main.cpp:165): white space, one sign, digits; never beyond the token's end
-__device__ __forceinline__ int64_t tk_atoll(const TokText& t, int64_t p)
+// atoll on the token that starts at p (main.cpp:165): white space, one sign, digits; never beyond the token's end.  The bytes of the
+// tile itself come from its copy in LDS (txt: the 8 KB the workgroup loaded, virtual bytes included) - a lane walks its digits one
+// dependent read at a time, and from global memory that walk was most of the kernel's time (74 of 180 us per 64 MB) -; a token that
+// runs beyond the tile continues in global memory.
+__device__ __forceinline__ int64_t tk_atoll(const TokText& t, const uint8_t* txt, int64_t tile0, int64_t p)
 {
-    auto ends = [&](int64_t q, int ch) {
-        return q >= t.hi || ch == '\t' || ch == '\n' || (ch == '\r' && tk_byte(t, q + 1) == '\n');
-    };
-    int ch = tk_byte(t, p);
-    while (!ends(p, ch) && (ch == ' ' || ch == '\r' || ch == '\v' || ch == '\f')) ch = tk_byte(t, ++p);
+    auto rd = [&](int64_t q) -> int { const int64_t o = q - tile0; return (o >= 0 && o < TK_TILE) ? (int)txt[o] : tk_byte(t, q); };
+    auto ends = [&](int64_t q, int ch) { return ch == '\t' || ch == '\n' || (ch == '\r' && rd(q + 1) == '\n'); };
+    int ch = rd(p);
+    while (!ends(p, ch) && (ch == ' ' || ch == '\r' || ch == '\v' || ch == '\f')) ch = rd(++p);
     bool neg = false;
-    if (!ends(p, ch) && (ch == '-' || ch == '+')) { neg = ch == '-'; ch = tk_byte(t, ++p); }
+    if (!ends(p, ch) && (ch == '-' || ch == '+')) { neg = ch == '-'; ch = rd(++p); }
     uint64_t v = 0;
-    while (!ends(p, ch) && ch >= '0' && ch <= '9') { v = v * 10u + (uint64_t)(ch - '0'); ch = tk_byte(t, ++p); }
+    while (ch >= '0' && ch <= '9') { v = v * 10u + (uint64_t)(ch - '0'); ch = rd(++p); }
     return neg ? (int64_t)(0ull - v) : (int64_t)v;
+}
+__device__ __forceinline__ void tk_stage_text(uint8_t* txt, const uint32_t (&w)[8])
+{
+    uint4* d = reinterpret_cast<uint4*>(txt + threadIdx.x * TK_CHUNK);
+    d[0] = uint4{w[0], w[1], w[2], w[3]}; d[1] = uint4{w[4], w[5], w[6], w[7]};
 }
 
 __global__ __launch_bounds__(TK_BLOCK) void k_tok_lines(TokText t, const int64_t* __restrict__ tile_nl, const int32_t* __restrict__ tile_st,
@@ -198,10 +205,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_lines(TokText t, const int64_t
                                                          int64_t* __restrict__ ws_meta)
 {
     __shared__ int sh[TK_BLOCK / 64][2];
+    __shared__ __attribute__((aligned(16))) uint8_t txt[TK_TILE];
     const int64_t p0 = (int64_t)blockIdx.x * TK_TILE + threadIdx.x * TK_CHUNK;
     uint32_t w[8];
     const TokMasks m = tk_load(t, p0, w);
-    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);
+    tk_stage_text(txt, w);
+    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);      // (its barriers publish txt)
     int cc = st_combine(tile_st[blockIdx.x], s.st_excl) & 7;       // token starts since the last newline in front of this chunk
     const int64_t line0 = tile_nl[blockIdx.x] + s.v_excl;          // newlines in front of this chunk = index of the line it starts in
     uint32_t ev = m.ts | m.nl, m4 = 0, err = 0;
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_lines(TokText t, const int64_t
             cc = cc < TK_SAT ? cc + 1 : TK_SAT;
             if (cc == 2) {
                 const int64_t line = line0 + __popc(m.nl & ((1u << b) - 1u));
-                const int64_t v = tk_atoll(t, p0 + b);
+                const int64_t v = tk_atoll(t, txt, (int64_t)blockIdx.x * TK_TILE, p0 + b);
                 if (line < cap_cols) {
                     pos[line] = v;
                     if (ref) {
@@ -330,9 +339,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_compact(TokText t, const int64
 // The five launches above read the text three times and spend two launches on single-workgroup scans: 180 us per 64 MB chunk, of which
 // the text itself is 25 us at HBM speed.  Here a tile keeps its 32 bytes per thread in registers, publishes its (newlines, token-start
 // state) aggregate, looks back over its predecessors' aggregates / prefixes for the line index and the token-start count at its first
-// byte, marks column 5, publishes its byte count, looks back for its output offset and compacts - the text is read once.  Tiles take
-// their index from a counter (a tile's predecessors have always started), descriptors are single 64-bit words:
-//   a: [63:62] 0 empty / 1 aggregate / 2 inclusive prefix, [61:58] token-start state, [57:0] newlines;   b: [63:62] likewise, [61:0] bytes
+// byte, marks column 5, publishes its byte count, looks back for its output offset and compacts - the text is read once.
+// Descriptors are single 64-bit words:
+//   a: [63:62] 0 empty / 1 aggregate / 2 inclusive prefix, [61:58] token-start state, [57:0] newlines;
+//   b: [63:62] likewise, [61:58] status bits met so far (OR), [57:0] column-5 bytes
+// Tiles are taken in blockIdx order (workgroups are dispatched in that order, so a tile's predecessors have always started); the last
+// tile's inclusive prefixes are the totals and the status of the whole text: no counter, no atomic read-modify-write anywhere.
 struct TokDesc { unsigned long long a, b; };
 constexpr unsigned long long TD_AGG = 1ull << 62, TD_PFX = 2ull << 62;
 __device__ __forceinline__ unsigned long long td_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -353,37 +365,36 @@ __device__ __forceinline__ void td_lookback(const TokDesc* desc, long long tile,
         }
         const unsigned long long pm = __ballot((d >> 62) == 2);
         const int P = pm ? __builtin_ctzll(pm) : 64;                            // the nearest tile that knows its inclusive prefix
-        long long v = lane <= P ? (long long)(d & (word ? ((1ull << 62) - 1) : ((1ull << 58) - 1))) : 0;
-        int st = (!word && lane <= P) ? (int)((d >> 58) & 15) : 0;
+        long long v = lane <= P ? (long long)(d & ((1ull << 58) - 1)) : 0;
+        int st = lane <= P ? (int)((d >> 58) & 15) : 0;          // word 0: token-start state (st_combine); word 1: status bits (OR)
         // lane l holds tile base - l: the window's value is  d[P] o ... o d[1] o d[0]  (earlier tiles on the left)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const long long ov = __shfl_down(v, o); const int os = __shfl_down(st, o);
-            if (lane + o < 64) { v += ov; st = st_combine(os, st); }
+            if (lane + o < 64) { v += ov; st = word ? (os | st) : st_combine(os, st); }
         }
         v = __shfl(v, 0); st = __shfl(st, 0);
-        run += v; run_st = st_combine(st, run_st);
+        run += v; run_st = word ? (st | run_st) : st_combine(st, run_st);
         if (pm) break;
     }
     sum_out = run; st_out = run_st;
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_tiles, TokDesc* __restrict__ desc, unsigned long long* __restrict__ ws_ctr,
+__global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_tiles, TokDesc* __restrict__ desc,
                                                          const uint8_t* __restrict__ chr_seq, int64_t chr_len, int64_t cap_cols, int64_t cap_bytes,
                                                          int64_t* __restrict__ pos, uint8_t* __restrict__ ref, int64_t* __restrict__ col_off,
                                                          uint8_t* __restrict__ bases, int64_t* __restrict__ meta)
 {
-    // ws_ctr: [0] next tile index, [1] tiles finished, [2] status bits, [3] lines, [4] bytes
     __shared__ int sh[TK_BLOCK / 64][2];
     __shared__ long long sh_b[4];
+    __shared__ int sh_err[TK_BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint8_t cbuf[TK_TILE + 32];
     const int tid = threadIdx.x, wave = tid >> 6;
-    if (tid == 0) sh_b[0] = (long long)atomicAdd(&ws_ctr[0], 1ull);
-    __syncthreads();
-    const long long tile = sh_b[0];
+    const long long tile = blockIdx.x;
     const int64_t p0 = tile * TK_TILE + tid * TK_CHUNK;
     uint32_t w[8];
     const TokMasks m = tk_load(t, p0, w);
+    tk_stage_text(cbuf, w);                          // the tile's bytes for tk_atoll (cbuf is free until the compaction: two barriers further down)
     const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);
     // ---- newlines and token-start state in front of this tile ----
     if (wave == 0) {
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_t
             if (cc == 5) s4 |= 1u << b;
             if (cc == 2) {
                 const int64_t line = line0 + __popc(m.nl & ((1u << b) - 1u));
-                const int64_t v = tk_atoll(t, p0 + b);
+                const int64_t v = tk_atoll(t, cbuf, tile * TK_TILE, p0 + b);
                 if (line < cap_cols) {
                     pos[line] = v;
                     if (ref) {
@@ -427,18 +438,24 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_t
     }
     if (cc == 5) m4 |= 0xffffffffu << prevb;
     m4 &= ~m.sep;
-    if (err) atomicOr(&ws_ctr[2], (unsigned long long)err);
-    // ---- column-5 bytes in front of this tile ----
-    const BlockScan sb = tk_block_scan(__popc(m4), 0, sh);
+    // ---- column-5 bytes in front of this tile; the status bits of the tile ride along ----
+    {
+        int e = (int)err;
+        for (int o = 32; o > 0; o >>= 1) e |= __shfl_xor(e, o);
+        if ((tid & 63) == 0) sh_err[wave] = e;
+    }
+    const BlockScan sb = tk_block_scan(__popc(m4), 0, sh);             // (its barriers publish sh_err)
     const int r0 = sb.v_excl, tile_cnt = sb.v_total;
     if (wave == 0) {
-        if (tid == 0) td_store(&desc[tile].b, (tile == 0 ? TD_PFX : TD_AGG) | (unsigned long long)tile_cnt);
-        long long b0 = 0; int unused = 0;
+        int terr = 0;
+        for (int k = 0; k < TK_BLOCK / 64; ++k) terr |= sh_err[k];
+        if (tid == 0) td_store(&desc[tile].b, (tile == 0 ? TD_PFX : TD_AGG) | ((unsigned long long)terr << 58) | (unsigned long long)tile_cnt);
+        long long b0 = 0; int perr = 0;
         if (tile > 0) {
-            td_lookback(desc, tile, 1, b0, unused);
-            if (tid == 0) td_store(&desc[tile].b, TD_PFX | (unsigned long long)(b0 + tile_cnt));
+            td_lookback(desc, tile, 1, b0, perr);
+            if (tid == 0) td_store(&desc[tile].b, TD_PFX | ((unsigned long long)(perr | terr) << 58) | (unsigned long long)(b0 + tile_cnt));
         }
-        if (tid == 0) sh_b[3] = b0;
+        if (tid == 0) { sh_b[3] = b0; sh_b[0] = perr | terr; }
     }
     __syncthreads();
     const int64_t out0 = sh_b[3];
@@ -471,22 +488,13 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_t
             }
         }
     }
-    // ---- totals and status: the last tile knows the totals, the tile that finishes last knows that every status bit is in ----
-    if (tid == 0) {
-        if (tile == n_tiles - 1) {
-            td_store(&ws_ctr[3], (unsigned long long)(sh_b[1] + s.v_total));
-            td_store(&ws_ctr[4], (unsigned long long)(out0 + tile_cnt));
-        }
-        __threadfence();
-        const unsigned long long done = atomicAdd(&ws_ctr[1], 1ull);
-        if (done == (unsigned long long)(n_tiles - 1)) {
-            __threadfence();
-            const int64_t n_cols = (int64_t)td_load(&ws_ctr[3]), n_bytes = (int64_t)td_load(&ws_ctr[4]);
-            int64_t status = (int64_t)td_load(&ws_ctr[2]);
-            if (n_cols > cap_cols || n_bytes > cap_bytes) status |= TOK_ERANGE;
-            else col_off[n_cols] = n_bytes;
-            meta[0] = n_cols; meta[1] = n_bytes; meta[2] = status; meta[3] = 0;
-        }
+    // ---- the last tile's inclusive prefixes are the totals and the status of the whole text ----
+    if (tid == 0 && tile == n_tiles - 1) {
+        const int64_t n_cols = sh_b[1] + s.v_total, n_bytes = out0 + tile_cnt;
+        int64_t status = sh_b[0];
+        if (n_cols > cap_cols || n_bytes > cap_bytes) status |= TOK_ERANGE;
+        else col_off[n_cols] = n_bytes;
+        meta[0] = n_cols; meta[1] = n_bytes; meta[2] = status; meta[3] = 0;
     }
 }
 
@@ -538,11 +546,10 @@ extern "C" int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t
         return NSNP_OK;
     }
     if (ctx->tok_fused) {
-        // one launch: descriptors + counters zeroed in front of it (64 bytes + 16 per tile)
-        unsigned long long* ctr = (unsigned long long*)ws;
+        // one launch: its descriptors (16 bytes per tile) zeroed in front of it
         TokDesc* desc = (TokDesc*)(ws + 64);
-        NSNP_HIP(ctx, hipMemsetAsync(ws, 0, 64 + (size_t)n_tiles * sizeof(TokDesc), s));
-        hipLaunchKernelGGL(k_tok_fused, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (long long)n_tiles, desc, ctr, chr_seq, chr_len, cap_cols, cap_bytes,
+        NSNP_HIP(ctx, hipMemsetAsync(desc, 0, (size_t)n_tiles * sizeof(TokDesc), s));
+        hipLaunchKernelGGL(k_tok_fused, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (long long)n_tiles, desc, chr_seq, chr_len, cap_cols, cap_bytes,
                            pos, ref, col_off, bases, meta);
         NSNP_HIP(ctx, hipGetLastError());
         return NSNP_OK;

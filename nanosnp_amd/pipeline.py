@@ -77,14 +77,17 @@ def ramp_cuts(text, lo, hi, chunk_bytes, first=None, growth=1.5):
     chunks (measured on the 6 M-column contig: 4.0 ms of 18.4 before the first forward starts); growth 1.5 keeps the copy of the next,
     larger chunk shorter than the compute of the current one (H2D 0.018 ms / MB against 0.029 ms / MB of device work)."""
     chunk_bytes = max(1, int(chunk_bytes))
+    if not first and os.environ.get("NSNP_RAMP_FIRST_MB"):           # (A/B measurements)
+        first = int(float(os.environ["NSNP_RAMP_FIRST_MB"]) * (1 << 20))
     first = int(first) if first else max(min(chunk_bytes, 1 << 20), chunk_bytes // 16)
-    cuts, size = [lo], float(min(first, chunk_bytes))
+    cuts, size, target = [lo], float(min(first, chunk_bytes)), float(lo)
     while cuts[-1] < hi:
-        g = cuts[-1] + int(size)
+        target += size                               # (targets accumulate: the chunks average `size` bytes however long the lines are)
+        g = max(int(target), cuts[-1] + 1)
         if g >= hi or hi - g < size / 2:             # (what is left is smaller than half a chunk: it joins this one)
             cuts.append(hi)
             break
-        nl = text.find(b"\n", max(g - 1, cuts[-1]), hi)
+        nl = text.find(b"\n", g - 1, hi)
         cuts.append(hi if nl < 0 else nl + 1)
         size = min(size * growth, float(chunk_bytes))
     return cuts
@@ -175,7 +178,7 @@ class _ColSet:
         self.bases = torch.empty(cap_bytes, dtype=torch.uint8, device=dev)
 
 
-def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows):
+def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows, defer=False):
     """stream_contig with the text cut into columns ON THE DEVICE (nsnp_mpileup_tokenise).  The host touches every byte of the text once - a
     multi-threaded copy of the chunk (whole lines, 16 lines of halo either side, found by a few find / rfind calls) from the page cache
     into pinned memory - and the chunks are worked off four things at a time:
@@ -187,7 +190,10 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
                         PileupModel forward + argmax / max of chunk k - 2 (its site count likewise)
 
     so this thread never waits for work it has just issued, and the device never waits for this thread.  Same rows as the host-parsed
-    path (tests/test_gpu_predict.py); text the reference's reader aborts on is refused with the same errors."""
+    path (tests/test_gpu_predict.py); text the reference's reader aborts on is refused with the same errors.
+    defer=True (call_contigs): returns (rows, done, finalize) as soon as the last chunk is ISSUED - `done` is an event behind the last kernel,
+    finalize() waits for it and adds the per-stage times to stats - so that the next contig's text is staged, copied and tokenised while
+    this one's last forward (1.4 ms of a 6 M-column contig's 15) still runs; the buffer sets carry their events from call to call."""
     import time
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
@@ -202,7 +208,8 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
     st["tokenise"] = "device"
     t_enter = time.perf_counter()
     if hi <= lo:
-        return torch.zeros((0, 13), dtype=torch.float64, device=dev)
+        empty = torch.zeros((0, 13), dtype=torch.float64, device=dev)
+        return (empty, None, lambda: None) if defer else empty
     cuts = ramp_cuts(finder, lo, hi, int(chunk_bytes))
     ranges = [halo_range(finder, cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k + 1] > cuts[k]]
     cap = max(b - a for a, b, _, _ in ranges) + 64
@@ -223,13 +230,30 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
         model._tok_meta_pin = torch.zeros((len(ranges), 4), dtype=torch.int64, pin_memory=True)
     meta_pin, tok_pin = model._meta_pin, model._tok_meta_pin
     main = torch.cuda.current_stream(dev)
-    for s_ in hsets:
-        s_.h2d_done = None
-    for t_ in tsets:
-        t_.free = None
-    d_seq = torch.from_numpy(np.ascontiguousarray(chr_seq)).to(dev)
-    cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
-    copy_stream.wait_stream(main)
+    # (the sets keep their events from the previous call: a pinned buffer is rewritten only behind the copy that read it, a device text buffer
+    # behind the tokeniser that read it - whichever call issued those; the column sets are written and read on the compute stream alone)
+    # the reference sequence: through a pinned buffer on the copy stream (a copy from pageable memory on the compute stream would wait for
+    # everything queued there - the previous contig's last forward - and stall this thread for as long)
+    n_seq = int(chr_seq.size)
+    sp = getattr(model, "_seq_pin", None)
+    if sp is None or sp.numel() < n_seq:
+        sp = model._seq_pin = torch.empty(max(n_seq + n_seq // 8, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        model._seq_pin_free = None
+    if getattr(model, "_seq_pin_free", None) is not None:
+        model._seq_pin_free.synchronize()              # (the previous contig's sequence has left the pinned buffer)
+    sp.numpy()[:n_seq] = np.ascontiguousarray(chr_seq)
+    with torch.cuda.stream(copy_stream):               # (allocated as the copy stream's memory: a block the compute stream has just freed may
+        d_seq = torch.empty(max(n_seq, 1), dtype=torch.uint8, device=dev)[:n_seq]      # still be read by work queued there)
+        d_seq.copy_(sp[:n_seq], non_blocking=True)
+        model._seq_pin_free = torch.cuda.Event(); model._seq_pin_free.record(copy_stream)
+    d_seq.record_stream(main)
+    main.wait_event(model._seq_pin_free)
+    cov_idx = getattr(model, "_cov_idx", None)
+    if cov_idx is None or cov_idx.device != dev:
+        cov_idx = model._cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
+    if getattr(model, "_stream_main", None) is not main:
+        copy_stream.wait_stream(main)                  # (another compute stream than last time: its queued work may still read the device sets)
+        model._stream_main = main
 
     trace = st.get("trace")
 
@@ -350,28 +374,35 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
                 calls_of(job)
             job = nxt_job
         st["issue_s"] += time.perf_counter() - t_i
-    t_d = time.perf_counter()
-    torch.cuda.synchronize(dev)
-    st["drain_s"] += time.perf_counter() - t_d
-    if trace is not None:
-        for k, e in enumerate(ev):
-            for what, x0, x1 in (("h2d", "h0", "h1"), ("tokenise", "t0", "t1"), ("encode+select", "a0", "a1"), ("forward+rows", "b0", "b1")):
+    rows = None if on_rows is not None else (torch.cat(rows_all) if rows_all else torch.zeros((0, 13), dtype=torch.float64, device=dev))
+    done = torch.cuda.Event(); done.record(main)
+
+    def finalize():
+        t_d = time.perf_counter()
+        done.synchronize()
+        copy_stream.synchronize()
+        st["drain_s"] += time.perf_counter() - t_d
+        if trace is not None:
+            for k, e in enumerate(ev):
+                for what, x0, x1 in (("h2d", "h0", "h1"), ("tokenise", "t0", "t1"), ("encode+select", "a0", "a1"), ("forward+rows", "b0", "b1")):
+                    try:
+                        trace.append((what, k, t_ev0 + ev0.elapsed_time(e[x0]) * 1e-3, t_ev0 + ev0.elapsed_time(e[x1]) * 1e-3))
+                    except (RuntimeError, ValueError):
+                        pass
+        for e in ev:
+            st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
+            tk = e["t0"].elapsed_time(e["t1"]) * 1e-3
+            st["tok_s"] += tk; st["gpu_s"] += tk
+            for x0, x1 in (("a0", "a1"), ("b0", "b1")):
                 try:
-                    trace.append((what, k, t_ev0 + ev0.elapsed_time(e[x0]) * 1e-3, t_ev0 + ev0.elapsed_time(e[x1]) * 1e-3))
-                except RuntimeError:
-                    pass
-    for e in ev:
-        st["h2d_s"] += e["h0"].elapsed_time(e["h1"]) * 1e-3
-        tk = e["t0"].elapsed_time(e["t1"]) * 1e-3
-        st["tok_s"] += tk; st["gpu_s"] += tk
-        for x0, x1 in (("a0", "a1"), ("b0", "b1")):
-            try:
-                st["gpu_s"] += e[x0].elapsed_time(e[x1]) * 1e-3
-            except (RuntimeError, ValueError):
-                pass                                   # (a chunk without columns of its own never recorded its last third)
-    if on_rows is not None:
-        return None
-    return torch.cat(rows_all) if rows_all else torch.zeros((0, 13), dtype=torch.float64, device=dev)
+                    st["gpu_s"] += e[x0].elapsed_time(e[x1]) * 1e-3
+                except (RuntimeError, ValueError):
+                    pass                               # (a chunk without columns of its own never recorded its last third)
+
+    if defer:
+        return rows, done, finalize
+    finalize()
+    return rows
 
 
 def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, min_coverage, stats, on_rows):
@@ -788,9 +819,11 @@ def call_contigs(model, items, out, min_af=0.12, min_coverage=6, batch_size=1000
     wctx = model._rows_ctx
     few = max(1, host.lib().nsnp_host_threads() // 4)
 
-    def finish(rows, name, seq, last):
+    def finish(rows, name, seq, last, done=None):
+        if done is not None:
+            done.synchronize()                              # (the contig's last kernels: its stream call returned when they were issued)
         t0 = time.perf_counter()
-        with torch.cuda.stream(side):                       # (stream_contig returned behind a device synchronize: the rows are complete)
+        with torch.cuda.stream(side):                       # (the rows are complete: behind `done`, or behind stream_contig's own synchronize)
             text, nr = _format_rows(rows, name, seq, batch_size, score_mode, as_view=True, nthreads=0 if last else few, ctx=wctx)
         t1 = time.perf_counter()
         if out is not None:
@@ -802,19 +835,31 @@ def call_contigs(model, items, out, min_af=0.12, min_coverage=6, batch_size=1000
     it = iter(items)
     nxt = next(it, None)
     pending = deque()
+    on_device = tokenise_mode() == "device"
+    finals = []
     with host.gc_paused(), ThreadPoolExecutor(max_workers=1) as writer:
-        while nxt is not None:
-            name, text, seq = nxt
-            rows = stream_contig(model, text, name, seq, 0, None, chunk_bytes, min_af, min_coverage, stats)
-            nxt = next(it, None)
-            n_sites += int(rows.shape[0])
-            st["sites"] = st.get("sites", 0) + int(rows.shape[0])
-            if rows.shape[0]:
-                pending.append(writer.submit(finish, rows, name, seq, nxt is None))
-            while len(pending) > 1 or (nxt is None and pending):          # at most one contig's rows behind the streaming one
-                t_w = time.perf_counter()
-                n_rows += pending.popleft().result()
-                st["wait_rows_s"] = st.get("wait_rows_s", 0.0) + time.perf_counter() - t_w
+        try:
+            while nxt is not None:
+                name, text, seq = nxt
+                done = None
+                if on_device:
+                    # returns when the contig's last chunk is issued: the next contig's text is on its way while this one's tail computes
+                    rows, done, fin = _stream_contig_dev(model, text, name, seq, 0, None, chunk_bytes, min_af, min_coverage, stats, None, defer=True)
+                    finals.append(fin)
+                else:
+                    rows = stream_contig(model, text, name, seq, 0, None, chunk_bytes, min_af, min_coverage, stats)
+                nxt = next(it, None)
+                n_sites += int(rows.shape[0])
+                st["sites"] = st.get("sites", 0) + int(rows.shape[0])
+                if rows.shape[0]:
+                    pending.append(writer.submit(finish, rows, name, seq, nxt is None, done))
+                while len(pending) > 1 or (nxt is None and pending):          # at most one contig's rows behind the streaming one
+                    t_w = time.perf_counter()
+                    n_rows += pending.popleft().result()
+                    st["wait_rows_s"] = st.get("wait_rows_s", 0.0) + time.perf_counter() - t_w
+        finally:
+            for fin in finals:                                                 # (per-stage times of the deferred contigs; waits for their last kernels)
+                fin()
     st["vcf_rows"] = st.get("vcf_rows", 0) + n_rows
     return n_sites, n_rows
 

@@ -372,3 +372,29 @@ def emit_line(full, tag=None, file=None):
     if path:
         print(f"bench.py: full result object -> {path}", file=sys.stderr, flush=True)
     print(dump_compact(compact_line(full, path)), file=file or sys.stdout, flush=True)
+
+
+# ---- marking the timed region for a rocprofv3 trace of the same run -------------------------------------------------------------------
+def clocks_ns():
+    """host clocks a tracer may stamp its records with (rocprofv3 writes nanoseconds of ONE of them; tools/summarize_pipeline_trace.py finds
+    out which by looking where the traced kernels fall)"""
+    import time
+    out = {}
+    for name in ("CLOCK_MONOTONIC", "CLOCK_BOOTTIME", "CLOCK_REALTIME", "CLOCK_MONOTONIC_RAW"):
+        c = getattr(time, name, None)
+        if c is not None:
+            try:
+                out[name] = time.clock_gettime_ns(c)
+            except OSError:
+                pass
+    return out
+
+
+def mark_region(begin, end, steps, extra=None):
+    """NSNP_TRACE_MARK=<path>: the clocks at both ends of the (first) timed region of a host-fed pipeline run + its steps -> that JSON file, so
+    that a kernel / memory-copy trace of the same process can be cut to the region the line's numbers come from"""
+    path = os.environ.get("NSNP_TRACE_MARK")
+    if not path or os.path.exists(path):
+        return
+    with open(path, "w") as f:
+        json.dump({"begin": begin, "end": end, "steps": steps, **(extra or {})}, f)

@@ -102,6 +102,7 @@ def run(args, rank, world, local_rank, emit=None):
     if world > 1:
         dist.barrier()
     stats = {}
+    clk0 = bc.clocks_ns()
     t0 = time.perf_counter()
     ms0 = torch.cuda.memory_stats(dev)
     cg0 = bc.cgroup_cpu_stat()
@@ -110,6 +111,7 @@ def run(args, rank, world, local_rank, emit=None):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    bc.mark_region(clk0, bc.clocks_ns(), K, {"workload": "e2e", "stats": {k: v for k, v in stats.items() if isinstance(v, (int, float))}})
     rows_text = rows_of_first_contig(K) if rank == 0 else b""
     cg1 = bc.cgroup_cpu_stat()
     ms1 = torch.cuda.memory_stats(dev)

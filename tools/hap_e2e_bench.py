@@ -205,12 +205,14 @@ def _run(args, rank, world, local_rank, emit, created):
             predict_haplotype_bins(ctx, [path], ref, out_path, pass_sites=pass_sites, narrow=narrow)
         torch.cuda.synchronize(dev); bc.settle_collector(); barrier()
         st = {}
+        clk0 = bc.clocks_ns()
         t0 = time.perf_counter()
         # the K steps = K files of one run (a directory of bins): ONE pipeline over all of them, as predict_dev.py's loop over
         # os.listdir is one run; the csv rows of file k are formatted and written while file k + 1 computes
         predict_haplotype_bins(ctx, [path] * steps, ref, out_path, pass_sites=pass_sites, narrow=narrow, stats=st)
         torch.cuda.synchronize(dev); barrier()
         dt = time.perf_counter() - t0
+        bc.mark_region(clk0, bc.clocks_ns(), steps, {"workload": "hap_e2e", "stats": {k: v for k, v in st.items() if isinstance(v, (int, float))}})   # (the first timed run only)
         if world > 1:
             tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
