@@ -11,20 +11,23 @@
 // Here the raw text crosses PCIe as it is and the device cuts it.
 //
 // The grammar of a line is sequential only through TWO small pieces of state: how many tokens have started since the last newline
-// (saturating at 7; token 1 = position, token 4 = bases) and how many newlines came before (the line's column index).  Both are
-// prefix "sums" under an associative operator, so the text is cut into 8 KB tiles (256 threads x 32 bytes) and processed in five
-// launches, every one a coalesced scan of the text or of an array an eighth of its size or smaller:
-//   k_tok_summary   per tile: newlines, token-start state                      (reads the text once)
-//   k_tok_scan      one workgroup: exclusive scan of the tile summaries
-//   k_tok_lines     per tile: every byte's token index -> bit mask of the bytes inside a token 4 (one bit per byte, to a bitmap),
-//                   bytes per tile; the thread that meets the start of a token 1 converts it (atoll) and writes pos / ref of its line;
-//                   lines the reference could not read (fewer than five tokens, empty) raise status bits      (reads the text again)
-//   k_tok_scan2     one workgroup: exclusive scan of the bytes per tile; totals and status -> meta
-//   k_tok_compact   per tile: the token-4 bytes compacted through LDS into `bases` with 16-byte stores, col_off of the columns that
-//                   start in the tile                                                       (reads the text a third time, + the bitmap)
-// Algorithmic bytes per text byte: 3 reads + 1/8 bitmap write + 1/8 read, ~0.37 written as bases: ~3.6 B per text byte.  No line-length
-// limit, no slow path: a line may span any number of tiles.  This five-launch form is the plain statement of the algorithm (option
-// "tok_fused" 0); the default is k_tok_fused below - the same grammar as ONE launch that reads the text once.
+// (saturating at 7; token 1 = position, token 4 = bases) and how many newlines came before (the line's column index).  The first is
+// LOCAL: a tile (8 KB: 256 threads x 32 bytes) finds it in the text just in front of itself (the 2 KB before it hold a newline unless a
+// line is longer than that; then it looks further back).  The second and the output offset are prefix sums over the tiles.  Three
+// launches, every one a coalesced scan, no workgroup ever waits for another:
+//   k_tok_count   per tile: byte-class masks (SWAR compares on the 32 bytes a thread loaded), the token index of every byte through a
+//                 workgroup scan of the token-start state, the bytes inside a token 4; -> newlines and column-5 bytes of the tile;
+//                 lines the reference could not read (fewer than five tokens, empty) raise status bits          (reads the text once)
+//   k_tok_scan    one workgroup: exclusive scans of both counts over the tiles; totals and status -> meta
+//   k_tok_emit    per tile again, now knowing the line index and output offset of its first byte: the thread that meets the start of a
+//                 token 1 converts it (atoll, digits read from the tile's copy in LDS) and writes pos / ref of its line, col_off of the
+//                 tokens 4 that start here, their bytes compacted through LDS into `bases` with 16-byte stores  (reads the text again)
+// (+ a one-thread launch that folds "position outside the reference", which only launch 3 can see, into meta.)  Algorithmic bytes: the
+// text once + what is written (column-5 bytes, 17 bytes per line); the kernels read the text twice (+ 2 KB per tile for the local state).
+// No line-length limit, no slow path.  k_tok_fused below is the same grammar as ONE launch (a chained scan; option "tok_fused" 1): with
+// the chip to itself it is no faster than this form, and its tiles spin on their predecessors' descriptors - when four processes shared
+// one GPU (tools/host_scaling.sh) a contig's tokenising took 40 s instead of 1.4 ms.  A kernel whose progress depends on how the device
+// is shared is not a default.
 #include "nsnp_common.hpp"
 
 namespace {
@@ -133,45 +136,31 @@ __device__ __forceinline__ BlockScan tk_block_scan(int v, int st, int (*sh)[2]) 
     return r;
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_tok_summary(TokText t, int64_t* __restrict__ tile_nl, int32_t* __restrict__ tile_st)
+// exclusive prefix of one value per thread over a workgroup of 1024 threads (16 waves): wave shuffles, one exchange through LDS.
+// v: a sum; st: the token-start state operator (pass 0 where it is not needed).  Returns the exclusive prefixes and the totals.
+struct WgScan { long long v_excl, v_total; int st_excl, st_total; };
+__device__ __forceinline__ WgScan tk_wg_scan1024(long long v, int st, long long* sh_v, int* sh_s)      // sh_v[16], sh_s[16]
 {
-    __shared__ int sh[TK_BLOCK / 64][2];
-    const int64_t p0 = (int64_t)blockIdx.x * TK_TILE + threadIdx.x * TK_CHUNK;
-    uint32_t w[8];
-    const TokMasks m = tk_load(t, p0, w);
-    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);
-    if (threadIdx.x == 0) { tile_nl[blockIdx.x] = s.v_total; tile_st[blockIdx.x] = s.st_total; }
-}
-
-// one workgroup: tile_nl -> newlines in front of every tile (in place), tile_st -> token starts since the last newline in front of
-// every tile (in place); the number of lines -> ws_meta[0]; the status word ws_meta[2] starts at zero
-__global__ __launch_bounds__(1024) void k_tok_scan(int64_t* __restrict__ tile_nl, int32_t* __restrict__ tile_st, int64_t n_tiles,
-                                                    int64_t* __restrict__ ws_meta)
-{
-    __shared__ int64_t part[1024];
-    __shared__ int pst[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = NSNP_CDIV(n_tiles, 1024);
-    const int64_t b0 = tid * per, b1 = (b0 + per < n_tiles) ? b0 + per : n_tiles;
-    int64_t s = 0; int st = 0;
-    for (int64_t b = b0; b < b1; ++b) { s += tile_nl[b]; st = st_combine(st, tile_st[b]); }
-    part[tid] = s; pst[tid] = st;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long vi = v; int si = st;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long pv = __shfl_up(vi, o); const int ps = __shfl_up(si, o);
+        if (lane >= o) { vi += pv; si = st_combine(ps, si); }
+    }
+    if (lane == 63) { sh_v[wave] = vi; sh_s[wave] = si; }
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int64_t v = tid >= o ? part[tid - o] : 0;
-        const int q = tid >= o ? pst[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v; pst[tid] = st_combine(q, pst[tid]);
-        __syncthreads();
+    long long vb = 0, vt = 0; int sb = 0, stt = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k == wave) { vb = vt; sb = stt; }
+        vt += sh_v[k]; stt = st_combine(stt, sh_s[k]);
     }
-    int64_t run = tid ? part[tid - 1] : 0;
-    int rst = tid ? pst[tid - 1] : 0;
-    for (int64_t b = b0; b < b1; ++b) {
-        const int64_t v = tile_nl[b]; const int q = tile_st[b];
-        tile_nl[b] = run; tile_st[b] = rst & 7;
-        run += v; rst = st_combine(rst, q);
-    }
-    if (tid == 1023) { ws_meta[0] = part[1023]; ws_meta[2] = 0; }
+    long long ve = __shfl_up(vi, 1); int se = __shfl_up(si, 1);
+    if (lane == 0) { ve = 0; se = 0; }
+    WgScan r;
+    r.v_excl = vb + ve; r.st_excl = st_combine(sb, se); r.v_total = vt; r.st_total = stt;
+    __syncthreads();
+    return r;
 }
 
 enum { TOK_EFORMAT = NSNP_TOK_EFORMAT, TOK_BLANK = NSNP_TOK_BLANK, TOK_EPOS = NSNP_TOK_EPOS, TOK_ERANGE = NSNP_TOK_ERANGE };
@@ -198,22 +187,31 @@ __device__ __forceinline__ void tk_stage_text(uint8_t* txt, const uint32_t (&w)[
     d[0] = uint4{w[0], w[1], w[2], w[3]}; d[1] = uint4{w[4], w[5], w[6], w[7]};
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_tok_lines(TokText t, const int64_t* __restrict__ tile_nl, const int32_t* __restrict__ tile_st,
-                                                         const uint8_t* __restrict__ chr_seq, int64_t chr_len, int64_t cap_cols,
-                                                         int64_t* __restrict__ pos, uint8_t* __restrict__ ref,
-                                                         uint32_t* __restrict__ bitmap, int64_t* __restrict__ tile_bytes,
-                                                         int64_t* __restrict__ ws_meta)
+
+// token starts since the last newline in front of tile0, found in the text itself: the 2 KB in front of the tile (64 lanes x 32 bytes), and
+// further back only when they hold no newline (a line longer than 2 KB).  One whole wave calls this; every lane returns the count.
+__device__ __forceinline__ int tk_local_carry(const TokText& t, int64_t tile0)
 {
-    __shared__ int sh[TK_BLOCK / 64][2];
-    __shared__ __attribute__((aligned(16))) uint8_t txt[TK_TILE];
-    const int64_t p0 = (int64_t)blockIdx.x * TK_TILE + threadIdx.x * TK_CHUNK;
-    uint32_t w[8];
-    const TokMasks m = tk_load(t, p0, w);
-    tk_stage_text(txt, w);
-    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);      // (its barriers publish txt)
-    int cc = st_combine(tile_st[blockIdx.x], s.st_excl) & 7;       // token starts since the last newline in front of this chunk
-    const int64_t line0 = tile_nl[blockIdx.x] + s.v_excl;          // newlines in front of this chunk = index of the line it starts in
-    uint32_t ev = m.ts | m.nl, m4 = 0, err = 0;
+    const int lane = threadIdx.x & 63;
+    int run = 0;
+    for (int64_t end = tile0; end > t.lo; end -= 64 * TK_CHUNK) {
+        uint32_t w[8];
+        const TokMasks m = tk_load(t, end - 64 * TK_CHUNK + lane * TK_CHUNK, w);
+        int si = st_of(m);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int ps = __shfl_up(si, o); if (lane >= o) si = st_combine(ps, si); }
+        run = st_combine(__shfl(si, 63), run);                   // (the window lies in front of what has been seen so far)
+        if (run & 8) break;
+    }
+    return run & 7;
+}
+
+// the grammar over one chunk's events, given the token starts since the last newline in front of it: bit masks of the bytes inside a
+// token 4 (m4), of the starts of tokens 4 (s4) and 1 (s2), status bits of the lines that end here
+struct TokEvents { uint32_t m4, s4, s2, err; };
+__device__ __forceinline__ TokEvents tk_events(const TokMasks& m, int cc)
+{
+    uint32_t ev = m.ts | m.nl, m4 = 0, s4 = 0, s2 = 0, err = 0;
     int prevb = 0;
     while (ev) {
         const int b = __ffs(ev) - 1;
@@ -224,97 +222,125 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_lines(TokText t, const int64_t
             cc = 0;
         } else {
             cc = cc < TK_SAT ? cc + 1 : TK_SAT;
-            if (cc == 2) {
-                const int64_t line = line0 + __popc(m.nl & ((1u << b) - 1u));
-                const int64_t v = tk_atoll(t, txt, (int64_t)blockIdx.x * TK_TILE, p0 + b);
-                if (line < cap_cols) {
-                    pos[line] = v;
-                    if (ref) {
-                        if (v >= 1 && v <= chr_len) ref[line] = chr_seq[v - 1];
-                        else { ref[line] = 'N'; err |= TOK_EPOS; }
-                    }
-                }
-            }
+            if (cc == 5) s4 |= 1u << b;
+            if (cc == 2) s2 |= 1u << b;
         }
         prevb = b;
     }
     if (cc == 5) m4 |= 0xffffffffu << prevb;
-    m4 &= ~m.sep;
-    bitmap[(int64_t)blockIdx.x * TK_BLOCK + threadIdx.x] = m4;
-    if (err) atomicOr(reinterpret_cast<unsigned long long*>(ws_meta + 2), (unsigned long long)err);
-    // bytes of this tile that belong to a token 4
-    int n = __popc(m4);
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][0] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) { int64_t tot = 0; for (int k = 0; k < TK_BLOCK / 64; ++k) tot += sh[k][0]; tile_bytes[blockIdx.x] = tot; }
+    return TokEvents{m4 & ~m.sep, s4, s2, err};
 }
 
-// one workgroup: tile_bytes -> token-4 bytes in front of every tile (in place); totals and status -> meta (any device-visible memory)
-__global__ __launch_bounds__(1024) void k_tok_scan2(int64_t* __restrict__ tile_bytes, int64_t n_tiles, int64_t* __restrict__ ws_meta,
-                                                     int64_t cap_cols, int64_t cap_bytes, int64_t* __restrict__ col_off,
-                                                     int64_t* __restrict__ meta)
-{
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = NSNP_CDIV(n_tiles, 1024);
-    const int64_t b0 = tid * per, b1 = (b0 + per < n_tiles) ? b0 + per : n_tiles;
-    int64_t s = 0;
-    for (int64_t b = b0; b < b1; ++b) s += tile_bytes[b];
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int64_t v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int64_t run = tid ? part[tid - 1] : 0;
-    for (int64_t b = b0; b < b1; ++b) { const int64_t v = tile_bytes[b]; tile_bytes[b] = run; run += v; }
-    if (tid == 1023) {
-        const int64_t n_cols = ws_meta[0], n_bytes = part[1023];
-        int64_t status = ws_meta[2];
-        if (n_cols > cap_cols || n_bytes > cap_bytes) status |= TOK_ERANGE;
-        else col_off[n_cols] = n_bytes;
-        ws_meta[1] = n_bytes;
-        meta[0] = n_cols; meta[1] = n_bytes; meta[2] = status; meta[3] = 0;
-    }
-}
-
-__global__ __launch_bounds__(TK_BLOCK) void k_tok_compact(TokText t, const int64_t* __restrict__ tile_nl, const int64_t* __restrict__ tile_bytes,
-                                                           const uint32_t* __restrict__ bitmap, int64_t cap_cols, int64_t cap_bytes,
-                                                           int64_t* __restrict__ col_off, uint8_t* __restrict__ bases)
+// launch 1 of 3: per tile the newlines and the column-5 bytes it holds (and the token-start count at its first byte, kept for launch 3)
+__global__ __launch_bounds__(TK_BLOCK) void k_tok_count(TokText t, int64_t* __restrict__ tile_nl, int64_t* __restrict__ tile_bytes,
+                                                         int32_t* __restrict__ tile_st, int64_t* __restrict__ ws_meta)
 {
     __shared__ int sh[TK_BLOCK / 64][2];
+    __shared__ int sh_carry;
+    const int64_t tile0 = (int64_t)blockIdx.x * TK_TILE;
+    uint32_t w[8];
+    const TokMasks m = tk_load(t, tile0 + threadIdx.x * TK_CHUNK, w);
+    if (threadIdx.x < 64) { const int c = blockIdx.x ? tk_local_carry(t, tile0) : 0; if (threadIdx.x == 0) sh_carry = c; }
+    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);                      // (its barriers publish sh_carry)
+    const TokEvents e = tk_events(m, st_combine(sh_carry, s.st_excl) & 7);
+    if (e.err) atomicOr(reinterpret_cast<unsigned long long*>(ws_meta + 2), (unsigned long long)e.err);
+    const BlockScan sb = tk_block_scan(__popc(e.m4), 0, sh);
+    if (threadIdx.x == 0) { tile_nl[blockIdx.x] = s.v_total; tile_bytes[blockIdx.x] = sb.v_total; tile_st[blockIdx.x] = sh_carry; }
+}
+
+// launch 2 of 3, one workgroup: tile_nl / tile_bytes -> newlines / column-5 bytes in front of every tile (in place); totals and status -> meta.
+// 8,192 tiles (64 MB of text) per round: their counts come in with coalesced loads (all in flight at once) and wait in LDS, a thread sums
+// its eight consecutive ones, the workgroup scans the 1,024 sums with wave shuffles, the prefixes go out as they are formed.
+constexpr int TK_SCAN_ROUND = 8192;
+__global__ __launch_bounds__(1024) void k_tok_scan(int64_t* __restrict__ tile_nl, int64_t* __restrict__ tile_bytes, int64_t n_tiles,
+                                                    const int64_t* __restrict__ ws_meta, int64_t cap_cols, int64_t cap_bytes,
+                                                    int64_t* __restrict__ col_off, int64_t* __restrict__ meta)
+{
+    __shared__ int vn[TK_SCAN_ROUND], vb[TK_SCAN_ROUND];          // (a tile holds at most 8,192 of either)
+    __shared__ long long sh_v[16];
+    __shared__ int sh_s[16];
+    const int tid = threadIdx.x;
+    long long carry_n = 0, carry_b = 0;
+    for (int64_t base = 0; base < n_tiles; base += TK_SCAN_ROUND) {
+        const int cnt = (int)(n_tiles - base < TK_SCAN_ROUND ? n_tiles - base : TK_SCAN_ROUND);
+#pragma unroll
+        for (int k = 0; k < TK_SCAN_ROUND / 1024; ++k) {
+            const int i = k * 1024 + tid;
+            vn[i] = i < cnt ? (int)tile_nl[base + i] : 0;
+            vb[i] = i < cnt ? (int)tile_bytes[base + i] : 0;
+        }
+        __syncthreads();
+        constexpr int PER = TK_SCAN_ROUND / 1024;
+        long long sn = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { sn += vn[PER * tid + k]; sb += vb[PER * tid + k]; }
+        const WgScan wn = tk_wg_scan1024(sn, 0, sh_v, sh_s);
+        const WgScan wb = tk_wg_scan1024(sb, 0, sh_v, sh_s);
+        long long rn = carry_n + wn.v_excl, rb = carry_b + wb.v_excl;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = PER * tid + k;
+            if (i < cnt) { tile_nl[base + i] = rn; tile_bytes[base + i] = rb; }
+            rn += vn[i]; rb += vb[i];
+        }
+        carry_n += wn.v_total; carry_b += wb.v_total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int64_t status = ws_meta[2];
+        if (carry_n > cap_cols || carry_b > cap_bytes) status |= TOK_ERANGE;
+        else col_off[carry_n] = carry_b;
+        meta[0] = carry_n; meta[1] = carry_b; meta[2] = status; meta[3] = 0;
+    }
+}
+
+// launch 3 of 3: per tile again, now with the line index and the output offset of its first byte: positions and reference bytes of the
+// lines whose token 1 starts here, column offsets of the tokens 4 that start here, their bytes compacted through LDS into `bases`
+__global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t* __restrict__ tile_nl, const int64_t* __restrict__ tile_bytes,
+                                                        const int32_t* __restrict__ tile_st, const uint8_t* __restrict__ chr_seq, int64_t chr_len,
+                                                        int64_t cap_cols, int64_t cap_bytes, int64_t* __restrict__ pos, uint8_t* __restrict__ ref,
+                                                        int64_t* __restrict__ col_off, uint8_t* __restrict__ bases, int64_t* __restrict__ ws_meta)
+{
+    __shared__ int sh[TK_BLOCK / 64][2];
+    __shared__ __attribute__((aligned(16))) uint8_t txt[TK_TILE];
     __shared__ __attribute__((aligned(16))) uint8_t cbuf[TK_TILE + 32];
-    const int64_t idx = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
-    const int64_t p0 = idx * TK_CHUNK;
+    const int tid = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * TK_TILE, p0 = tile0 + tid * TK_CHUNK;
     uint32_t w[8];
     const TokMasks m = tk_load(t, p0, w);
-    const uint32_t m4 = bitmap[idx];
-    const uint32_t prev_in = idx ? (bitmap[idx - 1] >> 31) : 0u;
-    // two sums at once: newlines and token-4 bytes in front of this chunk (the state slot of the scan is unused: newline-free states add)
-    const int n4 = __popc(m4);
-    int vi = (__popc(m.nl) << 16) | n4;            // <= 32 each per thread, <= 8192 per tile: 16-bit fields suffice
-    const BlockScan s = tk_block_scan(vi, 0, sh);
-    const int nl_excl = s.v_excl >> 16, r0 = s.v_excl & 0xffff, tile_cnt = s.v_total & 0xffff;
+    tk_stage_text(txt, w);
+    // two sums at once: newlines (high half) and - after the events - column-5 bytes; the state rides in the scan's second slot
+    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);                      // (its barriers publish txt)
+    const TokEvents e = tk_events(m, st_combine(tile_st[blockIdx.x], s.st_excl) & 7);
+    const int64_t line0 = tile_nl[blockIdx.x] + s.v_excl;
+    const BlockScan sb = tk_block_scan(__popc(e.m4), 0, sh);
+    const int r0 = sb.v_excl, tile_cnt = sb.v_total;
     const int64_t out0 = tile_bytes[blockIdx.x];
     const int mis = (int)(out0 & 15);
-    // columns that start in this chunk
-    uint32_t starts = m4 & ~((m4 << 1) | prev_in);
-    while (starts) {
-        const int b = __ffs(starts) - 1;
-        starts &= starts - 1;
-        const uint32_t below = (1u << b) - 1u;
-        const int64_t line = tile_nl[blockIdx.x] + nl_excl + __popc(m.nl & below);
-        if (line < cap_cols) col_off[line] = out0 + r0 + __popc(m4 & below);
+    uint32_t err = 0;
+    for (uint32_t s2 = e.s2; s2; s2 &= s2 - 1) {
+        const int b = __ffs(s2) - 1;
+        const int64_t line = line0 + __popc(m.nl & ((1u << b) - 1u));
+        const int64_t v = tk_atoll(t, txt, tile0, p0 + b);
+        if (line < cap_cols) {
+            pos[line] = v;
+            if (ref) {
+                if (v >= 1 && v <= chr_len) ref[line] = chr_seq[v - 1];
+                else { ref[line] = 'N'; err |= TOK_EPOS; }
+            }
+        }
     }
-    // the token-4 bytes of the tile, compacted: cbuf[mis + rank]
+    if (err) atomicOr(reinterpret_cast<unsigned long long*>(ws_meta + 3), (unsigned long long)err);
+    for (uint32_t s4 = e.s4; s4; s4 &= s4 - 1) {
+        const int b = __ffs(s4) - 1;
+        const uint32_t below = (1u << b) - 1u;
+        const int64_t line = line0 + __popc(m.nl & below);
+        if (line < cap_cols) col_off[line] = out0 + r0 + __popc(e.m4 & below);
+    }
     {
-        uint32_t rest = m4; int r = mis + r0;
-        while (rest) {
+        int r = mis + r0;
+        for (uint32_t rest = e.m4; rest; rest &= rest - 1) {
             const int b = __ffs(rest) - 1;
-            rest &= rest - 1;
             cbuf[r++] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
         }
     }
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_compact(TokText t, const int64
     // 16-byte pieces of bases[out0 - mis, out0 + tile_cnt): whole pieces as one store, the two ragged ones byte by byte
     const int span = mis + tile_cnt;
     uint8_t* __restrict__ gb = bases + (out0 - mis);
-    for (int o = threadIdx.x * 16; o < span; o += TK_BLOCK * 16) {
+    for (int o = tid * 16; o < span; o += TK_BLOCK * 16) {
         const bool whole = o >= mis && o + 16 <= span && out0 - mis + o + 16 <= cap_bytes && ((uintptr_t)(gb + o) & 15) == 0;
         if (whole) *reinterpret_cast<uint4*>(gb + o) = *reinterpret_cast<const uint4*>(cbuf + o);
         else {
@@ -334,6 +360,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_compact(TokText t, const int64
     }
 }
 
+// a position outside the reference is found by launch 3, behind the scan that wrote meta: one thread folds it in
+__global__ void k_tok_status(const int64_t* __restrict__ ws_meta, int64_t* __restrict__ meta) { if (ws_meta[3]) meta[2] |= ws_meta[3]; }
 
 // ---- the same in ONE launch: a chained scan (decoupled look-back) -------------------------------------------------------------------
 // The five launches above read the text three times and spend two launches on single-workgroup scans: 180 us per 64 MB chunk, of which
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_t
 // workspace of the tokeniser: grows when a longer text than ever before arrives (synchronous, like the selection scratch)
 static int tok_reserve(nsnp_ctx* ctx, int64_t n_tiles, hipStream_t s)
 {
-    const size_t need = (size_t)n_tiles * (8 + 8 + 4 + 4 * TK_BLOCK) + 64 + 256;       // (the one-launch form needs 16 bytes per tile + 64: less)
+    const size_t need = (size_t)n_tiles * (8 + 8 + 4) + 64 + 256;       // per tile: newlines, bytes, token-start count (the chained scan: 16 bytes)
     if (ctx->tok_ws_bytes >= need) return NSNP_OK;
     NSNP_HIP(ctx, hipStreamSynchronize(s));
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
@@ -528,6 +556,11 @@ extern "C" int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t
         (cap_cols > 0 && !pos) || (cap_bytes > 0 && !bases) || (ref && (!chr_seq || chr_len < 0)))
         return NSNP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (text_len == 0) {
+        NSNP_HIP(ctx, hipMemsetAsync(meta, 0, 4 * sizeof(int64_t), s));
+        NSNP_HIP(ctx, hipMemsetAsync(col_off, 0, sizeof(int64_t), s));
+        return NSNP_OK;
+    }
     const int mis = (int)((uintptr_t)text & 15);
     TokText t;
     t.base = text - mis; t.lo = mis; t.hi = mis + text_len;
@@ -535,16 +568,6 @@ extern "C" int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t
     int rc = tok_reserve(ctx, n_tiles, s);
     if (rc != NSNP_OK) return rc;
     uint8_t* ws = (uint8_t*)ctx->tok_ws;
-    int64_t* ws_meta = (int64_t*)ws;                               // [0] lines, [1] bytes, [2] status
-    int64_t* tile_nl = (int64_t*)(ws + 64);
-    int64_t* tile_bytes = tile_nl + n_tiles;
-    uint32_t* bitmap = (uint32_t*)(tile_bytes + n_tiles);
-    int32_t* tile_st = (int32_t*)(bitmap + n_tiles * TK_BLOCK);
-    if (text_len == 0) {
-        NSNP_HIP(ctx, hipMemsetAsync(meta, 0, 4 * sizeof(int64_t), s));
-        NSNP_HIP(ctx, hipMemsetAsync(col_off, 0, sizeof(int64_t), s));
-        return NSNP_OK;
-    }
     if (ctx->tok_fused) {
         // one launch: its descriptors (16 bytes per tile) zeroed in front of it
         TokDesc* desc = (TokDesc*)(ws + 64);
@@ -554,13 +577,16 @@ extern "C" int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t
         NSNP_HIP(ctx, hipGetLastError());
         return NSNP_OK;
     }
-    hipLaunchKernelGGL(k_tok_summary, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, tile_nl, tile_st);
-    hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(1024), 0, s, tile_nl, tile_st, n_tiles, ws_meta);
-    hipLaunchKernelGGL(k_tok_lines, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (const int64_t*)tile_nl, (const int32_t*)tile_st,
-                       chr_seq, chr_len, cap_cols, pos, ref, bitmap, tile_bytes, ws_meta);
-    hipLaunchKernelGGL(k_tok_scan2, dim3(1), dim3(1024), 0, s, tile_bytes, n_tiles, ws_meta, cap_cols, cap_bytes, col_off, meta);
-    hipLaunchKernelGGL(k_tok_compact, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (const int64_t*)tile_nl, (const int64_t*)tile_bytes,
-                       (const uint32_t*)bitmap, cap_cols, cap_bytes, col_off, bases);
+    int64_t* ws_meta = (int64_t*)ws;                               // [2] status bits of launch 1, [3] of launch 3
+    int64_t* tile_nl = (int64_t*)(ws + 64);
+    int64_t* tile_bytes = tile_nl + n_tiles;
+    int32_t* tile_st = (int32_t*)(tile_bytes + n_tiles);
+    NSNP_HIP(ctx, hipMemsetAsync(ws_meta, 0, 64, s));
+    hipLaunchKernelGGL(k_tok_count, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, tile_nl, tile_bytes, tile_st, ws_meta);
+    hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(1024), 0, s, tile_nl, tile_bytes, n_tiles, (const int64_t*)ws_meta, cap_cols, cap_bytes, col_off, meta);
+    hipLaunchKernelGGL(k_tok_emit, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (const int64_t*)tile_nl, (const int64_t*)tile_bytes,
+                       (const int32_t*)tile_st, chr_seq, chr_len, cap_cols, cap_bytes, pos, ref, col_off, bases, ws_meta);
+    if (ref) hipLaunchKernelGGL(k_tok_status, dim3(1), dim3(1), 0, s, (const int64_t*)ws_meta, meta);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }

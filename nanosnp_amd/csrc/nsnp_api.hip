@@ -47,7 +47,7 @@ extern "C" int nsnp_ctx_create(int device, nsnp_ctx** out)
     ctx->cat_conv_lds = 1;
     ctx->cat_conv_pix2 = 1;
     ctx->hap_b3x = 1;
-    ctx->tok_fused = 1;
+    ctx->tok_fused = 0;         // three launches, no workgroup waits for another (mpileup_tokenise.hip)
     ctx->proj1_tiles = 4;
     ctx->fused_l1 = 1;
     ctx->l0_rs = 1;

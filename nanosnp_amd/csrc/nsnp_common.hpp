@@ -125,8 +125,8 @@ struct nsnp_ctx {
     CatWeightsDev* cw;
     void*  cat_ws; size_t cat_ws_bytes;
     int64_t* sel_tmp; size_t sel_tmp_bytes;   // select_sites scratch
-    void* tok_ws; size_t tok_ws_bytes;        // mpileup tokeniser scratch: tile summaries + one bit per text byte (mpileup_tokenise.hip)
-    int tok_fused;      // mpileup tokeniser: 1 = one launch, chained scan (default), 0 = five launches
+    void* tok_ws; size_t tok_ws_bytes;        // mpileup tokeniser scratch: 20 bytes per 8 KB tile of text (mpileup_tokenise.hip)
+    int tok_fused;      // mpileup tokeniser: 0 = three launches (default), 1 = one launch, chained scan (opt-in: its tiles spin on their predecessors)
     // column encode: AF threshold + smallest-passing-count table of the last min_af (pileup_encode.hip)
     bool af_cached; uint64_t af_bits, af_t; int af_k, af_mode; uint32_t af_table_words[128];
     bool af2_cached; uint64_t af2_bits, af2_t; int af2_k, af2_mode; uint32_t af2_table_words[128];     // the indel threshold when it differs

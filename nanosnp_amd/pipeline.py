@@ -71,15 +71,17 @@ def line_cuts(text, n_parts, lo=0, hi=None):
 
 
 def ramp_cuts(text, lo, hi, chunk_bytes, first=None, growth=1.5):
-    """offsets cutting text[lo:hi] into chunks of whole lines whose sizes grow from `first` bytes (default chunk_bytes / 16, at least 1 MB) by
+    """offsets cutting text[lo:hi] into chunks of whole lines whose sizes grow from `first` bytes (default chunk_bytes / 4, at least 1 MB) by
     `growth` per chunk up to chunk_bytes: the pipeline's fill - nothing computes before the first chunk has been staged, copied, tokenised
-    and encoded, and the forward of chunk 0 is issued behind the tokeniser of chunk 2 - costs a sixteenth of what it costs with equal
-    chunks (measured on the 6 M-column contig: 4.0 ms of 18.4 before the first forward starts); growth 1.5 keeps the copy of the next,
-    larger chunk shorter than the compute of the current one (H2D 0.018 ms / MB against 0.029 ms / MB of device work)."""
+    and encoded, and the forward of chunk 0 is issued behind the tokeniser of chunk 2 - shrinks with the first chunks (with equal 64 MB
+    chunks the first forward of a 6 M-column contig started 4.0 ms into an 18.4 ms pass); growth 1.5 keeps the copy of the next, larger
+    chunk shorter than the compute of the current one (H2D 0.018 ms / MB against 0.029 ms / MB of device work).  Where to start is a
+    trade against the per-chunk issue cost (~0.3 ms of host time, ~30 launches): measured per contig of a run of contigs (the previous
+    contig's last forwards cover most of the fill there) 18.9 / 17.6 / 17.3 / 17.6 / 18.0 ms starting at 4 / 8 / 16 / 32 / 64 MB."""
     chunk_bytes = max(1, int(chunk_bytes))
     if not first and os.environ.get("NSNP_RAMP_FIRST_MB"):           # (A/B measurements)
         first = int(float(os.environ["NSNP_RAMP_FIRST_MB"]) * (1 << 20))
-    first = int(first) if first else max(min(chunk_bytes, 1 << 20), chunk_bytes // 16)
+    first = int(first) if first else max(min(chunk_bytes, 1 << 20), chunk_bytes // 4)
     cuts, size, target = [lo], float(min(first, chunk_bytes)), float(lo)
     while cuts[-1] < hi:
         target += size                               # (targets accumulate: the chunks average `size` bytes however long the lines are)
@@ -419,7 +421,7 @@ def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, mi
     Returns the call rows [n, 13] float64 (position, argmax / max of both heads, the eight coverage channels: all exact in float64)
     as a device tensor in position order - or, with on_rows, hands every chunk's rows to that callback as soon as they are issued
     and returns None.  stats (a dict) receives per-stage busy times (and, with a list under stats["trace"], the spans of every chunk's
-    parse / copy / encode / forward on one clock: tools/e2e_timeline.py).  The pinned and device buffer sets live on `model` between
+    parse / copy / encode / forward on one clock: tools/probes/e2e_timeline.py).  The pinned and device buffer sets live on `model` between
     calls: one call at a time per model (use one model per thread)."""
     import time
     from concurrent.futures import ThreadPoolExecutor
@@ -455,7 +457,7 @@ def _stream_contig(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af, mi
     dsets = getattr(model, "_dev_sets", None)
     # THREE device sets as well: with two, the copy of chunk k + 2 waits for the forward of chunk k (the last reader of its set) and the
     # encode of chunk k + 2 - in front of the forward of chunk k + 1 in stream order - waits for that copy: copies and forwards
-    # alternated (tools/e2e_timeline.py: 2.4 ms per chunk = copy 0.8 + encode 0.15 + forward 1.45); with three the copy runs beside
+    # alternated (tools/probes/e2e_timeline.py: 2.4 ms per chunk = copy 0.8 + encode 0.15 + forward 1.45); with three the copy runs beside
     # the forward of chunk k + 1
     if not dsets or len(dsets) < min(3, len(ranges)) or dsets[0].bases.device != dev or min(d_.bases.numel() for d_ in dsets) < cap:
         dsets = [_DevSet(cap, dev) for _ in range(min(3, len(ranges)))]

@@ -10,9 +10,9 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["one_launch", "five_launches"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["three_launches", "one_launch"])
 def ctx(request):
-    """both forms of the tokeniser: the chained scan in one launch (default) and the five-launch statement of the same grammar"""
+    """both forms of the tokeniser: three launches (default: no workgroup waits for another) and the opt-in chained scan in one launch"""
     from nanosnp_amd import _lib
     c = _lib.Context(0)
     c.set_option("tok_fused", request.param)
@@ -148,7 +148,7 @@ def test_capacity_is_respected(ctx):
 
 def test_many_tiles_and_repeated_calls(ctx):
     """a text of ~3,000 tiles (the chained scan's look-back windows span several rounds of 64 descriptors), tokenised repeatedly into the
-    same buffers (descriptors and counters are re-armed by every call): always the oracle's columns"""
+    same buffers (descriptors and status words are re-armed by every call): always the oracle's columns"""
     import torch
     cols = host.synth_columns(20260001, 280_000, coverage=30)
     text = np.frombuffer(bytes(cols.mpileup_text_native("chrS")), np.uint8)

@@ -229,13 +229,13 @@ def run(args, rank, world, local_rank, emit=None):
                  "vcf_s": "D2H + VCF formatting (nsnp_vcf_format_batches)"}
         h2d_bytes = text_bytes if dev_tok else int(cols.col_off[-1]) + 16 * n_cols
         # the tokeniser against HBM: algorithmic bytes = the text read once + what it writes (column-5 bytes, position 8 + offset 8 + reference
-        # byte 1 per line); its five launches read the text three times, so HBM traffic is ~2.6x this figure
+        # byte 1 per line); its launches read the text twice, so HBM traffic is ~1.7x this figure
         tok = None
         if dev_tok and stats.get("tok_s"):
             chunks_per_step = stats.get("chunks", 0) / K
             alg = stats.get("text_bytes", 0) / K * (1 + int(cols.col_off[-1]) / text_bytes) + 17 * (stats.get("columns", 0) / K)
-            tok = bc.roofline_hbm("mpileup_tokenise (5 launches)", alg / max(chunks_per_step, 1), stats["tok_s"] / K / max(chunks_per_step, 1) * 1e3,
-                                  int(stats.get("chunks", 0)), how="HIP events around the five launches of every chunk on the compute stream, inside the timed run "
+            tok = bc.roofline_hbm("mpileup_tokenise (3 launches)", alg / max(chunks_per_step, 1), stats["tok_s"] / K / max(chunks_per_step, 1) * 1e3,
+                                  int(stats.get("chunks", 0)), how="HIP events around the three launches of every chunk on the compute stream, inside the timed run "
                                   "(other streams' copies run beside them)", chunk_bytes=chunk, text_bytes_per_step=stats.get("text_bytes", 0) / K)
         cols_per_pass = stats.get("columns", 0) / K * (world if world > 1 else 1)
         out = {

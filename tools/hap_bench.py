@@ -90,7 +90,7 @@ class HapStage:
     def features_alone(self, b0, b1, int8=False, warm=32, timed=16):
         """the L = 33 feature launch alone on the chip -> (total ms, launches) of `timed` launches behind `warm` untimed ones of the
         same shape: the memory side of the chip takes tens of milliseconds to reach its clocks after an idle period (the first eight
-        launches after a synchronisation run 0.34 ms, the 130th 0.245: tools/feat_warm_probe.py), and inside a job the kernel never
+        launches after a synchronisation run 0.34 ms, the 130th 0.245: tools/probes/feat_warm_probe.py), and inside a job the kernel never
         meets a cold chip.  The timing accumulator is cleared first: launches of other shapes (L = 11) must not enter the average"""
         for _ in range(warm):
             self.features(b0, b1, int8=int8, which=(0,))

@@ -10,7 +10,8 @@ for wl in e2e hap-e2e pd-e2e; do
   for n in 1 2 4 8; do
     extra=""; [ $n -gt 1 ] && extra="--share-gpu --dist-backend gloo"
     timeout 900 python bench.py --workload $wl --gpus $n $extra --steps 4 --warmup 1 --no-cpu-baseline --no-second-precision \
-      > gpurun_out/host_scaling/${wl}_$n.json 2> gpurun_out/host_scaling/${wl}_$n.err
+      > gpurun_out/host_scaling/${wl}_$n.line 2> gpurun_out/host_scaling/${wl}_$n.err
     echo "$wl x$n rc=$?"
+    cp bench_details_${wl//-/_}.json gpurun_out/host_scaling/${wl}_$n.json      # (the run's full result object; stdout carries the driver's compact line)
   done
 done

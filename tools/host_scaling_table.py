@@ -15,7 +15,7 @@ for wl, hostk, waitk, fmtk in (("e2e", "parse_s", "wait_parse_s", "vcf_s"), ("ha
     for n in (1, 2, 4, 8):
         f = os.path.join(d, f"{wl}_{n}.json")
         try:
-            line = json.loads([l for l in open(f) if l.startswith("{")][0])
+            line = json.load(open(f))
         except Exception:
             continue
         pr = line.get("per_rank_s_per_step")

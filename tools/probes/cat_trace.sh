@@ -1,7 +1,7 @@
 #!/bin/bash
-# per-launch durations of the CatModel convolution launches (kernel trace of tools/cat_probe.py)
-cd "$(dirname "$0")/.."; export TMPDIR=/tmp; mkdir -p gpurun_out
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_cattrace -o run -- python3 tools/cat_probe.py 4096 2 ${1:-0} > gpurun_out/cattrace.log 2>&1
+# per-launch durations of the CatModel convolution launches (kernel trace of tools/probes/cat_probe.py)
+cd "$(dirname "$0")/../.."; export TMPDIR=/tmp; mkdir -p gpurun_out
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_cattrace -o run -- python3 tools/probes/cat_probe.py 4096 2 ${1:-0} > gpurun_out/cattrace.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/prof_cattrace/**/*kernel_trace.csv", recursive=True)[0]

@@ -10,7 +10,7 @@ about two seconds, and prints clock = 0.1 GHz x shader cycles / 100 MHz ticks su
 (nanosnp_amd/csrc/nsnp_devclock.hpp; MI355X_MICROARCH.md "DVFS give-back" item 6).  The peak of bench.py's rooflines is priced at
 2.4 GHz; this says how much of a fraction below 1 is clock the chip did not run."""
 import ctypes, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from nanosnp_amd import _lib

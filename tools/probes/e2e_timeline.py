@@ -2,7 +2,7 @@
 """Development probe: the timeline of one pass of pipeline.call_contig over the e2e bench's contig - parser thread, copy stream, compute
 stream and the issuing thread on one clock (ms since the start of the pass)."""
 import mmap, os, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import host

@@ -3,7 +3,7 @@
 generator of the bench draws 1..3), checked against the oracle and timed beside G2 columns of the same size.
     python tools/enc_long_indel_probe.py [windows] [coverage] [mean_len]"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib, host

@@ -3,7 +3,7 @@
 almost no arithmetic in the kernel's mapping (one 132-byte row per wave load) and with four rows per 16-byte wave load, against the
 product kernel on the same planes."""
 import ctypes as C, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 so = os.path.join(ROOT, "tools", "probes", "libfeat_skeleton.so")

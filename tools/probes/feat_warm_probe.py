@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch
 from tools.hap_bench import HapStage
 hs = HapStage(0, 16384, 16384, 30.0, 90, 20261236, timing=True)

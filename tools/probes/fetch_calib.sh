@@ -1,7 +1,7 @@
 #!/bin/bash
-# tools/fetch_calib.sh -- on the GPU box: FETCH_SIZE calibration for the access shapes of the HBM-bound kernels -> profiles/r04_fetch_calibration.json
+# tools/probes/fetch_calib.sh -- on the GPU box: FETCH_SIZE calibration for the access shapes of the HBM-bound kernels -> profiles/r04_fetch_calibration.json
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out build_tmp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/fetch_calib.hip -o build_tmp/fetch_calib || exit 1
@@ -17,7 +17,7 @@ for f in glob.glob("gpurun_out/prof_fetch_calib/**/*counter_collection.csv", rec
         if r["Counter_Name"] == "FETCH_SIZE":
             m = re.search(r"k_calib_\w+(<[^>]*>)?", r["Kernel_Name"])
             if m: acc[m.group(0)].append(float(r["Counter_Value"]))
-out = {"source": "tools/fetch_calib.sh: rocprofv3 --pmc FETCH_SIZE around tools/probes/fetch_calib.hip; every kernel streams the same buffer once",
+out = {"source": "tools/probes/fetch_calib.sh: rocprofv3 --pmc FETCH_SIZE around tools/probes/fetch_calib.hip; every kernel streams the same buffer once",
        "bytes_streamed_per_launch": n, "shapes": {}}
 for k, v in sorted(acc.items()):
     v = v[1:] if len(v) > 1 else v                      # (the first launch of a shape may find parts of the memset's lines on-die)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development probe: PileupModel forward alone at one batch size, per-kernel HIP-event times."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

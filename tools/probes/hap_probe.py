@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development probe: HaplotypeModel forward alone (sites/s): hap_probe.py [N] [precisions, e.g. 0 or 0,1] [pass sizes, e.g. 4096,16384]."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib

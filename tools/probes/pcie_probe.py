@@ -2,7 +2,7 @@
 """PCIe-inclusive rate of the bench workload: the column bytes / offsets / reference bases of every batch start in pinned
 host memory and are copied on the batch's stream before its kernels (never the bench `value`)."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C
 import numpy as np, torch

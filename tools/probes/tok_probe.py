@@ -3,7 +3,7 @@
 the HBM rate of its algorithmic bytes (text read once + column-5 bytes + 17 B per line written).  Under rocprofv3 --kernel-trace --stats
 the five launches are listed one by one (tools/prof_cmd.sh)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib, host
@@ -14,7 +14,7 @@ cols = host.synth_columns(20260900, n_cols, coverage=30.0, het_rate=0.03)
 text = torch.from_numpy(np.frombuffer(memoryview(cols.mpileup_text_native("chr20s")), np.uint8).copy()).cuda()
 seq = torch.from_numpy(cols.ref.copy()).cuda()
 ctx = _lib.Context(0)
-ctx.set_option("tok_fused", int(os.environ.get("NSNP_TOK_FUSED", "1")))
+ctx.set_option("tok_fused", int(os.environ.get("NSNP_TOK_FUSED", "0")))
 T = text.numel()
 cap = T // 10 + 2
 pos = torch.empty(cap, dtype=torch.int64, device="cuda"); off = torch.empty(cap + 1, dtype=torch.int64, device="cuda")

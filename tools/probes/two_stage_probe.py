@@ -9,7 +9,7 @@
 Synthetic: N windows from generator G2 for stage 2, generator G3 read planes for the selected sites (their generation is not
 timed: the reference gets them from a BAM).  Reports wall time and sites/s per stage.  Not the bench metric."""
 import sys, os, time, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from nanosnp_amd import _lib, host, merge

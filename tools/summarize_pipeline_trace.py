@@ -97,7 +97,7 @@ def main():
                         "kernel_and_copy_at_once": ms(total(intersect(kern_u, copy_u))), "nothing_running": ms(wall - total(any_u))},
         "fractions_of_the_region": {"kernel_busy": round(total(kern_u) / wall, 4), "copy_busy": round(total(copy_u) / wall, 4),
                                     "nothing_running": round(1 - total(any_u) / wall, 4)},
-        "dispatches_in_region": len(ks), "copies_in_region": len(cps),
+        "dispatches_in_region": len(ks), "copies_in_region": len(cps) if mf else "not traced (kernel trace only)",
         "largest_idle_gaps_ms": [round(g / 1e6, 3) for g in gaps[:5]],
         "kernels": {k: {"calls": v[0], "total_ms_per_step": ms(v[1]), "avg_us": round(v[1] / v[0] / 1e3, 2)} for k, v in sorted(per_k.items(), key=lambda kv: -kv[1][1])},
     }
@@ -109,7 +109,7 @@ def main():
         if dev_key:
             cmp_["device_busy_ms_per_step"] = {"line": round(sb[dev_key] * 1e3, 4), "trace_kernel_busy": out["per_step_ms"]["kernel_busy"],
                                                "relative_difference": round(sb[dev_key] * 1e3 / max(out["per_step_ms"]["kernel_busy"], 1e-9) - 1, 4)}
-        if h2d_key:
+        if h2d_key and cps:
             cmp_["h2d_busy_ms_per_step"] = {"line": round(sb[h2d_key] * 1e3, 4), "trace_h2d_busy": out["per_step_ms"]["h2d_busy"],
                                             "relative_difference": round(sb[h2d_key] * 1e3 / max(out["per_step_ms"]["h2d_busy"], 1e-9) - 1, 4)}
         cmp_["note"] = ("the line's device figure is HIP-event time between the first and last launch of every pass on the compute stream (it includes the "

@@ -44,7 +44,7 @@ def short(name):
 
 
 # FETCH_SIZE correction (MI355X_MICROARCH.md, HBM: 16 B/lane streaming reads are counted at exactly 1/2; "other access widths are
-# uncalibrated: calibrate on a known byte count in your own access pattern").  tools/fetch_calib.sh measured this repository's shapes
+# uncalibrated: calibrate on a known byte count in your own access pattern").  tools/probes/fetch_calib.sh measured this repository's shapes
 # (profiles/r04_fetch_calibration.json): 16 B/lane and 4 B/lane contiguous streams both read 2.00; rows of 33 int32 read by a wave each
 # (lanes 33..63 idle) 1.65 in the stand-alone probe.  k_hap_features itself - four planes, four loads in flight per lane, waves of one
 # workgroup on neighbouring rows - moves 778.6 MB of read planes per 16384-site launch at L = 33 and is counted at 395.7 MB: 1.97, i.e.

@@ -13,7 +13,7 @@ sites sharded across the GPUs, RCCL gather" (run_caller.sh:109-136).
 The TOTAL work is fixed and statically sharded by nanosnp_amd.dist.shard_range (strong scaling; a rank's stage-2 shard is cut to
 whole batches of 4096 windows, the line reports the windows actually processed); a *step* is one sweep of a rank's shard of
 both stages.  Text output (pileup.vcf / haplotype.csv / merged VCF) is host work outside the metric:
-tests/test_gpu_two_stage.py covers it against the reference, tools/two_stage_probe.py times it.
+tests/test_gpu_two_stage.py covers it against the reference, tools/probes/two_stage_probe.py times it.
 HaplotypeModel weights are seeded (the trained ones are absent upstream)."""
 from __future__ import annotations
 
