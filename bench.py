@@ -122,7 +122,7 @@ def launch_ranks(args):
     return 0
 
 
-from tools.bench_common import emit_line, usable_cores  # noqa: E402
+from tools.bench_common import emit_line, flush_native_stdout, usable_cores  # noqa: E402
 
 
 def selftest_launcher(args, rank, world):
@@ -361,6 +361,10 @@ def main():
             sys.exit(2)
         sub, sub_ok = run_all(args, rank, world, local_rank, only)
 
+    # every rank empties its native stdout buffers (RCCL's banner) BEFORE rank 0 prints: the line is the last thing on the job's stdout
+    flush_native_stdout()
+    if world > 1:
+        dist.barrier()
     exit_code = 0
     if rank == 0:
         out = {

@@ -365,12 +365,26 @@ def write_details(full, name="bench_details.json"):
     return None
 
 
+def flush_native_stdout():
+    """what native libraries hold in C stdio buffers -> out now (RCCL's version banner would otherwise appear at exit, behind the line)"""
+    import sys
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def emit_line(full, tag=None, file=None):
     """print the driver's line for a run's full result object and keep the object itself in bench_details[_<tag>].json"""
     import sys
     path = write_details(full, "bench_details.json" if not tag else f"bench_details_{tag}.json")
     if path:
         print(f"bench.py: full result object -> {path}", file=sys.stderr, flush=True)
+    # whatever native libraries still hold in C stdio buffers (RCCL prints a version banner to stdout at communicator init: it would be
+    # flushed at exit, BEHIND this line) goes out first: the line must be the last thing on stdout
+    flush_native_stdout()
     print(dump_compact(compact_line(full, path)), file=file or sys.stdout, flush=True)
 
 

@@ -23,3 +23,4 @@ for wl in e2e hap-e2e pd-e2e; do
       profiles/${TAG}_${name}_overlap.json profiles/${TAG}_${name}_kernel_stats.csv
   cp $OUT/prof_${TAG}_${name}_details.json profiles/${TAG}_${name}_line.json
 done
+mkdir -p $OUT/${TAG}_profiles && cp profiles/${TAG}_*e2e_* $OUT/${TAG}_profiles/      # (gpurun brings gpurun_out/ back, not profiles/)
