@@ -220,6 +220,20 @@ int nsnp_pileup_encode_columns2(nsnp_ctx* ctx, const uint8_t* bases, const int64
 int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M,
                              int64_t* center_idx, int64_t cap, int64_t* n_sites, void* stream);
 
+/* nsnp_pileup_select_sites for one chunk of a streamed text: the same selection, and in meta (int64 [4] in any memory the device can write:
+ * device or pinned host) { sites selected, how many of them lie in front of column own_lo, in front of column own_hi, sites selected } -
+ * the sites the chunk OWNS (its columns without the halo lines it re-reads: main.cpp:174-217 emits a site when its last column has been
+ * read) are entries [meta[1], meta[2]) of the ascending list.  No count comes back through the host. */
+int nsnp_pileup_select_sites_range(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M, int64_t own_lo, int64_t own_hi,
+                                   int64_t* center_idx, int64_t cap, int64_t* meta, void* stream);
+
+/* The per-site values PileupModel/predict.py:52-65 hands to its row loop, as one [N,13] float64 array on the device: position, argmax of
+ * the genotype / zygosity heads, their maxima, the coverage channels x[:, 16, [0, 1, 2, 3, 9, 10, 11, 12]] (predict.py:63) of the centre
+ * column center_idx[n] of counts [M,18].  pos: device int64 [M]; gt_arg / zy_arg / gt_max / zy_max: device arrays of N (the outputs of
+ * nsnp_pileup_forward_windows_calls). */
+int nsnp_pileup_call_rows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, const int64_t* pos, const uint8_t* gt_arg,
+                          const uint8_t* zy_arg, const float* gt_max, const float* zy_max, int64_t N, double* rows, void* stream);
+
 /* The reader in front of the column encode, on the device: samtools-mpileup text resident in HBM (whole lines; the end of the
  * text ends its last line) -> per line the position, the reference byte and the column-5 string, in line order:
  *   LineReader::getline  dna_sv_tensor/src/common/line_reader.cpp:95-127  ('\n' or "\r\n" ends a line)

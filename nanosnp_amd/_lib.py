@@ -52,6 +52,9 @@ _SIGNATURES = {
                                            C.c_int64, C.c_void_p, C.c_void_p]),
     "nsnp_pileup_gather_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p]),
+    "nsnp_pileup_select_sites_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_void_p]),
+    "nsnp_pileup_call_rows": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_void_p, C.c_void_p]),
     "nsnp_mpileup_tokenise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 6),
     "nsnp_hap_features": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nsnp_hap_features_i8": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -372,6 +375,29 @@ class Context:
             break
         tokenise_status_check(status)
         return pos[:m], off[:m + 1], bases[:nb], (ref[:m] if ref is not None else None)
+
+    def pileup_select_sites_range(self, pos, flags, own_lo, own_hi, meta, stream=None):
+        """select_sites for one chunk of a streamed text, without a host round trip: -> center_idx int64 [M] (the first meta[0] entries are the
+        selected centres, ascending); meta (int64 [4], on the device or pinned) receives {n, c_lo, c_hi, n}: the chunk's own sites - centres in
+        [own_lo, own_hi) - are center_idx[c_lo:c_hi]."""
+        import torch
+        m = pos.shape[0]
+        center = torch.empty(max(m, 1), dtype=torch.int64, device=pos.device)
+        check(self.lib.nsnp_pileup_select_sites_range(self.handle, _dptr(pos), _dptr(flags), m, int(own_lo), int(own_hi), _dptr(center), m,
+                                                      meta.data_ptr(), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_select_sites_range")
+        return center
+
+    def pileup_call_rows(self, counts, center_idx, pos, gt_arg, zy_arg, gt_max, zy_max, stream=None):
+        """-> the call rows [n,13] float64 of the text pipeline (position, argmax / max of both heads, the eight coverage channels of
+        predict.py:63 at the centre column) in one launch"""
+        import torch
+        n = int(center_idx.shape[0])
+        rows = torch.empty((n, 13), dtype=torch.float64, device=counts.device)
+        check(self.lib.nsnp_pileup_call_rows(self.handle, _dptr(counts), _dptr(center_idx), _dptr(pos), _dptr(gt_arg), _dptr(zy_arg), _dptr(gt_max),
+                                             _dptr(zy_max), n, _dptr(rows), _stream_ptr(stream)),
+              self.handle, "nsnp_pileup_call_rows")
+        return rows
 
     def pileup_gather_windows(self, counts, center_idx, stream=None):
         import torch

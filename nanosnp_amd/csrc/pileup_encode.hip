@@ -802,6 +802,77 @@ extern "C" int nsnp_pileup_select_sites(nsnp_ctx* ctx, const int64_t* pos, const
     return NSNP_OK;
 }
 
+// meta = { sites selected, how many of them lie in front of column own_lo, in front of own_hi, sites selected }: the selected centres are
+// ascending, so the sites a chunk OWNS (its columns without the halo it re-reads) are one run [meta[1], meta[2]) of the list.  One wave:
+// two binary searches.  meta may be pinned host memory (plain stores).
+namespace {
+__global__ void k_select_bounds(const int64_t* __restrict__ center_idx, const int64_t* __restrict__ n_sites, int64_t cap, int64_t own_lo, int64_t own_hi,
+                                int64_t* __restrict__ meta)
+{
+    if (threadIdx.x >= 2) return;
+    const int64_t n = *n_sites < cap ? *n_sites : cap;
+    const int64_t key = threadIdx.x ? own_hi : own_lo;
+    int64_t a = 0, b = n;                                  // first index whose centre is >= key
+    while (a < b) { const int64_t m = (a + b) >> 1; if (center_idx[m] < key) a = m + 1; else b = m; }
+    meta[1 + threadIdx.x] = a;
+    if (threadIdx.x == 0) { meta[0] = *n_sites; meta[3] = *n_sites; }
+}
+
+// the call rows of the text pipeline: [N][13] float64 = position, genotype / zygosity argmax and max, the eight coverage channels of
+// PileupModel/predict.py:63 at the centre column (all exact in float64) - one thread per site instead of a dozen elementwise launches
+__global__ void k_call_rows(const int32_t* __restrict__ counts, const int64_t* __restrict__ center_idx, const int64_t* __restrict__ pos,
+                            const uint8_t* __restrict__ ga, const uint8_t* __restrict__ za, const float* __restrict__ gm, const float* __restrict__ zm,
+                            int64_t n, double* __restrict__ rows)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c = center_idx[i];
+    const int32_t* q = counts + c * PC;
+    double* r = rows + i * 13;
+    r[0] = (double)pos[c]; r[1] = (double)ga[i]; r[2] = (double)za[i]; r[3] = (double)gm[i]; r[4] = (double)zm[i];
+    constexpr int CH[8] = {CH_A, CH_C, CH_G, CH_T, CH_a, CH_c, CH_g, CH_t};          // predict.py:63: x[:, 16, [0, 1, 2, 3, 9, 10, 11, 12]]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[5 + k] = (double)q[CH[k]];
+}
+}  // namespace
+
+extern "C" int nsnp_pileup_select_sites_range(nsnp_ctx* ctx, const int64_t* pos, const uint8_t* flags, int64_t M, int64_t own_lo, int64_t own_hi,
+                                              int64_t* center_idx, int64_t cap, int64_t* meta, void* stream)
+{
+    if (!ctx || M < 0 || cap < 0 || !meta || (M > 0 && (!pos || !flags)) || (cap > 0 && !center_idx)) return NSNP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) { NSNP_HIP(ctx, hipMemsetAsync(meta, 0, 4 * sizeof(int64_t), s)); return NSNP_OK; }
+    // the site count lives behind the block counts of the selection scratch (one word more than nsnp_pileup_select_sites needs)
+    const int64_t n_blocks = NSNP_CDIV(M, SEL_TILE);
+    const size_t need = (size_t)(n_blocks + 1) * sizeof(int64_t);
+    if (ctx->sel_tmp_bytes < need) {
+        NSNP_HIP(ctx, hipStreamSynchronize(s));
+        if (ctx->sel_tmp) (void)hipFree(ctx->sel_tmp);
+        ctx->sel_tmp = nullptr; ctx->sel_tmp_bytes = 0;
+        NSNP_HIP(ctx, hipMalloc((void**)&ctx->sel_tmp, need + need / 4));
+        ctx->sel_tmp_bytes = need + need / 4;
+    }
+    int64_t* n_sites = ctx->sel_tmp + n_blocks;
+    hipLaunchKernelGGL(k_select_count, dim3((unsigned)n_blocks), dim3(SEL_BLOCK), 0, s, pos, flags, M, ctx->sel_tmp);
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, s, ctx->sel_tmp, n_blocks, n_sites);
+    hipLaunchKernelGGL(k_select_scatter, dim3((unsigned)n_blocks), dim3(SEL_BLOCK), 0, s, pos, flags, M,
+                       (const int64_t*)ctx->sel_tmp, center_idx, cap);
+    hipLaunchKernelGGL(k_select_bounds, dim3(1), dim3(64), 0, s, (const int64_t*)center_idx, (const int64_t*)n_sites, cap, own_lo, own_hi, meta);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
+extern "C" int nsnp_pileup_call_rows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx, const int64_t* pos, const uint8_t* gt_arg,
+                                     const uint8_t* zy_arg, const float* gt_max, const float* zy_max, int64_t N, double* rows, void* stream)
+{
+    if (!ctx || N < 0 || (N > 0 && (!counts || !center_idx || !pos || !gt_arg || !zy_arg || !gt_max || !zy_max || !rows))) return NSNP_EINVAL;
+    if (N == 0) return NSNP_OK;
+    hipLaunchKernelGGL(k_call_rows, dim3((unsigned)NSNP_CDIV(N, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, counts, center_idx, pos, gt_arg, zy_arg,
+                       gt_max, zy_max, N, rows);
+    NSNP_HIP(ctx, hipGetLastError());
+    return NSNP_OK;
+}
+
 extern "C" int nsnp_pileup_gather_windows(nsnp_ctx* ctx, const int32_t* counts, const int64_t* center_idx,
                                           int64_t N, int32_t* x, void* stream)
 {

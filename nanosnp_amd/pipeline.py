@@ -299,9 +299,8 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
         if own > 0:
             d_pos = cs.pos[:M]
             counts, depth, flags = ctx.pileup_encode_columns(cs.bases[:max(nb, 1)], cs.off[:M + 1], cs.ref[:M], min_af, min_coverage)
-            center, n_sel = ctx.pileup_select_sites_async(d_pos, flags)
-            meta = torch.stack([n_sel[0], (center < n_lo).sum(), (center < M - n_hi).sum(), n_sel[0]])
-            meta_pin[k].copy_(meta, non_blocking=True)
+            # selection + the run of the chunk's own sites in the list, written into pinned memory by the last of its four launches
+            center = ctx.pileup_select_sites_range(d_pos, flags, n_lo, M - n_hi, meta_pin[k], stream=main)
             sel_done = torch.cuda.Event(); sel_done.record(main)
             job = (k, M, cs, counts, center, sel_done)
         ev[k]["a1"].record(main)
@@ -318,9 +317,7 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
         if c_hi > c_lo:
             centers = center[c_lo:c_hi]
             gt, zy, ga, za, gm, zm = ctx.pileup_forward_windows_calls(counts, centers)
-            cov = counts.index_select(0, centers).index_select(1, cov_idx).to(torch.float64)      # predict.py:63
-            f64 = lambda t: t.to(torch.float64)[:, None]
-            rows_k = torch.cat([f64(cs.pos[:M].index_select(0, centers)), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1)
+            rows_k = ctx.pileup_call_rows(counts, centers, cs.pos, ga, za, gm, zm)                  # predict.py:52-65, one launch
             if on_rows is not None:
                 on_rows(rows_k)
             else:

@@ -281,3 +281,41 @@ def test_af_test_in_integers_equals_the_float64_division(gpu_ctx):
             oc, od, of = oracle.encode_columns(cs.bases, cs.col_off, cs.ref, a, 2)
             assert np.array_equal(f.cpu().numpy(), of), a
             assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(d.cpu().numpy(), od)
+
+
+def test_select_sites_range_and_call_rows_equal_the_elementwise_forms(gpu_ctx):
+    """the two fused entries of the streamed text pipeline: nsnp_pileup_select_sites_range = select_sites + where the chunk's own sites lie
+    in the ascending list (into pinned memory, no host round trip), nsnp_pileup_call_rows = the [n,13] float64 rows in one launch"""
+    import torch
+    from nanosnp_amd.predict import COV_CHANNELS
+    cols = host.synth_columns(20260123, 120_000, coverage=30, het_rate=0.05)
+    dev = torch.device("cuda")
+    pos_np = np.arange(1, 120_001, dtype=np.int64)
+    pos_np[50_000:] += 7                                               # a gap: windows across it are not emitted
+    pos = torch.from_numpy(pos_np).to(dev)
+    c, d, f = _enc(gpu_ctx, cols.bases, cols.col_off, cols.ref)
+    centers, n = gpu_ctx.pileup_select_sites(pos, f)
+    assert n > 1000
+    for lo, hi in ((0, 120_000), (16, 119_984), (40_000, 80_000), (60_000, 60_000), (119_999, 120_000)):
+        meta = torch.full((4,), -1, dtype=torch.int64, pin_memory=True)
+        center = gpu_ctx.pileup_select_sites_range(pos, f, lo, hi, meta)
+        torch.cuda.synchronize()
+        m = meta.tolist()
+        assert m[0] == m[3] == n and torch.equal(center[:n], centers)
+        cn = centers.cpu().numpy()
+        assert m[1] == int((cn < lo).sum()) and m[2] == int((cn < hi).sum())
+    meta_d = torch.zeros(4, dtype=torch.int64, device=dev)            # meta on the device works as well
+    gpu_ctx.pileup_select_sites_range(pos, f, 100, 5000, meta_d)
+    cn = centers.cpu().numpy()
+    assert meta_d.tolist() == [n, int((cn < 100).sum()), int((cn < 5000).sum()), n]
+    # rows
+    k = centers.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ga = torch.randint(0, 21, (k,), generator=g, dtype=torch.uint8).to(dev); za = torch.randint(0, 3, (k,), generator=g, dtype=torch.uint8).to(dev)
+    gm = torch.rand(k, generator=g).to(dev); zm = torch.rand(k, generator=g).to(dev)
+    rows = gpu_ctx.pileup_call_rows(c, centers, pos, ga, za, gm, zm)
+    cov = c.index_select(0, centers).index_select(1, torch.tensor(COV_CHANNELS, device=dev)).to(torch.float64)
+    f64 = lambda t: t.to(torch.float64)[:, None]
+    want = torch.cat([f64(pos.index_select(0, centers)), f64(ga), f64(za), f64(gm), f64(zm), cov], dim=1)
+    assert rows.dtype == torch.float64 and torch.equal(rows, want)
+    assert gpu_ctx.pileup_call_rows(c, centers[:0], pos, ga[:0], za[:0], gm[:0], zm[:0]).shape == (0, 13)
