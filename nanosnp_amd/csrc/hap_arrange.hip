@@ -56,47 +56,43 @@ __global__ __launch_bounds__(ARR_BLOCK) void k_hap_arrange(
     __syncthreads();
     for (int r = tid; r < R; r += ARR_BLOCK)
         if (rank_acc[r] >= 0 && rank_acc[r] < D_out) src[rank_acc[r]] = r;
-    if (depth_out && tid < 64) {
+    // rows kept (after the depth cut): the sorted rows are the first `kept` output rows, everything behind them is padding
+    int32_t* kept_sh = rank_acc + R;                      // [1]
+    if (tid < 64) {
         int kept = 0;
         for (int r = tid; r < R; r += 64) kept += rank_acc[r] >= 0;
         for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-        if (tid == 0) depth_out[n] = kept < D_out ? kept : D_out;
+        kept = kept < D_out ? kept : D_out;
+        if (tid == 0) { *kept_sh = kept; if (depth_out) depth_out[n] = kept; }
     }
     __syncthreads();
     const size_t obase = (size_t)n * D_out * L;
-    const int total = D_out * L;
+    const int total = D_out * L, nreal = *kept_sh * L;
     const float inv_l = 1.0f / (float)L;                  // e / L for e < 2^22: (e + 0.5) / L is at least 0.5 / L away from an integer
-    // two output elements per thread and trip where the plane's base allows 8-byte stores (D_out x L even, or an even site): the
-    // output - mostly -2 padding at 30x (30 reads in 90 rows) - is 3/4 of the kernel's bytes
-    if (((obase & 1) == 0) && ((total & 1) == 0)) {
-        for (int e = 2 * tid; e < total; e += 2 * ARR_BLOCK) {
-            int32_t va[2], vb[2], vc[2], vh[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int d = (int)(((float)(e + k) + 0.5f) * inv_l), l = (e + k) - d * L;
-                const int r = src[d];
-                va[k] = vb[k] = vc[k] = vh[k] = -2;             // write_to_bins.py:15-30: constant_values=-2
-                if (r >= 0) {
-                    const size_t i = ibase + (size_t)r * L + l;
-                    va[k] = seq[i]; vb[k] = bq[i]; vc[k] = mq[i]; vh[k] = hap[i];
-                }
-            }
-            *reinterpret_cast<int2*>(oseq + obase + e) = int2{va[0], va[1]};
-            *reinterpret_cast<int2*>(obq + obase + e) = int2{vb[0], vb[1]};
-            *reinterpret_cast<int2*>(omq + obase + e) = int2{vc[0], vc[1]};
-            *reinterpret_cast<int2*>(ohap + obase + e) = int2{vh[0], vh[1]};
-        }
-        return;
+    // ---- the kept rows: a gather of 4-byte elements (source rows are 132 bytes, any alignment) ----
+    for (int e = tid; e < nreal; e += ARR_BLOCK) {
+        const int d = (int)(((float)e + 0.5f) * inv_l), l = e - d * L;
+        const size_t i = ibase + (size_t)src[d] * L + l;
+        oseq[obase + e] = seq[i]; obq[obase + e] = bq[i]; omq[obase + e] = mq[i]; ohap[obase + e] = hap[i];
     }
-    for (int e = tid; e < total; e += ARR_BLOCK) {
-        const int d = e / L, l = e - d * L;
-        const int r = src[d];
-        int32_t a = -2, b = -2, c = -2, h = -2;         // write_to_bins.py:15-30: constant_values=-2
-        if (r >= 0) {
-            const size_t i = ibase + (size_t)r * L + l;
-            a = seq[i]; b = bq[i]; c = mq[i]; h = hap[i];
+    // ---- the padding behind them (write_to_bins.py:15-30: constant_values=-2; two thirds of the output at 30x: 30 reads in 90 rows): no
+    // look-up, no load - 16-byte stores between a ragged head and tail (the four planes share one alignment: equal element offsets) ----
+    const size_t p0 = obase + nreal, p1 = obase + total;
+    const size_t a0 = (p0 + 3) & ~(size_t)3, a1 = p1 & ~(size_t)3;          // 16-byte aligned body [a0, a1) when the plane bases are
+    const bool vec = ((((uintptr_t)oseq | (uintptr_t)obq | (uintptr_t)omq | (uintptr_t)ohap) & 15) == 0) && a0 < a1;
+    if (vec) {
+        const int4 m2 = int4{-2, -2, -2, -2};
+        for (size_t q = a0 + 4 * (size_t)tid; q < a1; q += 4 * ARR_BLOCK) {
+            *reinterpret_cast<int4*>(oseq + q) = m2; *reinterpret_cast<int4*>(obq + q) = m2;
+            *reinterpret_cast<int4*>(omq + q) = m2; *reinterpret_cast<int4*>(ohap + q) = m2;
         }
-        oseq[obase + e] = a; obq[obase + e] = b; omq[obase + e] = c; ohap[obase + e] = h;
+        if (tid < 8) {                                     // at most three elements on either side
+            const size_t q = tid < 4 ? p0 + tid : a1 + (tid - 4);
+            const bool in = tid < 4 ? q < a0 : q < p1;
+            if (in) { oseq[q] = -2; obq[q] = -2; omq[q] = -2; ohap[q] = -2; }
+        }
+    } else {
+        for (size_t q = p0 + tid; q < p1; q += ARR_BLOCK) { oseq[q] = -2; obq[q] = -2; omq[q] = -2; ohap[q] = -2; }
     }
 }
 
@@ -109,7 +105,7 @@ extern "C" int nsnp_hap_arrange_reads(nsnp_ctx* ctx, const int32_t* seq, const i
     if (!ctx || N < 0 || R <= 0 || L <= 0 || D_out <= 0) return NSNP_EINVAL;
     if (N > 0 && (!seq || !bq || !mq || !hap || !oseq || !obq || !omq || !ohap)) return NSNP_EINVAL;
     if (N == 0) return NSNP_OK;
-    const size_t lds = (size_t)(2 * R + D_out) * sizeof(int32_t);
+    const size_t lds = (size_t)(2 * R + D_out + 1) * sizeof(int32_t);
     if (lds > 64 * 1024) return NSNP_ESHAPE;
     hipLaunchKernelGGL(k_hap_arrange, dim3((unsigned)N), dim3(ARR_BLOCK), lds, (hipStream_t)stream,
                        seq, bq, mq, hap, n_reads, R, L, D_out, oseq, obq, omq, ohap, depth);

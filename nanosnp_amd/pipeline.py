@@ -253,9 +253,9 @@ def _stream_contig_dev(model, text, contig, chr_seq, lo, hi, chunk_bytes, min_af
     cov_idx = getattr(model, "_cov_idx", None)
     if cov_idx is None or cov_idx.device != dev:
         cov_idx = model._cov_idx = torch.tensor(list(COV_CHANNELS), dtype=torch.int64, device=dev)
-    if getattr(model, "_stream_main", None) is not main:
+    if getattr(model, "_stream_main_id", None) != (main.device, main.stream_id):
         copy_stream.wait_stream(main)                  # (another compute stream than last time: its queued work may still read the device sets)
-        model._stream_main = main
+        model._stream_main_id = (main.device, main.stream_id)
 
     trace = st.get("trace")
 
