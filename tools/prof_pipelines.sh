@@ -21,6 +21,6 @@ for wl in e2e hap-e2e pd-e2e; do
   cp bench_details_$name.json $OUT/prof_${TAG}_${name}_details.json
   python3 tools/summarize_pipeline_trace.py $OUT/prof_${TAG}_$name $OUT/mark_$name.json $OUT/prof_${TAG}_${name}_details.json \
       profiles/${TAG}_${name}_overlap.json profiles/${TAG}_${name}_kernel_stats.csv
-  cp $OUT/prof_${TAG}_${name}_details.json profiles/${TAG}_${name}_line.json
+  cp $OUT/prof_${TAG}_${name}_details.json profiles/${TAG}_${name}_traced_line.json      # (the traced run: no second values; the full line is ${TAG}_${name}_line.json of tools/round_profiles.sh)
 done
 mkdir -p $OUT/${TAG}_profiles && cp profiles/${TAG}_*e2e_* $OUT/${TAG}_profiles/      # (gpurun brings gpurun_out/ back, not profiles/)
