@@ -210,6 +210,10 @@ def test_e2e_text_to_vcf_line():
     d = _run("--workload", "e2e", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1.5", env=env)
     assert d["scaling"] == "strong" and d["unit"] == "sites/s" and d["config"]["columns"] == 600000 and "NOT the headline" in d["config"]["workload"]
     assert d["parity_sample"]["ok"] and d["parity_sample"]["sites"] == d["config"]["candidate_sites"] > 5000
+    # the text is cut into columns on the device (nsnp_mpileup_tokenise); the same run with the host tokeniser rides along as a second value
+    # and its VCF is part of the parity sample; the tokeniser's launches are priced against HBM
+    assert d["tokenise"] == "device" and d["parity_sample"]["vcf_equals_the_host_parsed_run"] is True and d["host_parsed"]["value"] > 1e4
+    assert d["roofline_tokenise"]["bound"] == "hbm" and 0 < d["roofline_tokenise"]["frac"] <= 1 and 80 < d["bytes_over_pcie_per_column"] < 100
     assert d["value"] > 1e4 and d["columns_per_s"] > 1e6 and abs(d["value"] - d["config"]["candidate_sites"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert len(d["stage_busy_s_per_step"]) == 4 and d["bound_by"] in d["stage_busy_s_per_step"] and d["cpu_baseline"]["value"] > 0
     assert d["config"]["text_bytes"] // d["config"]["chunk_bytes"] >= 5          # several chunks in flight

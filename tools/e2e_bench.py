@@ -221,6 +221,9 @@ def run(args, rank, world, local_rank, emit=None):
             parity = {"ok": bool(bytes(whole) == rows_text and ns1 == n_sites), "vcf_bytes": len(rows_text), "sites": n_sites,
                       "what": "pileup.vcf rows of the chunked, double-buffered run byte-identical to the one-chunk run of the same text "
                               "(nanosnp_amd.pipeline.call_contig; against the reference's own rows: tests/test_gpu_predict.py)"}
+        if host_parsed and parity is not None:             # the device-tokenised VCF equals the host-parsed one, byte for byte: part of the sample
+            parity["vcf_equals_the_host_parsed_run"] = host_parsed["vcf_equals_the_device_tokenised_run"]
+            parity["ok"] = bool(parity["ok"] and host_parsed["vcf_equals_the_device_tokenised_run"])
         per = {k: stats.get(k, 0.0) / K for k in ("parse_s", "h2d_s", "gpu_s", "vcf_s")}
         bound = max(per, key=per.get)
         dev_tok = stats.get("tokenise") == "device"
@@ -280,9 +283,6 @@ def run(args, rank, world, local_rank, emit=None):
             emit(out)
         else:
             bc.emit_line(out, "e2e")
-        if host_parsed and parity is not None:
-            parity["vcf_equals_the_host_parsed_run"] = host_parsed["vcf_equals_the_device_tokenised_run"]
-            parity["ok"] = bool(parity["ok"] and host_parsed["vcf_equals_the_device_tokenised_run"])
         if (parity is not None and not parity["ok"]) or (second and not second["parity_sample"]["ok"]):
             print("bench.py: parity_sample FAILED: " + json.dumps([parity, second and second["parity_sample"]]), file=sys.stderr)
             exit_code = 1
