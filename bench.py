@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--timing-streams", type=int, default=4, help="record per-kernel HIP events on this many of the streams "
                     "(every kernel launch of those streams inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline sample time")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the measured configuration). "
                     "gloo + --share-gpu is a TEST configuration: the ranks share GPU 0 and the gathered calls cross host memory, so that the "
                     "whole multi-rank path runs on a one-GPU box (tests/test_gpu_bench_contract.py); its value is not a scaling number")

@@ -338,11 +338,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t*
         if (line < cap_cols) col_off[line] = out0 + r0 + __popc(e.m4 & below);
     }
     {
+        // (the bytes come from the tile's copy in LDS: picking byte b out of the eight registers is a chain of selects per byte)
         int r = mis + r0;
-        for (uint32_t rest = e.m4; rest; rest &= rest - 1) {
-            const int b = __ffs(rest) - 1;
-            cbuf[r++] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-        }
+        const uint8_t* mine = txt + tid * TK_CHUNK;
+        for (uint32_t rest = e.m4; rest; rest &= rest - 1) cbuf[r++] = mine[__ffs(rest) - 1];
     }
     __syncthreads();
     // 16-byte pieces of bases[out0 - mis, out0 + tile_cnt): whole pieces as one store, the two ragged ones byte by byte
