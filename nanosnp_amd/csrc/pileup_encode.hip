@@ -662,20 +662,30 @@ __device__ __forceinline__ bool site_ok(const int64_t* pos, const uint8_t* flags
     // main.cpp:174-178 resets its window at EVERY position that is not the previous one + 1.  For ascending positions the two end
     // differences say it all; a text whose positions repeat or step back (concatenated or damaged input) can have a gap of two and a
     // repeated position cancel inside the window, so a candidate that passed is confirmed step by step (2 % of the columns get here)
-    for (int k = -PCENTER; k < PCENTER; ++k)
-        if (pos[c + k + 1] - pos[c + k] != 1) return false;
-    return true;
+    // (all 33 positions loaded at once, no early exit: a loop that stops at the first bad step makes every load wait for the one before it,
+    //  and with one or two candidates per 64 columns every wave walked it - the selection kernels took 36 + 28 us per 760 k columns)
+    int64_t p[2 * PCENTER + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * PCENTER; ++k) p[k] = pos[c - PCENTER + k];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 2 * PCENTER; ++k) bad |= p[k + 1] - p[k] != 1;
+    return !bad;
 }
 
 constexpr int SEL_BLOCK = 256, SEL_PER_THREAD = 8, SEL_TILE = SEL_BLOCK * SEL_PER_THREAD;
 
+// A block owns SEL_TILE consecutive columns as SEL_PER_THREAD rows of SEL_BLOCK: in trip k a thread looks at column base + k * SEL_BLOCK + tid,
+// so the lanes of a wave read consecutive positions and flags (round 6: a thread used to own eight consecutive columns - every load
+// instruction touched 64 separate 64-byte segments - and the two kernels took 0.62 ms of a 6 M-column contig's 13 ms).
 __global__ __launch_bounds__(SEL_BLOCK) void k_select_count(const int64_t* pos, const uint8_t* flags, int64_t M,
                                                              int64_t* block_cnt)
 {
     __shared__ int wsum[SEL_BLOCK / 64];
-    const int64_t base = (int64_t)blockIdx.x * SEL_TILE + threadIdx.x * SEL_PER_THREAD;
+    const int64_t base = (int64_t)blockIdx.x * SEL_TILE + threadIdx.x;
     int n = 0;
-    for (int k = 0; k < SEL_PER_THREAD; ++k) { const int64_t c = base + k; if (c < M && site_ok(pos, flags, M, c)) ++n; }
+#pragma unroll
+    for (int k = 0; k < SEL_PER_THREAD; ++k) { const int64_t c = base + (int64_t)k * SEL_BLOCK; if (c < M && site_ok(pos, flags, M, c)) ++n; }
     for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
     __syncthreads();
@@ -707,21 +717,33 @@ __global__ __launch_bounds__(1024) void k_select_scan(int64_t* block_cnt, int64_
 __global__ __launch_bounds__(SEL_BLOCK) void k_select_scatter(const int64_t* pos, const uint8_t* flags, int64_t M,
                                                                const int64_t* block_off, int64_t* center_idx, int64_t cap)
 {
-    __shared__ int wsum[SEL_BLOCK / 64];
+    // ascending output: the sites of trip k lie behind those of the trips before it, inside a trip wave by wave, inside a wave lane by lane
+    __shared__ int wcnt[SEL_PER_THREAD][SEL_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * SEL_TILE + tid * SEL_PER_THREAD;
-    bool ok[SEL_PER_THREAD]; int n = 0;
+    const int64_t base = (int64_t)blockIdx.x * SEL_TILE + tid;
+    unsigned okm = 0; int before[SEL_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < SEL_PER_THREAD; ++k) { const int64_t c = base + k; ok[k] = c < M && site_ok(pos, flags, M, c); n += ok[k]; }
-    int incl = n;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[wave] = incl;
+    for (int k = 0; k < SEL_PER_THREAD; ++k) {
+        const int64_t c = base + (int64_t)k * SEL_BLOCK;
+        const bool ok = c < M && site_ok(pos, flags, M, c);
+        const unsigned long long bal = __ballot(ok);
+        before[k] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[k][wave] = __popcll(bal);
+        okm |= (unsigned)ok << k;
+    }
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    int64_t o = block_off[blockIdx.x] + woff + incl - n;
+    int run = 0;                                           // sites in front of (trip k, this wave)
 #pragma unroll
-    for (int k = 0; k < SEL_PER_THREAD; ++k) if (ok[k]) { if (o < cap) center_idx[o] = base + k; ++o; }
+    for (int k = 0; k < SEL_PER_THREAD; ++k) {
+#pragma unroll
+        for (int w = 0; w < SEL_BLOCK / 64; ++w) {
+            if (w == wave && ((okm >> k) & 1u)) {
+                const int64_t o = block_off[blockIdx.x] + run + before[k];
+                if (o < cap) center_idx[o] = base + (int64_t)k * SEL_BLOCK;
+            }
+            run += wcnt[k][w];
+        }
+    }
 }
 
 __global__ void k_gather_windows(const int32_t* __restrict__ counts, const int64_t* __restrict__ center_idx, int64_t N,
