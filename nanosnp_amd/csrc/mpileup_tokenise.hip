@@ -19,9 +19,11 @@
 //                 workgroup scan of the token-start state, the bytes inside a token 4; -> newlines and column-5 bytes of the tile;
 //                 lines the reference could not read (fewer than five tokens, empty) raise status bits          (reads the text once)
 //   k_tok_scan    one workgroup: exclusive scans of both counts over the tiles; totals and status -> meta
-//   k_tok_emit    per tile again, now knowing the line index and output offset of its first byte: the thread that meets the start of a
-//                 token 1 converts it (atoll, digits read from the tile's copy in LDS) and writes pos / ref of its line, col_off of the
-//                 tokens 4 that start here, their bytes compacted through LDS into `bases` with 16-byte stores  (reads the text again)
+//                 the four bit masks of every 32-byte chunk (newlines, column-5 bytes, starts of tokens 1 and 4) are kept for launch 3
+//   k_tok_emit    per tile again, now knowing the line index and output offset of its first byte, with the chunk masks of launch 1: the
+//                 thread that holds the start of a token 1 converts it (atoll, digits read from the tile's copy in LDS) and writes pos /
+//                 ref of its line, col_off of the tokens 4 that start here, their bytes compacted through LDS into `bases` with
+//                 16-byte stores                                                       (reads the text again + 16 B per 32 B of masks)
 // (+ a one-thread launch that folds "position outside the reference", which only launch 3 can see, into meta.)  Algorithmic bytes: the
 // text once + what is written (column-5 bytes, 17 bytes per line); the kernels read the text twice (+ 2 KB per tile for the local state).
 // No line-length limit, no slow path.  k_tok_fused below is the same grammar as ONE launch (a chained scan; option "tok_fused" 1): with
@@ -60,7 +62,7 @@ struct TokMasks { uint32_t nl, sep, ts; };
 
 // the 32 bytes at p0 (as words), the byte masks of the chunk: newlines, separators (tab, newline, a '\r' right in front of a
 // newline), token starts (a non-separator behind a separator)
-__device__ __forceinline__ TokMasks tk_load(const TokText& t, int64_t p0, uint32_t (&w)[8])
+__device__ __forceinline__ void tk_load_words(const TokText& t, int64_t p0, uint32_t (&w)[8])
 {
     if (p0 >= t.lo && p0 + TK_CHUNK <= t.hi) {
         const uint4 a = *reinterpret_cast<const uint4*>(t.base + p0), b = *reinterpret_cast<const uint4*>(t.base + p0 + 16);
@@ -76,6 +78,10 @@ __device__ __forceinline__ TokMasks tk_load(const TokText& t, int64_t p0, uint32
             w[k] = v;
         }
     }
+}
+__device__ __forceinline__ TokMasks tk_load(const TokText& t, int64_t p0, uint32_t (&w)[8])
+{
+    tk_load_words(t, p0, w);
     uint32_t nl = 0, tab = 0, cr = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -188,22 +194,38 @@ __device__ __forceinline__ void tk_stage_text(uint8_t* txt, const uint32_t (&w)[
 }
 
 
-// token starts since the last newline in front of tile0, found in the text itself: the 2 KB in front of the tile (64 lanes x 32 bytes), and
-// further back only when they hold no newline (a line longer than 2 KB).  One whole wave calls this; every lane returns the count.
+// token starts since the last newline in front of tile0, found in the text itself: one byte per lane, 64 bytes per window, nearest window
+// first - two ballots give the newline and separator masks of a window as scalars, the token starts behind the last newline are a
+// popcount; a window without a newline (a line longer than it) adds its starts and the walk goes on.  One whole wave calls this;
+// every lane returns the count.  (The first form ran tk_load's full 32-bytes-per-lane mask arithmetic over the 2 KB in front of the
+// tile: 300 vector instructions for one wave of every tile; this one is ~25 per window.)
 __device__ __forceinline__ int tk_local_carry(const TokText& t, int64_t tile0)
 {
     const int lane = threadIdx.x & 63;
     int run = 0;
-    for (int64_t end = tile0; end > t.lo; end -= 64 * TK_CHUNK) {
-        uint32_t w[8];
-        const TokMasks m = tk_load(t, end - 64 * TK_CHUNK + lane * TK_CHUNK, w);
-        int si = st_of(m);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int ps = __shfl_up(si, o); if (lane >= o) si = st_combine(ps, si); }
-        run = st_combine(__shfl(si, 63), run);                   // (the window lies in front of what has been seen so far)
-        if (run & 8) break;
+    bool pending = false;                                  // the nearest byte seen so far is a non-separator: it starts a token iff the byte in front of it is one
+    int next = tk_byte(t, tile0);                          // the byte behind the window
+    for (int64_t end = tile0; end > t.lo; end -= 64) {
+        const int ch = tk_byte(t, end - 64 + lane);
+        int nx = __shfl_down(ch, 1);
+        if (lane == 63) nx = next;
+        const bool nl = ch == '\n';
+        const bool sep = nl || ch == '\t' || (ch == '\r' && nx == '\n');
+        const unsigned long long nlm = __ballot(nl), sepm = __ballot(sep);
+        if (pending && (sepm >> 63)) ++run;                // the window's last byte is a separator: the pending byte behind it starts a token
+        const unsigned long long ts = ~sepm & (sepm << 1);                                   // starts whose predecessor lies in this window
+        if (nlm) {
+            const int top = 63 - __builtin_clzll(nlm);
+            run += top == 63 ? 0 : __popcll(ts >> (top + 1));
+            return run > TK_SAT ? TK_SAT : run;
+        }
+        run += __popcll(ts);
+        pending = !(sepm & 1ull);                          // lane 0's byte is a non-separator whose predecessor is in the next window
+        if (run > TK_SAT) run = TK_SAT;
+        next = __shfl(ch, 0);
     }
-    return run & 7;
+    if (pending) ++run;                                    // in front of the text: a separator (the text starts a line)
+    return run > TK_SAT ? TK_SAT : run;
 }
 
 // the grammar over one chunk's events, given the token starts since the last newline in front of it: bit masks of the bytes inside a
@@ -233,7 +255,7 @@ __device__ __forceinline__ TokEvents tk_events(const TokMasks& m, int cc)
 
 // launch 1 of 3: per tile the newlines and the column-5 bytes it holds (and the token-start count at its first byte, kept for launch 3)
 __global__ __launch_bounds__(TK_BLOCK) void k_tok_count(TokText t, int64_t* __restrict__ tile_nl, int64_t* __restrict__ tile_bytes,
-                                                         int32_t* __restrict__ tile_st, int64_t* __restrict__ ws_meta)
+                                                         uint4* __restrict__ chunk_masks, int64_t* __restrict__ ws_meta)
 {
     __shared__ int sh[TK_BLOCK / 64][2];
     __shared__ int sh_carry;
@@ -244,8 +266,19 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_count(TokText t, int64_t* __re
     const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);                      // (its barriers publish sh_carry)
     const TokEvents e = tk_events(m, st_combine(sh_carry, s.st_excl) & 7);
     if (e.err) atomicOr(reinterpret_cast<unsigned long long*>(ws_meta + 2), (unsigned long long)e.err);
-    const BlockScan sb = tk_block_scan(__popc(e.m4), 0, sh);
-    if (threadIdx.x == 0) { tile_nl[blockIdx.x] = s.v_total; tile_bytes[blockIdx.x] = sb.v_total; tile_st[blockIdx.x] = sh_carry; }
+    // what launch 3 needs of this chunk's grammar: 16 bytes per 32 bytes of text (it then skips the mask arithmetic, the state scan and
+    // the event walk: 500 of its 1,100 vector instructions per wave; both kernels sit at their vector-issue bound)
+    chunk_masks[(int64_t)blockIdx.x * TK_BLOCK + threadIdx.x] = uint4{m.nl, e.m4, e.s4, e.s2};
+    int n = __popc(e.m4);
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][0] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < TK_BLOCK / 64; ++k) tot += sh[k][0];
+        tile_nl[blockIdx.x] = s.v_total; tile_bytes[blockIdx.x] = tot;
+    }
 }
 
 // launch 2 of 3, one workgroup: tile_nl / tile_bytes -> newlines / column-5 bytes in front of every tile (in place); totals and status -> meta.
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(1024) void k_tok_scan(int64_t* __restrict__ tile_nl
 // launch 3 of 3: per tile again, now with the line index and the output offset of its first byte: positions and reference bytes of the
 // lines whose token 1 starts here, column offsets of the tokens 4 that start here, their bytes compacted through LDS into `bases`
 __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t* __restrict__ tile_nl, const int64_t* __restrict__ tile_bytes,
-                                                        const int32_t* __restrict__ tile_st, const uint8_t* __restrict__ chr_seq, int64_t chr_len,
+                                                        const uint4* __restrict__ chunk_masks, const uint8_t* __restrict__ chr_seq, int64_t chr_len,
                                                         int64_t cap_cols, int64_t cap_bytes, int64_t* __restrict__ pos, uint8_t* __restrict__ ref,
                                                         int64_t* __restrict__ col_off, uint8_t* __restrict__ bases, int64_t* __restrict__ ws_meta)
 {
@@ -307,14 +340,15 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t*
     const int tid = threadIdx.x;
     const int64_t tile0 = (int64_t)blockIdx.x * TK_TILE, p0 = tile0 + tid * TK_CHUNK;
     uint32_t w[8];
-    const TokMasks m = tk_load(t, p0, w);
+    tk_load_words(t, p0, w);
     tk_stage_text(txt, w);
-    // two sums at once: newlines (high half) and - after the events - column-5 bytes; the state rides in the scan's second slot
-    const BlockScan s = tk_block_scan(__popc(m.nl), st_of(m), sh);                      // (its barriers publish txt)
-    const TokEvents e = tk_events(m, st_combine(tile_st[blockIdx.x], s.st_excl) & 7);
-    const int64_t line0 = tile_nl[blockIdx.x] + s.v_excl;
-    const BlockScan sb = tk_block_scan(__popc(e.m4), 0, sh);
-    const int r0 = sb.v_excl, tile_cnt = sb.v_total;
+    const uint4 cm = chunk_masks[(int64_t)blockIdx.x * TK_BLOCK + tid];
+    struct { uint32_t nl; } m{cm.x};
+    const TokEvents e{cm.y, cm.z, cm.w, 0u};
+    // one scan, two sums: newlines (high half) and column-5 bytes (low half) in front of this chunk inside the tile
+    const BlockScan s2 = tk_block_scan((__popc(m.nl) << 16) | __popc(e.m4), 0, sh);            // (its barriers publish txt)
+    const int64_t line0 = tile_nl[blockIdx.x] + (s2.v_excl >> 16);
+    const int r0 = s2.v_excl & 0xffff, tile_cnt = s2.v_total & 0xffff;
     const int64_t out0 = tile_bytes[blockIdx.x];
     const int mis = (int)(out0 & 15);
     uint32_t err = 0;
@@ -360,7 +394,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t*
 }
 
 // a position outside the reference is found by launch 3, behind the scan that wrote meta: one thread folds it in
-__global__ void k_tok_status(const int64_t* __restrict__ ws_meta, int64_t* __restrict__ meta) { if (ws_meta[3]) meta[2] |= ws_meta[3]; }
+// (it also re-arms the two status words for the next call: no memset in front of every call)
+__global__ void k_tok_status(int64_t* __restrict__ ws_meta, int64_t* __restrict__ meta)
+{
+    if (ws_meta[3]) meta[2] |= ws_meta[3];
+    ws_meta[2] = 0; ws_meta[3] = 0;
+}
 
 // ---- the same in ONE launch: a chained scan (decoupled look-back) -------------------------------------------------------------------
 // The five launches above read the text three times and spend two launches on single-workgroup scans: 180 us per 64 MB chunk, of which
@@ -530,7 +569,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_fused(TokText t, long long n_t
 // workspace of the tokeniser: grows when a longer text than ever before arrives (synchronous, like the selection scratch)
 static int tok_reserve(nsnp_ctx* ctx, int64_t n_tiles, hipStream_t s)
 {
-    const size_t need = (size_t)n_tiles * (8 + 8 + 4) + 64 + 256;       // per tile: newlines, bytes, token-start count (the chained scan: 16 bytes)
+    const size_t need = (size_t)n_tiles * (8 + 8 + 16 * TK_BLOCK) + 64 + 256;      // per tile: newlines, bytes, 16 bytes of masks per thread (the chained scan: 16 per tile)
     if (ctx->tok_ws_bytes >= need) return NSNP_OK;
     NSNP_HIP(ctx, hipStreamSynchronize(s));
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
@@ -538,6 +577,7 @@ static int tok_reserve(nsnp_ctx* ctx, int64_t n_tiles, hipStream_t s)
     const size_t want = need + need / 4;
     NSNP_HIP(ctx, hipMalloc(&ctx->tok_ws, want));
     ctx->tok_ws_bytes = want;
+    NSNP_HIP(ctx, hipMemsetAsync(ctx->tok_ws, 0, 64, s));            // the status words start at zero; every call leaves them so (k_tok_status)
     return NSNP_OK;
 }
 
@@ -579,13 +619,12 @@ extern "C" int nsnp_mpileup_tokenise(nsnp_ctx* ctx, const uint8_t* text, int64_t
     int64_t* ws_meta = (int64_t*)ws;                               // [2] status bits of launch 1, [3] of launch 3
     int64_t* tile_nl = (int64_t*)(ws + 64);
     int64_t* tile_bytes = tile_nl + n_tiles;
-    int32_t* tile_st = (int32_t*)(tile_bytes + n_tiles);
-    NSNP_HIP(ctx, hipMemsetAsync(ws_meta, 0, 64, s));
-    hipLaunchKernelGGL(k_tok_count, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, tile_nl, tile_bytes, tile_st, ws_meta);
+    uint4* chunk_masks = (uint4*)(tile_bytes + n_tiles);           // (64 + 16 n_tiles bytes in: 16-byte aligned)
+    hipLaunchKernelGGL(k_tok_count, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, tile_nl, tile_bytes, chunk_masks, ws_meta);
     hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(1024), 0, s, tile_nl, tile_bytes, n_tiles, (const int64_t*)ws_meta, cap_cols, cap_bytes, col_off, meta);
     hipLaunchKernelGGL(k_tok_emit, dim3((unsigned)n_tiles), dim3(TK_BLOCK), 0, s, t, (const int64_t*)tile_nl, (const int64_t*)tile_bytes,
-                       (const int32_t*)tile_st, chr_seq, chr_len, cap_cols, cap_bytes, pos, ref, col_off, bases, ws_meta);
-    if (ref) hipLaunchKernelGGL(k_tok_status, dim3(1), dim3(1), 0, s, (const int64_t*)ws_meta, meta);
+                       (const uint4*)chunk_masks, chr_seq, chr_len, cap_cols, cap_bytes, pos, ref, col_off, bases, ws_meta);
+    hipLaunchKernelGGL(k_tok_status, dim3(1), dim3(1), 0, s, ws_meta, meta);
     NSNP_HIP(ctx, hipGetLastError());
     return NSNP_OK;
 }
