@@ -261,3 +261,32 @@ def test_host_thread_budget(tmp_path):
     auto = child()
     assert child(LOCAL_WORLD_SIZE="2") == max(1, auto // 2)
     assert child(LOCAL_WORLD_SIZE="4096") == 1
+
+
+def test_ramp_cuts_cover_the_text_in_whole_lines_with_growing_chunks():
+    """pipeline.ramp_cuts: the chunks of the streamed text path - whole lines, every byte exactly once, sizes growing by 1.5 from a quarter
+    of the chunk size (the pipeline's fill shrinks with its first chunk), averaging the chunk size whatever the line length, one line per
+    chunk when a chunk is shorter than a line, a short remainder joined to the last chunk"""
+    from nanosnp_amd.pipeline import ramp_cuts
+    text = (b"x" * 87 + b"\n") * 60000
+    for cb in (1 << 20, 100_000, 20_000, 3_000, 700, 64):
+        c = ramp_cuts(text, 0, len(text), cb)
+        n = len(c) - 1
+        assert c[0] == 0 and c[-1] == len(text) and all(c[i + 1] > c[i] for i in range(n))
+        assert all(text[x - 1:x] == b"\n" for x in c[1:])
+        sizes = [c[i + 1] - c[i] for i in range(n)]
+        if cb == 64:
+            assert set(sizes) == {88}
+        else:
+            assert max(sizes) <= 1.5 * cb + 88 and n >= len(text) // cb
+    c = ramp_cuts(text, 0, len(text), 4 << 20)          # 5.28 MB of text, 4 MB chunks: 1 MB, 1.5 MB, then the rest (what is left behind a 2.25 MB
+    sizes = [c[i + 1] - c[i] for i in range(len(c) - 1)]  # chunk would be less than half a chunk: it joins it)
+    assert abs(sizes[0] - (1 << 20)) < 100 and abs(sizes[1] - 1.5 * (1 << 20)) < 100 and len(sizes) == 3
+    # a byte range of the text (one rank's share), a text without its last newline, nothing at all
+    lo = text.find(b"\n", 1_000_000) + 1
+    hi = text.find(b"\n", 3_000_000) + 1
+    c = ramp_cuts(text, lo, hi, 300_000)
+    assert c[0] == lo and c[-1] == hi and all(text[x - 1:x] == b"\n" for x in c)
+    c = ramp_cuts(text[:-1], 0, len(text) - 1, 1 << 20)
+    assert c[-1] == len(text) - 1
+    assert ramp_cuts(b"", 0, 0, 64) == [0]
