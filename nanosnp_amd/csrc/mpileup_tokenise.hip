@@ -343,10 +343,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t*
     tk_load_words(t, p0, w);
     tk_stage_text(txt, w);
     const uint4 cm = chunk_masks[(int64_t)blockIdx.x * TK_BLOCK + tid];
-    struct { uint32_t nl; } m{cm.x};
+    const uint32_t nlm = cm.x;
     const TokEvents e{cm.y, cm.z, cm.w, 0u};
     // one scan, two sums: newlines (high half) and column-5 bytes (low half) in front of this chunk inside the tile
-    const BlockScan s2 = tk_block_scan((__popc(m.nl) << 16) | __popc(e.m4), 0, sh);            // (its barriers publish txt)
+    const BlockScan s2 = tk_block_scan((__popc(nlm) << 16) | __popc(e.m4), 0, sh);            // (its barriers publish txt)
     const int64_t line0 = tile_nl[blockIdx.x] + (s2.v_excl >> 16);
     const int r0 = s2.v_excl & 0xffff, tile_cnt = s2.v_total & 0xffff;
     const int64_t out0 = tile_bytes[blockIdx.x];
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t*
     uint32_t err = 0;
     for (uint32_t s2 = e.s2; s2; s2 &= s2 - 1) {
         const int b = __ffs(s2) - 1;
-        const int64_t line = line0 + __popc(m.nl & ((1u << b) - 1u));
+        const int64_t line = line0 + __popc(nlm & ((1u << b) - 1u));
         const int64_t v = tk_atoll(t, txt, tile0, p0 + b);
         if (line < cap_cols) {
             pos[line] = v;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_tok_emit(TokText t, const int64_t*
     for (uint32_t s4 = e.s4; s4; s4 &= s4 - 1) {
         const int b = __ffs(s4) - 1;
         const uint32_t below = (1u << b) - 1u;
-        const int64_t line = line0 + __popc(m.nl & below);
+        const int64_t line = line0 + __popc(nlm & below);
         if (line < cap_cols) col_off[line] = out0 + r0 + __popc(e.m4 & below);
     }
     {
