@@ -23,4 +23,5 @@ for wl in e2e hap-e2e pd-e2e; do
       profiles/${TAG}_${name}_overlap.json profiles/${TAG}_${name}_kernel_stats.csv
   cp $OUT/prof_${TAG}_${name}_details.json profiles/${TAG}_${name}_traced_line.json      # (the traced run: no second values; the full line is ${TAG}_${name}_line.json of tools/round_profiles.sh)
 done
-mkdir -p $OUT/${TAG}_profiles && cp profiles/${TAG}_*e2e_* $OUT/${TAG}_profiles/      # (gpurun brings gpurun_out/ back, not profiles/)
+mkdir -p $OUT/${TAG}_profiles      # (gpurun brings gpurun_out/ back, not profiles/: this script's own outputs travel through it)
+for name in e2e hap_e2e pd_e2e; do cp profiles/${TAG}_${name}_overlap.json profiles/${TAG}_${name}_kernel_stats.csv profiles/${TAG}_${name}_traced_line.json $OUT/${TAG}_profiles/; done
