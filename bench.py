@@ -217,6 +217,11 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if rank != 0:
+        # torchrun hands every rank the job's stdout: whatever a rank other than 0 (or a native library inside it: RCCL's banner) writes there
+        # would land around - or behind - rank 0's line.  Their stdout IS their stderr from here on.
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if args.selftest_launcher:
         sys.exit(selftest_launcher(args, rank, world))
     if args.hw_queues:
