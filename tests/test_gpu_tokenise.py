@@ -157,3 +157,13 @@ def test_many_tiles_and_repeated_calls(ctx):
     for _ in range(4):
         pos, off, bases, _ = ctx.mpileup_tokenise(d)
         assert np.array_equal(pos.cpu().numpy(), opos) and np.array_equal(off.cpu().numpy(), ooff) and np.array_equal(bases.cpu().numpy(), obases)
+
+
+def test_random_bytes_equal_the_oracle_reader(ctx):
+    """lines of arbitrary bytes (no tab / newline inside a field, '\\r' anywhere), runs of tabs, CRLF, atoll-style positions: the generator of
+    tests/test_host.py's host-tokeniser fuzz, here through the device tokeniser at several alignments"""
+    from tests.test_host import _random_mpileup_text
+    rng = np.random.default_rng(20260607)
+    for rnd in range(6):
+        text = _random_mpileup_text(rng, 4000)
+        _check(ctx, text, shift=int(rng.integers(0, 40)))

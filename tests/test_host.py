@@ -290,3 +290,51 @@ def test_ramp_cuts_cover_the_text_in_whole_lines_with_growing_chunks():
     c = ramp_cuts(text[:-1], 0, len(text) - 1, 1 << 20)
     assert c[-1] == len(text) - 1
     assert ramp_cuts(b"", 0, 0, 64) == [0]
+
+
+def _random_mpileup_text(rng, n_lines, weird=0.3):
+    """lines of >= 5 tab-separated non-empty fields made of arbitrary bytes (no tab / newline inside a field; '\\r' allowed anywhere), with
+    runs of tabs, leading / trailing tabs, CRLF ends, extra fields and atoll-style position tokens mixed in"""
+    alphabet = np.array([b for b in range(1, 256) if b not in (9, 10)], np.uint8)
+    lines = []
+    for i in range(n_lines):
+        nf = int(rng.integers(5, 9))
+        f = [bytes(rng.choice(alphabet, int(rng.integers(1, 40)))) for _ in range(nf)]
+        u = rng.random()
+        if u < 0.6: f[1] = b"%d" % int(rng.integers(1, 10 ** int(rng.integers(1, 12))))
+        elif u < 0.7: f[1] = b" \r\v\f" + (b"-" if rng.random() < 0.5 else b"+") + b"%d" % int(rng.integers(0, 10 ** 9)) + b"zz9"
+        seps = [b"\t" * int(1 + (rng.random() < weird) * rng.integers(0, 4)) for _ in range(nf - 1)]
+        l = b"".join(x + s for x, s in zip(f, seps + [b""]))
+        if rng.random() < weird: l = b"\t" * int(rng.integers(1, 3)) + l
+        if rng.random() < weird: l = l + b"\t" * int(rng.integers(1, 3))
+        if rng.random() < weird: l = l + b"\r"
+        while l.endswith(b"\r\r") or l == b"\r":            # ("...\r\r\n": the reader strips ONE '\r'; keep the case, but not an empty line)
+            l = l[:-1] + b"x"
+        lines.append(l)
+    text = b"\n".join(lines)
+    return text + (b"\n" if rng.random() < 0.7 else b"")
+
+
+def test_host_tokeniser_equals_the_oracle_reader_on_random_bytes():
+    """nsnp_mpileup_parse (all its code paths: portable, line-oriented and block-oriented AVX2 / AVX-512 where the CPU has them) against the
+    oracle's byte-at-a-time restatement of the reference's reader, on lines of arbitrary bytes"""
+    from oracle import oracle
+    rng = np.random.default_rng(20260606)
+    modes = ["1", "2", "3", "4", None]
+    for rnd in range(6):
+        text = _random_mpileup_text(rng, 3000)
+        opos, ooff, obases = oracle.mpileup_tokenise(text)
+        for mode in modes:
+            old = os.environ.get("NSNP_PARSE_GENERIC")
+            try:
+                if mode is None:
+                    os.environ.pop("NSNP_PARSE_GENERIC", None)
+                else:
+                    os.environ["NSNP_PARSE_GENERIC"] = mode
+                pos, off, bases = host.mpileup_parse(text)
+            finally:
+                if old is None:
+                    os.environ.pop("NSNP_PARSE_GENERIC", None)
+                else:
+                    os.environ["NSNP_PARSE_GENERIC"] = old
+            assert np.array_equal(pos, opos) and np.array_equal(off, ooff) and np.array_equal(bases, obases), (rnd, mode)
