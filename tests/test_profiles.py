@@ -9,12 +9,13 @@ import pytest
 
 from tests.helpers import ROOT
 
-ROUND = "r05"
+ROUND = "r06"
 LINES = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*_line.json")) if "e2e" not in p)
 
 
 def _load(path):
-    return json.loads(open(path).read().strip().splitlines()[-1])
+    """a committed *_line.json is a run's FULL result object (bench_details*.json); the driver's compact line is *_stdout.txt beside it"""
+    return json.load(open(path))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -84,6 +85,9 @@ def test_all_workloads_have_a_line():
     h = _load(os.path.join(ROOT, "profiles", f"{ROUND}_hap_e2e_line.json"))
     assert h["parity_sample"]["ok"] and h["parity_sample"]["timed_run_equals_the_one_pass_run"] and h["parity_sample"]["two_stage_fixture"]["ok"]
     assert h["fraction_of_hbm_resident_rate"] >= 0.8 and h["bound_by"].startswith("device")
+    # the text path with the tokeniser on the device (round 6): device-bound, the host-parsed VCF is part of its parity sample, >= 12 M sites/s
+    assert e2e["tokenise"] == "device" and e2e["bound_by"].startswith("device") and e2e["parity_sample"]["vcf_equals_the_host_parsed_run"] is True
+    assert e2e["value"] >= 12e6 and e2e["host_parsed"]["value"] < e2e["value"] and 0 < e2e["roofline_tokenise"]["frac"] <= 1
     for k in ("int32_file_narrowed_while_staged", "int32_file_sent_as_int32"):
         assert h["second_values"][k]["fraction_of_hbm_resident_rate"] >= 0.8, k
     assert h["second_values"]["int32_file_sent_as_int32"]["bytes_over_pcie_per_site"] > 63360
@@ -109,3 +113,35 @@ def test_pd_e2e_line_is_committed():
     assert h["fraction_of_hbm_resident_rate"] >= 0.75 and h["compute_stream_idle_between_passes_s_per_step"] < 0.002
     assert set(h["second_values"]) == {"int32_counts_on_disk_narrowed_while_staged", "int32_counts_on_disk_sent_as_int32"}
     assert all(v["vcf_equals_the_int16_run"] for v in h["second_values"].values())
+
+
+def test_the_drivers_lines_are_committed_beside_the_full_objects():
+    """profiles/<round>_*_stdout.txt: what `bench.py` printed - the last line is the flat object the driver parses (a 58 KB
+    line could not be read back): under 4 KB, one "metric" key, its numbers the full object's"""
+    n = 0
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*_stdout.txt"))):
+        last = open(p).read().strip().splitlines()[-1]
+        line = json.loads(last)
+        assert len(last) < 4096 and last.count('"metric"') == 1, p
+        full = json.load(open(p.replace("_stdout.txt", "_line.json")))
+        assert abs(line["value"] - full["value"]) <= 1e-6 * full["value"] and line["metric"] == full["metric"], p
+        for k in ("roofline", "cpu_baseline", "parity_ok", "config", "timed_region_s"):
+            assert k in line, (p, k)
+        n += 1
+    assert n >= 7
+    d = json.loads(open(os.path.join(ROOT, "profiles", f"{ROUND}_default_stdout.txt")).read().strip().splitlines()[-1])
+    assert set(d["workloads"]) == {"haplotype", "two_stage", "deep60", "hap_e2e", "e2e", "pd_e2e"} and d["parity_ok"] is True
+    assert all(w["parity_ok"] is True and w["value"] > 0 for w in d["workloads"].values())
+    assert d["workloads"]["haplotype"]["sites_per_step"] == 15000 and d["workloads"]["two_stage"]["sites_per_step"] > 1_400_000      # BASELINE sizes
+
+
+def test_pipeline_traces_are_committed():
+    """rocprofv3 kernel (+ memory-copy) traces of the three host-fed bench runs, cut to their timed regions: the line's device-busy figure
+    is within 5 % of the trace's union of dispatch intervals"""
+    for name in ("e2e", "hap_e2e", "pd_e2e"):
+        o = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_{name}_overlap.json")))
+        assert o["workload"] == name and o["per_step_ms"]["kernel_busy"] > 0 and o["dispatches_in_region"] > 50
+        assert abs(o["line_against_trace"]["device_busy_ms_per_step"]["relative_difference"]) <= 0.05, name
+        assert os.path.exists(os.path.join(ROOT, "profiles", f"{ROUND}_{name}_kernel_stats.csv"))
+    t = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_tokenise.json")))
+    assert t["roofline"]["bound"] == "hbm" and 0 < t["roofline"]["frac"] <= 1 and t["roofline"]["traffic"] >= t["algorithmic_bytes_per_call"]
