@@ -60,7 +60,7 @@ def parse_args(argv=None):
                          "HaplotypeModel fwd (+ the legacy crnn.py CatModel fwd) on 150 k G3 sites; two-stage = configs[3]: stage 2 + stage 5 "
                          "on a chr20-sized candidate set, sites sharded over the ranks, gathered calls merged on rank 0; deep60 = configs[4]: "
                          "60x columns + D = 180 read planes + fp16-split conv weights; e2e = a labelled text-to-VCF measurement: samtools-mpileup text of a synthetic contig "
-                         "on the page cache -> host parse beside H2D + encode + forward -> pileup.vcf (tools/e2e_bench.py); hap-e2e = the same for stage 5: a haplotype "
+                         "on the page cache -> pinned staging beside H2D beside tokenise + encode + forward on the device -> pileup.vcf (tools/e2e_bench.py); hap-e2e = the same for stage 5: a haplotype "
                          "site file on the page cache -> pinned staging beside H2D beside features + HaplotypeModel fwd -> haplotype.csv (tools/hap_e2e_bench.py); pd-e2e = stage 2 from "
                          ".pd.bin window files: pread + int16 narrowing beside H2D beside PileupModel fwd -> pileup.vcf (tools/pd_e2e_bench.py; one rank)")
     ap.add_argument("--encode-group", type=int, default=32, help="batches encoded per column-encode launch (on the encode stream, into a "

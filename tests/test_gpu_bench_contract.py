@@ -305,3 +305,21 @@ def test_two_ranks_with_the_other_configurations_in_the_same_line():
     for name, line in d["workloads"].items():
         assert "error" not in line and line["n_gpus"] == 2 and line["config"]["world_size_observed"] == 2 and line["summary"]["parity_ok"] is True, name
     assert d["workloads"]["hap_e2e"]["parity_sample"]["rows"] == 6000
+
+
+def test_direct_torchrun_keeps_the_line_last_on_the_jobs_stdout():
+    """the driver's N > 1 command: `python -m torch.distributed.run ... bench.py --gpus N` - every rank inherits the job's stdout, so ranks
+    other than 0 send theirs to stderr and rank 0 flushes native buffers before it prints: the LAST line of the merged stdout is the line
+    (here: two ranks sharing GPU 0 over gloo, the TEST configuration)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "65536",
+                          "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-second-precision", "--workloads", "none"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _parse(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["_line"]["parity_ok"] is True

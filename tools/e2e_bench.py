@@ -4,9 +4,11 @@
 them) - a labelled measurement, never the headline `value` of the repository (BASELINE's metric is quoted with inputs in HBM).
 
     a synthetic contig of NSNP_E2E_COLS columns (default 6,000,000: generator G1, 30x) written as samtools-mpileup text to a file that
-    sits in the page cache -> memory-mapped -> nanosnp_amd.pipeline.call_contig: chunks of whole lines, parse of chunk k + 1
-    (libnanosnp_host.so, OpenMP, into pinned buffers) beside H2D + column encode + site selection + PileupModel forward + argmax of
-    chunk k -> call rows gathered -> nsnp_vcf_format_batches -> pileup.vcf written.  One *step* = the whole contig.
+    sits in the page cache -> memory-mapped -> nanosnp_amd.pipeline.call_contigs: chunks of whole lines copied into pinned buffers
+    (libnanosnp_host.so, OpenMP) beside their H2D copies beside nsnp_mpileup_tokenise + column encode + site selection + PileupModel
+    forward + argmax of earlier chunks -> call rows -> nsnp_vcf_format_batches -> pileup.vcf written.  One *step* = the whole contig.
+    (NSNP_TOKENISE=host: the text is cut into columns by the host tokeniser instead, the path of rounds 1-5; it rides along as the
+    `host_parsed` second value and its VCF must equal the device-tokenised one.)
 
 Under N ranks the TEXT is sharded by byte range (every rank parses only its lines) and the calls are gathered to rank 0 (strong
 scaling).  The line carries the per-stage busy times and names the stage that bounds the pipeline; parity = the VCF of the chunked
@@ -242,11 +244,11 @@ def run(args, rank, world, local_rank, emit=None):
                                   "(other streams' copies run beside them)", chunk_bytes=chunk, text_bytes_per_step=stats.get("text_bytes", 0) / K)
         cols_per_pass = stats.get("columns", 0) / K * (world if world > 1 else 1)
         out = {
-            "metric": "candidate SNP sites/sec, mpileup text to VCF (text on the page cache, parse + H2D + encode + forward + VCF)",
+            "metric": "candidate SNP sites/sec, mpileup text to VCF (text on the page cache: staging + H2D + tokenise + encode + forward + VCF)",
             "value": n_sites * K / dt, "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "text to VCF: a synthetic G1 contig of %d columns at %gx as samtools-mpileup text (%.0f MB, page cache) -> "
-                                   "chunks of %d MB: host parse beside H2D + column encode + site selection + PileupModel fwd (fp32) -> pileup.vcf; "
+                                   "chunks of %d MB: staging into pinned memory beside H2D beside tokenise + column encode + site selection + PileupModel fwd (fp32) -> pileup.vcf; "
                                    "NOT the headline configuration (BASELINE configs[1] has its inputs in HBM)" % (n_cols, args.coverage, text_bytes / 1e6, chunk >> 20),
                        "columns": n_cols, "text_bytes": text_bytes, "chunk_bytes": chunk, "candidate_sites": n_sites, "vcf_rows": n_rows,
                        "parallelism": f"text sharded by byte range x{world}, calls gathered to rank 0",

@@ -2,7 +2,7 @@
 """The other BASELINE configurations inside the default bench line.
 
 `python bench.py` (workload pileup = BASELINE configs[1], the metric's configuration) prints ONE JSON line whose `value` is the
-headline; after its timed region, in the same process, short runs of the existing workload tools on reduced resident pools fill
+headline; after its timed region, in the same process, short runs of the existing workload tools (sizes: PLAN below) fill
 
     "workloads": {"haplotype": configs[2], "two_stage": configs[3], "deep60": configs[4], "hap_e2e": stage 5 from host memory,
                   "e2e": mpileup text to VCF, "pd_e2e": window files to VCF}
