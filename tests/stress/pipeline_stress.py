@@ -4,7 +4,7 @@ base-like characters, N reads, very deep and very shallow columns, position gaps
 must equal, byte for byte, the one-chunk run; the one-chunk run itself is checked against the oracle chain (mpileup parse -> oracle encode
 -> oracle site selection -> oracle forward on the selected windows: calls within 1e-4)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import numpy as np, torch
 import make_golden as mg

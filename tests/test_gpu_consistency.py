@@ -35,8 +35,8 @@ def test_no_kernel_reads_lds_or_workspace_it_never_wrote():
 
 
 def test_text_pipeline_on_adversarial_contigs():
-    """tools/pipeline_stress.py: three rounds (adversarial columns; positions that step back / repeat, cut alleles; the reader's corner
+    """tests/stress/pipeline_stress.py: three rounds (adversarial columns; positions that step back / repeat, cut alleles; the reader's corner
     cases - runs of tabs, CRLF, no quality column, atoll-style positions): every chunk size and the host-parsed run give the one-chunk
     device-tokenised VCF byte for byte; its sites and calls equal the oracle chain's"""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pipeline_stress.py"), "3", "8000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stress", "pipeline_stress.py"), "3", "8000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0 and p.stdout.count(": ok") == 3 and "DIFFER" not in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
